@@ -1,0 +1,171 @@
+/*
+ * rgbid.h -- C-ABI of the MI355X-native dense RGB-iD alignment front-end.
+ *
+ * This is the drop-in boundary: every entry point replaces one host
+ * wrapper of the reference's bridge API `namespace RGBID_SLAM::device` (src/internal.h:187-453)
+ * and is what a replacement shared library must export.  Signatures are plain C: device
+ * pointers + pitch + sizes + scalars, no C++/torch/Eigen types.  include/rgbid/internal.h wraps
+ * these back into the reference's own C++ signatures (DeviceArray2D<T>&, Intr, Mat33, float3).
+ *
+ * Conventions
+ *  - rgbid_img.data is DEVICE memory, row-major, `step` bytes between rows (the reference's
+ *    PtrStep convention, ThirdParty/pcl_gpu_containers/include/kernel_containers.h:78-92).
+ *  - invalid pixels are quiet NaN (src/cuda/utils.hpp:76-77); all maps are fp32.
+ *  - R_proj is row-major 3x3 (= reference Mat33, three float3 rows, src/internal.h:166-169).
+ *  - Every function returns 0 on success, a positive hipError_t, or a negative RGBID_E_* code;
+ *    nothing throws.  `ms` (nullable) receives the elapsed device time in milliseconds, the
+ *    reference wrappers' return value (cudaTimer, src/cuda/device.hpp:83-106).
+ *  - Calls are synchronous on return (the reference does cudaStreamSynchronize after every
+ *    launch) unless the context was switched to asynchronous mode with rgbid_ctx_set_async().
+ *  - A context owns a HIP stream + scratch arena; use one context per host thread (the
+ *    reference relies on nvcc --default-stream per-thread, CMakeLists.txt:97).
+ */
+#ifndef RGBID_H_
+#define RGBID_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGBID_OK 0
+#define RGBID_E_INVALID (-1)   /* bad argument (null pointer, mismatched sizes) */
+#define RGBID_E_NOMEM   (-2)
+#define RGBID_E_NODEV   (-3)   /* no HIP device / HIP runtime unusable */
+
+typedef struct rgbid_ctx rgbid_ctx;
+
+typedef struct rgbid_img {
+  void*  data;   /* device pointer */
+  size_t step;   /* bytes between consecutive rows */
+  int    rows;
+  int    cols;
+} rgbid_img;
+
+/* src/internal.h:119-140 Intr (distortion coefficients are unused on this path) */
+typedef struct rgbid_intr { float fx, fy, cx, cy; } rgbid_intr;
+
+/* enums of src/internal.h:66-72 */
+enum { RGBID_LSQ = 0, RGBID_HUBER, RGBID_TUKEY, RGBID_STUDENT };
+enum { RGBID_NO_MM = 0, RGBID_CONSTANT_VELOCITY };
+enum { RGBID_SIGMA_MAD = 0, RGBID_SIGMA_PDF, RGBID_SIGMA_CONS };
+enum { RGBID_INDEPENDENT = 0, RGBID_MIN_WEIGHT, RGBID_GEOM_ONLY, RGBID_PHOT_ONLY };
+enum { RGBID_WARP_FIRST = 0, RGBID_PYR_FIRST };
+enum { RGBID_CHI_SQUARED = 0, RGBID_ALL_ITERS };
+enum { RGBID_NO_FILTERS = 0, RGBID_FILTER_GRADS };
+/* bilinear filter of the intensity warp: exact fp32 weights, or the CUDA texture unit's 1.8
+ * fixed-point weights (what the reference's tex2D computes; default) */
+enum { RGBID_INTERP_EXACT = 0, RGBID_INTERP_TEX8 = 1 };
+
+/* ---- library / context ------------------------------------------------------------------- */
+const char* rgbid_version(void);
+const char* rgbid_error_string(int err);
+int rgbid_device_count(int* n);
+/* stream: a hipStream_t to launch on (e.g. torch's current stream) or NULL for a private stream */
+int rgbid_ctx_create(rgbid_ctx** ctx, int device, void* stream);
+int rgbid_ctx_destroy(rgbid_ctx* ctx);
+int rgbid_ctx_set_stream(rgbid_ctx* ctx, void* stream);
+int rgbid_ctx_set_async(rgbid_ctx* ctx, int async_on);       /* default 0: synchronous on return */
+int rgbid_ctx_set_interp_mode(rgbid_ctx* ctx, int mode);     /* default RGBID_INTERP_TEX8 */
+int rgbid_ctx_sync(rgbid_ctx* ctx);                          /* internal.h:456-457 sync() */
+/* showGPUMemoryUsage(), src/cuda/misc.cu:526-540 */
+int rgbid_mem_info(size_t* free_bytes, size_t* total_bytes);
+
+/* ---- memory (pcl_gpu_containers: src/device_memory.cpp:107-321) -------------------------- */
+int rgbid_malloc(void** ptr, size_t bytes);
+int rgbid_malloc_pitch(void** ptr, size_t* step, size_t width_bytes, size_t rows); /* step is 256-B aligned */
+int rgbid_free(void* ptr);
+int rgbid_memcpy_h2d(rgbid_ctx* ctx, void* dst, const void* src, size_t bytes);
+int rgbid_memcpy_d2h(rgbid_ctx* ctx, void* dst, const void* src, size_t bytes);
+int rgbid_memcpy_d2d(rgbid_ctx* ctx, void* dst, const void* src, size_t bytes);
+int rgbid_memcpy2d_h2d(rgbid_ctx* ctx, void* dst, size_t dstep, const void* src, size_t sstep, size_t width_bytes, size_t rows);
+int rgbid_memcpy2d_d2h(rgbid_ctx* ctx, void* dst, size_t dstep, const void* src, size_t sstep, size_t width_bytes, size_t rows);
+int rgbid_memcpy2d_d2d(rgbid_ctx* ctx, void* dst, size_t dstep, const void* src, size_t sstep, size_t width_bytes, size_t rows);
+
+/* ---- frame preparation (src/cuda/misc.cu) ------------------------------------------------- */
+/* convertDepth2InvDepth misc.cu:365-374: u16 mm -> m^-1, 0 -> NaN */
+int rgbid_depth_to_invdepth(rgbid_ctx*, const rgbid_img* depth_u16, const rgbid_img* dst, float factor_depth);
+/* computeIntensity misc.cu:377-386: packed r,g,b bytes -> luma */
+int rgbid_compute_intensity(rgbid_ctx*, const rgbid_img* rgb_u8x3, const rgbid_img* dst);
+/* decomposeRGBInChannels misc.cu:388-397 */
+int rgbid_decompose_rgb(rgbid_ctx*, const rgbid_img* rgb_u8x3, const rgbid_img* r, const rgbid_img* g, const rgbid_img* b);
+/* computeGradientIntensity / computeGradientDepth misc.cu:400-441 (same kernel) */
+int rgbid_compute_gradient(rgbid_ctx*, const rgbid_img* src, const rgbid_img* dst_hor, const rgbid_img* dst_vert, float* ms);
+/* copyImages :445-455, copyImage :458-467, copyImageRGB :469-478 */
+int rgbid_copy_images(rgbid_ctx*, const rgbid_img* src_depth, const rgbid_img* src_int, const rgbid_img* dst_depth, const rgbid_img* dst_int);
+int rgbid_copy_image(rgbid_ctx*, const rgbid_img* src, const rgbid_img* dst);
+int rgbid_copy_image_rgb(rgbid_ctx*, const rgbid_img* src_u8x3, const rgbid_img* dst_u8x3);
+/* initialiseWeightKeyframe misc.cu:480-489 */
+int rgbid_init_weight_keyframe(rgbid_ctx*, const rgbid_img* src_depth, const rgbid_img* dst_weight);
+/* initialiseDeviceMemory2D<T> misc.cu:491-512; elem_size in {1,4}; value is the raw bit pattern */
+int rgbid_fill_2d(rgbid_ctx*, const rgbid_img* img, int elem_size, uint32_t value_bits);
+
+/* ---- pyramid (src/cuda/pyrdown.cu:194-242): dst must be (rows/2) x (cols/2) --------------- */
+int rgbid_pyr_down(rgbid_ctx*, const rgbid_img* src, const rgbid_img* dst, float* ms);
+
+/* ---- bilateral (src/cuda/filters.cu:139-162) --------------------------------------------- */
+int rgbid_bilateral_filter(rgbid_ctx*, const rgbid_img* src, const rgbid_img* dst, float sigma_floatmap, float* ms);
+
+/* ---- warps, fusion, visibility (src/cuda/warping_registration.cu) ------------------------ */
+/* warpInvDepthWithTrafo3D :971-1019 */
+int rgbid_warp_invdepth(rgbid_ctx*, const rgbid_img* src, const rgbid_img* dst, const rgbid_img* depthinv_prev,
+                        const float R_proj[9], const float t_proj[3], float* ms);
+/* warpIntensityWithTrafo3DInvDepth :920-967 */
+int rgbid_warp_intensity(rgbid_ctx*, const rgbid_img* src, const rgbid_img* dst, const rgbid_img* depthinv_prev,
+                         const float R_proj[9], const float t_proj[3], float* ms);
+/* warpInvDepthWithTrafo3DWeighted :1021-1069 */
+int rgbid_warp_invdepth_weighted(rgbid_ctx*, const rgbid_img* src, const rgbid_img* dst, const rgbid_img* depthinv_prev,
+                                 const rgbid_img* weight_warped, const float R_proj[9], const float t_proj[3], float* ms);
+/* integrateWarpedFrame :1072-1095 */
+int rgbid_integrate_warped_frame(rgbid_ctx*, const rgbid_img* warped_depthinv, const rgbid_img* warped_weight,
+                                 const rgbid_img* depthinv_dst, const rgbid_img* weight_dst, float* ms);
+/* getVisibilityRatio :825-869 / getVisibilityRatioWithOverlapMask :873-913 (overlap_mask nullable, u8) */
+int rgbid_visibility_ratio(rgbid_ctx*, const rgbid_img* depthinv_src, const rgbid_img* depthinv_dst,
+                           const float R_proj[9], const float t_proj[3], const rgbid_img* overlap_mask,
+                           float* visibility_ratio, float* ms);
+
+/* ---- vertex / normal maps (src/cuda/maps.cu:300-344, 396-443); planar 3*rows x cols ------ */
+int rgbid_create_vmap(rgbid_ctx*, rgbid_intr intr, const rgbid_img* depthinv, const rgbid_img* vmap);
+int rgbid_create_nmap_gradients(rgbid_ctx*, rgbid_intr intr, const rgbid_img* depthinv, const rgbid_img* grad_x,
+                                const rgbid_img* grad_y, const rgbid_img* nmap);
+/* generateImageRGB image_generator.cu:206-224 (rgb nullable -> generateImage :187-203) */
+int rgbid_generate_image(rgbid_ctx*, const rgbid_img* vmap, const rgbid_img* nmap, const rgbid_img* rgb_u8x3,
+                         const float light_pos[3], const rgbid_img* dst_u8x3);
+
+/* ---- residual lattice + scale estimation (src/cuda/sigmaFuncs.cu) ------------------------ */
+/* lattice geometry of computeErrorGridStride :701-765 (host-side, no device work) */
+int rgbid_error_lattice_size(int rows, int cols, int min_nsamples, int* n_samples, int* lat_rows, int* lat_cols, int* stride);
+/* computeErrorGridStride: error must hold n_samples floats (device) */
+int rgbid_compute_error(rgbid_ctx*, const rgbid_img* im1, const rgbid_img* im0, float* error_dev, int min_nsamples,
+                        int* n_samples, float* ms);
+/* computeSigmaAndNuStudent :858-1066; bias/sigma/nu are host in/out */
+int rgbid_sigma_nu_student(rgbid_ctx*, const float* error_dev, int n, float* bias, float* sigma, float* nu,
+                           int mestimator, float* ms);
+/* computeNuStudent :1068-1222 */
+int rgbid_nu_student(rgbid_ctx*, const float* error_dev, int n, float bias, float sigma, float* nu, float* ms);
+/* computeSigmaPdf :773-854 */
+int rgbid_sigma_pdf(rgbid_ctx*, const float* error_dev, int n, float* bias, float* sigma, int mestimator, float* ms);
+/* computeChiSquare :1225-1297 */
+int rgbid_chi_square(rgbid_ctx*, const float* error_int_dev, const float* error_depth_dev, int n, float sigma_int,
+                     float sigma_depth, int mestimator, float* chi_square, float* chi_test, float* ndof, float* ms);
+
+/* ---- normal equations (src/cuda/estimate_VO.cu) ------------------------------------------ */
+/* buildSystemGridStride :505-645.  A: 6x6 row-major symmetric (host), b: 6 (host). */
+int rgbid_build_system(rgbid_ctx*, const rgbid_img* W0, const rgbid_img* I0, const rgbid_img* gradW0_x,
+                       const rgbid_img* gradW0_y, const rgbid_img* gradI0_x, const rgbid_img* gradI0_y,
+                       const rgbid_img* W1, const rgbid_img* I1, int mestimator, int weighting,
+                       float sigma_depthinv, float sigma_int, float bias_depthinv, float bias_int,
+                       rgbid_intr intr, double A[36], double b[6], float* ms);
+/* buildSystemStudentNuGridStride :649-789 */
+int rgbid_build_system_student_nu(rgbid_ctx*, const rgbid_img* W0, const rgbid_img* I0, const rgbid_img* gradW0_x,
+                                  const rgbid_img* gradW0_y, const rgbid_img* gradI0_x, const rgbid_img* gradI0_y,
+                                  const rgbid_img* W1, const rgbid_img* I1, int mestimator, int weighting,
+                                  float sigma_depthinv, float sigma_int, float bias_depthinv, float bias_int,
+                                  float nu_depthinv, float nu_int, rgbid_intr intr, double A[36], double b[6], float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGBID_H_ */

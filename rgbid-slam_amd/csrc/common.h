@@ -1,0 +1,100 @@
+// common.h -- shared device helpers / launch descriptors for the gfx950 kernels.
+//
+// Every kernel in csrc/ is natively BATCHED: an image argument is an ImgB = one allocation holding
+// `B` lanes (independent frame pairs / tracker lanes) of identical geometry, lane l at
+// base + l*lane_stride.  The single-image C-ABI calls are the B == 1 case (lane_stride == 0).
+// Per-lane scalars come either by value in the kernarg segment (compat wrappers) or from a device
+// array indexed by lane (batched engine) -- see ByValue / ByLane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rgbid {
+
+struct ImgB {
+  void* base;
+  size_t pitch;        // bytes between rows
+  size_t lane_stride;  // bytes between lanes (0 for a single image)
+  int rows, cols;
+};
+
+template <typename T>
+__device__ __forceinline__ T* row_ptr(const ImgB& im, int lane, int y) {
+  return reinterpret_cast<T*>(static_cast<char*>(im.base) + (size_t)lane * im.lane_stride + (size_t)y * im.pitch);
+}
+template <typename T>
+__device__ __forceinline__ T& px(const ImgB& im, int lane, int y, int x) { return row_ptr<T>(im, lane, y)[x]; }
+
+template <class T> struct ByValue {
+  T v;
+  __device__ __forceinline__ const T& get(int) const { return v; }
+};
+template <class T> struct ByLane {
+  const T* p;
+  __device__ __forceinline__ const T& get(int lane) const { return p[lane]; }
+};
+
+// lane predicate: kernels skip lanes whose mask byte != want (mask == nullptr -> all lanes run)
+struct LaneMask {
+  const int* flags;
+  int want;
+  __device__ __forceinline__ bool on(int lane) const { return flags == nullptr || flags[lane] == want; }
+};
+
+__device__ __forceinline__ float qnan() { return __int_as_float(0x7fffffff); }  // utils.hpp:76-77
+
+// CUDA __float2int_rd / __float2int_rn: saturating, NaN -> 0
+__device__ __forceinline__ int f2i_rd(float x) {
+  if (x != x) return 0;
+  if (x >= 2147483648.f) return 2147483647;
+  if (x <= -2147483648.f) return (-2147483647 - 1);
+  return (int)floorf(x);
+}
+__device__ __forceinline__ int f2i_rn(float x) {
+  if (x != x) return 0;
+  if (x >= 2147483648.f) return 2147483647;
+  if (x <= -2147483648.f) return (-2147483647 - 1);
+  return (int)rintf(x);
+}
+
+struct WarpParams {  // K R^-1 K^-1 (row-major) and K t^-1, float (visodo.cpp:1108-1114)
+  float R[9];
+  float t[3];
+};
+
+// registerPixel (warping_registration.cu:129-146).  fp contraction is OFF here so the projected
+// coordinates -- and therefore every floor()/rint() pixel selection -- are bit-identical to the
+// scalar oracle; the divisions are IEEE (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
+__device__ __forceinline__ float register_pixel(float& xc, float& yc, int xd, int yd, float wd, const WarpParams& P) {
+#pragma clang fp contract(off)
+  float zd = 1.f / wd;
+  float X = (float)xd * zd, Y = (float)yd * zd;
+  float X0 = (P.R[0] * X + P.R[1] * Y + P.R[2] * zd) + P.t[0];
+  float X1 = (P.R[3] * X + P.R[4] * Y + P.R[5] * zd) + P.t[1];
+  float X2 = (P.R[6] * X + P.R[7] * Y + P.R[8] * zd) + P.t[2];
+  float wc = 1.f / X2;
+  xc = X0 * wc;
+  yc = X1 * wc;
+  return wc;
+}
+
+__device__ __forceinline__ bool in_bounds_rd(float xs, float ys, int cols, int rows) {
+  int ix = f2i_rd(xs), iy = f2i_rd(ys);
+  return !(ix < 0 || iy < 0 || ix >= cols || iy >= rows);
+}
+
+// wave64 reductions (no LDS): butterfly over 64 lanes
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace rgbid

@@ -1,0 +1,60 @@
+// kernels.h -- internal (C++) launch API shared by the C-ABI wrappers (c_api.hip) and the batched
+// engine (engine.hip).  All launchers are asynchronous on `stream`; `B` is the number of lanes.
+#pragma once
+#include "common.h"
+
+namespace rgbid {
+
+// ---- per-lane parameter blocks ---------------------------------------------------------------
+struct SysParams {     // inputs of constraintsHandler (estimate_VO.cu:95-139)
+  float fx, fy, cx, cy;
+  float sigma_d, sigma_i, bias_d, bias_i, nu_d, nu_i;
+  int mestimator, weighting, student_nu;
+};
+struct SigmaIO { float bias, sigma, nu; };
+struct IntrP { float fx, fy, cx, cy; };
+struct LightP { float x, y, z; };
+
+enum { SYS_TERMS = 27 };
+
+// ---- prep (kernels_prep.hip) -------------------------------------------------------------------
+void launch_depth_to_invdepth(hipStream_t s, int B, ImgB src_u16, ImgB dst, float factor_depth, LaneMask m);
+void launch_intensity(hipStream_t s, int B, ImgB rgb, ImgB dst, LaneMask m);
+void launch_decompose_rgb(hipStream_t s, int B, ImgB rgb, ImgB r, ImgB g, ImgB b, LaneMask m);
+void launch_gradient(hipStream_t s, int B, ImgB src, ImgB gx, ImgB gy, LaneMask m);
+void launch_copy_bytes(hipStream_t s, int B, ImgB src, ImgB dst, int elem_size, LaneMask m);  // row-wise D2D copy kernel
+void launch_fill(hipStream_t s, int B, ImgB dst, int elem_size, uint32_t bits, LaneMask m);
+void launch_pyr_down(hipStream_t s, int B, ImgB src, ImgB dst, LaneMask m);
+void launch_bilateral(hipStream_t s, int B, ImgB src, ImgB dst, float sigma_floatmap, LaneMask m);
+
+// ---- warps / fusion / maps (kernels_warp.hip) ---------------------------------------------------
+// params: host pointer (by value) when lane_params == nullptr, else device array [B]
+void launch_warp_invdepth(hipStream_t s, int B, ImgB src, ImgB grid, ImgB dst, const WarpParams* host_p, const WarpParams* lane_p, LaneMask m);
+void launch_warp_intensity(hipStream_t s, int B, ImgB src, ImgB grid, ImgB dst, const WarpParams* host_p, const WarpParams* lane_p, int interp_mode, LaneMask m);
+void launch_warp_invdepth_weighted(hipStream_t s, int B, ImgB src, ImgB grid, ImgB dst, ImgB weight, const WarpParams* host_p, const WarpParams* lane_p, LaneMask m);
+void launch_integrate_warped(hipStream_t s, int B, ImgB warped, ImgB wweight, ImgB kf, ImgB kfweight, LaneMask m);
+// counts[lane*2+0] = visible, [lane*2+1] = valid (float, must be zeroed by the caller); mask.base nullable
+void launch_visibility(hipStream_t s, int B, ImgB src, ImgB dst, ImgB mask, const WarpParams* host_p, const WarpParams* lane_p, unsigned int* counts, LaneMask m);
+void launch_vmap(hipStream_t s, int B, ImgB depthinv, ImgB vmap, IntrP k, LaneMask m);
+void launch_nmap_gradients(hipStream_t s, int B, ImgB depthinv, ImgB gx, ImgB gy, ImgB nmap, IntrP k, LaneMask m);
+void launch_generate_image(hipStream_t s, int B, ImgB vmap, ImgB nmap, ImgB rgb, ImgB dst, const LightP* host_l, const LightP* lane_l, LaneMask m);
+
+// ---- residual lattice + sigma/nu (kernels_sigma.hip) --------------------------------------------
+void lattice_geometry(int rows, int cols, int min_nsamples, int* n, int* lrows, int* lcols, int* stride);
+void launch_error_lattice(hipStream_t s, int B, ImgB im1, ImgB im0, float* err, size_t err_lane_stride, int lrows, int lcols, int stride, LaneMask m);
+// mode 0: computeSigmaAndNuStudent, 1: computeNuStudent, 2: computeSigmaPdf.  io: device [B]
+void launch_sigma(hipStream_t s, int B, int mode, const float* err, size_t err_lane_stride, int n, SigmaIO* io, int mestimator, LaneMask m);
+// out: device [B][3] = chi_square, chi_test, ndof
+void launch_chi_square(hipStream_t s, int B, const float* err_int, const float* err_depth, size_t err_lane_stride, int n,
+                       float sigma_int, float sigma_depth, int mestimator, float* out, LaneMask m);
+
+// ---- normal equations (kernels_system.hip) ------------------------------------------------------
+// number of partial-sum blocks per lane the build-system kernel will use for this geometry
+int system_blocks_per_lane(int rows, int cols, int B);
+// partials: device double [B][nblk][27] (size it with system_blocks_per_lane); returns the nblk used.
+// sums: device double [B][27] (packed upper-tri + b, reference order estimate_VO.cu:774-786)
+int launch_build_system(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB W1, ImgB I1,
+                        const SysParams* host_p, const SysParams* lane_p, double* partials, LaneMask m);
+void launch_reduce_system(hipStream_t s, int B, const double* partials, int nblk, double* sums, LaneMask m);
+
+}  // namespace rgbid

@@ -1,0 +1,278 @@
+// kernels_sigma.hip -- residual lattice + robust scale estimation (bias, sigma, Student-t nu) and the
+// chi-square statistic for gfx950.  Replaces src/cuda/sigmaFuncs.cu of the reference.
+//
+// The reference runs every IRLS / bisection step as two kernel launches + two stream syncs + a 4-8 byte
+// D2H copy (16-32 launches and 7 cudaMalloc/cudaFree pairs per call, sigmaFuncs.cu:858-1066), with
+// boost::math::digamma evaluated on the host.  Here one 1024-thread workgroup per lane keeps its
+// <=24 residual samples per thread in VGPRs (19 200 samples at every pyramid level of a 640x480
+// frame), runs ALL iterations in-kernel (moments -> wave64 shuffle reduction -> LDS across 16 waves ->
+// broadcast), evaluates digamma on the device, and writes (bias, sigma, nu): one launch, no host trips.
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace rgbid {
+
+// ---- lattice geometry: computeErrorGridStride sigmaFuncs.cu:701-765 --------------------------------
+void lattice_geometry(int rows, int cols, int min_nsamples, int* n, int* lrows, int* lcols, int* stride) {
+  int error_size = cols * rows;
+  int cols_prev = cols, rows_prev = rows;
+  if (min_nsamples < error_size) {
+    for (;;) {
+      int cols_curr = cols_prev / 2, rows_curr = rows_prev / 2;
+      if (((2 * cols_curr - cols_prev) != 0) || ((2 * rows_curr - rows_prev) != 0) || (min_nsamples > cols_curr * rows_curr)) {
+        error_size = cols_prev * rows_prev;
+        break;
+      }
+      cols_prev = cols_curr;
+      rows_prev = rows_curr;
+    }
+  }
+  int s = 1;
+  while ((long long)(s + 1) * (s + 1) <= (long long)((rows * cols) / error_size)) ++s;  // == (int)sqrt(.)
+  *n = error_size; *lrows = rows_prev; *lcols = cols_prev; *stride = s;
+}
+
+// errorHandler::computeErrorGridStride sigmaFuncs.cu:90-135
+__global__ __launch_bounds__(256) void k_error_lattice(ImgB im1, ImgB im0, float* err, size_t err_lane_stride, int lrows, int lcols, int stride, LaneMask m) {
+  int lane = blockIdx.z;
+  if (!m.on(lane)) return;
+  int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= lcols || y >= lrows) return;
+  float v = px<float>(im1, lane, stride * y, stride * x) - px<float>(im0, lane, stride * y, stride * x);
+  err[(size_t)lane * err_lane_stride + (size_t)y * lcols + x] = v;
+}
+void launch_error_lattice(hipStream_t s, int B, ImgB im1, ImgB im0, float* err, size_t err_lane_stride, int lrows, int lcols, int stride, LaneMask m) {
+  hipLaunchKernelGGL(k_error_lattice, dim3(div_up(lcols, 64), div_up(lrows, 4), B), dim3(64, 4), 0, s, im1, im0, err, err_lane_stride, lrows, lcols, stride, m);
+}
+
+// ---- digamma (device.hpp:76-80 -> boost::math::digamma): recurrence + asymptotic series, double ----
+__device__ __forceinline__ float digamma_f(float x) {
+  double xd = x, r = 0.0;
+  while (xd < 10.0) { r -= 1.0 / xd; xd += 1.0; }
+  double f = 1.0 / (xd * xd);
+  double s = f * (-1.0 / 12.0 + f * (1.0 / 120.0 + f * (-1.0 / 252.0 + f * (1.0 / 240.0 + f * (-1.0 / 132.0 + f * (691.0 / 32760.0 + f * (-1.0 / 12.0)))))));
+  return (float)(r + log(xd) - 0.5 / xd + s);
+}
+
+static constexpr int SIG_T = 1024, SIG_MAXPT = 24, SIG_W = SIG_T / 64;
+static constexpr float TH_HUBER = 1.345f, TH_TUKEY = 4.685f, STUDENT_DOF = 5.f;
+
+// block-wide sum of 4 doubles, result broadcast to every thread.  sm: SIG_W*4 + 4 doubles of LDS.
+__device__ __forceinline__ void block_sum4(double v[4], double* sm) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
+  int wid = threadIdx.x >> 6, lid = threadIdx.x & 63;
+  __syncthreads();
+  if (lid == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sm[wid * 4 + k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double t = 0.0;
+    for (int w = 0; w < SIG_W; ++w) t += sm[w * 4 + threadIdx.x];  // fixed order: deterministic
+    sm[SIG_W * 4 + threadIdx.x] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = sm[SIG_W * 4 + k];
+}
+
+template <bool REG>
+struct Samples {
+  float e[REG ? SIG_MAXPT : 1];
+  const float* g;
+  int n, tid;
+  __device__ __forceinline__ void load(const float* err, int n_, int tid_) {
+    g = err; n = n_; tid = tid_;
+    if constexpr (REG) {
+#pragma unroll
+      for (int j = 0; j < SIG_MAXPT; ++j) {
+        int i = tid + j * SIG_T;
+        e[j] = (i < n) ? err[i] : 0.f;
+      }
+    }
+  }
+  template <class F>
+  __device__ __forceinline__ void for_each(F&& f) const {
+    if constexpr (REG) {
+#pragma unroll
+      for (int j = 0; j < SIG_MAXPT; ++j)
+        if (tid + j * SIG_T < n) f(e[j]);
+    } else {
+      for (int i = tid; i < n; i += SIG_T) f(g[i]);
+    }
+  }
+};
+
+// one moments pass: partialBiasAndSigmaStudent (:258-332) when student_variant, else partialBiasAndSigma (:179-255)
+template <bool REG>
+__device__ __forceinline__ void pass_moments(const Samples<REG>& S, float bias, float sigma, float nu, int mest, bool student_variant,
+                                             double* sm, float& swsr, float& swr, float& sw, float& nel) {
+  double a[4] = {0, 0, 0, 0};
+  S.for_each([&](float er) {
+    float is_valid = 0.f, wsr = 0.f, wr = 0.f, weight = 0.f;
+    if (!isinf(er) && !isnan(er)) {
+      if (student_variant) {
+        is_valid = 1.f;
+        if (mest == 0) weight = 1.f;
+        else {
+          float en = (er - bias) / sigma;
+          weight = (nu + 1.f) / (nu + en * en);
+        }
+      } else {
+        weight = 1.f; is_valid = 1.f;
+        float en = (er - bias) / sigma;
+        if ((mest == 1) && (fabsf(en) > TH_HUBER)) weight = TH_HUBER / fabsf(en);
+        else if (mest == 2) {
+          if (fabsf(en) < TH_TUKEY) { float aux1 = (en / TH_TUKEY) * (en / TH_TUKEY); weight = (1.f - aux1) * (1.f - aux1); }
+          else { weight = 0.f; is_valid = 0.f; }
+        } else if (mest == 3) weight = (STUDENT_DOF + 1.f) / (STUDENT_DOF + en * en);
+      }
+      wr = er * weight;
+      wsr = wr * er;
+    }
+    a[0] += wsr; a[1] += wr; a[2] += weight; a[3] += is_valid;
+  });
+  block_sum4(a, sm);
+  swsr = (float)a[0]; swr = (float)a[1]; sw = (float)a[2]; nel = (float)a[3];
+}
+
+// finalReductionBiasAndSigma :361-407
+__device__ __forceinline__ void final_bias_sigma(float swsr, float swr, float sw, float nel, float& bias, float& sigma) {
+  float b = swr / sw;
+  bias = b;
+  sigma = sqrtf((swsr - 2.f * b * swr + b * b * sw) / nel);
+}
+
+// partialFuncWeightsNu :410-468 + finalReductionFuncWeightsNu :471-512
+template <bool REG>
+__device__ __forceinline__ float func_weights_nu(const Samples<REG>& S, float bias, float sigma, float nu, double* sm) {
+  double a[4] = {0, 0, 0, 0};
+  S.for_each([&](float er) {
+    if (!isinf(er) && !isnan(er)) {
+      float en = (er - bias) / sigma;
+      float weight = (nu + 1.f) / (nu + en * en);
+      a[0] += logf(weight); a[1] += weight; a[2] += 1.0;
+    }
+  });
+  block_sum4(a, sm);
+  return ((float)a[0] - (float)a[1]) / (float)a[2];
+}
+
+__device__ __forceinline__ float C_nu(float nu, float fw) {
+  return -digamma_f(nu / 2.f) + logf(nu / 2.f) + fw + 1.f + digamma_f((nu + 1.f) / 2.f) - logf((nu + 1.f) / 2.f);
+}
+
+// bisection of C(nu) on [2,10]: sigmaFuncs.cu:934-1039 == :1100-1205
+template <bool REG>
+__device__ __forceinline__ float estimate_nu(const Samples<REG>& S, float bias, float sigma, double* sm) {
+  float nu_up = 10.f, nu_down = 2.f, nu_new = 0.f, nu;
+  float C_down = C_nu(nu_down, func_weights_nu(S, bias, sigma, nu_down, sm));
+  float C_up = C_nu(nu_up, func_weights_nu(S, bias, sigma, nu_up, sm));
+  if (C_up * C_down > 0) {
+    nu = (C_down <= 0.f) ? nu_down : nu_up;
+  } else {
+    for (int j = 0; j < 5; j++) {
+      nu_new = (nu_up + nu_down) / 2;
+      if ((nu_up - nu_down) < 1.f) break;
+      float C_new = C_nu(nu_new, func_weights_nu(S, bias, sigma, nu_new, sm));
+      if (C_new * C_up > 0) { C_up = C_new; nu_up = nu_new; }
+      else { C_down = C_new; nu_down = nu_new; }
+    }
+    nu = nu_new;
+  }
+  return nu;
+}
+
+template <bool REG>
+__global__ __launch_bounds__(SIG_T) void k_sigma(int mode, const float* err, size_t err_lane_stride, int n, SigmaIO* io, int mestimator, LaneMask m) {
+  int lane = blockIdx.x;
+  if (!m.on(lane)) return;
+  __shared__ double sm[SIG_W * 4 + 4];
+  Samples<REG> S;
+  S.load(err + (size_t)lane * err_lane_stride, n, threadIdx.x);
+  SigmaIO v = io[lane];
+  float bias = v.bias, sigma = v.sigma, nu = v.nu;
+  float swsr, swr, sw, nel;
+  if (mode == 0) {
+    // computeSigmaAndNuStudent :858-1066
+    float sh_sigma = sigma, sh_bias = bias, sh_nu = 5.f, sigma_prev;
+    int sh_mest = 0;
+    for (int i = 0; i < 10; i++) {
+      pass_moments(S, sh_bias, sh_sigma, sh_nu, sh_mest, true, sm, swsr, swr, sw, nel);
+      final_bias_sigma(swsr, swr, sw, nel, bias, sigma);
+      sigma_prev = sh_sigma;
+      sh_bias = bias; sh_sigma = sigma; sh_mest = mestimator;
+      if ((i > 0) && ((fabsf(sigma - sigma_prev) / sigma_prev) < 0.1f)) break;
+    }
+    nu = estimate_nu(S, sh_bias, sh_sigma, sm);
+  } else if (mode == 1) {
+    // computeNuStudent :1068-1222
+    nu = estimate_nu(S, bias, sigma, sm);
+  } else {
+    // computeSigmaPdf :773-854
+    float sh_sigma = sigma, sh_bias = bias;
+    int sh_mest = 0;
+    for (int i = 0; i < 10; i++) {
+      pass_moments(S, sh_bias, sh_sigma, 5.f, sh_mest, false, sm, swsr, swr, sw, nel);
+      final_bias_sigma(swsr, swr, sw, nel, bias, sigma);
+      if ((i > 0) && ((fabsf(sigma - sh_sigma) / sh_sigma) < 0.1f)) break;
+      sh_bias = bias; sh_sigma = sigma; sh_mest = mestimator;
+    }
+  }
+  if (threadIdx.x == 0) { v.bias = bias; v.sigma = sigma; v.nu = nu; io[lane] = v; }
+}
+
+void launch_sigma(hipStream_t s, int B, int mode, const float* err, size_t err_lane_stride, int n, SigmaIO* io, int mestimator, LaneMask m) {
+  if (n <= SIG_T * SIG_MAXPT)
+    hipLaunchKernelGGL(k_sigma<true>, dim3(B), dim3(SIG_T), 0, s, mode, err, err_lane_stride, n, io, mestimator, m);
+  else
+    hipLaunchKernelGGL(k_sigma<false>, dim3(B), dim3(SIG_T), 0, s, mode, err, err_lane_stride, n, io, mestimator, m);
+}
+
+// ---- computeChiSquare sigmaFuncs.cu:1225-1297 (+ :137-150, :541-646) --------------------------------
+__global__ __launch_bounds__(SIG_T) void k_chi_square(const float* err_int, const float* err_depth, size_t err_lane_stride, int n,
+                                                      float sigma_int, float sigma_depth, int mest, float* out, LaneMask m) {
+  int lane = blockIdx.x;
+  if (!m.on(lane)) return;
+  __shared__ double sm[SIG_W * 4 + 4];
+  double a[4] = {0, 0, 0, 0};
+  for (int half = 0; half < 2; ++half) {
+    const float* e = (half == 0 ? err_int : err_depth) + (size_t)lane * err_lane_stride;
+    float sg = half == 0 ? sigma_int : sigma_depth;
+    for (int i = threadIdx.x; i < n; i += SIG_T) {
+      float en = e[i] / sg;
+      float rho = 0.f;
+      if (!isinf(en) && !isnan(en)) {
+        a[0] += 1.0;
+        rho = (en * en) / 2.f;
+        if ((mest == 1) && (fabsf(en) > TH_HUBER)) rho = TH_HUBER * (fabsf(en) - TH_HUBER / 2.f);
+        else if (mest == 2) {
+          if (fabsf(en) < TH_TUKEY) {
+            float aux1 = (en / TH_TUKEY) * (en / TH_TUKEY);
+            float aux2 = (1.f - aux1) * (1.f - aux1) * (1.f - aux1);
+            rho = ((TH_TUKEY * TH_TUKEY) / 6.f) * (1.f - aux2);
+          } else rho = ((TH_TUKEY * TH_TUKEY) / 6.f);
+        } else if (mest == 3) rho = ((STUDENT_DOF + 1.f) / 2.f) * logf(1.f + (en * en) / STUDENT_DOF);
+      }
+      a[1] += rho;
+    }
+  }
+  block_sum4(a, sm);
+  if (threadIdx.x == 0) {
+    float fN = (float)a[0], frho = (float)a[1];
+    float chi = frho / fN;
+    float z_gauss = (chi - fN) / (sqrtf(2.f * fN));
+    out[lane * 3 + 0] = chi;
+    out[lane * 3 + 1] = 0.5f * (1.f + erff(z_gauss / sqrtf(2.f)));
+    out[lane * 3 + 2] = fN;
+  }
+}
+void launch_chi_square(hipStream_t s, int B, const float* err_int, const float* err_depth, size_t err_lane_stride, int n,
+                       float sigma_int, float sigma_depth, int mestimator, float* out, LaneMask m) {
+  hipLaunchKernelGGL(k_chi_square, dim3(B), dim3(SIG_T), 0, s, err_int, err_depth, err_lane_stride, n, sigma_int, sigma_depth, mestimator, out, m);
+}
+
+}  // namespace rgbid

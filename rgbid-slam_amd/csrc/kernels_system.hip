@@ -1,0 +1,234 @@
+// kernels_system.hip -- per-pixel photometric + inverse-depth residual/Jacobian rows and the 21+6 term
+// Gauss-Newton normal-equation reduction for gfx950 (the headline kernel).  Replaces
+// src/cuda/estimate_VO.cu: constraintsHandler (:95-441), FinalReductionKernel (:459-500) and the host
+// wrappers buildSystemGridStride (:505-645) / buildSystemStudentNuGridStride (:649-789).
+//
+// Reference geometry (NOT reproduced): 32x2-thread blocks, grid capped at 120 blocks (tuned for a 5-SM
+// GTX 850M), 27 sequential __syncthreads-bracketed shared-memory tree reductions, a second kernel and
+// two stream syncs + a 216-byte D2H per call.
+//
+// CDNA4 design: a pure 8-stream read (32 B/px, no reuse -> no LDS staging).  Each lane of a wave64 owns
+// 4 consecutive pixels and issues eight 16-byte loads (1 KiB per wave per map, fully coalesced); 27 fp32
+// accumulators live in VGPRs; the workgroup (4 waves) reduces with wave64 shuffles -> 4x27 floats of LDS
+// -> doubles, and writes ONE 27-double partial row per workgroup.  Partials are summed in a fixed order
+// by a second tiny kernel (or by the batched engine's solve kernel), so results are deterministic --
+// no floating-point atomics.  blockIdx is remapped so that the 8 XCDs each stream a contiguous slab.
+#include "kernels.h"
+
+namespace rgbid {
+
+static constexpr int SYS_T = 256;
+static constexpr float TH_HUBER = 1.345f, TH_TUKEY = 4.685f, STUDENT_DOF = 5.f;
+
+struct SysConst {  // per-thread derived constants
+  float inv_fx, inv_fy, inv_sd, inv_si, be_d, be_i, wmul_d, wmul_i;
+};
+
+__device__ __forceinline__ float m_weight(float e, int mest) {  // computeWeight estimate_VO.cu:141-167
+  float weight = 1.f;
+  if (mest == 1) { if (fabsf(e) > TH_HUBER) weight = TH_HUBER / fabsf(e); }
+  else if (mest == 2) {
+    if (fabsf(e) < TH_TUKEY) { float a = (e / TH_TUKEY) * (e / TH_TUKEY); weight = (1.f - a) * (1.f - a); }
+    else weight = 0.f;
+  } else if (mest == 3) weight = (STUDENT_DOF + 1.f) * __builtin_amdgcn_rcpf(STUDENT_DOF + e * e);
+  return weight;
+}
+
+// one pixel: invDepthConstraint (:214-262) + intensityConstraint (:176-212) + the 27-term update (:408-418)
+__device__ __forceinline__ void accumulate_pixel(float acc[SYS_TERMS], float xf, float yf, float w0, float i0, float gwx, float gwy,
+                                                 float gix, float giy, float w1, float i1, const SysParams& P, const SysConst& C) {
+  float px_ = (xf - P.cx) * C.inv_fx, py_ = (yf - P.cy) * C.inv_fy;
+  // ---- inverse-depth row
+  bool vd = !(isnan(w0) || isnan(w1) || isnan(gwx) || isnan(gwy));
+  float gx = gwx * P.fx, gy = gwy * P.fy;
+  float gz = -(gx * px_ + gy * py_);
+  float iw0 = __builtin_amdgcn_rcpf(w0);
+  float nx = gx * iw0, ny = gy * iw0, nz = gz * iw0 + 1.f;
+  float ndp = nx * px_ + ny * py_ + nz;                               // n . p   (p.z = 1)
+  float nn = nx * nx + ny * ny + nz * nz, pp = px_ * px_ + py_ * py_ + 1.f;
+  float nfac = fabsf(ndp) * __builtin_amdgcn_rsqf(nn * pp);            // |n^ . p^|
+  float Jd[6];
+  Jd[0] = gx * w0 * C.inv_sd;
+  Jd[1] = gy * w0 * C.inv_sd;
+  Jd[2] = (gz * w0 + w0 * w1) * C.inv_sd;
+  float gz1 = gz + w1;
+  Jd[3] = (gz1 * py_ - gy) * C.inv_sd;                                 // -(g x p).x
+  Jd[4] = (gx - gz1 * px_) * C.inv_sd;
+  Jd[5] = (gy * px_ - gx * py_) * C.inv_sd;
+  float ed = -(w1 - w0) * C.inv_sd;
+  float eu = ed - C.be_d;
+  float wd = P.student_nu ? (P.nu_d + 1.f) * __builtin_amdgcn_rcpf(P.nu_d + eu * eu) : m_weight(eu, P.mestimator);
+  wd *= C.wmul_d;
+  // ---- intensity row
+  bool vi = !(isnan(w0) || isnan(i0) || isnan(i1) || isnan(gix) || isnan(giy));
+  float hx = gix * P.fx, hy = giy * P.fy;
+  float hz = -(hx * px_ + hy * py_);
+  float Ji[6];
+  Ji[0] = hx * w0 * C.inv_si;
+  Ji[1] = hy * w0 * C.inv_si;
+  Ji[2] = hz * w0 * C.inv_si;
+  Ji[3] = (hz * py_ - hy) * C.inv_si;
+  Ji[4] = (hx - hz * px_) * C.inv_si;
+  Ji[5] = (hy * px_ - hx * py_) * C.inv_si;
+  float ei = -(i1 - i0) * C.inv_si;
+  float eiu = ei - C.be_i;
+  float wi = P.student_nu ? (P.nu_i + 1.f) * __builtin_amdgcn_rcpf(P.nu_i + eiu * eiu) : m_weight(eiu, P.mestimator);
+  wi *= C.wmul_i;
+  // invalid constraints contribute exactly nothing (reference: weight 0 times a stale finite row)
+  if (!vd) { wd = 0.f; nfac = 0.f; ed = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Jd[k] = 0.f; }
+  if (!vi) { wi = 0.f; ei = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Ji[k] = 0.f; }
+  if (P.weighting == 1) wi = fminf(wd, wi);  // MIN_WEIGHT (:403-406)
+  float sd = nfac * wd;
+  int s = 0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    float a = wi * Ji[r], d = sd * Jd[r];
+#pragma unroll
+    for (int c = r; c < 6; ++c) acc[s++] += a * Ji[c] + d * Jd[c];
+    acc[s++] += a * ei + d * ed;
+  }
+}
+
+__device__ __forceinline__ SysConst make_const(const SysParams& P) {
+  SysConst C;
+  C.inv_fx = 1.f / P.fx; C.inv_fy = 1.f / P.fy;
+  C.inv_sd = 1.f / P.sigma_d; C.inv_si = 1.f / P.sigma_i;
+  C.be_d = P.bias_d / P.sigma_d; C.be_i = P.bias_i / P.sigma_i;
+  C.wmul_d = (float)(1 - (P.weighting == 3));  // PHOT_ONLY
+  C.wmul_i = (float)(1 - (P.weighting == 2));  // GEOM_ONLY
+  return C;
+}
+
+// workgroup reduction of 27 per-thread fp32 sums -> one row of doubles in `out`
+__device__ __forceinline__ void block_reduce_store(float acc[SYS_TERMS], double* out) {
+  __shared__ float sm[SYS_T / 64][SYS_TERMS + 1];
+  int wid = threadIdx.x >> 6, lid = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < SYS_TERMS; ++k) {
+    float v = wave_sum(acc[k]);
+    if (lid == 0) sm[wid][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < SYS_TERMS) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < SYS_T / 64; ++w) t += (double)sm[w][threadIdx.x];
+    out[threadIdx.x] = t;
+  }
+}
+
+// XCD-aware logical block id: hardware places block b on XCD b % 8; give every XCD a contiguous slab
+__device__ __forceinline__ int xcd_slab_block(int b, int n) {
+  int per = n >> 3;
+  if (per == 0 || b >= (per << 3)) return b;  // tail blocks keep their id
+  return (b & 7) * per + (b >> 3);
+}
+
+template <class PS, bool VEC>
+__global__ __launch_bounds__(SYS_T) void k_build_system(ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB W1, ImgB I1,
+                                                        PS ps, double* partials, int nblk, int upt, LaneMask m) {
+  int gb = xcd_slab_block(blockIdx.x, gridDim.x);
+  int lane = gb / nblk, blk = gb - lane * nblk;
+  double* out = partials + ((size_t)lane * nblk + blk) * SYS_TERMS;
+  if (!m.on(lane)) return;
+  const SysParams P = ps.get(lane);
+  const SysConst C = make_const(P);
+  float acc[SYS_TERMS];
+#pragma unroll
+  for (int k = 0; k < SYS_TERMS; ++k) acc[k] = 0.f;
+  const int rows = W0.rows, cols = W0.cols;
+  if (VEC) {
+    const int upr = cols >> 2;  // float4 units per row
+    const int units = rows * upr;
+    int u0 = blk * (SYS_T * upt) + threadIdx.x;
+#pragma unroll 1
+    for (int j = 0; j < upt; ++j) {
+      int u = u0 + j * SYS_T;
+      if (u < units) {
+        int y = u / upr, x = (u - y * upr) << 2;
+        float4 w0 = *reinterpret_cast<const float4*>(row_ptr<float>(W0, lane, y) + x);
+        float4 i0 = *reinterpret_cast<const float4*>(row_ptr<float>(I0, lane, y) + x);
+        float4 a = *reinterpret_cast<const float4*>(row_ptr<float>(gWx, lane, y) + x);
+        float4 b = *reinterpret_cast<const float4*>(row_ptr<float>(gWy, lane, y) + x);
+        float4 c = *reinterpret_cast<const float4*>(row_ptr<float>(gIx, lane, y) + x);
+        float4 d = *reinterpret_cast<const float4*>(row_ptr<float>(gIy, lane, y) + x);
+        float4 w1 = *reinterpret_cast<const float4*>(row_ptr<float>(W1, lane, y) + x);
+        float4 i1 = *reinterpret_cast<const float4*>(row_ptr<float>(I1, lane, y) + x);
+        float yf = (float)y, xf = (float)x;
+        accumulate_pixel(acc, xf, yf, w0.x, i0.x, a.x, b.x, c.x, d.x, w1.x, i1.x, P, C);
+        accumulate_pixel(acc, xf + 1.f, yf, w0.y, i0.y, a.y, b.y, c.y, d.y, w1.y, i1.y, P, C);
+        accumulate_pixel(acc, xf + 2.f, yf, w0.z, i0.z, a.z, b.z, c.z, d.z, w1.z, i1.z, P, C);
+        accumulate_pixel(acc, xf + 3.f, yf, w0.w, i0.w, a.w, b.w, c.w, d.w, w1.w, i1.w, P, C);
+      }
+    }
+  } else {
+    const int units = rows * cols;
+    int u0 = blk * (SYS_T * upt) + threadIdx.x;
+#pragma unroll 1
+    for (int j = 0; j < upt; ++j) {
+      int u = u0 + j * SYS_T;
+      if (u < units) {
+        int y = u / cols, x = u - y * cols;
+        accumulate_pixel(acc, (float)x, (float)y, px<float>(W0, lane, y, x), px<float>(I0, lane, y, x), px<float>(gWx, lane, y, x),
+                         px<float>(gWy, lane, y, x), px<float>(gIx, lane, y, x), px<float>(gIy, lane, y, x), px<float>(W1, lane, y, x),
+                         px<float>(I1, lane, y, x), P, C);
+      }
+    }
+  }
+  block_reduce_store(acc, out);
+}
+
+static inline bool vec_ok(const ImgB& a) { return ((a.pitch & 15) == 0) && ((a.lane_stride & 15) == 0) && ((((uintptr_t)a.base) & 15) == 0); }
+
+// launch plan: units per thread (upt) and blocks per lane
+static void system_plan(int rows, int cols, int B, bool vec, int* upt, int* nblk) {
+  long long units = vec ? (long long)rows * (cols / 4) : (long long)rows * cols;
+  int u = 1;
+  // grow the per-thread run while the launch still has >= 2048 workgroups (8 per CU); cap at 8 units
+  // (32 px) so the per-thread fp32 partial sums stay short
+  while (u < (vec ? 8 : 32) && (units * B) / ((long long)SYS_T * (u * 2)) >= 2048) u *= 2;
+  *upt = u;
+  *nblk = (int)((units + (long long)SYS_T * u - 1) / ((long long)SYS_T * u));
+}
+
+int system_blocks_per_lane(int rows, int cols, int B) {
+  // worst case over both code paths so scratch sized with this is always sufficient
+  int upt, nb1, nb2;
+  system_plan(rows, cols, B, true, &upt, &nb1);
+  system_plan(rows, cols, B, false, &upt, &nb2);
+  return nb1 > nb2 ? nb1 : nb2;
+}
+
+int launch_build_system(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB W1, ImgB I1,
+                        const SysParams* hp, const SysParams* lp, double* partials, LaneMask m) {
+  bool vec = (W0.cols % 4 == 0) && vec_ok(W0) && vec_ok(I0) && vec_ok(gWx) && vec_ok(gWy) && vec_ok(gIx) && vec_ok(gIy) && vec_ok(W1) && vec_ok(I1);
+  int upt, nblk;
+  system_plan(W0.rows, W0.cols, B, vec, &upt, &nblk);
+  dim3 g(nblk * B), b(SYS_T);
+#define RGBID_SYS_LAUNCH(PSV, V) hipLaunchKernelGGL((k_build_system<decltype(PSV), V>), g, b, 0, s, W0, I0, gWx, gWy, gIx, gIy, W1, I1, PSV, partials, nblk, upt, m)
+  if (lp) { ByLane<SysParams> p{lp}; if (vec) RGBID_SYS_LAUNCH(p, true); else RGBID_SYS_LAUNCH(p, false); }
+  else { ByValue<SysParams> p{*hp}; if (vec) RGBID_SYS_LAUNCH(p, true); else RGBID_SYS_LAUNCH(p, false); }
+#undef RGBID_SYS_LAUNCH
+  return nblk;
+}
+
+// FinalReductionKernel estimate_VO.cu:459-500 (all-double here; the reference's tree is fp32)
+__global__ __launch_bounds__(64) void k_reduce_system(const double* partials, int nblk, double* sums, LaneMask m) {
+  int lane = blockIdx.x;
+  if (!m.on(lane)) return;
+  if (threadIdx.x < SYS_TERMS) {
+    const double* p = partials + (size_t)lane * nblk * SYS_TERMS + threadIdx.x;
+    double t = 0.0;
+    for (int b = 0; b < nblk; ++b) t += p[(size_t)b * SYS_TERMS];
+    sums[lane * SYS_TERMS + threadIdx.x] = t;
+  }
+}
+void launch_reduce_system(hipStream_t s, int B, const double* partials, int nblk, double* sums, LaneMask m) {
+  hipLaunchKernelGGL(k_reduce_system, dim3(B), dim3(64), 0, s, partials, nblk, sums, m);
+}
+
+}  // namespace rgbid

@@ -1,0 +1,283 @@
+// kernels_warp.hip -- inverse warps, keyframe iD fusion, visibility ratio, vertex/normal maps and the
+// preview image for gfx950.  Replaces src/cuda/warping_registration.cu (:297-669, 825-1095),
+// src/cuda/maps.cu (:63-90,134-179) and src/cuda/image_generator.cu (:66-185) of the reference.
+//
+// The reference samples through CUDA texture objects created and destroyed on every call; CDNA has
+// no texture path for fp32 linear filtering of pitched memory that would be worth it, so the point
+// sample is a plain gather and the bilinear sample is four gathers combined in fp32, with the texture
+// unit's 1.8 fixed-point weight quantisation available as RGBID_INTERP_TEX8 (what tex2D computes).
+// The gathers hit L2 / Infinity Cache: a warped tile's footprint in the source frame is compact.
+#include "kernels.h"
+
+// Whole file: no FMA contraction, so every fp32 expression is evaluated operation by operation exactly
+// like the scalar oracle (divisions/sqrt are IEEE by hipcc default).  These kernels are bandwidth-bound.
+#pragma clang fp contract(off)
+
+namespace rgbid {
+
+static constexpr int TX = 64, TY = 4;
+static inline dim3 grid2d(int cols, int rows, int B) { return dim3(div_up(cols, TX), div_up(rows, TY), B); }
+
+// CUDA linear filtering at unnormalised coordinates with clamp addressing
+__device__ __forceinline__ float tex2d_linear(const ImgB& src, int lane, float xs, float ys, int mode) {
+  float xB = xs - 0.5f, yB = ys - 0.5f;
+  float fx0 = floorf(xB), fy0 = floorf(yB);
+  float a = xB - fx0, b = yB - fy0;
+  if (mode == 1) {  // RGBID_INTERP_TEX8
+    a = rintf(a * 256.f) * 0.00390625f;
+    b = rintf(b * 256.f) * 0.00390625f;
+  }
+  int i0 = f2i_rd(fx0), j0 = f2i_rd(fy0);
+  int i1 = min(max(i0 + 1, 0), src.cols - 1), j1 = min(max(j0 + 1, 0), src.rows - 1);
+  i0 = min(max(i0, 0), src.cols - 1);
+  j0 = min(max(j0, 0), src.rows - 1);
+  const float* r0 = row_ptr<float>(src, lane, j0);
+  const float* r1 = row_ptr<float>(src, lane, j1);
+  float T00 = r0[i0], T10 = r0[i1], T01 = r1[i0], T11 = r1[i1];
+  float oa = 1.f - a, ob = 1.f - b;
+  return (oa * ob) * T00 + (a * ob) * T10 + (oa * b) * T01 + (a * b) * T11;
+}
+
+// ---- trafo3DKernelInvDepthGridStride (:505-546) ---------------------------------------------------
+template <class PS>
+__global__ __launch_bounds__(256) void k_warp_invdepth(ImgB src, ImgB grid, ImgB dst, PS ps, LaneMask m) {
+  int lane = blockIdx.z;
+  if (!m.on(lane)) return;
+  int x = blockIdx.x * TX + threadIdx.x, y = blockIdx.y * TY + threadIdx.y;
+  if (x >= dst.cols || y >= dst.rows) return;
+  const WarpParams& P = ps.get(lane);
+  float out = qnan();
+  float w = px<float>(grid, lane, y, x);
+  if (!isnan(w)) {
+    float xs, ys;
+    float w3 = register_pixel(xs, ys, x, y, w, P);
+    xs += 0.5f; ys += 0.5f;
+    if (in_bounds_rd(xs, ys, src.cols, src.rows)) {
+      float w2 = px<float>(src, lane, f2i_rd(ys), f2i_rd(xs));
+      float tz = P.t[2];
+      float v1_z = (1.f / w3 - tz) * w;
+      float res = (v1_z / (1.f - w2 * tz)) * w2;
+      if (res > 0.f) out = res;
+    }
+  }
+  px<float>(dst, lane, y, x) = out;
+}
+void launch_warp_invdepth(hipStream_t s, int B, ImgB src, ImgB grid, ImgB dst, const WarpParams* hp, const WarpParams* lp, LaneMask m) {
+  dim3 g = grid2d(dst.cols, dst.rows, B), b(TX, TY);
+  if (lp) hipLaunchKernelGGL(k_warp_invdepth<ByLane<WarpParams>>, g, b, 0, s, src, grid, dst, ByLane<WarpParams>{lp}, m);
+  else hipLaunchKernelGGL(k_warp_invdepth<ByValue<WarpParams>>, g, b, 0, s, src, grid, dst, ByValue<WarpParams>{*hp}, m);
+}
+
+// ---- trafo3DKernelIntensityWithInvDepthGridStride (:465-501) --------------------------------------
+template <class PS>
+__global__ __launch_bounds__(256) void k_warp_intensity(ImgB src, ImgB grid, ImgB dst, PS ps, int interp_mode, LaneMask m) {
+  int lane = blockIdx.z;
+  if (!m.on(lane)) return;
+  int x = blockIdx.x * TX + threadIdx.x, y = blockIdx.y * TY + threadIdx.y;
+  if (x >= dst.cols || y >= dst.rows) return;
+  const WarpParams& P = ps.get(lane);
+  float res = qnan();
+  float w = px<float>(grid, lane, y, x);
+  if (!isnan(w)) {
+    float xs, ys;
+    register_pixel(xs, ys, x, y, w, P);
+    xs += 0.5f; ys += 0.5f;
+    if (in_bounds_rd(xs, ys, src.cols, src.rows)) {
+      res = tex2d_linear(src, lane, xs, ys, interp_mode);
+      res = fmaxf(0.f, fminf(res, 255.f));  // NaN -> 255, as CUDA's min/max
+    }
+  }
+  px<float>(dst, lane, y, x) = res;
+}
+void launch_warp_intensity(hipStream_t s, int B, ImgB src, ImgB grid, ImgB dst, const WarpParams* hp, const WarpParams* lp, int interp_mode, LaneMask m) {
+  dim3 g = grid2d(dst.cols, dst.rows, B), b(TX, TY);
+  if (lp) hipLaunchKernelGGL(k_warp_intensity<ByLane<WarpParams>>, g, b, 0, s, src, grid, dst, ByLane<WarpParams>{lp}, interp_mode, m);
+  else hipLaunchKernelGGL(k_warp_intensity<ByValue<WarpParams>>, g, b, 0, s, src, grid, dst, ByValue<WarpParams>{*hp}, interp_mode, m);
+}
+
+// ---- trafo3DKernelInvDepthWeightedGridStride (:549-594) -------------------------------------------
+template <class PS>
+__global__ __launch_bounds__(256) void k_warp_invdepth_weighted(ImgB src, ImgB grid, ImgB dst, ImgB weight, PS ps, LaneMask m) {
+  int lane = blockIdx.z;
+  if (!m.on(lane)) return;
+  int x = blockIdx.x * TX + threadIdx.x, y = blockIdx.y * TY + threadIdx.y;
+  if (x >= dst.cols || y >= dst.rows) return;
+  const WarpParams& P = ps.get(lane);
+  float out = qnan();
+  float w = px<float>(grid, lane, y, x);
+  if (!isnan(w)) {
+    float xs, ys;
+    float w3 = register_pixel(xs, ys, x, y, w, P);
+    xs += 0.5f; ys += 0.5f;
+    if (in_bounds_rd(xs, ys, src.cols, src.rows)) {
+      float w2 = px<float>(src, lane, f2i_rd(ys), f2i_rd(xs));
+      float tz = P.t[2];
+      float v1_z = (1.f / w3 - tz) * w;
+      float w_factor = 1.f - w2 * tz;
+      float w_factor2 = w_factor * w_factor;
+      float weight_res = (w_factor2 * w_factor2) / (v1_z * v1_z);
+      float res = (v1_z / w_factor) * w2;
+      if (res > 0.f) out = res;
+      if (weight_res > 0.f) px<float>(weight, lane, y, x) = weight_res;  // untouched otherwise, as the reference
+    }
+  }
+  px<float>(dst, lane, y, x) = out;
+}
+void launch_warp_invdepth_weighted(hipStream_t s, int B, ImgB src, ImgB grid, ImgB dst, ImgB weight, const WarpParams* hp, const WarpParams* lp, LaneMask m) {
+  dim3 g = grid2d(dst.cols, dst.rows, B), b(TX, TY);
+  if (lp) hipLaunchKernelGGL(k_warp_invdepth_weighted<ByLane<WarpParams>>, g, b, 0, s, src, grid, dst, weight, ByLane<WarpParams>{lp}, m);
+  else hipLaunchKernelGGL(k_warp_invdepth_weighted<ByValue<WarpParams>>, g, b, 0, s, src, grid, dst, weight, ByValue<WarpParams>{*hp}, m);
+}
+
+// ---- integrateWarpedFrameKernel (:637-669) --------------------------------------------------------
+__global__ __launch_bounds__(256) void k_integrate(ImgB warped, ImgB wweight, ImgB kf, ImgB kfw, LaneMask m) {
+  int lane = blockIdx.z;
+  if (!m.on(lane)) return;
+  int x = blockIdx.x * TX + threadIdx.x, y = blockIdx.y * TY + threadIdx.y;
+  if (x >= kf.cols || y >= kf.rows) return;
+  float w_sum = px<float>(warped, lane, y, x);
+  if (!isnan(w_sum)) {
+    float w_KF = px<float>(kf, lane, y, x);
+    float dw = fabsf(w_sum - w_KF);
+    if (isnan(w_KF)) {
+      px<float>(kf, lane, y, x) = w_sum;
+      px<float>(kfw, lane, y, x) = px<float>(wweight, lane, y, x);
+    } else if (dw < 3 * 0.0075f) {  // 3*DEPTHINV_INTEGR_TH (:80)
+      float q = px<float>(kfw, lane, y, x), qs = px<float>(wweight, lane, y, x);
+      float new_weight = q + qs;
+      px<float>(kf, lane, y, x) = (w_KF * q + w_sum * qs) / new_weight;
+      px<float>(kfw, lane, y, x) = new_weight;
+    }
+  }
+}
+void launch_integrate_warped(hipStream_t s, int B, ImgB warped, ImgB wweight, ImgB kf, ImgB kfw, LaneMask m) {
+  hipLaunchKernelGGL(k_integrate, grid2d(kf.cols, kf.rows, B), dim3(TX, TY), 0, s, warped, wweight, kf, kfw, m);
+}
+
+// ---- partialVisibility(WithOverlapMask)Kernel (:297-437) -----------------------------------------
+// The reference reduces float counters through shared memory + a second kernel + a per-call malloc;
+// here each wave ballots its predicate, popcounts and issues one integer atomic per counter.
+template <class PS>
+__global__ __launch_bounds__(256) void k_visibility(ImgB src, ImgB dst, ImgB mask, PS ps, unsigned int* counts, LaneMask m) {
+  int lane = blockIdx.z;
+  if (!m.on(lane)) return;
+  int x = blockIdx.x * TX + threadIdx.x, y = blockIdx.y * TY + threadIdx.y;
+  bool valid = false, visible = false;
+  if (x < src.cols && y < src.rows) {
+    float w = px<float>(src, lane, y, x);
+    if (!isnan(w)) {
+      const WarpParams& P = ps.get(lane);
+      float xd, yd;
+      float w_dst = register_pixel(xd, yd, x, y, w, P);
+      valid = true;
+      if ((xd > 0) && (xd < (float)(src.cols - 1)) && (yd > 0) && (yd < (float)(src.rows - 1))) {
+        int xi = f2i_rn(xd), yi = f2i_rn(yd);
+        if (fabsf(w_dst - px<float>(dst, lane, yi, xi)) < 0.020f) visible = true;
+      }
+      if (mask.base) px<uint8_t>(mask, lane, y, x) = visible ? 1 : 0;
+    }
+  }
+  unsigned long long bv = __ballot(valid), bs = __ballot(visible);
+  if (threadIdx.x == 0) {  // lane 0 of each wave (TX == 64)
+    if (bs) atomicAdd(&counts[2 * lane + 0], (unsigned int)__popcll(bs));
+    if (bv) atomicAdd(&counts[2 * lane + 1], (unsigned int)__popcll(bv));
+  }
+}
+void launch_visibility(hipStream_t s, int B, ImgB src, ImgB dst, ImgB mask, const WarpParams* hp, const WarpParams* lp, unsigned int* counts, LaneMask m) {
+  dim3 g = grid2d(src.cols, src.rows, B), b(TX, TY);
+  if (lp) hipLaunchKernelGGL(k_visibility<ByLane<WarpParams>>, g, b, 0, s, src, dst, mask, ByLane<WarpParams>{lp}, counts, m);
+  else hipLaunchKernelGGL(k_visibility<ByValue<WarpParams>>, g, b, 0, s, src, dst, mask, ByValue<WarpParams>{*hp}, counts, m);
+}
+
+// ---- computeVmapKernel (maps.cu:63-90) -----------------------------------------------------------
+__global__ __launch_bounds__(256) void k_vmap(ImgB depthinv, ImgB vmap, IntrP k, LaneMask m) {
+  int lane = blockIdx.z;
+  if (!m.on(lane)) return;
+  int u = blockIdx.x * TX + threadIdx.x, v = blockIdx.y * TY + threadIdx.y;
+  if (u >= depthinv.cols || v >= depthinv.rows) return;
+  int rows = depthinv.rows;
+  float fx_inv = 1.f / k.fx, fy_inv = 1.f / k.fy;
+  float z = 1.f / px<float>(depthinv, lane, v, u);
+  if (!isnan(z)) {
+    px<float>(vmap, lane, v, u) = z * ((float)u - k.cx) * fx_inv;
+    px<float>(vmap, lane, v + rows, u) = z * ((float)v - k.cy) * fy_inv;
+    px<float>(vmap, lane, v + 2 * rows, u) = z;
+  } else {
+    px<float>(vmap, lane, v, u) = qnan();
+  }
+}
+void launch_vmap(hipStream_t s, int B, ImgB depthinv, ImgB vmap, IntrP k, LaneMask m) {
+  hipLaunchKernelGGL(k_vmap, grid2d(depthinv.cols, depthinv.rows, B), dim3(TX, TY), 0, s, depthinv, vmap, k, m);
+}
+
+// ---- computeNmapGradientsKernel (maps.cu:134-179) -------------------------------------------------
+__global__ __launch_bounds__(256) void k_nmap_grad(ImgB depthinv, ImgB gx_, ImgB gy_, ImgB nmap, IntrP k, LaneMask m) {
+  int lane = blockIdx.z;
+  if (!m.on(lane)) return;
+  int u = blockIdx.x * TX + threadIdx.x, v = blockIdx.y * TY + threadIdx.y;
+  if (u >= depthinv.cols || v >= depthinv.rows) return;
+  int rows = depthinv.rows;
+  float w = px<float>(depthinv, lane, v, u), gx = px<float>(gx_, lane, v, u), gy = px<float>(gy_, lane, v, u);
+  float n0 = qnan();
+  if (!(isnan(w) || isnan(gx) || isnan(gy))) {
+    float nx = gx * k.fx, ny = gy * k.fy, nz = gx * (k.cx - (float)u) + gy * (k.cy - (float)v) + w;
+    float rn = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz);
+    nx *= rn; ny *= rn; nz *= rn;
+    float z = 1.f / w;
+    float vx = z * ((float)u - k.cx) * (1.f / k.fx), vy = z * ((float)v - k.cy) * (1.f / k.fy), vz = z;
+    float rv = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
+    vx *= rv; vy *= rv; vz *= rv;
+    float acos_vn = vx * nx + vy * ny + vz * nz;
+    if ((double)acos_vn > 0.1) {
+      n0 = nx;
+      px<float>(nmap, lane, v + rows, u) = ny;
+      px<float>(nmap, lane, v + 2 * rows, u) = nz;
+    }
+  }
+  px<float>(nmap, lane, v, u) = n0;
+}
+void launch_nmap_gradients(hipStream_t s, int B, ImgB depthinv, ImgB gx, ImgB gy, ImgB nmap, IntrP k, LaneMask m) {
+  hipLaunchKernelGGL(k_nmap_grad, grid2d(depthinv.cols, depthinv.rows, B), dim3(TX, TY), 0, s, depthinv, gx, gy, nmap, k, m);
+}
+
+// ---- ImageGenerator(RGB) (image_generator.cu:66-185) ----------------------------------------------
+template <class PS>
+__global__ __launch_bounds__(256) void k_generate_image(ImgB vmap, ImgB nmap, ImgB rgb, ImgB dst, PS ps, LaneMask m) {
+  int lane = blockIdx.z;
+  if (!m.on(lane)) return;
+  int x = blockIdx.x * TX + threadIdx.x, y = blockIdx.y * TY + threadIdx.y;
+  if (x >= dst.cols || y >= dst.rows) return;
+  int rows = dst.rows;
+  uint8_t c0 = 0, c1 = 0, c2 = 0;
+  float vx = px<float>(vmap, lane, y, x), nx = px<float>(nmap, lane, y, x);
+  if (!isnan(vx) && !isnan(nx)) {
+    const LightP& L = ps.get(lane);
+    float vy = px<float>(vmap, lane, y + rows, x), vz = px<float>(vmap, lane, y + 2 * rows, x);
+    float ny = px<float>(nmap, lane, y + rows, x), nz = px<float>(nmap, lane, y + 2 * rows, x);
+    float dx = L.x - vx, dy = L.y - vy, dz = L.z - vz;
+    float rd = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    dx *= rd; dy *= rd; dz *= rd;
+    float weight = 1.f;
+    weight *= fabsf(dx * nx + dy * ny + dz * nz);
+    int br = (int)(205 * weight) + 50;
+    br = max(0, min(255, br));
+    if (rgb.base) {
+      float br_f = (float)br / 255.f;
+      const uint8_t* p = row_ptr<uint8_t>(rgb, lane, y) + 3 * x;
+      c0 = (uint8_t)f2i_rn((float)p[0] * br_f);
+      c1 = (uint8_t)f2i_rn((float)p[1] * br_f);
+      c2 = (uint8_t)f2i_rn((float)p[2] * br_f);
+    } else {
+      c0 = c1 = c2 = (uint8_t)br;
+    }
+  }
+  uint8_t* d = row_ptr<uint8_t>(dst, lane, y) + 3 * x;
+  d[0] = c0; d[1] = c1; d[2] = c2;
+}
+void launch_generate_image(hipStream_t s, int B, ImgB vmap, ImgB nmap, ImgB rgb, ImgB dst, const LightP* hl, const LightP* ll, LaneMask m) {
+  dim3 g = grid2d(dst.cols, dst.rows, B), b(TX, TY);
+  if (ll) hipLaunchKernelGGL(k_generate_image<ByLane<LightP>>, g, b, 0, s, vmap, nmap, rgb, dst, ByLane<LightP>{ll}, m);
+  else hipLaunchKernelGGL(k_generate_image<ByValue<LightP>>, g, b, 0, s, vmap, nmap, rgb, dst, ByValue<LightP>{*hl}, m);
+}
+
+}  // namespace rgbid

@@ -1,0 +1,58 @@
+"""CPU checks of the drop-in boundary: the in-tree HIP library loads and exports every symbol that
+include/rgbid.h declares (no compute call is made: there is no GPU in the authoring container)."""
+import ctypes
+import os
+import re
+
+from rgbid import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(rgbid_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    _lib.build()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared("rgbid.h")
+    if os.path.exists(os.path.join(ROOT, "include", "rgbid_engine.h")):
+        names += _declared("rgbid_engine.h")
+    assert len(names) >= 40
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    # the Python binding's own list must not drift from the header
+    assert set(_lib.EXPORTS) <= set(names)
+
+
+def test_version_and_error_strings():
+    L = _lib.lib()
+    assert b"gfx950" in L.rgbid_version()
+    assert L.rgbid_error_string(0) == b"ok"
+    assert b"invalid" in L.rgbid_error_string(-1)
+
+
+def test_no_device_is_a_loud_error():
+    """Without a HIP device the context cannot be created: the product never falls back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    assert L.rgbid_ctx_create(ctypes.byref(h), 0, None) != 0
+    assert not h.value
+
+
+def test_lattice_geometry_host_logic():
+    """rgbid_error_lattice_size is pure host logic (sigmaFuncs.cu:712-741): check against the oracle on CPU."""
+    from rgbid import device
+    from oracle import oracle as O
+    import numpy as np
+    for rows, cols, ns in [(480, 640, 10000), (240, 320, 10000), (120, 160, 10000), (960, 1280, 10000), (480, 640, 9999999),
+                           (61, 83, 100), (64, 64, 1000), (480, 640, 1), (30, 40, 300)]:
+        a = np.zeros((rows, cols), np.float32)
+        e, geo = O.error_lattice(a, a, ns)
+        assert device.error_lattice_size(rows, cols, ns) == (e.size, geo[0], geo[1], geo[2])

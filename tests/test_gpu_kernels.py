@@ -1,0 +1,349 @@
+"""GPU parity tests: every C-ABI kernel wrapper vs the CPU oracle on the same seeded inputs.
+
+Tolerances (stated per test):
+  * integer / index / validity work (NaN patterns, u8 masks, counts, lattice geometry): bit-exact;
+  * element-wise fp32 kernels whose arithmetic is evaluated operation-by-operation on both sides
+    (converters, Sobel, warps, fusion, vmap): bit-exact (0 ULP);
+  * kernels through expf / logf (pyrDown, bilateral, sigma/nu): 4 ULP resp. rel 2e-5;
+  * the normal equations (fp32 per-thread partial sums, fast reciprocals): |dA_ij| <= 2e-5 sqrt(A_ii A_jj).
+All sizes run through the C-ABI (rgbid.device.Context -> librgbid_hip.so); nothing here falls back to the CPU.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import util
+from tests.util import assert_bits, assert_rel
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(48, 64), (61, 83), (480, 640)]
+SMALL = [(48, 64), (61, 83)]
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def K_for(rows, cols):
+    s = cols / 640.0
+    return (525.0 * s, 525.0 * s, 319.5 * s, 239.5 * s)
+
+
+def new(rows, cols, dtype=torch.float32):
+    return torch.full((rows, cols), float("nan") if dtype == torch.float32 else 0, dtype=dtype, device="cuda")
+
+
+@pytest.mark.parametrize("rows,cols", SIZES)
+@pytest.mark.parametrize("factor", [1.0, 0.96])
+def test_depth_to_invdepth(ctx, rows, cols, factor):
+    r = util.rng(1)
+    d = r.integers(0, 12000, (rows, cols)).astype(np.uint16)
+    d[r.random((rows, cols)) < 0.1] = 0
+    d[0, 0] = 65535
+    out = new(rows, cols)
+    ctx.convertDepth2InvDepth(dev(d.view(np.int16)), out, factor)
+    assert_bits(out.cpu().numpy(), O.depth2invdepth(d, factor), 0, "depth2invdepth")
+
+
+@pytest.mark.parametrize("rows,cols", SIZES)
+def test_intensity_and_decompose(ctx, rows, cols):
+    r = util.rng(2)
+    rgb = r.integers(0, 256, (rows, cols, 3)).astype(np.uint8)
+    out = new(rows, cols)
+    ctx.computeIntensity(dev(rgb), out)
+    assert_bits(out.cpu().numpy(), O.intensity(rgb), 0, "intensity")
+    ch = [new(rows, cols) for _ in range(3)]
+    ctx.decomposeRGBInChannels(dev(rgb), *ch)
+    for a, b in zip(ch, O.decompose_rgb(rgb)):
+        assert_bits(a.cpu().numpy(), b, 0, "decompose")
+
+
+@pytest.mark.parametrize("rows,cols", SIZES)
+def test_gradient(ctx, rows, cols):
+    r = util.rng(3)
+    src = util.rand_invdepth(r, rows, cols, nan_frac=0.03)
+    gx, gy = new(rows, cols), new(rows, cols)
+    ctx.computeGradient(util.padded(dev(src)), gx, gy)
+    ogx, ogy = O.gradient(src)
+    assert_bits(gx.cpu().numpy(), ogx, 0, "gradient x")
+    assert_bits(gy.cpu().numpy(), ogy, 0, "gradient y")
+
+
+@pytest.mark.parametrize("rows,cols", SIZES)
+def test_pyr_down(ctx, rows, cols):
+    r = util.rng(4)
+    for src in (util.rand_invdepth(r, rows, cols, nan_frac=0.3), util.rand_intensity(r, rows, cols)):
+        dst = new(rows // 2, cols // 2)
+        ctx.pyrDown(dev(src), dst)
+        ref = O.pyr_down(src)
+        got = dst.cpu().numpy()
+        # validity (count > 12) is integer work: the NaN pattern must be identical; values go through expf
+        assert_bits(got, ref, 4, "pyrDown")
+    # NaN-free input: three corners are invalid at every level
+    src = util.rand_intensity(r, rows, cols)
+    dst = new(rows // 2, cols // 2)
+    ctx.pyrDown(dev(src), dst)
+    g = dst.cpu().numpy()
+    assert np.isnan(g[0, 0]) and np.isnan(g[0, -1]) and np.isnan(g[-1, 0]) and not np.isnan(g[-1, -1])
+    assert np.count_nonzero(np.isnan(g)) == 3
+
+
+@pytest.mark.parametrize("rows,cols", SIZES)
+@pytest.mark.parametrize("sigma", [0.005, 3.0])
+def test_bilateral(ctx, rows, cols, sigma):
+    r = util.rng(5)
+    src = util.rand_invdepth(r, rows, cols, nan_frac=0.05) if sigma < 1 else util.rand_intensity(r, rows, cols)
+    dst = new(rows, cols)
+    ctx.bilateralFilter(dev(src), dst, sigma)
+    assert_bits(dst.cpu().numpy(), O.bilateral(src, sigma), 8, "bilateral")
+
+
+def _warp_case(rows, cols, seed, trans=0.03, rot=1.5):
+    r = util.rng(seed)
+    K = K_for(rows, cols)
+    grid = util.rand_invdepth(r, rows, cols, nan_frac=0.05)
+    src = util.rand_invdepth(r, rows, cols, nan_frac=0.05)
+    inten = util.rand_intensity(r, rows, cols)
+    R, t = util.small_motion(r, K, trans, rot)
+    Rp, tp = util.project(K, *util.inv_pose(R, t))
+    return K, grid, src, inten, Rp, tp
+
+
+@pytest.mark.parametrize("rows,cols", SIZES)
+def test_warp_invdepth(ctx, rows, cols):
+    K, grid, src, inten, Rp, tp = _warp_case(rows, cols, 6)
+    dst = new(rows, cols)
+    ctx.warpInvDepthWithTrafo3D(dev(src), dst, dev(grid), Rp, tp)
+    assert_bits(dst.cpu().numpy(), O.warp_invdepth(src, grid, Rp, tp), 0, "warp iD")
+
+
+@pytest.mark.parametrize("rows,cols", SIZES)
+@pytest.mark.parametrize("mode", [O.INTERP_EXACT, O.INTERP_TEX8])
+def test_warp_intensity(ctx, rows, cols, mode):
+    K, grid, src, inten, Rp, tp = _warp_case(rows, cols, 7)
+    # pyramid levels >= 1 carry NaN corners in the intensity map: exercise the NaN -> 255 clamp
+    inten[0, 0] = np.nan
+    dst = new(rows, cols)
+    ctx.set_interp_mode(mode)
+    try:
+        ctx.warpIntensityWithTrafo3DInvDepth(dev(inten), dst, dev(grid), Rp, tp)
+    finally:
+        ctx.set_interp_mode(O.INTERP_TEX8)
+    assert_bits(dst.cpu().numpy(), O.warp_intensity(inten, grid, Rp, tp, mode), 0, "warp intensity")
+
+
+@pytest.mark.parametrize("rows,cols", SMALL)
+def test_warp_identity_is_exact(ctx, rows, cols):
+    """Analytic KAT: identity transform => W1 == W0 wherever W0 is valid, I1 == I0 (exact bilinear at integer coords)."""
+    r = util.rng(8)
+    K = K_for(rows, cols)
+    w0 = util.rand_invdepth(r, rows, cols, nan_frac=0.1)
+    i0 = util.rand_intensity(r, rows, cols)
+    Rp, tp = util.project(K, np.eye(3), np.zeros(3))
+    d1, d2 = new(rows, cols), new(rows, cols)
+    ctx.warpInvDepthWithTrafo3D(dev(w0), d1, dev(w0), Rp, tp)
+    ctx.warpIntensityWithTrafo3DInvDepth(dev(i0), d2, dev(w0), Rp, tp)
+    g1, g2 = d1.cpu().numpy(), d2.cpu().numpy()
+    valid = ~np.isnan(w0)
+    # projection in fp32 may land a hair off the pixel centre; the point sample is still the same pixel
+    assert np.array_equal(np.isnan(g1), ~valid)
+    np.testing.assert_allclose(g1[valid], w0[valid], rtol=2e-6)
+    np.testing.assert_allclose(g2[valid], i0[valid], atol=0.51)  # TEX8 weights: <= 1/512 of a neighbour difference
+
+
+@pytest.mark.parametrize("rows,cols", SIZES)
+def test_warp_weighted_and_integrate(ctx, rows, cols):
+    K, grid, src, inten, Rp, tp = _warp_case(rows, cols, 9, trans=0.01, rot=0.5)
+    r = util.rng(10)
+    winit = r.uniform(0.5, 2.0, (rows, cols)).astype(np.float32)
+    dst, w = new(rows, cols), dev(winit.copy())
+    ctx.warpInvDepthWithTrafo3DWeighted(dev(src), dst, dev(grid), w, Rp, tp)
+    od, ow = O.warp_invdepth_weighted(src, grid, Rp, tp, weight_init=winit)
+    assert_bits(dst.cpu().numpy(), od, 0, "weighted warp iD")
+    assert_bits(w.cpu().numpy(), ow, 0, "weighted warp weight")
+    kf = grid.copy(); kf[r.random((rows, cols)) < 0.05] = np.nan
+    kfw = np.ones((rows, cols), np.float32)
+    dkf, dkfw = dev(kf.copy()), dev(kfw.copy())
+    ctx.integrateWarpedFrame(dst, w, dkf, dkfw)
+    okf, okfw = O.integrate_warped(od, ow, kf, kfw)
+    assert_bits(dkf.cpu().numpy(), okf, 0, "fused iD")
+    assert_bits(dkfw.cpu().numpy(), okfw, 0, "fused weight")
+
+
+@pytest.mark.parametrize("rows,cols", SIZES)
+def test_visibility(ctx, rows, cols):
+    K, grid, src, inten, Rp, tp = _warp_case(rows, cols, 11)
+    # dst = the surface seen from the other camera: use the warped map so a large share is "visible"
+    dstmap = O.warp_invdepth(src, grid, Rp, tp)
+    ratio = ctx.getVisibilityRatio(dev(src), dev(dstmap), Rp, tp)
+    oratio, nvis, nval, _ = O.visibility_ratio(src, dstmap, Rp, tp)
+    assert ratio == oratio, (ratio, oratio, nvis, nval)
+    mask0 = util.rng(12).integers(0, 2, (rows, cols)).astype(np.uint8)
+    m = dev(mask0.copy())
+    ratio2 = ctx.getVisibilityRatioWithOverlapMask(dev(src), dev(dstmap), Rp, tp, overlap_mask=m)
+    _, _, _, omask = O.visibility_ratio(src, dstmap, Rp, tp, with_mask=True, mask_init=mask0)
+    assert ratio2 == oratio
+    assert np.array_equal(m.cpu().numpy(), omask)
+
+
+@pytest.mark.parametrize("rows,cols", SIZES)
+def test_vmap_nmap_image(ctx, rows, cols):
+    r = util.rng(13)
+    K = K_for(rows, cols)
+    w = util.rand_invdepth(r, rows, cols, nan_frac=0.05)
+    vm = torch.zeros((3 * rows, cols), device="cuda")
+    ctx.createVMap(K, dev(w), vm)
+    ov = O.vmap(w, K)
+    got = vm.cpu().numpy()
+    valid = ~np.isnan(ov[:rows])
+    assert_bits(got[:rows], ov[:rows], 0, "vmap x")
+    for p in (1, 2):  # planes 1,2 are only written where valid (maps.cu:78-85)
+        assert_bits(got[p * rows:(p + 1) * rows][valid], ov[p * rows:(p + 1) * rows][valid], 0, f"vmap plane {p}")
+    gx, gy = O.gradient(w)
+    nm = torch.zeros((3 * rows, cols), device="cuda")
+    ctx.createNMapGradients(K, dev(w), dev(gx), dev(gy), nm)
+    on = O.nmap_gradients(w, gx, gy, K)
+    gn = nm.cpu().numpy()
+    nvalid = ~np.isnan(on[:rows])
+    assert_bits(gn[:rows], on[:rows], 2, "nmap x")
+    for p in (1, 2):
+        assert_bits(gn[p * rows:(p + 1) * rows][nvalid], on[p * rows:(p + 1) * rows][nvalid], 2, f"nmap plane {p}")
+    rgb = r.integers(0, 256, (rows, cols, 3)).astype(np.uint8)
+    out = torch.zeros((rows, cols, 3), dtype=torch.uint8, device="cuda")
+    light = (0.1, -0.05, 0.02)
+    ctx.generateImageRGB(dev(ov), dev(on), dev(rgb), light, out)
+    oi = O.generate_image_rgb(ov, on, rgb, light)
+    diff = np.abs(out.cpu().numpy().astype(int) - oi.astype(int))
+    assert diff.max() <= 1 and np.count_nonzero(diff) <= 1e-3 * diff.size, (diff.max(), np.count_nonzero(diff))
+
+
+@pytest.mark.parametrize("rows,cols,ns", [(480, 640, 10000), (240, 320, 10000), (120, 160, 10000), (480, 640, 9999999), (61, 83, 1000), (960, 1280, 10000)])
+def test_error_lattice(ctx, rows, cols, ns):
+    r = util.rng(14)
+    a, b = util.rand_intensity(r, rows, cols, nan_frac=0.02), util.rand_intensity(r, rows, cols)
+    from rgbid import device
+    oerr, geo = O.error_lattice(a, b, ns)
+    n, lr, lc, st = device.error_lattice_size(rows, cols, ns)
+    assert (n, lr, lc, st) == (oerr.size, geo[0], geo[1], geo[2])  # integer geometry: exact
+    if (rows, cols, ns) in ((480, 640, 10000), (240, 320, 10000), (120, 160, 10000), (960, 1280, 10000)):
+        assert n == 19200  # always the 160x120 lattice
+    err = torch.zeros(rows * cols, device="cuda")
+    n2 = ctx.computeErrorGridStride(dev(a), dev(b), err, ns)
+    assert n2 == n
+    assert_bits(err[:n].cpu().numpy(), oerr, 0, "error lattice")
+
+
+def _student_samples(r, n, nu, sigma, bias, outliers=0.02):
+    e = (bias + sigma * r.standard_t(nu, n)).astype(np.float32)
+    k = int(outliers * n)
+    e[r.integers(0, n, k)] = np.nan
+    return e
+
+
+@pytest.mark.parametrize("n", [19200, 4800, 307200])
+@pytest.mark.parametrize("nu,sigma,bias,s0", [(3.0, 0.004, 0.0005, 0.0025), (5.0, 7.0, -1.0, 5.0), (8.0, 2.0, 0.0, 5.0)])
+def test_sigma_nu_student(ctx, n, nu, sigma, bias, s0):
+    r = util.rng(15)
+    e = _student_samples(r, n, nu, sigma, bias)
+    b, s, v = ctx.computeSigmaAndNuStudent(dev(e), n, 0.0, s0, 5.0, O.STUDENT)
+    ob, os_, ov = O.sigma_nu_student(e, 0.0, s0, 5.0, O.STUDENT)
+    assert v == ov, (v, ov)                      # bisection grid value: exact
+    assert abs(s - os_) <= 2e-5 * os_ and abs(b - ob) <= 2e-5 * os_, (b, ob, s, os_)
+    assert abs(v - nu) <= 2.0                    # recovers the generating nu within the bisection resolution
+    v2 = ctx.computeNuStudent(dev(e), n, ob, os_)
+    assert v2 == O.nu_student(e, ob, os_)
+    for mest in (O.LSQ, O.HUBER, O.TUKEY, O.STUDENT):
+        b3, s3 = ctx.computeSigmaPdf(dev(e), n, 0.0, s0, mest)
+        ob3, os3 = O.sigma_pdf(e, 0.0, s0, mest)
+        assert abs(s3 - os3) <= 2e-5 * os3 and abs(b3 - ob3) <= 2e-5 * os3, (mest, b3, ob3, s3, os3)
+
+
+@pytest.mark.parametrize("mest", [O.LSQ, O.HUBER, O.TUKEY, O.STUDENT])
+def test_chi_square(ctx, mest):
+    r = util.rng(16)
+    n = 19200
+    ei = _student_samples(r, n, 5.0, 5.0, 0.0)
+    ed = _student_samples(r, n, 5.0, 0.0025, 0.0)
+    x, t, d = ctx.computeChiSquare(dev(ei), dev(ed), n, 5.0, 0.0025, mest)
+    ox, ot, od = O.chi_square(ei, ed, 5.0, 0.0025, mest)
+    assert d == od
+    assert abs(x - ox) <= 2e-5 * abs(ox) and abs(t - ot) <= 1e-5
+
+
+def _system_case(rows, cols, seed):
+    r = util.rng(seed)
+    K = K_for(rows, cols)
+    W0 = util.rand_invdepth(r, rows, cols, nan_frac=0.05)
+    I0 = util.rand_intensity(r, rows, cols)
+    gWx, gWy = O.gradient(W0)
+    gIx, gIy = O.gradient(I0)
+    R, t = util.small_motion(r, K, 0.01, 0.4)
+    Rp, tp = util.project(K, *util.inv_pose(R, t))
+    Wc = util.rand_invdepth(r, rows, cols, nan_frac=0.05)
+    W1 = O.warp_invdepth(W0 * np.float32(1.001), W0, Rp, tp) + (0.002 * r.standard_normal((rows, cols))).astype(np.float32)
+    I1 = O.warp_intensity(I0, W1, Rp, tp) + (3 * r.standard_normal((rows, cols))).astype(np.float32)
+    return K, (W0, I0, gWx, gWy, gIx, gIy, W1.astype(np.float32), I1.astype(np.float32))
+
+
+def _check_system(A, b, oA, ob):
+    assert np.array_equal(A, A.T)
+    d = np.sqrt(np.diag(oA))
+    assert (np.abs(A - oA) <= 2e-5 * np.outer(d, d)).all(), np.abs(A - oA) / np.outer(d, d)
+    # b_i = sum J_i w e: bound by sqrt(A_ii * sum w e^2) ~ sqrt(A_ii * N); compare on the scale of A_ii * |x|
+    x = np.linalg.solve(oA, ob)
+    scale = d * (d @ np.abs(x)) + 1e-30
+    assert (np.abs(b - ob) <= 2e-5 * scale + 2e-5 * np.abs(ob)).all(), (np.abs(b - ob) / scale)
+
+
+@pytest.mark.parametrize("rows,cols", SIZES + [(240, 320), (120, 160)])
+@pytest.mark.parametrize("weighting", [O.INDEPENDENT, O.MIN_WEIGHT, O.GEOM_ONLY, O.PHOT_ONLY])
+def test_build_system_student_nu(ctx, rows, cols, weighting):
+    K, maps = _system_case(rows, cols, 17)
+    if (rows, cols) == (480, 640) and weighting != O.INDEPENDENT:
+        pytest.skip("full size covered by INDEPENDENT")
+    args = dict(sigma_depthinv=0.003, sigma_int=6.0, bias_depthinv=0.0002, bias_int=-0.5, nu_depthinv=3.5, nu_int=6.25)
+    dm = [util.padded(dev(m), 4) for m in maps]
+    A, b = ctx.buildSystemStudentNuGridStride(*dm, O.STUDENT, weighting, args["sigma_depthinv"], args["sigma_int"], args["bias_depthinv"],
+                                              args["bias_int"], args["nu_depthinv"], args["nu_int"], K)
+    oA, ob = O.build_system(*maps, K, student_nu=True, mestimator=O.STUDENT, weighting=weighting, **args)
+    _check_system(A, b, oA, ob)
+    # determinism: fixed-order partial sums, no fp atomics
+    A2, b2 = ctx.buildSystemStudentNuGridStride(*dm, O.STUDENT, weighting, args["sigma_depthinv"], args["sigma_int"], args["bias_depthinv"],
+                                                args["bias_int"], args["nu_depthinv"], args["nu_int"], K)
+    assert np.array_equal(A, A2) and np.array_equal(b, b2)
+
+
+@pytest.mark.parametrize("rows,cols", SMALL + [(480, 640)])
+@pytest.mark.parametrize("mest", [O.LSQ, O.HUBER, O.TUKEY, O.STUDENT])
+def test_build_system_fixed_nu(ctx, rows, cols, mest):
+    K, maps = _system_case(rows, cols, 18)
+    dm = [dev(m) for m in maps]   # dense tensors: pitch == cols*4 (83 cols -> scalar path, 64/640 -> float4 path)
+    A, b = ctx.buildSystemGridStride(*dm, mest, O.INDEPENDENT, 0.0025, 5.0, 0.0, 0.0, K)
+    oA, ob = O.build_system(*maps, K, student_nu=False, mestimator=mest, weighting=O.INDEPENDENT,
+                            sigma_depthinv=0.0025, sigma_int=5.0, bias_depthinv=0.0, bias_int=0.0)
+    _check_system(A, b, oA, ob)
+
+
+def test_identity_system_kat(ctx):
+    """Analytic KAT: W1 == W0 and I1 == I0 => b == 0 exactly and A is symmetric PSD."""
+    rows, cols = 48, 64
+    K, maps = _system_case(rows, cols, 19)
+    W0, I0, gWx, gWy, gIx, gIy, _, _ = maps
+    dm = [dev(m) for m in (W0, I0, gWx, gWy, gIx, gIy, W0, I0)]
+    A, b = ctx.buildSystemStudentNuGridStride(*dm, O.STUDENT, O.INDEPENDENT, 0.0025, 5.0, 0.0, 0.0, 5.0, 5.0, K)
+    assert np.all(b == 0.0)
+    assert np.linalg.eigvalsh(A).min() > -1e-6 * np.abs(A).max()
+
+
+def test_invalid_arguments(ctx):
+    """Error behaviour of the C-ABI: bad sizes return RGBID_E_INVALID (-1), never crash."""
+    from rgbid._lib import RgbidError
+    a, b = new(48, 64), new(20, 30)
+    with pytest.raises(RgbidError):
+        ctx.pyrDown(a, b)
+    with pytest.raises(RgbidError):
+        ctx.copyImage(a, b)
+    with pytest.raises(RgbidError):
+        ctx.bilateralFilter(a, a, 1.0)  # in-place is not allowed
