@@ -81,7 +81,9 @@ def test_pyr_down(ctx, rows, cols):
         got = dst.cpu().numpy()
         # validity (count > 12) is integer work: the NaN pattern must be identical; values go through expf
         assert_bits(got, ref, 4, "pyrDown")
-    # NaN-free input: three corners are invalid at every level
+    if rows % 2 or cols % 2:
+        return
+    # NaN-free input, even size: three corners are invalid at every level
     src = util.rand_intensity(r, rows, cols)
     dst = new(rows // 2, cols // 2)
     ctx.pyrDown(dev(src), dst)
