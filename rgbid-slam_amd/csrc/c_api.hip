@@ -437,14 +437,14 @@ static int run_system(rgbid_ctx* c, const rgbid_img* W0, const rgbid_img* I0, co
 int rgbid_build_system(rgbid_ctx* c, const rgbid_img* W0, const rgbid_img* I0, const rgbid_img* gWx, const rgbid_img* gWy,
                        const rgbid_img* gIx, const rgbid_img* gIy, const rgbid_img* W1, const rgbid_img* I1, int mest, int weighting,
                        float sigma_d, float sigma_i, float bias_d, float bias_i, rgbid_intr k, double A[36], double b[6], float* ms) {
-  SysParams P{k.fx, k.fy, k.cx, k.cy, sigma_d, sigma_i, bias_d, bias_i, 5.f, 5.f, mest, weighting, 0};
+  SysParams P{k.fx, k.fy, k.cx, k.cy, sigma_d, sigma_i, bias_d, bias_i, 5.f, 5.f, mest, weighting, 0, 0};
   return run_system(c, W0, I0, gWx, gWy, gIx, gIy, W1, I1, P, A, b, ms);
 }
 int rgbid_build_system_student_nu(rgbid_ctx* c, const rgbid_img* W0, const rgbid_img* I0, const rgbid_img* gWx, const rgbid_img* gWy,
                                   const rgbid_img* gIx, const rgbid_img* gIy, const rgbid_img* W1, const rgbid_img* I1, int mest, int weighting,
                                   float sigma_d, float sigma_i, float bias_d, float bias_i, float nu_d, float nu_i, rgbid_intr k,
                                   double A[36], double b[6], float* ms) {
-  SysParams P{k.fx, k.fy, k.cx, k.cy, sigma_d, sigma_i, bias_d, bias_i, nu_d, nu_i, mest, weighting, 1};
+  SysParams P{k.fx, k.fy, k.cx, k.cy, sigma_d, sigma_i, bias_d, bias_i, nu_d, nu_i, mest, weighting, 1, 0};
   return run_system(c, W0, I0, gWx, gWy, gIx, gIy, W1, I1, P, A, b, ms);
 }
 

@@ -83,15 +83,31 @@ __device__ __forceinline__ bool in_bounds_rd(float xs, float ys, int cols, int r
   return !(ix < 0 || iy < 0 || ix >= cols || iy >= rows);
 }
 
-// wave64 reductions (no LDS): butterfly over 64 lanes
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+// wave64 reductions on the VALU with DPP (no LDS traffic, no ds_bpermute round trips):
+// xor-1 / xor-2 quad permutes, half-row mirror, row mirror leave every lane of a 16-lane row holding the
+// row sum; row_bcast:15 / row_bcast:31 fold the four rows so lane 63 holds the wave total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  int s = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
+  return v + __int_as_float(s);
+}
+// total valid in lane 63 only
+__device__ __forceinline__ float wave_sum_l63(float v) {
+  v = dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xf>(v);  // row_half_mirror
+  v = dpp_add<0x140, 0xf>(v);  // row_mirror
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
   return v;
+}
+// wave total broadcast to every lane (uniform, lives in an SGPR)
+__device__ __forceinline__ float wave_sum(float v) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_l63(v)), 63));
 }
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
 

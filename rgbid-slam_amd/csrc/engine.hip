@@ -1,0 +1,802 @@
+// engine.hip -- batched, device-resident VisodoTracker (C-ABI in include/rgbid_engine.h).
+//
+// One `step` == VisodoTracker::trackNewFrame (src/visodo.cpp:1967-2247) for `lanes` independent trackers
+// in lock-step.  Every image kernel is the batched kernel of kernels.h (blockIdx.z / block-id = lane); the
+// host-side double-precision logic of the reference (constant-velocity prediction, LLT solve, exp-map
+// update, covariance, keyframe decisions, pose composition) runs in small per-lane kernels below, so the
+// whole step is a static launch sequence: no host round trip, capturable as one hipGraph.  Data-dependent
+// control flow (lost tracking, keyframe switches, fuse-vs-reset) is expressed as per-lane flag arrays that
+// predicate whole workgroups (LaneMask).
+#include "../../include/rgbid_engine.h"
+#include "ctx.h"
+#include "kernels.h"
+#include "se3.h"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace rgbid;
+
+namespace {
+
+constexpr int MAXL = 8;
+
+// ---- per-lane tracker state (the scalar members of VisodoTracker, include/visodo.h:280-390) -----------------
+struct LaneState {
+  double delta_R[9], delta_t[3], delta_cov[36];          // delta_rotation_/translation_/covariance_
+  double dprev_R[9], dprev_t[3], dprev_cov[36];          // their values at the start of trackNewFrame
+  double prev_R[9], prev_t[3];                           // previous_rotation/translation of estimateVisualOdometry
+  double cur_R[9], cur_t[3];                             // current_rotation/translation (GN working pose)
+  double odoKF_R[9], odoKF_t[3];                         // last_odoKF_global_*
+  double integrKF_R[9], integrKF_t[3];                   // last_integrKF_global_*
+  double last_est_R[9], last_est_t[3];                   // last_estimated_*
+  double o2i_last_R[9], o2i_last_t[3], o2i_last_cov[36]; // delta_*_odo2integr_last_
+  double o2i_next_R[9], o2i_next_t[3], o2i_next_cov[36]; // delta_*_odo2integr_next_
+  double dI_R[9], dI_t[3];                               // delta_integr_rotation/translation of this frame
+  double velocity[3], omega[3];
+  int global_time, lost, odoKF_count, integrKF_count, last_odoKF_index, last_integrKF_index;
+  int gn_failed;
+  int status;       // RGBID_ST_* bits of the current step
+  float vis_odo, vis_int;
+  float rec_sigma_i, rec_sigma_d, rec_nu_i, rec_nu_d;  // scale estimates of the last GN iteration (diagnostics)
+};
+
+struct Flags {  // int[B] each; consumed through LaneMask
+  int *track, *first, *gn, *vis, *sw_odo, *sw_int, *overlap, *fuse, *maps;
+};
+
+struct StepCfg {  // by-value kernel argument with what the scalar kernels need
+  float fx, fy, cx, cy;
+  int levels, finest_level, motion_model, max_odoKF_count, max_integrKF_count;
+  float visratio_odo, visratio_integr, delta_t;
+  int mestimator, weighting;
+};
+
+__device__ void set_warp_from_pose(const StepCfg& c, int level, const double* R, const double* t, WarpParams& wp) {
+  // inverse pose, projected with the level's K (visodo.cpp:1066-1067,1108-1114)
+  double Ri[9], ti[3];
+  se3::m3_inv(R, Ri);
+  se3::m3_mulv(Ri, t, ti);
+  ti[0] = -ti[0]; ti[1] = -ti[1]; ti[2] = -ti[2];
+  int div = 1 << level;
+  se3::project_trafo(c.fx / div, c.fy / div, c.cx / div, c.cy / div, Ri, ti, wp.R, wp.t);
+}
+
+__device__ void reset_odometry_keyframe(LaneState& s) {
+  // resetOdometryKeyframe visodo.cpp:1541-1575
+  s.odoKF_count = 0;
+  double J[36], tn[3], S[9];
+  se3::m6_zero(J);
+  se3::m6_set_block(J, 0, 0, s.o2i_next_R, 1.0);
+  se3::m6_set_block(J, 3, 3, s.o2i_next_R, 1.0);
+  se3::m3_mulv(s.o2i_next_R, s.delta_t, tn);
+  se3::skew(tn, S);
+  se3::m6_set_block(J, 0, 3, S, 1.0);
+  se3::m6_JCJt_add(J, s.delta_cov, s.o2i_next_cov);
+  for (int i = 0; i < 3; ++i) s.o2i_next_t[i] = tn[i] + s.o2i_next_t[i];
+  se3::m3_mul(s.o2i_next_R, s.delta_R, s.o2i_next_R);
+  s.last_odoKF_index = s.global_time;
+  se3::m3_copy(s.last_est_R, s.odoKF_R);
+  for (int i = 0; i < 3; ++i) s.odoKF_t[i] = s.last_est_t[i];
+  se3::m3_id(s.delta_R);
+  for (int i = 0; i < 3; ++i) s.delta_t[i] = 0.0;
+  se3::m6_zero(s.delta_cov);
+}
+
+__device__ void reset_integration_keyframe(LaneState& s) {
+  // resetIntegrationKeyframe visodo.cpp:1577-1672 (the Keyframe / PoseConstraint pushes feed the CPU back-end: out of scope)
+  s.integrKF_count = 0;
+  double J[36], tn[3], S[9];
+  se3::m6_zero(J);
+  se3::m6_set_block(J, 0, 0, s.o2i_next_R, 1.0);
+  se3::m6_set_block(J, 3, 3, s.o2i_next_R, 1.0);
+  se3::m3_mulv(s.o2i_next_R, s.delta_t, tn);
+  se3::skew(tn, S);
+  se3::m6_set_block(J, 0, 3, S, 1.0);
+  se3::m6_JCJt_add(J, s.delta_cov, s.o2i_next_cov);
+  for (int i = 0; i < 3; ++i) s.o2i_next_t[i] = tn[i] + s.o2i_next_t[i];
+  se3::m3_mul(s.o2i_next_R, s.delta_R, s.o2i_next_R);
+  s.last_integrKF_index = s.global_time;
+  se3::m3_copy(s.last_est_R, s.integrKF_R);
+  for (int i = 0; i < 3; ++i) s.integrKF_t[i] = s.last_est_t[i];
+  se3::m3_copy(s.delta_R, s.o2i_last_R);
+  for (int i = 0; i < 3; ++i) s.o2i_last_t[i] = s.delta_t[i];
+  for (int i = 0; i < 36; ++i) s.o2i_last_cov[i] = s.delta_cov[i];
+  se3::m3_id(s.o2i_next_R);
+  for (int i = 0; i < 3; ++i) s.o2i_next_t[i] = 0.0;
+  se3::m6_zero(s.o2i_next_cov);
+}
+
+// ---- step begin: first-frame initialisation or GN start (visodo.cpp:1994-2045, 1012-1035) ------------------
+__global__ void k_step_begin(LaneState* st, Flags f, WarpParams* wp, SysParams* sp, StepCfg c, int B) {
+  int lane = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lane >= B) return;
+  LaneState& s = st[lane];
+  s.status = 0; s.gn_failed = 0; s.vis_odo = 0.f; s.vis_int = 0.f;
+  f.vis[lane] = 0; f.overlap[lane] = 0; f.fuse[lane] = 0;
+  if (s.global_time == 0) {
+    f.first[lane] = 1; f.track[lane] = 0; f.gn[lane] = 0; f.sw_odo[lane] = 1; f.sw_int[lane] = 1; f.maps[lane] = 1;
+    s.global_time = 1;
+    s.odoKF_count = 0; s.last_odoKF_index = 0;
+    se3::m3_id(s.odoKF_R); se3::m3_id(s.integrKF_R); se3::m3_id(s.delta_R); se3::m3_id(s.last_est_R);
+    se3::m3_id(s.o2i_last_R); se3::m3_id(s.o2i_next_R);
+    for (int i = 0; i < 3; ++i) { s.odoKF_t[i] = s.integrKF_t[i] = s.delta_t[i] = s.last_est_t[i] = s.o2i_last_t[i] = s.o2i_next_t[i] = 0.0; s.velocity[i] = s.omega[i] = 0.0; }
+    se3::m6_zero(s.delta_cov); se3::m6_zero(s.o2i_last_cov); se3::m6_zero(s.o2i_next_cov);
+    s.integrKF_count = 0; s.last_integrKF_index = 0;
+    s.lost = 0;
+    s.status = RGBID_ST_FIRST | RGBID_ST_ODO_KF | RGBID_ST_INTEGR_KF;
+    return;
+  }
+  f.first[lane] = 0; f.track[lane] = 1; f.gn[lane] = 1; f.sw_odo[lane] = 0; f.sw_int[lane] = 0; f.maps[lane] = 0;
+  se3::m3_copy(s.delta_R, s.dprev_R);
+  for (int i = 0; i < 3; ++i) s.dprev_t[i] = s.delta_t[i];
+  for (int i = 0; i < 36; ++i) s.dprev_cov[i] = s.delta_cov[i];
+  se3::m3_copy(s.delta_R, s.prev_R);
+  for (int i = 0; i < 3; ++i) s.prev_t[i] = s.delta_t[i];
+  if ((s.global_time > 1) && (c.motion_model == RGBID_CONSTANT_VELOCITY) && (!s.lost)) {
+    double vt[3], wt[3], dR[9], dt[3], tmp[3];
+    for (int i = 0; i < 3; ++i) { vt[i] = s.velocity[i] * c.delta_t; wt[i] = s.omega[i] * c.delta_t; }
+    se3::expmap(wt, vt, dR, dt);
+    se3::m3_mulv(s.prev_R, dt, tmp);
+    for (int i = 0; i < 3; ++i) s.cur_t[i] = tmp[i] + s.prev_t[i];
+    se3::m3_mul(s.prev_R, dR, s.cur_R);
+  } else {
+    se3::m3_copy(s.prev_R, s.cur_R);
+    for (int i = 0; i < 3; ++i) s.cur_t[i] = s.prev_t[i];
+  }
+  set_warp_from_pose(c, c.levels - 1, s.cur_R, s.cur_t, wp[lane]);
+  (void)sp;
+}
+
+// sets the per-level constants of the lane's SysParams before a level's iterations / the covariance pass
+__global__ void k_set_sys(SysParams* sp, LaneState* st, StepCfg c, int level, int cov_pass, int B) {
+  int lane = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lane >= B) return;
+  int div = 1 << level;
+  SysParams& p = sp[lane];
+  if (cov_pass) {
+    st[lane].rec_sigma_i = p.sigma_i; st[lane].rec_sigma_d = p.sigma_d;
+    st[lane].rec_nu_i = fmaxf(p.nu_i, p.nu_d); st[lane].rec_nu_d = p.nu_d;  // nu_int = max(nu_int, nu_depthinv), visodo.cpp:1186
+  }
+  p.fx = c.fx / div; p.fy = c.fy / div; p.cx = c.cx / div; p.cy = c.cy / div;
+  p.weighting = c.weighting;
+  if (cov_pass) {
+    // visodo.cpp:1349-1365: STUDENT with the fixed reference sigmas, zero bias
+    p.mestimator = RGBID_STUDENT; p.student_nu = 0; p.nu_i_max = 0;
+    p.sigma_i = (float)exp(log((double)5.f)); p.sigma_d = (float)exp(log((double)0.0025f));
+    p.bias_i = 0.f; p.bias_d = 0.f; p.nu_i = 5.f; p.nu_d = 5.f;
+  } else {
+    p.mestimator = c.mestimator; p.student_nu = 1; p.nu_i_max = 1;
+    p.sigma_i = 5.f; p.sigma_d = 0.0025f; p.bias_i = 0.f; p.bias_d = 0.f; p.nu_i = 5.f; p.nu_d = 5.f;  // visodo.cpp:1168-1173
+  }
+}
+
+// ---- one GN update: reduce partials, LLT solve, exp-map, pose update, next warp (visodo.cpp:1242-1274) -------
+__global__ __launch_bounds__(256) void k_solve_update(const double* partials, int nblk, LaneState* st, Flags f, WarpParams* wp,
+                                                      StepCfg c, int next_level) {
+  int lane = blockIdx.x;
+  if (!f.gn[lane]) return;
+  __shared__ double sm[8][32];
+  __shared__ double sums[SYS_TERMS];
+  int k = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  double t = 0.0;
+  if (k < SYS_TERMS) {
+    const double* p = partials + (size_t)lane * nblk * SYS_TERMS + k;
+    for (int b = sl; b < nblk; b += 8) t += p[(size_t)b * SYS_TERMS];
+  }
+  sm[sl][k] = t;
+  __syncthreads();
+  if (threadIdx.x < SYS_TERMS) {
+    double r = 0.0;
+    for (int i = 0; i < 8; ++i) r += sm[i][threadIdx.x];
+    sums[threadIdx.x] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  LaneState& s = st[lane];
+  double A[36], b[6], x[6];
+  int shift = 0;  // estimate_VO.cu:774-786
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 7; ++j) {
+      double v = sums[shift++];
+      if (j == 6) b[i] = v; else A[j * 6 + i] = A[i * 6 + j] = v;
+    }
+  se3::llt_solve6(A, b, x);
+  double inc_inv[9], inc[9], tinc[3], tmp[3];
+  se3::expmap_rot(x + 3, inc_inv);
+  se3::m3_inv(inc_inv, inc);
+  se3::m3_mulv(inc, x, tinc);
+  tinc[0] = -tinc[0]; tinc[1] = -tinc[1]; tinc[2] = -tinc[2];
+  se3::m3_mulv(inc, s.cur_t, tmp);
+  for (int i = 0; i < 3; ++i) s.cur_t[i] = tmp[i] + tinc[i];
+  se3::m3_mul(inc, s.cur_R, s.cur_R);
+  if (se3::has_nan(s.cur_R, s.cur_t)) {  // :1265-1274
+    s.gn_failed = 1;
+    f.gn[lane] = 0;
+    return;
+  }
+  set_warp_from_pose(c, next_level, s.cur_R, s.cur_t, wp[lane]);
+}
+
+// ---- end of estimateVisualOdometry + pose bookkeeping of trackNewFrame (visodo.cpp:1367-1468, 2051-2170) -----
+__global__ __launch_bounds__(256) void k_frame_finish(const double* partials, int nblk, LaneState* st, Flags f, const SysParams* sp,
+                                                      WarpParams* vis_ab, WarpParams* vis_ba, WarpParams* ivis_ab, WarpParams* ivis_ba,
+                                                      rgbid_pose_record* rec, StepCfg c) {
+  int lane = blockIdx.x;
+  if (!f.track[lane]) return;
+  __shared__ double sm[8][32];
+  __shared__ double sums[SYS_TERMS];
+  int k = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  double t = 0.0;
+  LaneState& s = st[lane];
+  bool ok = !s.gn_failed;
+  if (ok && k < SYS_TERMS) {
+    const double* p = partials + (size_t)lane * nblk * SYS_TERMS + k;
+    for (int b = sl; b < nblk; b += 8) t += p[(size_t)b * SYS_TERMS];
+  }
+  sm[sl][k] = t;
+  __syncthreads();
+  if (threadIdx.x < SYS_TERMS) {
+    double r = 0.0;
+    for (int i = 0; i < 8; ++i) r += sm[i][threadIdx.x];
+    sums[threadIdx.x] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  rgbid_pose_record& R = rec[lane];
+  R.frame = s.global_time;
+  R.sigma_int = s.rec_sigma_i; R.sigma_depthinv = s.rec_sigma_d; R.nu_int = s.rec_nu_i; R.nu_depthinv = s.rec_nu_d;
+  if (ok) {
+    double A[36];
+    int shift = 0;
+    for (int i = 0; i < 6; ++i)
+      for (int j = i; j < 7; ++j) {
+        double v = sums[shift++];
+        if (j != 6) A[j * 6 + i] = A[i * 6 + j] = v;
+      }
+    se3::m3_copy(s.cur_R, s.delta_R);
+    for (int i = 0; i < 3; ++i) s.delta_t[i] = s.cur_t[i];
+    se3::inverse6(A, s.delta_cov);  // resulting_covariance = A_final.inverse() :1409
+    // velocity / omega :1459-1468
+    double pT[9], dR[9], d[3], dt[3], twist[6];
+    se3::m3_T(s.prev_R, pT);
+    se3::m3_mul(pT, s.cur_R, dR);
+    for (int i = 0; i < 3; ++i) d[i] = s.cur_t[i] - s.prev_t[i];
+    se3::m3_mulv(pT, d, dt);
+    se3::logmap(dR, dt, twist);
+    float inv_dt = 1.f / c.delta_t;
+    for (int i = 0; i < 3; ++i) { s.velocity[i] = twist[i] * (double)inv_dt; s.omega[i] = twist[3 + i] * (double)inv_dt; }
+  } else {
+    // resulting = previous, covariance = 100 I :1267-1269
+    se3::m3_copy(s.prev_R, s.delta_R);
+    for (int i = 0; i < 3; ++i) s.delta_t[i] = s.prev_t[i];
+    se3::m6_zero(s.delta_cov);
+    for (int i = 0; i < 6; ++i) s.delta_cov[i * 7] = 100.0;
+  }
+  // ---- trackNewFrame :2051-2117
+  bool proceed = false;
+  if (!s.lost) {
+    double tmp[3];
+    se3::m3_mulv(s.odoKF_R, s.delta_t, tmp);
+    for (int i = 0; i < 3; ++i) s.last_est_t[i] = s.odoKF_t[i] + tmp[i];
+    se3::m3_mul(s.odoKF_R, s.delta_R, s.last_est_R);
+    if (!ok) {
+      s.lost = 1;
+      reset_odometry_keyframe(s);
+      reset_integration_keyframe(s);
+      f.sw_odo[lane] = 1; f.sw_int[lane] = 1; f.maps[lane] = 1;
+      s.status = RGBID_ST_LOST | RGBID_ST_ODO_KF | RGBID_ST_INTEGR_KF;
+      ++s.global_time;
+    } else proceed = true;
+  } else {
+    if (ok) {
+      s.lost = 0;
+      double tmp[3];
+      se3::m3_mulv(s.odoKF_R, s.delta_t, tmp);
+      for (int i = 0; i < 3; ++i) s.last_est_t[i] = s.odoKF_t[i] + tmp[i];
+      se3::m3_mul(s.odoKF_R, s.delta_R, s.last_est_R);
+      proceed = true;
+    } else {
+      f.sw_odo[lane] = 1; f.sw_int[lane] = 1; f.maps[lane] = 1;
+      s.status = RGBID_ST_LOST | RGBID_ST_ODO_KF | RGBID_ST_INTEGR_KF;
+    }
+  }
+  se3::m3_copy(s.last_est_R, R.R);
+  for (int i = 0; i < 3; ++i) R.t[i] = s.last_est_t[i];
+  se3::m3_copy(s.delta_R, R.kf_R);
+  for (int i = 0; i < 3; ++i) R.kf_t[i] = s.delta_t[i];
+  for (int i = 0; i < 36; ++i) R.kf_cov[i] = s.delta_cov[i];
+  if (!proceed) {
+    se3::m3_id(R.odo_R);
+    for (int i = 0; i < 3; ++i) R.odo_t[i] = 0.0;
+    for (int i = 0; i < 36; ++i) R.odo_cov[i] = (i % 7 == 0) ? 100.0 : 0.0;  // dummy constraint :2070-2071
+    return;
+  }
+  s.odoKF_count++; s.integrKF_count++;
+  {
+    // sequential odometry + covariance :2128-2152
+    double pT[9], Rseq[9], d[3], tseq[3], Jn[36], Jl[36], S[9], SR[9];
+    se3::m3_T(s.dprev_R, pT);
+    se3::m3_mul(pT, s.delta_R, Rseq);
+    for (int i = 0; i < 3; ++i) d[i] = s.delta_t[i] - s.dprev_t[i];
+    se3::m3_mulv(pT, d, tseq);
+    se3::m6_zero(Jn); se3::m6_set_block(Jn, 0, 0, pT, 1.0); se3::m6_set_block(Jn, 3, 3, pT, 1.0);
+    se3::m6_zero(Jl); se3::m6_set_block(Jl, 0, 0, pT, -1.0); se3::m6_set_block(Jl, 3, 3, pT, -1.0);
+    se3::skew(tseq, S); se3::m3_mul(S, pT, SR); se3::m6_set_block(Jl, 0, 3, SR, 1.0);
+    se3::m6_zero(R.odo_cov);
+    se3::m6_JCJt_add(Jl, s.dprev_cov, R.odo_cov);
+    se3::m6_JCJt_add(Jn, s.delta_cov, R.odo_cov);
+    se3::m3_copy(Rseq, R.odo_R);
+    for (int i = 0; i < 3; ++i) R.odo_t[i] = tseq[i];
+  }
+  f.vis[lane] = 1;
+  s.status = RGBID_ST_TRACKED;
+  // covisibility transforms (computeCovisibility visodo.cpp:1481-1514) for the odometry keyframe ...
+  {
+    double Ri[9], zero[3] = {0, 0, 0};
+    float dummy[3];
+    se3::project_trafo(c.fx, c.fy, c.cx, c.cy, s.delta_R, s.delta_t, vis_ab[lane].R, vis_ab[lane].t);
+    se3::m3_inv(s.delta_R, Ri);
+    se3::project_trafo(c.fx, c.fy, c.cx, c.cy, Ri, zero, vis_ba[lane].R, dummy);
+    // translation_BtoA_f = -K*Rinv.cast<float>()*t.cast<float>() in float
+    float K[9] = {c.fx, 0.f, c.cx, 0.f, c.fy, c.cy, 0.f, 0.f, 1.f}, Rf[9], T[9];
+    float tf[3] = {(float)s.delta_t[0], (float)s.delta_t[1], (float)s.delta_t[2]};
+    for (int i = 0; i < 9; ++i) Rf[i] = (float)Ri[i];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T[i * 3 + j] = -K[i * 3] * Rf[j] + -K[i * 3 + 1] * Rf[3 + j] + -K[i * 3 + 2] * Rf[6 + j];
+    for (int i = 0; i < 3; ++i) vis_ba[lane].t[i] = T[i * 3] * tf[0] + T[i * 3 + 1] * tf[1] + T[i * 3 + 2] * tf[2];
+  }
+  // ... and for the integration keyframe (:2182-2186)
+  {
+    double iRi[9], d[3], Ri[9], zero[3] = {0, 0, 0};
+    float dummy[3];
+    se3::m3_inv(s.integrKF_R, iRi);
+    se3::m3_mul(iRi, s.last_est_R, s.dI_R);
+    for (int i = 0; i < 3; ++i) d[i] = s.last_est_t[i] - s.integrKF_t[i];
+    se3::m3_mulv(iRi, d, s.dI_t);
+    se3::project_trafo(c.fx, c.fy, c.cx, c.cy, s.dI_R, s.dI_t, ivis_ab[lane].R, ivis_ab[lane].t);
+    se3::m3_inv(s.dI_R, Ri);
+    se3::project_trafo(c.fx, c.fy, c.cx, c.cy, Ri, zero, ivis_ba[lane].R, dummy);
+    float K[9] = {c.fx, 0.f, c.cx, 0.f, c.fy, c.cy, 0.f, 0.f, 1.f}, Rf[9], T[9];
+    float tf[3] = {(float)s.dI_t[0], (float)s.dI_t[1], (float)s.dI_t[2]};
+    for (int i = 0; i < 9; ++i) Rf[i] = (float)Ri[i];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T[i * 3 + j] = -K[i * 3] * Rf[j] + -K[i * 3 + 1] * Rf[3 + j] + -K[i * 3 + 2] * Rf[6 + j];
+    for (int i = 0; i < 3; ++i) ivis_ba[lane].t[i] = T[i * 3] * tf[0] + T[i * 3 + 1] * tf[1] + T[i * 3 + 2] * tf[2];
+  }
+}
+
+// counts: [4][B][2] = {odo B->A, odo A->B, integr B->A, integr A->B} x {visible, valid}
+__global__ void k_decide(LaneState* st, Flags f, const unsigned int* counts, WarpParams* fuse_wp, StepCfg c, int B) {
+  int lane = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lane >= B || !f.vis[lane]) return;
+  LaneState& s = st[lane];
+  auto ratio = [&](int which) {
+    float vis = (float)counts[(which * B + lane) * 2 + 0], val = (float)counts[(which * B + lane) * 2 + 1];
+    return (val < 1.f) ? 0.f : vis / val;  // warping_registration.cu:862-865
+  };
+  // odometry keyframe :2172-2180.  NOTE: evaluated with the pre-switch delta pose, exactly as the reference.
+  s.vis_odo = fminf(ratio(1), ratio(0));
+  if ((s.odoKF_count >= c.max_odoKF_count) || (s.vis_odo < c.visratio_odo)) {
+    reset_odometry_keyframe(s);
+    f.sw_odo[lane] = 1;
+    s.status |= RGBID_ST_ODO_KF;
+  }
+  // integration keyframe :2188-2211
+  s.vis_int = fminf(ratio(3), ratio(2));
+  if ((s.integrKF_count >= c.max_integrKF_count) || (s.vis_int < c.visratio_integr)) {
+    reset_integration_keyframe(s);
+    f.sw_int[lane] = 1; f.overlap[lane] = 1; f.maps[lane] = 1;
+    s.status |= RGBID_ST_INTEGR_KF;
+  } else {
+    f.fuse[lane] = 1; f.maps[lane] = 1;
+    // integrateImagesIntoKeyframes :1674-1700: K R K^-1 in DOUBLE, inverted, then cast to float
+    double K[9] = {(double)c.fx, 0, (double)c.cx, 0, (double)c.fy, (double)c.cy, 0, 0, 1};
+    double Ki[9], T[9], Rp[9], tp[3], Rpi[9], tpi[3];
+    se3::m3_inv(K, Ki);
+    se3::m3_mul(K, s.dI_R, T); se3::m3_mul(T, Ki, Rp);
+    se3::m3_mulv(K, s.dI_t, tp);
+    se3::m3_inv(Rp, Rpi);
+    se3::m3_mulv(Rpi, tp, tpi);
+    for (int i = 0; i < 9; ++i) fuse_wp[lane].R[i] = (float)Rpi[i];
+    for (int i = 0; i < 3; ++i) fuse_wp[lane].t[i] = (float)(-tpi[i]);
+  }
+  ++s.global_time;
+}
+
+__global__ void k_step_end(LaneState* st, rgbid_pose_record* rec, int B) {
+  int lane = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lane >= B) return;
+  LaneState& s = st[lane];
+  rgbid_pose_record& R = rec[lane];
+  R.status = s.status;
+  R.vis_odo = s.vis_odo; R.vis_integr = s.vis_int;
+  if (s.status & RGBID_ST_FIRST) {
+    R.frame = 0;
+    se3::m3_id(R.R); se3::m3_id(R.odo_R); se3::m3_id(R.kf_R);
+    for (int i = 0; i < 3; ++i) R.t[i] = R.odo_t[i] = R.kf_t[i] = 0.0;
+    for (int i = 0; i < 36; ++i) R.odo_cov[i] = R.kf_cov[i] = 0.0;
+    R.sigma_int = R.sigma_depthinv = R.nu_int = R.nu_depthinv = 0.f;
+  }
+}
+
+}  // namespace
+
+// ---- host side ----------------------------------------------------------------------------------------------
+struct rgbid_engine {
+  rgbid_ctx* ctx = nullptr;
+  rgbid_engine_config cfg{};
+  int B = 0, L = 0;
+  std::vector<void*> allocs;
+  size_t bytes = 0;
+  // images
+  ImgB in_depth, in_rgb;
+  ImgB iD_curr[MAXL], I_curr[MAXL], iD_kf[MAXL], I_kf[MAXL], iD_kf_f[MAXL], I_kf_f[MAXL];
+  ImgB gxI[MAXL], gyI[MAXL], gxD[MAXL], gyD[MAXL], gxI_c[MAXL], gyI_c[MAXL], gxD_c[MAXL], gyD_c[MAXL];
+  ImgB wiD[MAXL], wI[MAXL];
+  ImgB r_curr, g_curr, b_curr;
+  ImgB iD_integr, iD_integr_raw, w_integr, warped_iD_integr, warped_w, vmap, nmap, gxD_integr, gyD_integr, colors_integr, overlap_mask, preview;
+  float *res_I = nullptr, *res_D = nullptr;
+  float* chi_out = nullptr;
+  double* partials = nullptr;
+  int nblk_cap = 0;
+  LaneState* state = nullptr;
+  Flags flags{};
+  WarpParams *wp = nullptr, *vis_ab = nullptr, *vis_ba = nullptr, *ivis_ab = nullptr, *ivis_ba = nullptr, *fuse_wp = nullptr;
+  SysParams* sp = nullptr;
+  LightP* light = nullptr;
+  unsigned int* counts = nullptr;
+  rgbid_pose_record* records = nullptr;  // [capacity][B]
+  rgbid_pose_record* rec_cur = nullptr;  // [B] staging written by the step, copied into the ring
+  int steps = 0;
+  int launches = 0;
+  hipGraphExec_t graph_first = nullptr, graph_next = nullptr;
+  bool graph_ready_first = false, graph_ready_next = false;
+};
+
+namespace {
+
+int alloc_dev(rgbid_engine* e, void** p, size_t bytes, bool zero = true) {
+  hipError_t err = hipMalloc(p, bytes);
+  if (err != hipSuccess) return err == hipErrorOutOfMemory ? RGBID_E_NOMEM : (int)err;
+  e->allocs.push_back(*p);
+  e->bytes += bytes;
+  if (zero) {
+    err = hipMemsetAsync(*p, 0, bytes, e->ctx->stream);
+    if (err != hipSuccess) return (int)err;
+  }
+  return RGBID_OK;
+}
+
+int alloc_img(rgbid_engine* e, ImgB* im, int rows, int cols, int elem) {
+  size_t pitch = ((size_t)cols * elem + 255) & ~(size_t)255;
+  size_t lane_stride = pitch * rows;
+  void* p = nullptr;
+  int r = alloc_dev(e, &p, lane_stride * e->B);
+  if (r) return r;
+  *im = ImgB{p, pitch, lane_stride, rows, cols};
+  return RGBID_OK;
+}
+
+inline LaneMask M(const int* flag) { return LaneMask{flag, 1}; }
+const LaneMask ALL{nullptr, 0};
+
+StepCfg step_cfg(const rgbid_engine_config& c) {
+  StepCfg s;
+  s.fx = c.fx; s.fy = c.fy; s.cx = c.cx; s.cy = c.cy;
+  s.levels = c.levels; s.finest_level = c.finest_level; s.motion_model = c.motion_model;
+  s.max_odoKF_count = c.max_odoKF_count; s.max_integrKF_count = c.max_integrKF_count;
+  s.visratio_odo = c.visratio_odo; s.visratio_integr = c.visratio_integr; s.delta_t = c.delta_t;
+  s.mestimator = c.mestimator; s.weighting = c.weighting;
+  return s;
+}
+
+// saveCurrentImagesAsOdoKeyframes (visodo.cpp:826-878) for the lanes flagged sw_odo
+void enqueue_save_odo_kf(rgbid_engine* e, hipStream_t s) {
+  const int B = e->B, L = e->L;
+  LaneMask m = M(e->flags.sw_odo);
+  for (int i = 0; i < L; ++i) {
+    launch_copy_bytes(s, B, e->iD_curr[i], e->iD_kf[i], 4, m);
+    launch_copy_bytes(s, B, e->I_curr[i], e->I_kf[i], 4, m);
+    e->launches += 2;
+  }
+  launch_bilateral(s, B, e->iD_kf[0], e->iD_kf_f[0], 2.f * 0.0025f, m);
+  launch_bilateral(s, B, e->I_kf[0], e->I_kf_f[0], 3.f, m);
+  launch_gradient(s, B, e->I_kf_f[0], e->gxI_c[0], e->gyI_c[0], m);
+  launch_gradient(s, B, e->iD_kf_f[0], e->gxD_c[0], e->gyD_c[0], m);
+  e->launches += 4;
+  for (int i = 1; i < L; ++i) {
+    launch_pyr_down(s, B, e->iD_kf_f[i - 1], e->iD_kf_f[i], m);
+    launch_pyr_down(s, B, e->I_kf_f[i - 1], e->I_kf_f[i], m);
+    launch_gradient(s, B, e->I_kf_f[i], e->gxI_c[i], e->gyI_c[i], m);
+    launch_gradient(s, B, e->iD_kf_f[i], e->gxD_c[i], e->gyD_c[i], m);
+    e->launches += 4;
+  }
+  for (int i = 0; i < L; ++i) {
+    if (e->cfg.image_filtering == RGBID_FILTER_GRADS) {
+      launch_copy_bytes(s, B, e->gxI_c[i], e->gxI[i], 4, m); launch_copy_bytes(s, B, e->gyI_c[i], e->gyI[i], 4, m);
+      launch_copy_bytes(s, B, e->gxD_c[i], e->gxD[i], 4, m); launch_copy_bytes(s, B, e->gyD_c[i], e->gyD[i], 4, m);
+      e->launches += 4;
+    } else {
+      launch_gradient(s, B, e->I_kf[i], e->gxI[i], e->gyI[i], m);
+      launch_gradient(s, B, e->iD_kf[i], e->gxD[i], e->gyD[i], m);
+      e->launches += 2;
+    }
+  }
+}
+
+// the whole step as a launch sequence on stream s
+int enqueue_step(rgbid_engine* e, hipStream_t s) {
+  const rgbid_engine_config& c = e->cfg;
+  const int B = e->B, L = e->L;
+  const StepCfg sc = step_cfg(c);
+  const IntrP K0{c.fx, c.fy, c.cx, c.cy};
+  const int tb = 64, gb = div_up(B, tb);
+  e->launches = 0;
+  Flags& f = e->flags;
+  // ---- prepareImages (visodo.cpp:760-773)
+  launch_intensity(s, B, e->in_rgb, e->I_curr[0], ALL);
+  launch_decompose_rgb(s, B, e->in_rgb, e->r_curr, e->g_curr, e->b_curr, ALL);
+  launch_depth_to_invdepth(s, B, e->in_depth, e->iD_curr[0], c.factor_depth, ALL);
+  e->launches += 3;
+  for (int i = 1; i < L; ++i) {
+    launch_pyr_down(s, B, e->I_curr[i - 1], e->I_curr[i], ALL);
+    launch_pyr_down(s, B, e->iD_curr[i - 1], e->iD_curr[i], ALL);
+    e->launches += 2;
+  }
+  hipLaunchKernelGGL(k_step_begin, dim3(gb), dim3(tb), 0, s, e->state, f, e->wp, e->sp, sc, B);
+  e->launches++;
+  // ---- estimateVisualOdometry (visodo.cpp:1041-1281), PYR_FIRST
+  for (int level = L - 1; level >= c.finest_level; --level) {
+    hipLaunchKernelGGL(k_set_sys, dim3(gb), dim3(tb), 0, s, e->sp, e->state, sc, level, 0, B);
+    e->launches++;
+    int iters = c.iters[level];
+    for (int it = 0; it < iters; ++it) {
+      bool last_of_level = (it == iters - 1);
+      int next_level = last_of_level ? (level > c.finest_level ? level - 1 : c.finest_level) : level;
+      launch_warp_invdepth(s, B, e->iD_curr[level], e->iD_kf[level], e->wiD[level], nullptr, e->wp, M(f.gn));
+      launch_warp_intensity(s, B, e->I_curr[level], e->wiD[level], e->wI[level], nullptr, e->wp, c.interp_mode, M(f.gn));
+      e->launches += 2;
+      if (c.sigma_estimator == RGBID_SIGMA_PDF) {
+        launch_sigma_pair(s, B, e->wiD[level], e->iD_kf[level], e->wI[level], e->I_kf[level], c.nsamples, e->sp, c.mestimator, M(f.gn));
+        e->launches++;
+      }
+      int nblk = launch_build_system(s, B, e->iD_kf[level], e->I_kf[level], e->gxD[level], e->gyD[level], e->gxI[level], e->gyI[level],
+                                     e->wiD[level], e->wI[level], nullptr, e->sp, e->partials, M(f.gn));
+      hipLaunchKernelGGL(k_solve_update, dim3(B), dim3(256), 0, s, e->partials, nblk, e->state, f, e->wp, sc, next_level);
+      e->launches += 2;
+    }
+  }
+  // ---- covariance pass (visodo.cpp:1283-1409)
+  {
+    int fl = c.finest_level;
+    hipLaunchKernelGGL(k_set_sys, dim3(gb), dim3(tb), 0, s, e->sp, e->state, sc, fl, 1, B);
+    launch_warp_invdepth(s, B, e->iD_curr[fl], e->iD_kf[fl], e->wiD[fl], nullptr, e->wp, M(f.gn));
+    launch_warp_intensity(s, B, e->I_curr[fl], e->wiD[fl], e->wI[fl], nullptr, e->wp, c.interp_mode, M(f.gn));
+    int nblk = launch_build_system(s, B, e->iD_kf[fl], e->I_kf[fl], e->gxD_c[fl], e->gyD_c[fl], e->gxI_c[fl], e->gyI_c[fl],
+                                   e->wiD[fl], e->wI[fl], nullptr, e->sp, e->partials, M(f.gn));
+    e->launches += 4;
+    if (c.chi_square_stats) {  // :1411-1415 (results unused by the reference)
+      int n, lr, lc, st;
+      lattice_geometry(e->wI[fl].rows, e->wI[fl].cols, 9999999, &n, &lr, &lc, &st);
+      launch_error_lattice(s, B, e->wI[fl], e->I_kf[fl], e->res_I, (size_t)c.rows * c.cols, lr, lc, st, M(f.gn));
+      launch_error_lattice(s, B, e->wiD[fl], e->iD_kf[fl], e->res_D, (size_t)c.rows * c.cols, lr, lc, st, M(f.gn));
+      launch_chi_square(s, B, e->res_I, e->res_D, (size_t)c.rows * c.cols, n, 5.f, 0.0025f, c.mestimator, e->chi_out, M(f.gn));
+      e->launches += 3;
+    }
+    hipLaunchKernelGGL(k_frame_finish, dim3(B), dim3(256), 0, s, e->partials, nblk, e->state, f, e->sp, e->vis_ab, e->vis_ba,
+                       e->ivis_ab, e->ivis_ba, e->rec_cur, sc);
+    e->launches++;
+  }
+  // ---- covisibility with both keyframes (visodo.cpp:2172-2188), 4 ratio evaluations
+  hipMemsetAsync(e->counts, 0, sizeof(unsigned int) * 8 * B, s);
+  ImgB none{nullptr, 0, 0, 0, 0};
+  launch_visibility(s, B, e->iD_curr[0], e->iD_kf[0], none, nullptr, e->vis_ab, e->counts + 0 * 2 * B, M(f.vis));
+  launch_visibility(s, B, e->iD_kf[0], e->iD_curr[0], none, nullptr, e->vis_ba, e->counts + 1 * 2 * B, M(f.vis));
+  launch_visibility(s, B, e->iD_curr[0], e->iD_integr_raw, none, nullptr, e->ivis_ab, e->counts + 2 * 2 * B, M(f.vis));
+  launch_visibility(s, B, e->iD_integr_raw, e->iD_curr[0], none, nullptr, e->ivis_ba, e->counts + 3 * 2 * B, M(f.vis));
+  hipLaunchKernelGGL(k_decide, dim3(gb), dim3(tb), 0, s, e->state, f, e->counts, e->fuse_wp, sc, B);
+  e->launches += 6;
+  // ---- odometry keyframe switch
+  enqueue_save_odo_kf(e, s);
+  // ---- integration keyframe: computeOverlapping (:1517-1539) + saveCurrentImagesAsIntegrationKeyframes (:880-893) ...
+  hipMemsetAsync(e->counts, 0, sizeof(unsigned int) * 2 * B, s);
+  launch_visibility(s, B, e->iD_curr[0], e->iD_integr_raw, e->overlap_mask, nullptr, e->ivis_ab, e->counts, M(f.overlap));
+  launch_copy_bytes(s, B, e->iD_curr[0], e->iD_integr, 4, M(f.sw_int));
+  launch_copy_bytes(s, B, e->iD_curr[0], e->iD_integr_raw, 4, M(f.sw_int));
+  launch_copy_bytes(s, B, e->in_rgb, e->colors_integr, 3, M(f.sw_int));
+  launch_fill(s, B, e->w_integr, 4, 0x3f800000u, M(f.sw_int));
+  launch_fill(s, B, e->overlap_mask, 1, 0u, M(f.first));  // initialiseDeviceMemory2D(overlap_mask, 0) :2021
+  e->launches += 7;
+  // ... or integrateImagesIntoKeyframes (:1674-1764)
+  launch_warp_invdepth_weighted(s, B, e->iD_curr[0], e->iD_integr, e->warped_iD_integr, e->warped_w, nullptr, e->fuse_wp, M(f.fuse));
+  launch_integrate_warped(s, B, e->warped_iD_integr, e->warped_w, e->iD_integr, e->w_integr, M(f.fuse));
+  launch_vmap(s, B, e->iD_integr, e->vmap, K0, M(f.maps));
+  launch_gradient(s, B, e->iD_integr, e->gxD_integr, e->gyD_integr, M(f.maps));
+  launch_nmap_gradients(s, B, e->iD_integr, e->gxD_integr, e->gyD_integr, e->nmap, K0, M(f.maps));
+  e->launches += 5;
+  if (c.preview) {  // getImage :559-580
+    launch_generate_image(s, B, e->vmap, e->nmap, e->colors_integr, e->preview, nullptr, e->light, ALL);
+    e->launches++;
+  }
+  hipLaunchKernelGGL(k_step_end, dim3(gb), dim3(tb), 0, s, e->state, e->rec_cur, B);
+  e->launches++;
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? RGBID_OK : (int)err;
+}
+
+}  // namespace
+
+extern "C" {
+
+void rgbid_engine_default_config(rgbid_engine_config* c) {
+  if (!c) return;
+  memset(c, 0, sizeof(*c));
+  c->rows = 480; c->cols = 640; c->levels = 3; c->lanes = 1;
+  c->iters[0] = 10; c->iters[1] = 5; c->iters[2] = 3;                     // visodo.cpp:65
+  c->mestimator = RGBID_STUDENT; c->motion_model = RGBID_CONSTANT_VELOCITY; c->sigma_estimator = RGBID_SIGMA_PDF;
+  c->weighting = RGBID_INDEPENDENT;
+  c->max_odoKF_count = 9999999; c->finest_level = 0; c->image_filtering = RGBID_NO_FILTERS;
+  c->visratio_odo = 0.9f; c->visratio_integr = 0.7f; c->max_integrKF_count = 9999999; c->nsamples = 10000;
+  c->fx = 525.f; c->fy = 525.f; c->cx = 319.5f; c->cy = 239.5f; c->factor_depth = 1.f;   // calibration_factory.ini
+  c->interp_mode = RGBID_INTERP_TEX8;
+  c->delta_t = 0.03333f;
+  c->use_graph = 1; c->fused_gn = 0; c->chi_square_stats = 0; c->preview = 0;
+  c->record_capacity = 64;
+}
+
+int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_config* cfg) {
+  if (!out || !ctx || !cfg) return RGBID_E_INVALID;
+  *out = nullptr;
+  if (cfg->rows <= 0 || cfg->cols <= 0 || cfg->levels < 1 || cfg->levels > MAXL || cfg->lanes < 1 || cfg->finest_level < 0 ||
+      cfg->finest_level >= cfg->levels || (cfg->rows >> (cfg->levels - 1)) < 4 || (cfg->cols >> (cfg->levels - 1)) < 4 ||
+      cfg->record_capacity < 1) return RGBID_E_INVALID;
+  rgbid_engine* e = new (std::nothrow) rgbid_engine();
+  if (!e) return RGBID_E_NOMEM;
+  e->ctx = ctx; e->cfg = *cfg; e->B = cfg->lanes; e->L = cfg->levels;
+  hipSetDevice(ctx->device);
+  const int B = e->B, rows = cfg->rows, cols = cfg->cols;
+  int r = RGBID_OK;
+#define A_IMG(im, rr, cc, el) if (!r) r = alloc_img(e, &(im), rr, cc, el)
+  A_IMG(e->in_depth, rows, cols, 2); A_IMG(e->in_rgb, rows, cols, 3);
+  for (int l = 0; l < e->L; ++l) {
+    int pr = rows >> l, pc = cols >> l;
+    ImgB* per_level[] = {&e->iD_curr[l], &e->I_curr[l], &e->iD_kf[l], &e->I_kf[l], &e->iD_kf_f[l], &e->I_kf_f[l], &e->gxI[l], &e->gyI[l],
+                         &e->gxD[l], &e->gyD[l], &e->gxI_c[l], &e->gyI_c[l], &e->gxD_c[l], &e->gyD_c[l], &e->wiD[l], &e->wI[l]};
+    for (ImgB* im : per_level) A_IMG(*im, pr, pc, 4);
+  }
+  A_IMG(e->r_curr, rows, cols, 4); A_IMG(e->g_curr, rows, cols, 4); A_IMG(e->b_curr, rows, cols, 4);
+  A_IMG(e->iD_integr, rows, cols, 4); A_IMG(e->iD_integr_raw, rows, cols, 4); A_IMG(e->w_integr, rows, cols, 4);
+  A_IMG(e->warped_iD_integr, rows, cols, 4); A_IMG(e->warped_w, rows, cols, 4);
+  A_IMG(e->vmap, 3 * rows, cols, 4); A_IMG(e->nmap, 3 * rows, cols, 4);
+  A_IMG(e->gxD_integr, rows, cols, 4); A_IMG(e->gyD_integr, rows, cols, 4);
+  A_IMG(e->colors_integr, rows, cols, 3); A_IMG(e->overlap_mask, rows, cols, 1);
+  if (cfg->preview) A_IMG(e->preview, rows, cols, 3);
+#undef A_IMG
+  if (cfg->chi_square_stats) {
+    if (!r) r = alloc_dev(e, (void**)&e->res_I, sizeof(float) * (size_t)rows * cols * B);
+    if (!r) r = alloc_dev(e, (void**)&e->res_D, sizeof(float) * (size_t)rows * cols * B);
+    if (!r) r = alloc_dev(e, (void**)&e->chi_out, sizeof(float) * 3 * B);
+  }
+  e->nblk_cap = system_blocks_per_lane(rows, cols, B);
+  for (int l = 1; l < e->L; ++l) { int nb = system_blocks_per_lane(rows >> l, cols >> l, B); if (nb > e->nblk_cap) e->nblk_cap = nb; }
+  if (!r) r = alloc_dev(e, (void**)&e->partials, sizeof(double) * SYS_TERMS * (size_t)e->nblk_cap * B);
+  if (!r) r = alloc_dev(e, (void**)&e->state, sizeof(LaneState) * B);
+  int** fl[] = {&e->flags.track, &e->flags.first, &e->flags.gn, &e->flags.vis, &e->flags.sw_odo, &e->flags.sw_int, &e->flags.overlap, &e->flags.fuse, &e->flags.maps};
+  for (int** p : fl) if (!r) r = alloc_dev(e, (void**)p, sizeof(int) * B);
+  WarpParams** wps[] = {&e->wp, &e->vis_ab, &e->vis_ba, &e->ivis_ab, &e->ivis_ba, &e->fuse_wp};
+  for (WarpParams** p : wps) if (!r) r = alloc_dev(e, (void**)p, sizeof(WarpParams) * B);
+  if (!r) r = alloc_dev(e, (void**)&e->sp, sizeof(SysParams) * B);
+  if (!r) r = alloc_dev(e, (void**)&e->light, sizeof(LightP) * B);
+  if (!r) r = alloc_dev(e, (void**)&e->counts, sizeof(unsigned int) * 8 * B);
+  if (!r) r = alloc_dev(e, (void**)&e->records, sizeof(rgbid_pose_record) * (size_t)cfg->record_capacity * B);
+  if (!r) r = alloc_dev(e, (void**)&e->rec_cur, sizeof(rgbid_pose_record) * B);
+  if (!r) { hipError_t he = hipStreamSynchronize(ctx->stream); if (he != hipSuccess) r = (int)he; }
+  if (r) { rgbid_engine_destroy(e); return r; }
+  *out = e;
+  return RGBID_OK;
+}
+
+int rgbid_engine_destroy(rgbid_engine* e) {
+  if (!e) return RGBID_OK;
+  hipSetDevice(e->ctx->device);
+  hipStreamSynchronize(e->ctx->stream);
+  if (e->graph_first) hipGraphExecDestroy(e->graph_first);
+  if (e->graph_next) hipGraphExecDestroy(e->graph_next);
+  for (void* p : e->allocs) hipFree(p);
+  delete e;
+  return RGBID_OK;
+}
+
+int rgbid_engine_reset(rgbid_engine* e) {
+  if (!e) return RGBID_E_INVALID;
+  hipError_t he = hipMemsetAsync(e->state, 0, sizeof(LaneState) * e->B, e->ctx->stream);  // global_time = 0 -> first-frame path
+  if (he != hipSuccess) return (int)he;
+  // warped_weight_curr_ is never initialised by the reference (uninitialised device memory); the engine defines it as 0
+  he = hipMemsetAsync(e->warped_w.base, 0, e->warped_w.lane_stride * e->B, e->ctx->stream);
+  if (he != hipSuccess) return (int)he;
+  e->steps = 0;
+  return RGBID_OK;
+}
+
+int rgbid_engine_step(rgbid_engine* e, const void* depth_dev, const void* rgb_dev) {
+  if (!e || !depth_dev || !rgb_dev) return RGBID_E_INVALID;
+  hipStream_t s = e->ctx->stream;
+  const rgbid_engine_config& c = e->cfg;
+  hipSetDevice(e->ctx->device);
+  // stage the inputs into the engine's pitched buffers (dense [lanes][rows][cols] -> pitched lanes)
+  hipError_t he = hipMemcpy2DAsync(e->in_depth.base, e->in_depth.pitch, depth_dev, (size_t)c.cols * 2, (size_t)c.cols * 2, (size_t)c.rows * e->B,
+                                   hipMemcpyDeviceToDevice, s);
+  if (he != hipSuccess) return (int)he;
+  he = hipMemcpy2DAsync(e->in_rgb.base, e->in_rgb.pitch, rgb_dev, (size_t)c.cols * 3, (size_t)c.cols * 3, (size_t)c.rows * e->B, hipMemcpyDeviceToDevice, s);
+  if (he != hipSuccess) return (int)he;
+  int r = RGBID_OK;
+  if (c.use_graph) {
+    // the launch sequence is identical every step (flags live in device memory), so one captured graph is replayed
+    if (!e->graph_ready_next) {
+      hipGraph_t g = nullptr;
+      he = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+      if (he != hipSuccess) return (int)he;
+      r = enqueue_step(e, s);
+      he = hipStreamEndCapture(s, &g);
+      if (r) return r;
+      if (he != hipSuccess) return (int)he;
+      he = hipGraphInstantiate(&e->graph_next, g, nullptr, nullptr, 0);
+      hipGraphDestroy(g);
+      if (he != hipSuccess) return (int)he;
+      e->graph_ready_next = true;
+    }
+    he = hipGraphLaunch(e->graph_next, s);
+    if (he != hipSuccess) return (int)he;
+  } else {
+    r = enqueue_step(e, s);
+    if (r) return r;
+  }
+  int slot = e->steps % c.record_capacity;
+  he = hipMemcpyAsync(e->records + (size_t)slot * e->B, e->rec_cur, sizeof(rgbid_pose_record) * e->B, hipMemcpyDeviceToDevice, s);
+  if (he != hipSuccess) return (int)he;
+  e->steps++;
+  if (!e->ctx->async) { he = hipStreamSynchronize(s); if (he != hipSuccess) return (int)he; }
+  return RGBID_OK;
+}
+
+int rgbid_engine_steps(const rgbid_engine* e) { return e ? e->steps : 0; }
+
+int rgbid_engine_read_records(rgbid_engine* e, int first_step, int n_steps, rgbid_pose_record* out) {
+  if (!e || !out || n_steps < 0 || first_step < 0 || first_step + n_steps > e->steps || e->steps - first_step > e->cfg.record_capacity) return RGBID_E_INVALID;
+  for (int k = 0; k < n_steps; ++k) {
+    int slot = (first_step + k) % e->cfg.record_capacity;
+    hipError_t he = hipMemcpyAsync(out + (size_t)k * e->B, e->records + (size_t)slot * e->B, sizeof(rgbid_pose_record) * e->B, hipMemcpyDeviceToHost, e->ctx->stream);
+    if (he != hipSuccess) return (int)he;
+  }
+  hipError_t he = hipStreamSynchronize(e->ctx->stream);
+  return he == hipSuccess ? RGBID_OK : (int)he;
+}
+
+int rgbid_engine_records_dev(rgbid_engine* e, void** ptr, int* capacity) {
+  if (!e || !ptr) return RGBID_E_INVALID;
+  *ptr = e->records;
+  if (capacity) *capacity = e->cfg.record_capacity;
+  return RGBID_OK;
+}
+
+static rgbid_img lane_img(const ImgB& im, int lane) {
+  rgbid_img r;
+  r.data = (char*)im.base + (size_t)lane * im.lane_stride; r.step = im.pitch; r.rows = im.rows; r.cols = im.cols;
+  return r;
+}
+
+int rgbid_engine_keyframe_maps(rgbid_engine* e, int lane, rgbid_img* depthinv, rgbid_img* weight, rgbid_img* vmap, rgbid_img* nmap, rgbid_img* overlap_mask) {
+  if (!e || lane < 0 || lane >= e->B) return RGBID_E_INVALID;
+  if (depthinv) *depthinv = lane_img(e->iD_integr, lane);
+  if (weight) *weight = lane_img(e->w_integr, lane);
+  if (vmap) *vmap = lane_img(e->vmap, lane);
+  if (nmap) *nmap = lane_img(e->nmap, lane);
+  if (overlap_mask) *overlap_mask = lane_img(e->overlap_mask, lane);
+  return RGBID_OK;
+}
+
+int rgbid_engine_bytes(const rgbid_engine* e, size_t* bytes) { if (!e || !bytes) return RGBID_E_INVALID; *bytes = e->bytes; return RGBID_OK; }
+int rgbid_engine_launches_per_step(const rgbid_engine* e) { return e ? e->launches : 0; }
+
+}  // extern "C"

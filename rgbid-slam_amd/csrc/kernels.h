@@ -10,6 +10,7 @@ struct SysParams {     // inputs of constraintsHandler (estimate_VO.cu:95-139)
   float fx, fy, cx, cy;
   float sigma_d, sigma_i, bias_d, bias_i, nu_d, nu_i;
   int mestimator, weighting, student_nu;
+  int nu_i_max;   // engine: nu_i := max(nu_i, nu_d) as visodo.cpp:1186 does after the two sigma calls
 };
 struct SigmaIO { float bias, sigma, nu; };
 struct IntrP { float fx, fy, cx, cy; };
@@ -44,6 +45,8 @@ void lattice_geometry(int rows, int cols, int min_nsamples, int* n, int* lrows, 
 void launch_error_lattice(hipStream_t s, int B, ImgB im1, ImgB im0, float* err, size_t err_lane_stride, int lrows, int lcols, int stride, LaneMask m);
 // mode 0: computeSigmaAndNuStudent, 1: computeNuStudent, 2: computeSigmaPdf.  io: device [B]
 void launch_sigma(hipStream_t s, int B, int mode, const float* err, size_t err_lane_stride, int n, SigmaIO* io, int mestimator, LaneMask m);
+// engine: lattice sampling + computeSigmaAndNuStudent for both channels of every lane, results into sp[lane]
+void launch_sigma_pair(hipStream_t s, int B, ImgB W1, ImgB W0, ImgB I1, ImgB I0, int min_nsamples, SysParams* sp, int mestimator, LaneMask m);
 // out: device [B][3] = chi_square, chi_test, ndof
 void launch_chi_square(hipStream_t s, int B, const float* err_int, const float* err_depth, size_t err_lane_stride, int n,
                        float sigma_int, float sigma_depth, int mestimator, float* out, LaneMask m);

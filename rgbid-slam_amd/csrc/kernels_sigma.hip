@@ -8,6 +8,7 @@
 // frame), runs ALL iterations in-kernel (moments -> wave64 shuffle reduction -> LDS across 16 waves ->
 // broadcast), evaluates digamma on the device, and writes (bias, sigma, nu): one launch, no host trips.
 #include "kernels.h"
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -46,51 +47,76 @@ void launch_error_lattice(hipStream_t s, int B, ImgB im1, ImgB im0, float* err, 
   hipLaunchKernelGGL(k_error_lattice, dim3(div_up(lcols, 64), div_up(lrows, 4), B), dim3(64, 4), 0, s, im1, im0, err, err_lane_stride, lrows, lcols, stride, m);
 }
 
-// ---- digamma (device.hpp:76-80 -> boost::math::digamma): recurrence + asymptotic series, double ----
-__device__ __forceinline__ float digamma_f(float x) {
+// ---- digamma (device.hpp:76-80 -> boost::math::digamma<float>): recurrence + asymptotic series in double.
+// The bisection of computeSigmaAndNuStudent only ever visits nu in {2, 2.5, ..., 10}, so the four
+// transcendental terms of C(nu) are tabulated once on the host (the reference also evaluates them on the
+// host) and passed to the kernel by value; the kernel keeps the reference's left-to-right fp32 evaluation.
+static float digamma_host(float x) {
   double xd = x, r = 0.0;
   while (xd < 10.0) { r -= 1.0 / xd; xd += 1.0; }
   double f = 1.0 / (xd * xd);
   double s = f * (-1.0 / 12.0 + f * (1.0 / 120.0 + f * (-1.0 / 252.0 + f * (1.0 / 240.0 + f * (-1.0 / 132.0 + f * (691.0 / 32760.0 + f * (-1.0 / 12.0)))))));
   return (float)(r + log(xd) - 0.5 / xd + s);
 }
+struct NuTable { float t[17][4]; };  // nu = 2 + k/2: {-psi(nu/2), ln(nu/2), psi((nu+1)/2), ln((nu+1)/2)}
+static const NuTable& nu_table() {
+  static const NuTable T = [] {
+    NuTable t;
+    for (int k = 0; k < 17; ++k) {
+      float nu = 2.f + 0.5f * (float)k;
+      t.t[k][0] = -digamma_host(nu / 2.f);
+      t.t[k][1] = logf(nu / 2.f);
+      t.t[k][2] = digamma_host((nu + 1.f) / 2.f);
+      t.t[k][3] = logf((nu + 1.f) / 2.f);
+    }
+    return t;
+  }();
+  return T;
+}
 
 static constexpr int SIG_T = 1024, SIG_MAXPT = 24, SIG_W = SIG_T / 64;
 static constexpr float TH_HUBER = 1.345f, TH_TUKEY = 4.685f, STUDENT_DOF = 5.f;
 
-// block-wide sum of 4 doubles, result broadcast to every thread.  sm: SIG_W*4 + 4 doubles of LDS.
-__device__ __forceinline__ void block_sum4(double v[4], double* sm) {
+// block-wide sum of 4 per-thread fp32 partials: DPP wave reduction in fp32, then the 16 wave totals are
+// added in double in a fixed order and broadcast.  sm: SIG_W*4 + 4 doubles of LDS.
+__device__ __forceinline__ void block_sum4(const float in[4], double out[4], double* sm) {
+  float w[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
+  for (int k = 0; k < 4; ++k) w[k] = wave_sum_l63(in[k]);
   int wid = threadIdx.x >> 6, lid = threadIdx.x & 63;
   __syncthreads();
-  if (lid == 0) {
+  if (lid == 63) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) sm[wid * 4 + k] = v[k];
+    for (int k = 0; k < 4; ++k) sm[wid * 4 + k] = (double)w[k];
   }
   __syncthreads();
   if (threadIdx.x < 4) {
     double t = 0.0;
-    for (int w = 0; w < SIG_W; ++w) t += sm[w * 4 + threadIdx.x];  // fixed order: deterministic
+    for (int i = 0; i < SIG_W; ++i) t += sm[i * 4 + threadIdx.x];  // fixed order: deterministic
     sm[SIG_W * 4 + threadIdx.x] = t;
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 4; ++k) v[k] = sm[SIG_W * 4 + k];
+  for (int k = 0; k < 4; ++k) out[k] = sm[SIG_W * 4 + k];
 }
 
-template <bool REG>
+// Per-thread residual samples, produced by a getter get(i) (a plain array for the bridge calls; a lattice
+// sample of two maps for the batched engine).  REG: <= 24 samples per thread held in VGPRs (slots beyond n are
+// NaN and are skipped by the validity test); otherwise the getter is re-evaluated on every pass.
+template <bool REG, class Getter>
 struct Samples {
+  // register path: <= 24 fp32 adds per thread; streaming path (up to a full frame per thread-stride): double
+  using Acc = typename std::conditional<REG, float, double>::type;
   float e[REG ? SIG_MAXPT : 1];
-  const float* g;
-  int n, tid;
-  __device__ __forceinline__ void load(const float* err, int n_, int tid_) {
-    g = err; n = n_; tid = tid_;
+  Getter get;
+  int n, tid, cnt;
+  __device__ __forceinline__ Samples(const Getter& g, int n_, int tid_) : get(g), n(n_), tid(tid_) {
+    cnt = (n + SIG_T - 1) / SIG_T;
     if constexpr (REG) {
 #pragma unroll
       for (int j = 0; j < SIG_MAXPT; ++j) {
         int i = tid + j * SIG_T;
-        e[j] = (i < n) ? err[i] : 0.f;
+        e[j] = (i < n) ? get(i) : qnan();
       }
     }
   }
@@ -99,44 +125,51 @@ struct Samples {
     if constexpr (REG) {
 #pragma unroll
       for (int j = 0; j < SIG_MAXPT; ++j)
-        if (tid + j * SIG_T < n) f(e[j]);
+        if (j < cnt) f(e[j]);  // wave-uniform
     } else {
-      for (int i = tid; i < n; i += SIG_T) f(g[i]);
+      for (int i = tid; i < n; i += SIG_T) f(get(i));
     }
   }
 };
 
-// one moments pass: partialBiasAndSigmaStudent (:258-332) when student_variant, else partialBiasAndSigma (:179-255)
-template <bool REG>
-__device__ __forceinline__ void pass_moments(const Samples<REG>& S, float bias, float sigma, float nu, int mest, bool student_variant,
+__device__ __forceinline__ bool finite_f(float x) { return fabsf(x) < __builtin_inff(); }  // !isinf && !isnan
+
+// one moments pass: partialBiasAndSigmaStudent (:258-332) when student_variant, else partialBiasAndSigma (:179-255).
+// Per-sample divisions are reciprocal multiplies (<= 1 ulp) and the per-thread partial sums are fp32: the pass
+// is VALU-bound on one CU, and the moments only feed a 10%-tolerance fixed point.
+template <class SM>
+__device__ __forceinline__ void pass_moments(const SM& S, float bias, float sigma, float nu, int mest, bool student_variant,
                                              double* sm, float& swsr, float& swr, float& sw, float& nel) {
-  double a[4] = {0, 0, 0, 0};
+  typename SM::Acc a[4] = {0, 0, 0, 0};
+  const float inv_sigma = 1.f / sigma, nup1 = nu + 1.f;
   S.for_each([&](float er) {
     float is_valid = 0.f, wsr = 0.f, wr = 0.f, weight = 0.f;
-    if (!isinf(er) && !isnan(er)) {
+    if (finite_f(er)) {
       if (student_variant) {
         is_valid = 1.f;
         if (mest == 0) weight = 1.f;
         else {
-          float en = (er - bias) / sigma;
-          weight = (nu + 1.f) / (nu + en * en);
+          float en = (er - bias) * inv_sigma;
+          weight = nup1 * __builtin_amdgcn_rcpf(nu + en * en);
         }
       } else {
         weight = 1.f; is_valid = 1.f;
-        float en = (er - bias) / sigma;
+        float en = (er - bias) * inv_sigma;
         if ((mest == 1) && (fabsf(en) > TH_HUBER)) weight = TH_HUBER / fabsf(en);
         else if (mest == 2) {
           if (fabsf(en) < TH_TUKEY) { float aux1 = (en / TH_TUKEY) * (en / TH_TUKEY); weight = (1.f - aux1) * (1.f - aux1); }
           else { weight = 0.f; is_valid = 0.f; }
-        } else if (mest == 3) weight = (STUDENT_DOF + 1.f) / (STUDENT_DOF + en * en);
+        } else if (mest == 3) weight = (STUDENT_DOF + 1.f) * __builtin_amdgcn_rcpf(STUDENT_DOF + en * en);
       }
       wr = er * weight;
       wsr = wr * er;
     }
     a[0] += wsr; a[1] += wr; a[2] += weight; a[3] += is_valid;
   });
-  block_sum4(a, sm);
-  swsr = (float)a[0]; swr = (float)a[1]; sw = (float)a[2]; nel = (float)a[3];
+  double t[4];
+  float af[4] = {(float)a[0], (float)a[1], (float)a[2], (float)a[3]};
+  block_sum4(af, t, sm);
+  swsr = (float)t[0]; swr = (float)t[1]; sw = (float)t[2]; nel = (float)t[3];
 }
 
 // finalReductionBiasAndSigma :361-407
@@ -147,37 +180,42 @@ __device__ __forceinline__ void final_bias_sigma(float swsr, float swr, float sw
 }
 
 // partialFuncWeightsNu :410-468 + finalReductionFuncWeightsNu :471-512
-template <bool REG>
-__device__ __forceinline__ float func_weights_nu(const Samples<REG>& S, float bias, float sigma, float nu, double* sm) {
-  double a[4] = {0, 0, 0, 0};
+template <class SM>
+__device__ __forceinline__ float func_weights_nu(const SM& S, float bias, float sigma, float nu, double* sm) {
+  typename SM::Acc a[4] = {0, 0, 0, 0};
+  const float inv_sigma = 1.f / sigma, nup1 = nu + 1.f;
   S.for_each([&](float er) {
-    if (!isinf(er) && !isnan(er)) {
-      float en = (er - bias) / sigma;
-      float weight = (nu + 1.f) / (nu + en * en);
-      a[0] += logf(weight); a[1] += weight; a[2] += 1.0;
+    if (finite_f(er)) {
+      float en = (er - bias) * inv_sigma;
+      float weight = nup1 * __builtin_amdgcn_rcpf(nu + en * en);
+      a[0] += __logf(weight); a[1] += weight; a[2] += 1.f;
     }
   });
-  block_sum4(a, sm);
-  return ((float)a[0] - (float)a[1]) / (float)a[2];
+  double t[4];
+  float af[4] = {(float)a[0], (float)a[1], (float)a[2], 0.f};
+  block_sum4(af, t, sm);
+  return ((float)t[0] - (float)t[1]) / (float)t[2];
 }
 
-__device__ __forceinline__ float C_nu(float nu, float fw) {
-  return -digamma_f(nu / 2.f) + logf(nu / 2.f) + fw + 1.f + digamma_f((nu + 1.f) / 2.f) - logf((nu + 1.f) / 2.f);
+// C(nu) = -psi(nu/2) + ln(nu/2) + mean(ln w - w) + 1 + psi((nu+1)/2) - ln((nu+1)/2)   (sigmaFuncs.cu:951)
+__device__ __forceinline__ float C_nu(const NuTable& T, float nu, float fw) {
+  int k = (int)((nu - 2.f) * 2.f);  // exact: nu is a multiple of 0.5 in [2,10]
+  return T.t[k][0] + T.t[k][1] + fw + 1.f + T.t[k][2] - T.t[k][3];
 }
 
 // bisection of C(nu) on [2,10]: sigmaFuncs.cu:934-1039 == :1100-1205
-template <bool REG>
-__device__ __forceinline__ float estimate_nu(const Samples<REG>& S, float bias, float sigma, double* sm) {
+template <class SM>
+__device__ __forceinline__ float estimate_nu(const SM& S, const NuTable& T, float bias, float sigma, double* sm) {
   float nu_up = 10.f, nu_down = 2.f, nu_new = 0.f, nu;
-  float C_down = C_nu(nu_down, func_weights_nu(S, bias, sigma, nu_down, sm));
-  float C_up = C_nu(nu_up, func_weights_nu(S, bias, sigma, nu_up, sm));
+  float C_down = C_nu(T, nu_down, func_weights_nu(S, bias, sigma, nu_down, sm));
+  float C_up = C_nu(T, nu_up, func_weights_nu(S, bias, sigma, nu_up, sm));
   if (C_up * C_down > 0) {
     nu = (C_down <= 0.f) ? nu_down : nu_up;
   } else {
     for (int j = 0; j < 5; j++) {
       nu_new = (nu_up + nu_down) / 2;
       if ((nu_up - nu_down) < 1.f) break;
-      float C_new = C_nu(nu_new, func_weights_nu(S, bias, sigma, nu_new, sm));
+      float C_new = C_nu(T, nu_new, func_weights_nu(S, bias, sigma, nu_new, sm));
       if (C_new * C_up > 0) { C_up = C_new; nu_up = nu_new; }
       else { C_down = C_new; nu_down = nu_new; }
     }
@@ -186,15 +224,9 @@ __device__ __forceinline__ float estimate_nu(const Samples<REG>& S, float bias, 
   return nu;
 }
 
-template <bool REG>
-__global__ __launch_bounds__(SIG_T) void k_sigma(int mode, const float* err, size_t err_lane_stride, int n, SigmaIO* io, int mestimator, LaneMask m) {
-  int lane = blockIdx.x;
-  if (!m.on(lane)) return;
-  __shared__ double sm[SIG_W * 4 + 4];
-  Samples<REG> S;
-  S.load(err + (size_t)lane * err_lane_stride, n, threadIdx.x);
-  SigmaIO v = io[lane];
-  float bias = v.bias, sigma = v.sigma, nu = v.nu;
+// the three host wrappers of the reference as one device routine over a sample set
+template <class SM>
+__device__ __forceinline__ void sigma_core(const SM& S, const NuTable& T, int mode, int mestimator, float& bias, float& sigma, float& nu, double* sm) {
   float swsr, swr, sw, nel;
   if (mode == 0) {
     // computeSigmaAndNuStudent :858-1066
@@ -207,10 +239,10 @@ __global__ __launch_bounds__(SIG_T) void k_sigma(int mode, const float* err, siz
       sh_bias = bias; sh_sigma = sigma; sh_mest = mestimator;
       if ((i > 0) && ((fabsf(sigma - sigma_prev) / sigma_prev) < 0.1f)) break;
     }
-    nu = estimate_nu(S, sh_bias, sh_sigma, sm);
+    nu = estimate_nu(S, T, sh_bias, sh_sigma, sm);
   } else if (mode == 1) {
     // computeNuStudent :1068-1222
-    nu = estimate_nu(S, bias, sigma, sm);
+    nu = estimate_nu(S, T, bias, sigma, sm);
   } else {
     // computeSigmaPdf :773-854
     float sh_sigma = sigma, sh_bias = bias;
@@ -222,14 +254,67 @@ __global__ __launch_bounds__(SIG_T) void k_sigma(int mode, const float* err, siz
       sh_bias = bias; sh_sigma = sigma; sh_mest = mestimator;
     }
   }
+}
+
+struct ArrayGetter {
+  const float* p;
+  __device__ __forceinline__ float operator()(int i) const { return p[i]; }
+};
+
+template <bool REG>
+__global__ __launch_bounds__(SIG_T) void k_sigma(NuTable T, int mode, const float* err, size_t err_lane_stride, int n, SigmaIO* io, int mestimator, LaneMask m) {
+  int lane = blockIdx.x;
+  if (!m.on(lane)) return;
+  __shared__ double sm[SIG_W * 4 + 4];
+  Samples<REG, ArrayGetter> S(ArrayGetter{err + (size_t)lane * err_lane_stride}, n, threadIdx.x);
+  SigmaIO v = io[lane];
+  float bias = v.bias, sigma = v.sigma, nu = v.nu;
+  sigma_core(S, T, mode, mestimator, bias, sigma, nu, sm);
   if (threadIdx.x == 0) { v.bias = bias; v.sigma = sigma; v.nu = nu; io[lane] = v; }
 }
 
 void launch_sigma(hipStream_t s, int B, int mode, const float* err, size_t err_lane_stride, int n, SigmaIO* io, int mestimator, LaneMask m) {
   if (n <= SIG_T * SIG_MAXPT)
-    hipLaunchKernelGGL(k_sigma<true>, dim3(B), dim3(SIG_T), 0, s, mode, err, err_lane_stride, n, io, mestimator, m);
+    hipLaunchKernelGGL(k_sigma<true>, dim3(B), dim3(SIG_T), 0, s, nu_table(), mode, err, err_lane_stride, n, io, mestimator, m);
   else
-    hipLaunchKernelGGL(k_sigma<false>, dim3(B), dim3(SIG_T), 0, s, mode, err, err_lane_stride, n, io, mestimator, m);
+    hipLaunchKernelGGL(k_sigma<false>, dim3(B), dim3(SIG_T), 0, s, nu_table(), mode, err, err_lane_stride, n, io, mestimator, m);
+}
+
+// ---- batched engine: both channels of one GN iteration in ONE launch (grid = lanes x 2) -----------------
+// blockIdx.y == 0: inverse depth (W1 - W0), == 1: intensity (I1 - I0).  The residual lattice of
+// computeErrorGridStride (sigmaFuncs.cu:90-135) is sampled straight from the maps, the start values are the
+// ones visodo.cpp:1168-1173 sets each iteration, and (bias, sigma, nu) land in the lane's SysParams.
+struct LatticeGetter {
+  ImgB a, b;  // a - b
+  int lane, lcols, stride;
+  __device__ __forceinline__ float operator()(int i) const {
+    int y = i / lcols, x = i - y * lcols;
+    return px<float>(a, lane, stride * y, stride * x) - px<float>(b, lane, stride * y, stride * x);
+  }
+};
+
+template <bool REG>
+__global__ __launch_bounds__(SIG_T) void k_sigma_pair(NuTable T, ImgB W1, ImgB W0, ImgB I1, ImgB I0, int lrows, int lcols, int stride,
+                                                      SysParams* sp, int mestimator, LaneMask m) {
+  int lane = blockIdx.x, ch = blockIdx.y;
+  if (!m.on(lane)) return;
+  __shared__ double sm[SIG_W * 4 + 4];
+  LatticeGetter g{ch == 0 ? W1 : I1, ch == 0 ? W0 : I0, lane, lcols, stride};
+  Samples<REG, LatticeGetter> S(g, lrows * lcols, threadIdx.x);
+  float bias = 0.f, sigma = ch == 0 ? 0.0025f : 5.f, nu = 5.f;
+  sigma_core(S, T, 0, mestimator, bias, sigma, nu, sm);
+  if (threadIdx.x == 0) {
+    if (ch == 0) { sp[lane].bias_d = bias; sp[lane].sigma_d = sigma; sp[lane].nu_d = nu; }
+    else { sp[lane].bias_i = bias; sp[lane].sigma_i = sigma; sp[lane].nu_i = nu; }
+  }
+}
+void launch_sigma_pair(hipStream_t s, int B, ImgB W1, ImgB W0, ImgB I1, ImgB I0, int min_nsamples, SysParams* sp, int mestimator, LaneMask m) {
+  int n, lr, lc, st;
+  lattice_geometry(W0.rows, W0.cols, min_nsamples, &n, &lr, &lc, &st);
+  if (n <= SIG_T * SIG_MAXPT)
+    hipLaunchKernelGGL(k_sigma_pair<true>, dim3(B, 2), dim3(SIG_T), 0, s, nu_table(), W1, W0, I1, I0, lr, lc, st, sp, mestimator, m);
+  else
+    hipLaunchKernelGGL(k_sigma_pair<false>, dim3(B, 2), dim3(SIG_T), 0, s, nu_table(), W1, W0, I1, I0, lr, lc, st, sp, mestimator, m);
 }
 
 // ---- computeChiSquare sigmaFuncs.cu:1225-1297 (+ :137-150, :541-646) --------------------------------
@@ -238,7 +323,7 @@ __global__ __launch_bounds__(SIG_T) void k_chi_square(const float* err_int, cons
   int lane = blockIdx.x;
   if (!m.on(lane)) return;
   __shared__ double sm[SIG_W * 4 + 4];
-  double a[4] = {0, 0, 0, 0};
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
   for (int half = 0; half < 2; ++half) {
     const float* e = (half == 0 ? err_int : err_depth) + (size_t)lane * err_lane_stride;
     float sg = half == 0 ? sigma_int : sigma_depth;
@@ -246,7 +331,7 @@ __global__ __launch_bounds__(SIG_T) void k_chi_square(const float* err_int, cons
       float en = e[i] / sg;
       float rho = 0.f;
       if (!isinf(en) && !isnan(en)) {
-        a[0] += 1.0;
+        a[0] += 1.f;
         rho = (en * en) / 2.f;
         if ((mest == 1) && (fabsf(en) > TH_HUBER)) rho = TH_HUBER * (fabsf(en) - TH_HUBER / 2.f);
         else if (mest == 2) {
@@ -260,9 +345,10 @@ __global__ __launch_bounds__(SIG_T) void k_chi_square(const float* err_int, cons
       a[1] += rho;
     }
   }
-  block_sum4(a, sm);
+  double t[4];
+  block_sum4(a, t, sm);
   if (threadIdx.x == 0) {
-    float fN = (float)a[0], frho = (float)a[1];
+    float fN = (float)t[0], frho = (float)t[1];
     float chi = frho / fN;
     float z_gauss = (chi - fN) / (sqrtf(2.f * fN));
     out[lane * 3 + 0] = chi;

@@ -109,8 +109,8 @@ __device__ __forceinline__ void block_reduce_store(float acc[SYS_TERMS], double*
   int wid = threadIdx.x >> 6, lid = threadIdx.x & 63;
 #pragma unroll
   for (int k = 0; k < SYS_TERMS; ++k) {
-    float v = wave_sum(acc[k]);
-    if (lid == 0) sm[wid][k] = v;
+    float v = wave_sum_l63(acc[k]);
+    if (lid == 63) sm[wid][k] = v;
   }
   __syncthreads();
   if (threadIdx.x < SYS_TERMS) {
@@ -135,7 +135,8 @@ __global__ __launch_bounds__(SYS_T) void k_build_system(ImgB W0, ImgB I0, ImgB g
   int lane = gb / nblk, blk = gb - lane * nblk;
   double* out = partials + ((size_t)lane * nblk + blk) * SYS_TERMS;
   if (!m.on(lane)) return;
-  const SysParams P = ps.get(lane);
+  SysParams P = ps.get(lane);
+  if (P.nu_i_max) P.nu_i = fmaxf(P.nu_i, P.nu_d);
   const SysConst C = make_const(P);
   float acc[SYS_TERMS];
 #pragma unroll
@@ -216,19 +217,30 @@ int launch_build_system(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB g
   return nblk;
 }
 
-// FinalReductionKernel estimate_VO.cu:459-500 (all-double here; the reference's tree is fp32)
-__global__ __launch_bounds__(64) void k_reduce_system(const double* partials, int nblk, double* sums, LaneMask m) {
+// FinalReductionKernel estimate_VO.cu:459-500 (all-double here; the reference's tree is fp32).
+// 8 slices x 32 threads: slice s sums blocks s, s+8, ... of one term, then the 8 slice sums are added in
+// a fixed order -> deterministic for a given launch plan.
+__global__ __launch_bounds__(256) void k_reduce_system(const double* partials, int nblk, double* sums, LaneMask m) {
   int lane = blockIdx.x;
   if (!m.on(lane)) return;
+  __shared__ double sm[8][32];
+  int k = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  double t = 0.0;
+  if (k < SYS_TERMS) {
+    const double* p = partials + (size_t)lane * nblk * SYS_TERMS + k;
+    for (int b = sl; b < nblk; b += 8) t += p[(size_t)b * SYS_TERMS];
+  }
+  sm[sl][k] = t;
+  __syncthreads();
   if (threadIdx.x < SYS_TERMS) {
-    const double* p = partials + (size_t)lane * nblk * SYS_TERMS + threadIdx.x;
-    double t = 0.0;
-    for (int b = 0; b < nblk; ++b) t += p[(size_t)b * SYS_TERMS];
-    sums[lane * SYS_TERMS + threadIdx.x] = t;
+    double r = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r += sm[i][threadIdx.x];
+    sums[lane * SYS_TERMS + threadIdx.x] = r;
   }
 }
 void launch_reduce_system(hipStream_t s, int B, const double* partials, int nblk, double* sums, LaneMask m) {
-  hipLaunchKernelGGL(k_reduce_system, dim3(B), dim3(64), 0, s, partials, nblk, sums, m);
+  hipLaunchKernelGGL(k_reduce_system, dim3(B), dim3(256), 0, s, partials, nblk, sums, m);
 }
 
 }  // namespace rgbid

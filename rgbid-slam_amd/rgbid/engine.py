@@ -1,0 +1,120 @@
+"""Python binding of the batched device-resident tracker (include/rgbid_engine.h).
+
+`Engine` runs VisodoTracker::trackNewFrame (src/visodo.cpp:1967-2247) for `lanes` independent trackers per step;
+inputs are CUDA tensors depth [lanes, rows, cols] (int16/uint16 bits, millimetres) and rgb [lanes, rows, cols, 3]
+uint8.  Results come back as pose records (numpy structured array mirroring rgbid_pose_record).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Img, check
+from .device import Context
+
+ST_TRACKED, ST_LOST, ST_ODO_KF, ST_INTEGR_KF, ST_FIRST = 1, 2, 4, 8, 16
+
+
+class EngineConfig(C.Structure):
+    _fields_ = [
+        ("rows", C.c_int), ("cols", C.c_int), ("levels", C.c_int), ("lanes", C.c_int),
+        ("iters", C.c_int * 8),
+        ("mestimator", C.c_int), ("motion_model", C.c_int), ("sigma_estimator", C.c_int), ("weighting", C.c_int),
+        ("max_odoKF_count", C.c_int), ("finest_level", C.c_int), ("image_filtering", C.c_int),
+        ("visratio_odo", C.c_float), ("visratio_integr", C.c_float),
+        ("max_integrKF_count", C.c_int), ("nsamples", C.c_int),
+        ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("factor_depth", C.c_float),
+        ("interp_mode", C.c_int), ("delta_t", C.c_float),
+        ("use_graph", C.c_int), ("fused_gn", C.c_int), ("chi_square_stats", C.c_int), ("preview", C.c_int),
+        ("record_capacity", C.c_int),
+    ]
+
+
+RECORD_DTYPE = np.dtype([
+    ("frame", np.int32), ("status", np.int32), ("vis_odo", np.float32), ("vis_integr", np.float32),
+    ("sigma_int", np.float32), ("sigma_depthinv", np.float32), ("nu_int", np.float32), ("nu_depthinv", np.float32),
+    ("R", np.float64, (3, 3)), ("t", np.float64, (3,)),
+    ("odo_R", np.float64, (3, 3)), ("odo_t", np.float64, (3,)), ("odo_cov", np.float64, (6, 6)),
+    ("kf_R", np.float64, (3, 3)), ("kf_t", np.float64, (3,)), ("kf_cov", np.float64, (6, 6)),
+], align=True)
+
+
+def default_config(**kw):
+    c = EngineConfig()
+    _lib.lib().rgbid_engine_default_config(C.byref(c))
+    for k, v in kw.items():
+        if k == "iters":
+            for i in range(8):
+                c.iters[i] = int(v[i]) if i < len(v) else 0
+        elif k == "K":
+            c.fx, c.fy, c.cx, c.cy = [float(x) for x in v]
+        else:
+            setattr(c, k, v)
+    return c
+
+
+class Engine:
+    def __init__(self, ctx: Context, cfg: EngineConfig = None, **kw):
+        self.ctx = ctx
+        self.cfg = cfg if cfg is not None else default_config(**kw)
+        self.L = _lib.lib()
+        self._h = C.c_void_p()
+        check(self.L.rgbid_engine_create(C.byref(self._h), ctx._h, C.byref(self.cfg)))
+        assert RECORD_DTYPE.itemsize == 4 * 8 + 8 * (9 + 3 + 9 + 3 + 36 + 9 + 3 + 36), RECORD_DTYPE.itemsize
+
+    @property
+    def lanes(self):
+        return self.cfg.lanes
+
+    def close(self):
+        if self._h:
+            self.L.rgbid_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        check(self.L.rgbid_engine_reset(self._h))
+
+    def step(self, depth, rgb):
+        """depth: CUDA tensor [lanes, rows, cols] of 16-bit ints; rgb: CUDA uint8 [lanes, rows, cols, 3] (contiguous)."""
+        c = self.cfg
+        assert depth.is_cuda and rgb.is_cuda and depth.is_contiguous() and rgb.is_contiguous()
+        assert depth.element_size() == 2 and tuple(depth.shape) == (c.lanes, c.rows, c.cols), depth.shape
+        assert rgb.dtype == torch.uint8 and tuple(rgb.shape) == (c.lanes, c.rows, c.cols, 3), rgb.shape
+        check(self.L.rgbid_engine_step(self._h, C.c_void_p(depth.data_ptr()), C.c_void_p(rgb.data_ptr())))
+
+    def steps(self):
+        return self.L.rgbid_engine_steps(self._h)
+
+    def records(self, first_step=0, n_steps=None):
+        n = self.steps() - first_step if n_steps is None else n_steps
+        out = np.zeros((n, self.cfg.lanes), RECORD_DTYPE)
+        check(self.L.rgbid_engine_read_records(self._h, int(first_step), int(n), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def bytes(self):
+        b = C.c_size_t()
+        check(self.L.rgbid_engine_bytes(self._h, C.byref(b)))
+        return b.value
+
+    def launches_per_step(self):
+        return self.L.rgbid_engine_launches_per_step(self._h)
+
+    def keyframe_maps(self, lane):
+        """Host copies of a lane's fused keyframe maps: depthinv, weight, vmap, nmap, overlap mask."""
+        imgs = [Img() for _ in range(5)]
+        check(self.L.rgbid_engine_keyframe_maps(self._h, int(lane), *[C.byref(i) for i in imgs]))
+        self.ctx.sync()
+        outs = []
+        for im, dt in zip(imgs, (np.float32, np.float32, np.float32, np.float32, np.uint8)):
+            host = np.empty((im.rows, im.cols), dt)
+            check(self.L.rgbid_memcpy2d_d2h(self.ctx._h, host.ctypes.data_as(C.c_void_p), C.c_size_t(im.cols * host.itemsize),
+                                            C.c_void_p(im.data), C.c_size_t(im.step), C.c_size_t(im.cols * host.itemsize), C.c_size_t(im.rows)))
+            outs.append(host)
+        return outs
