@@ -75,6 +75,12 @@ int rgbid_engine_records_dev(rgbid_engine* e, void** ptr, int* capacity);
 /* debugging / parity access to a lane's fused keyframe maps (device pointers + geometry) */
 int rgbid_engine_keyframe_maps(rgbid_engine* e, int lane, rgbid_img* depthinv, rgbid_img* weight, rgbid_img* vmap,
                                rgbid_img* nmap, rgbid_img* overlap_mask);
+/* Event timing of the dominant kernel: while profiling is on, every launch of the level-0 (full resolution)
+ * residual + normal-equation kernel is bracketed by a hipEvent pair on the context's stream (steps run eagerly,
+ * not as a graph).  profile_end synchronises and returns the summed kernel time, the number of launches and the
+ * algorithmic bytes one launch processes (32 B/px x rows x cols x lanes, SURVEY.md section 8d unit U1). */
+int rgbid_engine_profile_begin(rgbid_engine* e, int max_launches);
+int rgbid_engine_profile_end(rgbid_engine* e, double* total_ms, int* n_launches, double* bytes_per_launch);
 /* total HBM bytes the engine allocated */
 int rgbid_engine_bytes(const rgbid_engine* e, size_t* bytes);
 /* name + launch count of every kernel enqueued by the last step (for DESIGN.md / profiling); returns #launches */

@@ -452,6 +452,10 @@ struct rgbid_engine {
   int launches = 0;
   hipGraphExec_t graph_first = nullptr, graph_next = nullptr;
   bool graph_ready_first = false, graph_ready_next = false;
+  // event timing of the dominant kernel (level-0 normal equations), see rgbid_engine_profile_begin
+  std::vector<hipEvent_t> prof_ev;
+  int prof_used = 0;
+  bool prof_on = false;
 };
 
 namespace {
@@ -554,15 +558,31 @@ int enqueue_step(rgbid_engine* e, hipStream_t s) {
     for (int it = 0; it < iters; ++it) {
       bool last_of_level = (it == iters - 1);
       int next_level = last_of_level ? (level > c.finest_level ? level - 1 : c.finest_level) : level;
-      launch_warp_invdepth(s, B, e->iD_curr[level], e->iD_kf[level], e->wiD[level], nullptr, e->wp, M(f.gn));
-      launch_warp_intensity(s, B, e->I_curr[level], e->wiD[level], e->wI[level], nullptr, e->wp, c.interp_mode, M(f.gn));
-      e->launches += 2;
-      if (c.sigma_estimator == RGBID_SIGMA_PDF) {
-        launch_sigma_pair(s, B, e->wiD[level], e->iD_kf[level], e->wI[level], e->I_kf[level], c.nsamples, e->sp, c.mestimator, M(f.gn));
-        e->launches++;
+      bool prof = e->prof_on && level == 0 && e->prof_used + 2 <= (int)e->prof_ev.size();
+      int nblk;
+      if (c.fused_gn) {
+        if (c.sigma_estimator == RGBID_SIGMA_PDF) {
+          launch_sigma_pair_fused(s, B, e->iD_curr[level], e->iD_kf[level], e->I_curr[level], e->I_kf[level], e->wp, c.interp_mode, c.nsamples,
+                                  e->sp, c.mestimator, M(f.gn));
+          e->launches++;
+        }
+        if (prof) hipEventRecord(e->prof_ev[e->prof_used++], s);
+        nblk = launch_gn_fused(s, B, e->iD_kf[level], e->I_kf[level], e->gxD[level], e->gyD[level], e->gxI[level], e->gyI[level],
+                               e->iD_curr[level], e->I_curr[level], e->wp, c.interp_mode, e->sp, e->partials, M(f.gn), level < 2 ? level : 2);
+        if (prof) hipEventRecord(e->prof_ev[e->prof_used++], s);
+      } else {
+        launch_warp_invdepth(s, B, e->iD_curr[level], e->iD_kf[level], e->wiD[level], nullptr, e->wp, M(f.gn));
+        launch_warp_intensity(s, B, e->I_curr[level], e->wiD[level], e->wI[level], nullptr, e->wp, c.interp_mode, M(f.gn));
+        e->launches += 2;
+        if (c.sigma_estimator == RGBID_SIGMA_PDF) {
+          launch_sigma_pair(s, B, e->wiD[level], e->iD_kf[level], e->wI[level], e->I_kf[level], c.nsamples, e->sp, c.mestimator, M(f.gn));
+          e->launches++;
+        }
+        if (prof) hipEventRecord(e->prof_ev[e->prof_used++], s);
+        nblk = launch_build_system(s, B, e->iD_kf[level], e->I_kf[level], e->gxD[level], e->gyD[level], e->gxI[level], e->gyI[level],
+                                   e->wiD[level], e->wI[level], nullptr, e->sp, e->partials, M(f.gn), level < 2 ? level : 2);
+        if (prof) hipEventRecord(e->prof_ev[e->prof_used++], s);
       }
-      int nblk = launch_build_system(s, B, e->iD_kf[level], e->I_kf[level], e->gxD[level], e->gyD[level], e->gxI[level], e->gyI[level],
-                                     e->wiD[level], e->wI[level], nullptr, e->sp, e->partials, M(f.gn));
       hipLaunchKernelGGL(k_solve_update, dim3(B), dim3(256), 0, s, e->partials, nblk, e->state, f, e->wp, sc, next_level);
       e->launches += 2;
     }
@@ -571,11 +591,24 @@ int enqueue_step(rgbid_engine* e, hipStream_t s) {
   {
     int fl = c.finest_level;
     hipLaunchKernelGGL(k_set_sys, dim3(gb), dim3(tb), 0, s, e->sp, e->state, sc, fl, 1, B);
-    launch_warp_invdepth(s, B, e->iD_curr[fl], e->iD_kf[fl], e->wiD[fl], nullptr, e->wp, M(f.gn));
-    launch_warp_intensity(s, B, e->I_curr[fl], e->wiD[fl], e->wI[fl], nullptr, e->wp, c.interp_mode, M(f.gn));
-    int nblk = launch_build_system(s, B, e->iD_kf[fl], e->I_kf[fl], e->gxD_c[fl], e->gyD_c[fl], e->gxI_c[fl], e->gyI_c[fl],
-                                   e->wiD[fl], e->wI[fl], nullptr, e->sp, e->partials, M(f.gn));
-    e->launches += 4;
+    bool prof = e->prof_on && fl == 0 && e->prof_used + 2 <= (int)e->prof_ev.size();
+    bool fuse_cov = c.fused_gn && !c.chi_square_stats;  // the chi-square statistics need W1 / I1 in memory
+    int nblk;
+    if (fuse_cov) {
+      if (prof) hipEventRecord(e->prof_ev[e->prof_used++], s);
+      nblk = launch_gn_fused(s, B, e->iD_kf[fl], e->I_kf[fl], e->gxD_c[fl], e->gyD_c[fl], e->gxI_c[fl], e->gyI_c[fl],
+                             e->iD_curr[fl], e->I_curr[fl], e->wp, c.interp_mode, e->sp, e->partials, M(f.gn), fl < 2 ? fl : 2);
+      if (prof) hipEventRecord(e->prof_ev[e->prof_used++], s);
+      e->launches += 2;
+    } else {
+      launch_warp_invdepth(s, B, e->iD_curr[fl], e->iD_kf[fl], e->wiD[fl], nullptr, e->wp, M(f.gn));
+      launch_warp_intensity(s, B, e->I_curr[fl], e->wiD[fl], e->wI[fl], nullptr, e->wp, c.interp_mode, M(f.gn));
+      if (prof) hipEventRecord(e->prof_ev[e->prof_used++], s);
+      nblk = launch_build_system(s, B, e->iD_kf[fl], e->I_kf[fl], e->gxD_c[fl], e->gyD_c[fl], e->gxI_c[fl], e->gyI_c[fl],
+                                 e->wiD[fl], e->wI[fl], nullptr, e->sp, e->partials, M(f.gn), fl < 2 ? fl : 2);
+      if (prof) hipEventRecord(e->prof_ev[e->prof_used++], s);
+      e->launches += 4;
+    }
     if (c.chi_square_stats) {  // :1411-1415 (results unused by the reference)
       int n, lr, lc, st;
       lattice_geometry(e->wI[fl].rows, e->wI[fl].cols, 9999999, &n, &lr, &lc, &st);
@@ -704,6 +737,7 @@ int rgbid_engine_destroy(rgbid_engine* e) {
   if (e->graph_first) hipGraphExecDestroy(e->graph_first);
   if (e->graph_next) hipGraphExecDestroy(e->graph_next);
   for (void* p : e->allocs) hipFree(p);
+  for (hipEvent_t ev : e->prof_ev) hipEventDestroy(ev);
   delete e;
   return RGBID_OK;
 }
@@ -731,7 +765,7 @@ int rgbid_engine_step(rgbid_engine* e, const void* depth_dev, const void* rgb_de
   he = hipMemcpy2DAsync(e->in_rgb.base, e->in_rgb.pitch, rgb_dev, (size_t)c.cols * 3, (size_t)c.cols * 3, (size_t)c.rows * e->B, hipMemcpyDeviceToDevice, s);
   if (he != hipSuccess) return (int)he;
   int r = RGBID_OK;
-  if (c.use_graph) {
+  if (c.use_graph && !e->prof_on) {
     // the launch sequence is identical every step (flags live in device memory), so one captured graph is replayed
     if (!e->graph_ready_next) {
       hipGraph_t g = nullptr;
@@ -793,6 +827,40 @@ int rgbid_engine_keyframe_maps(rgbid_engine* e, int lane, rgbid_img* depthinv, r
   if (vmap) *vmap = lane_img(e->vmap, lane);
   if (nmap) *nmap = lane_img(e->nmap, lane);
   if (overlap_mask) *overlap_mask = lane_img(e->overlap_mask, lane);
+  return RGBID_OK;
+}
+
+int rgbid_engine_profile_begin(rgbid_engine* e, int max_launches) {
+  if (!e || max_launches < 1) return RGBID_E_INVALID;
+  while ((int)e->prof_ev.size() < 2 * max_launches) {
+    hipEvent_t ev;
+    // no system-scope fence around the timed kernel: the events only order against work on this stream
+    hipError_t he = hipEventCreateWithFlags(&ev, hipEventDisableSystemFence);
+    if (he != hipSuccess) he = hipEventCreate(&ev);
+    if (he != hipSuccess) return (int)he;
+    e->prof_ev.push_back(ev);
+  }
+  e->prof_used = 0;
+  e->prof_on = true;
+  return RGBID_OK;
+}
+
+int rgbid_engine_profile_end(rgbid_engine* e, double* total_ms, int* n_launches, double* bytes_per_launch) {
+  if (!e || !total_ms || !n_launches) return RGBID_E_INVALID;
+  hipError_t he = hipStreamSynchronize(e->ctx->stream);
+  if (he != hipSuccess) return (int)he;
+  double tot = 0.0;
+  for (int i = 0; i + 1 < e->prof_used; i += 2) {
+    float ms = 0.f;
+    he = hipEventElapsedTime(&ms, e->prof_ev[i], e->prof_ev[i + 1]);
+    if (he != hipSuccess) return (int)he;
+    tot += ms;
+  }
+  *total_ms = tot;
+  *n_launches = e->prof_used / 2;
+  // unit U1: 8 fp32 maps read per pixel of the level-0 frame, for every lane of the launch
+  if (bytes_per_launch) *bytes_per_launch = 32.0 * (double)e->cfg.rows * (double)e->cfg.cols * (double)e->B;
+  e->prof_on = false;
   return RGBID_OK;
 }
 

@@ -47,6 +47,9 @@ void launch_error_lattice(hipStream_t s, int B, ImgB im1, ImgB im0, float* err, 
 void launch_sigma(hipStream_t s, int B, int mode, const float* err, size_t err_lane_stride, int n, SigmaIO* io, int mestimator, LaneMask m);
 // engine: lattice sampling + computeSigmaAndNuStudent for both channels of every lane, results into sp[lane]
 void launch_sigma_pair(hipStream_t s, int B, ImgB W1, ImgB W0, ImgB I1, ImgB I0, int min_nsamples, SysParams* sp, int mestimator, LaneMask m);
+// same, but W1 / I1 are produced on the fly from the current frame (fused engine path: they are never stored)
+void launch_sigma_pair_fused(hipStream_t s, int B, ImgB Wcur, ImgB W0, ImgB Icur, ImgB I0, const WarpParams* lane_wp, int interp_mode,
+                             int min_nsamples, SysParams* sp, int mestimator, LaneMask m);
 // out: device [B][3] = chi_square, chi_test, ndof
 void launch_chi_square(hipStream_t s, int B, const float* err_int, const float* err_depth, size_t err_lane_stride, int n,
                        float sigma_int, float sigma_depth, int mestimator, float* out, LaneMask m);
@@ -57,7 +60,10 @@ int system_blocks_per_lane(int rows, int cols, int B);
 // partials: device double [B][nblk][27] (size it with system_blocks_per_lane); returns the nblk used.
 // sums: device double [B][27] (packed upper-tri + b, reference order estimate_VO.cu:774-786)
 int launch_build_system(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB W1, ImgB I1,
-                        const SysParams* host_p, const SysParams* lane_p, double* partials, LaneMask m);
+                        const SysParams* host_p, const SysParams* lane_p, double* partials, LaneMask m, int level_tag = 0);
+// fused Gauss-Newton evaluation (engine): warp of the current frame + residual rows + 27-term reduction in one kernel
+int launch_gn_fused(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB Wcur, ImgB Icur,
+                    const WarpParams* lane_wp, int interp_mode, const SysParams* lane_p, double* partials, LaneMask m, int level_tag);
 void launch_reduce_system(hipStream_t s, int B, const double* partials, int nblk, double* sums, LaneMask m);
 
 }  // namespace rgbid

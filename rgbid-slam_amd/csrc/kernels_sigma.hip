@@ -8,6 +8,7 @@
 // frame), runs ALL iterations in-kernel (moments -> wave64 shuffle reduction -> LDS across 16 waves ->
 // broadcast), evaluates digamma on the device, and writes (bias, sigma, nu): one launch, no host trips.
 #include "kernels.h"
+#include "warp_device.h"
 #include <type_traits>
 
 #pragma clang fp contract(off)
@@ -315,6 +316,45 @@ void launch_sigma_pair(hipStream_t s, int B, ImgB W1, ImgB W0, ImgB I1, ImgB I0,
     hipLaunchKernelGGL(k_sigma_pair<true>, dim3(B, 2), dim3(SIG_T), 0, s, nu_table(), W1, W0, I1, I0, lr, lc, st, sp, mestimator, m);
   else
     hipLaunchKernelGGL(k_sigma_pair<false>, dim3(B, 2), dim3(SIG_T), 0, s, nu_table(), W1, W0, I1, I0, lr, lc, st, sp, mestimator, m);
+}
+
+// fused engine path: the lattice residuals are warped on the fly (W1, I1 are never materialised)
+struct FusedLatticeGetter {
+  ImgB cur_iD, cur_I, W0, I0;
+  WarpParams P;
+  int lane, lcols, stride, ch, interp_mode;
+  __device__ __forceinline__ float operator()(int i) const {
+    int y = (i / lcols) * stride, x = (i - (i / lcols) * lcols) * stride;
+    float w0 = px<float>(W0, lane, y, x);
+    float w1 = warp_invdepth_px(cur_iD, lane, x, y, w0, P);
+    if (ch == 0) return w1 - w0;
+    return warp_intensity_px(cur_I, lane, x, y, w1, P, interp_mode) - px<float>(I0, lane, y, x);
+  }
+};
+
+template <bool REG>
+__global__ __launch_bounds__(SIG_T) void k_sigma_pair_fused(NuTable T, ImgB Wcur, ImgB W0, ImgB Icur, ImgB I0, const WarpParams* wp, int interp_mode,
+                                                            int lrows, int lcols, int stride, SysParams* sp, int mestimator, LaneMask m) {
+  int lane = blockIdx.x, ch = blockIdx.y;
+  if (!m.on(lane)) return;
+  __shared__ double sm[SIG_W * 4 + 4];
+  FusedLatticeGetter g{Wcur, Icur, W0, I0, wp[lane], lane, lcols, stride, ch, interp_mode};
+  Samples<REG, FusedLatticeGetter> S(g, lrows * lcols, threadIdx.x);
+  float bias = 0.f, sigma = ch == 0 ? 0.0025f : 5.f, nu = 5.f;
+  sigma_core(S, T, 0, mestimator, bias, sigma, nu, sm);
+  if (threadIdx.x == 0) {
+    if (ch == 0) { sp[lane].bias_d = bias; sp[lane].sigma_d = sigma; sp[lane].nu_d = nu; }
+    else { sp[lane].bias_i = bias; sp[lane].sigma_i = sigma; sp[lane].nu_i = nu; }
+  }
+}
+void launch_sigma_pair_fused(hipStream_t s, int B, ImgB Wcur, ImgB W0, ImgB Icur, ImgB I0, const WarpParams* lane_wp, int interp_mode,
+                             int min_nsamples, SysParams* sp, int mestimator, LaneMask m) {
+  int n, lr, lc, st;
+  lattice_geometry(W0.rows, W0.cols, min_nsamples, &n, &lr, &lc, &st);
+  if (n <= SIG_T * SIG_MAXPT)
+    hipLaunchKernelGGL(k_sigma_pair_fused<true>, dim3(B, 2), dim3(SIG_T), 0, s, nu_table(), Wcur, W0, Icur, I0, lane_wp, interp_mode, lr, lc, st, sp, mestimator, m);
+  else
+    hipLaunchKernelGGL(k_sigma_pair_fused<false>, dim3(B, 2), dim3(SIG_T), 0, s, nu_table(), Wcur, W0, Icur, I0, lane_wp, interp_mode, lr, lc, st, sp, mestimator, m);
 }
 
 // ---- computeChiSquare sigmaFuncs.cu:1225-1297 (+ :137-150, :541-646) --------------------------------

@@ -14,6 +14,7 @@
 // by a second tiny kernel (or by the batched engine's solve kernel), so results are deterministic --
 // no floating-point atomics.  blockIdx is remapped so that the 8 XCDs each stream a contiguous slab.
 #include "kernels.h"
+#include "warp_device.h"
 
 namespace rgbid {
 
@@ -128,9 +129,17 @@ __device__ __forceinline__ int xcd_slab_block(int b, int n) {
   return (b & 7) * per + (b >> 3);
 }
 
-template <class PS, bool VEC>
+// LEVEL is only a tag: it gives each pyramid level its own kernel symbol, so profilers (rocprofv3 --stats) and the
+// benchmark's event timing report the 640x480 level-0 evaluation (unit U1 of SURVEY 8d) separately.
+// FUSED: W1 / I1 are not read from memory but produced in registers by the per-pixel inverse warps of
+// warp_device.h from the CURRENT frame's inverse-depth and intensity maps (passed in the W1 / I1 slots), with the
+// lane's WarpParams: one Gauss-Newton iteration then moves 24 B/px of keyframe maps + cache-resident gathers
+// instead of 56 B/px (12+12 for the two warp kernels, 32 for this one) and two launches disappear.
+struct FusedArgs { const WarpParams* wp; int interp_mode; };
+
+template <class PS, bool VEC, int LEVEL, bool FUSED>
 __global__ __launch_bounds__(SYS_T) void k_build_system(ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB W1, ImgB I1,
-                                                        PS ps, double* partials, int nblk, int upt, LaneMask m) {
+                                                        PS ps, double* partials, int nblk, int upt, LaneMask m, FusedArgs fa) {
   int gb = xcd_slab_block(blockIdx.x, gridDim.x);
   int lane = gb / nblk, blk = gb - lane * nblk;
   double* out = partials + ((size_t)lane * nblk + blk) * SYS_TERMS;
@@ -138,6 +147,8 @@ __global__ __launch_bounds__(SYS_T) void k_build_system(ImgB W0, ImgB I0, ImgB g
   SysParams P = ps.get(lane);
   if (P.nu_i_max) P.nu_i = fmaxf(P.nu_i, P.nu_d);
   const SysConst C = make_const(P);
+  WarpParams WP;
+  if (FUSED) WP = fa.wp[lane];
   float acc[SYS_TERMS];
 #pragma unroll
   for (int k = 0; k < SYS_TERMS; ++k) acc[k] = 0.f;
@@ -157,8 +168,16 @@ __global__ __launch_bounds__(SYS_T) void k_build_system(ImgB W0, ImgB I0, ImgB g
         float4 b = *reinterpret_cast<const float4*>(row_ptr<float>(gWy, lane, y) + x);
         float4 c = *reinterpret_cast<const float4*>(row_ptr<float>(gIx, lane, y) + x);
         float4 d = *reinterpret_cast<const float4*>(row_ptr<float>(gIy, lane, y) + x);
-        float4 w1 = *reinterpret_cast<const float4*>(row_ptr<float>(W1, lane, y) + x);
-        float4 i1 = *reinterpret_cast<const float4*>(row_ptr<float>(I1, lane, y) + x);
+        float4 w1, i1;
+        if (FUSED) {
+          w1.x = warp_invdepth_px(W1, lane, x, y, w0.x, WP);     i1.x = warp_intensity_px(I1, lane, x, y, w1.x, WP, fa.interp_mode);
+          w1.y = warp_invdepth_px(W1, lane, x + 1, y, w0.y, WP); i1.y = warp_intensity_px(I1, lane, x + 1, y, w1.y, WP, fa.interp_mode);
+          w1.z = warp_invdepth_px(W1, lane, x + 2, y, w0.z, WP); i1.z = warp_intensity_px(I1, lane, x + 2, y, w1.z, WP, fa.interp_mode);
+          w1.w = warp_invdepth_px(W1, lane, x + 3, y, w0.w, WP); i1.w = warp_intensity_px(I1, lane, x + 3, y, w1.w, WP, fa.interp_mode);
+        } else {
+          w1 = *reinterpret_cast<const float4*>(row_ptr<float>(W1, lane, y) + x);
+          i1 = *reinterpret_cast<const float4*>(row_ptr<float>(I1, lane, y) + x);
+        }
         float yf = (float)y, xf = (float)x;
         accumulate_pixel(acc, xf, yf, w0.x, i0.x, a.x, b.x, c.x, d.x, w1.x, i1.x, P, C);
         accumulate_pixel(acc, xf + 1.f, yf, w0.y, i0.y, a.y, b.y, c.y, d.y, w1.y, i1.y, P, C);
@@ -174,9 +193,11 @@ __global__ __launch_bounds__(SYS_T) void k_build_system(ImgB W0, ImgB I0, ImgB g
       int u = u0 + j * SYS_T;
       if (u < units) {
         int y = u / cols, x = u - y * cols;
-        accumulate_pixel(acc, (float)x, (float)y, px<float>(W0, lane, y, x), px<float>(I0, lane, y, x), px<float>(gWx, lane, y, x),
-                         px<float>(gWy, lane, y, x), px<float>(gIx, lane, y, x), px<float>(gIy, lane, y, x), px<float>(W1, lane, y, x),
-                         px<float>(I1, lane, y, x), P, C);
+        float w0 = px<float>(W0, lane, y, x), w1, i1;
+        if (FUSED) { w1 = warp_invdepth_px(W1, lane, x, y, w0, WP); i1 = warp_intensity_px(I1, lane, x, y, w1, WP, fa.interp_mode); }
+        else { w1 = px<float>(W1, lane, y, x); i1 = px<float>(I1, lane, y, x); }
+        accumulate_pixel(acc, (float)x, (float)y, w0, px<float>(I0, lane, y, x), px<float>(gWx, lane, y, x),
+                         px<float>(gWy, lane, y, x), px<float>(gIx, lane, y, x), px<float>(gIy, lane, y, x), w1, i1, P, C);
       }
     }
   }
@@ -204,17 +225,35 @@ int system_blocks_per_lane(int rows, int cols, int B) {
   return nb1 > nb2 ? nb1 : nb2;
 }
 
-int launch_build_system(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB W1, ImgB I1,
-                        const SysParams* hp, const SysParams* lp, double* partials, LaneMask m) {
-  bool vec = (W0.cols % 4 == 0) && vec_ok(W0) && vec_ok(I0) && vec_ok(gWx) && vec_ok(gWy) && vec_ok(gIx) && vec_ok(gIy) && vec_ok(W1) && vec_ok(I1);
+static int launch_system_impl(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB W1, ImgB I1,
+                              const SysParams* hp, const SysParams* lp, double* partials, LaneMask m, int level_tag, bool fused, FusedArgs fa) {
+  bool vec = (W0.cols % 4 == 0) && vec_ok(W0) && vec_ok(I0) && vec_ok(gWx) && vec_ok(gWy) && vec_ok(gIx) && vec_ok(gIy) && (fused || (vec_ok(W1) && vec_ok(I1)));
   int upt, nblk;
   system_plan(W0.rows, W0.cols, B, vec, &upt, &nblk);
   dim3 g(nblk * B), b(SYS_T);
-#define RGBID_SYS_LAUNCH(PSV, V) hipLaunchKernelGGL((k_build_system<decltype(PSV), V>), g, b, 0, s, W0, I0, gWx, gWy, gIx, gIy, W1, I1, PSV, partials, nblk, upt, m)
-  if (lp) { ByLane<SysParams> p{lp}; if (vec) RGBID_SYS_LAUNCH(p, true); else RGBID_SYS_LAUNCH(p, false); }
-  else { ByValue<SysParams> p{*hp}; if (vec) RGBID_SYS_LAUNCH(p, true); else RGBID_SYS_LAUNCH(p, false); }
+#define RGBID_SYS_LAUNCH(PSV, V, T, F) hipLaunchKernelGGL((k_build_system<decltype(PSV), V, T, F>), g, b, 0, s, W0, I0, gWx, gWy, gIx, gIy, W1, I1, PSV, partials, nblk, upt, m, fa)
+#define RGBID_SYS_LEVELS(PSV, V, F) do { if (level_tag == 0) RGBID_SYS_LAUNCH(PSV, V, 0, F); else if (level_tag == 1) RGBID_SYS_LAUNCH(PSV, V, 1, F); else RGBID_SYS_LAUNCH(PSV, V, 2, F); } while (0)
+  if (lp) {
+    ByLane<SysParams> p{lp};
+    if (fused) { if (vec) RGBID_SYS_LEVELS(p, true, true); else RGBID_SYS_LAUNCH(p, false, 0, true); }
+    else { if (vec) RGBID_SYS_LEVELS(p, true, false); else RGBID_SYS_LEVELS(p, false, false); }
+  } else {
+    ByValue<SysParams> p{*hp};
+    if (vec) RGBID_SYS_LEVELS(p, true, false); else RGBID_SYS_LAUNCH(p, false, 0, false);
+  }
+#undef RGBID_SYS_LEVELS
 #undef RGBID_SYS_LAUNCH
   return nblk;
+}
+
+int launch_build_system(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB W1, ImgB I1,
+                        const SysParams* hp, const SysParams* lp, double* partials, LaneMask m, int level_tag) {
+  return launch_system_impl(s, B, W0, I0, gWx, gWy, gIx, gIy, W1, I1, hp, lp, partials, m, level_tag, false, FusedArgs{nullptr, 0});
+}
+
+int launch_gn_fused(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB Wcur, ImgB Icur,
+                    const WarpParams* lane_wp, int interp_mode, const SysParams* lane_p, double* partials, LaneMask m, int level_tag) {
+  return launch_system_impl(s, B, W0, I0, gWx, gWy, gIx, gIy, Wcur, Icur, nullptr, lane_p, partials, m, level_tag, true, FusedArgs{lane_wp, interp_mode});
 }
 
 // FinalReductionKernel estimate_VO.cu:459-500 (all-double here; the reference's tree is fp32).

@@ -8,6 +8,7 @@
 // unit's 1.8 fixed-point weight quantisation available as RGBID_INTERP_TEX8 (what tex2D computes).
 // The gathers hit L2 / Infinity Cache: a warped tile's footprint in the source frame is compact.
 #include "kernels.h"
+#include "warp_device.h"
 
 // Whole file: no FMA contraction, so every fp32 expression is evaluated operation by operation exactly
 // like the scalar oracle (divisions/sqrt are IEEE by hipcc default).  These kernels are bandwidth-bound.
@@ -18,26 +19,6 @@ namespace rgbid {
 static constexpr int TX = 64, TY = 4;
 static inline dim3 grid2d(int cols, int rows, int B) { return dim3(div_up(cols, TX), div_up(rows, TY), B); }
 
-// CUDA linear filtering at unnormalised coordinates with clamp addressing
-__device__ __forceinline__ float tex2d_linear(const ImgB& src, int lane, float xs, float ys, int mode) {
-  float xB = xs - 0.5f, yB = ys - 0.5f;
-  float fx0 = floorf(xB), fy0 = floorf(yB);
-  float a = xB - fx0, b = yB - fy0;
-  if (mode == 1) {  // RGBID_INTERP_TEX8
-    a = rintf(a * 256.f) * 0.00390625f;
-    b = rintf(b * 256.f) * 0.00390625f;
-  }
-  int i0 = f2i_rd(fx0), j0 = f2i_rd(fy0);
-  int i1 = min(max(i0 + 1, 0), src.cols - 1), j1 = min(max(j0 + 1, 0), src.rows - 1);
-  i0 = min(max(i0, 0), src.cols - 1);
-  j0 = min(max(j0, 0), src.rows - 1);
-  const float* r0 = row_ptr<float>(src, lane, j0);
-  const float* r1 = row_ptr<float>(src, lane, j1);
-  float T00 = r0[i0], T10 = r0[i1], T01 = r1[i0], T11 = r1[i1];
-  float oa = 1.f - a, ob = 1.f - b;
-  return (oa * ob) * T00 + (a * ob) * T10 + (oa * b) * T01 + (a * b) * T11;
-}
-
 // ---- trafo3DKernelInvDepthGridStride (:505-546) ---------------------------------------------------
 template <class PS>
 __global__ __launch_bounds__(256) void k_warp_invdepth(ImgB src, ImgB grid, ImgB dst, PS ps, LaneMask m) {
@@ -46,21 +27,7 @@ __global__ __launch_bounds__(256) void k_warp_invdepth(ImgB src, ImgB grid, ImgB
   int x = blockIdx.x * TX + threadIdx.x, y = blockIdx.y * TY + threadIdx.y;
   if (x >= dst.cols || y >= dst.rows) return;
   const WarpParams& P = ps.get(lane);
-  float out = qnan();
-  float w = px<float>(grid, lane, y, x);
-  if (!isnan(w)) {
-    float xs, ys;
-    float w3 = register_pixel(xs, ys, x, y, w, P);
-    xs += 0.5f; ys += 0.5f;
-    if (in_bounds_rd(xs, ys, src.cols, src.rows)) {
-      float w2 = px<float>(src, lane, f2i_rd(ys), f2i_rd(xs));
-      float tz = P.t[2];
-      float v1_z = (1.f / w3 - tz) * w;
-      float res = (v1_z / (1.f - w2 * tz)) * w2;
-      if (res > 0.f) out = res;
-    }
-  }
-  px<float>(dst, lane, y, x) = out;
+  px<float>(dst, lane, y, x) = warp_invdepth_px(src, lane, x, y, px<float>(grid, lane, y, x), P);
 }
 void launch_warp_invdepth(hipStream_t s, int B, ImgB src, ImgB grid, ImgB dst, const WarpParams* hp, const WarpParams* lp, LaneMask m) {
   dim3 g = grid2d(dst.cols, dst.rows, B), b(TX, TY);
@@ -76,18 +43,7 @@ __global__ __launch_bounds__(256) void k_warp_intensity(ImgB src, ImgB grid, Img
   int x = blockIdx.x * TX + threadIdx.x, y = blockIdx.y * TY + threadIdx.y;
   if (x >= dst.cols || y >= dst.rows) return;
   const WarpParams& P = ps.get(lane);
-  float res = qnan();
-  float w = px<float>(grid, lane, y, x);
-  if (!isnan(w)) {
-    float xs, ys;
-    register_pixel(xs, ys, x, y, w, P);
-    xs += 0.5f; ys += 0.5f;
-    if (in_bounds_rd(xs, ys, src.cols, src.rows)) {
-      res = tex2d_linear(src, lane, xs, ys, interp_mode);
-      res = fmaxf(0.f, fminf(res, 255.f));  // NaN -> 255, as CUDA's min/max
-    }
-  }
-  px<float>(dst, lane, y, x) = res;
+  px<float>(dst, lane, y, x) = warp_intensity_px(src, lane, x, y, px<float>(grid, lane, y, x), P, interp_mode);
 }
 void launch_warp_intensity(hipStream_t s, int B, ImgB src, ImgB grid, ImgB dst, const WarpParams* hp, const WarpParams* lp, int interp_mode, LaneMask m) {
   dim3 g = grid2d(dst.cols, dst.rows, B), b(TX, TY);
@@ -155,36 +111,48 @@ void launch_integrate_warped(hipStream_t s, int B, ImgB warped, ImgB wweight, Im
 }
 
 // ---- partialVisibility(WithOverlapMask)Kernel (:297-437) -----------------------------------------
-// The reference reduces float counters through shared memory + a second kernel + a per-call malloc;
-// here each wave ballots its predicate, popcounts and issues one integer atomic per counter.
+// The reference reduces float counters through shared memory + a second kernel + a per-call malloc.
+// Here a workgroup sweeps a 64 x 32 pixel strip; every wave ballots its predicates, popcounts into scalar
+// registers, the four waves meet in LDS and the workgroup issues ONE integer atomic per counter
+// (150 atomics per counter for a 640x480 lane: no contention, exact integer counts).
+static constexpr int VIS_ROWS = 32;
 template <class PS>
 __global__ __launch_bounds__(256) void k_visibility(ImgB src, ImgB dst, ImgB mask, PS ps, unsigned int* counts, LaneMask m) {
   int lane = blockIdx.z;
   if (!m.on(lane)) return;
-  int x = blockIdx.x * TX + threadIdx.x, y = blockIdx.y * TY + threadIdx.y;
-  bool valid = false, visible = false;
-  if (x < src.cols && y < src.rows) {
-    float w = px<float>(src, lane, y, x);
-    if (!isnan(w)) {
-      const WarpParams& P = ps.get(lane);
-      float xd, yd;
-      float w_dst = register_pixel(xd, yd, x, y, w, P);
-      valid = true;
-      if ((xd > 0) && (xd < (float)(src.cols - 1)) && (yd > 0) && (yd < (float)(src.rows - 1))) {
-        int xi = f2i_rn(xd), yi = f2i_rn(yd);
-        if (fabsf(w_dst - px<float>(dst, lane, yi, xi)) < 0.020f) visible = true;
+  __shared__ unsigned int sm[2][4];
+  const WarpParams P = ps.get(lane);
+  int x = blockIdx.x * TX + threadIdx.x;
+  unsigned int nvis = 0, nval = 0;
+  for (int yy = threadIdx.y; yy < VIS_ROWS; yy += TY) {
+    int y = blockIdx.y * VIS_ROWS + yy;
+    bool valid = false, visible = false;
+    if (x < src.cols && y < src.rows) {
+      float w = px<float>(src, lane, y, x);
+      if (!isnan(w)) {
+        float xd, yd;
+        float w_dst = register_pixel(xd, yd, x, y, w, P);
+        valid = true;
+        if ((xd > 0) && (xd < (float)(src.cols - 1)) && (yd > 0) && (yd < (float)(src.rows - 1))) {
+          int xi = f2i_rn(xd), yi = f2i_rn(yd);
+          if (fabsf(w_dst - px<float>(dst, lane, yi, xi)) < 0.020f) visible = true;
+        }
+        if (mask.base) px<uint8_t>(mask, lane, y, x) = visible ? 1 : 0;
       }
-      if (mask.base) px<uint8_t>(mask, lane, y, x) = visible ? 1 : 0;
     }
+    nvis += (unsigned int)__popcll(__ballot(visible));  // wave-uniform
+    nval += (unsigned int)__popcll(__ballot(valid));
   }
-  unsigned long long bv = __ballot(valid), bs = __ballot(visible);
-  if (threadIdx.x == 0) {  // lane 0 of each wave (TX == 64)
-    if (bs) atomicAdd(&counts[2 * lane + 0], (unsigned int)__popcll(bs));
-    if (bv) atomicAdd(&counts[2 * lane + 1], (unsigned int)__popcll(bv));
+  if (threadIdx.x == 0) { sm[0][threadIdx.y] = nvis; sm[1][threadIdx.y] = nval; }  // one wave per threadIdx.y (TX == 64)
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0) {
+    unsigned int a = sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3], b = sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3];
+    if (a) atomicAdd(&counts[2 * lane + 0], a);
+    if (b) atomicAdd(&counts[2 * lane + 1], b);
   }
 }
 void launch_visibility(hipStream_t s, int B, ImgB src, ImgB dst, ImgB mask, const WarpParams* hp, const WarpParams* lp, unsigned int* counts, LaneMask m) {
-  dim3 g = grid2d(src.cols, src.rows, B), b(TX, TY);
+  dim3 g(div_up(src.cols, TX), div_up(src.rows, VIS_ROWS), B), b(TX, TY);
   if (lp) hipLaunchKernelGGL(k_visibility<ByLane<WarpParams>>, g, b, 0, s, src, dst, mask, ByLane<WarpParams>{lp}, counts, m);
   else hipLaunchKernelGGL(k_visibility<ByValue<WarpParams>>, g, b, 0, s, src, dst, mask, ByValue<WarpParams>{*hp}, counts, m);
 }

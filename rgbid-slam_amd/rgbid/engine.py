@@ -98,6 +98,15 @@ class Engine:
         check(self.L.rgbid_engine_read_records(self._h, int(first_step), int(n), out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def profile_begin(self, max_launches):
+        check(self.L.rgbid_engine_profile_begin(self._h, int(max_launches)))
+
+    def profile_end(self):
+        """-> (total_ms, n_launches, bytes_per_launch) of the level-0 residual + normal-equation kernel."""
+        t, n, b = C.c_double(), C.c_int(), C.c_double()
+        check(self.L.rgbid_engine_profile_end(self._h, C.byref(t), C.byref(n), C.byref(b)))
+        return t.value, n.value, b.value
+
     def bytes(self):
         b = C.c_size_t()
         check(self.L.rgbid_engine_bytes(self._h, C.byref(b)))

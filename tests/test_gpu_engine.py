@@ -34,7 +34,7 @@ def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph):
     for k in range(n_frames):
         eng.step(depth[k], rgb[k])
     rec = eng.records()
-    okw = dict(cfg_kw)
+    okw = {k: v for k, v in cfg_kw.items() if k != "fused_gn"}
     okw.update(rows=rows, cols=cols, fx=K[0], fy=K[1], cx=K[2], cy=K[3])
     worst_r = worst_t = 0.0
     for l in range(n_lanes):
@@ -88,6 +88,27 @@ def test_engine_vs_oracle_small(ctx, use_graph):
     K = (K[0], K[1], (synth.TUM_K[2] + 0.5) / 4 - 0.5, (synth.TUM_K[3] + 0.5) / 4 - 0.5)
     wr, wt = run_case(ctx, 120, 160, K, n_lanes=3, n_frames=7, cfg_kw=dict(), seq_kw=dict(trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8)), use_graph=use_graph)
     print("worst pose deviation engine vs oracle:", wr, wt)
+
+
+def test_engine_fused_gn_is_bit_identical(ctx):
+    """The fused warp+residual+JTJ kernel computes W1/I1 with the same per-pixel device functions and accumulates in the
+    same per-thread order as the unfused kernels: poses must be IDENTICAL, not merely close."""
+    K = (131.25, 131.25, 79.5, 59.5)
+    seqs, depth, rgb = make_lanes(3, 6, 120, 160, K, trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8))
+    recs = []
+    for fused in (0, 1):
+        eng = E.Engine(ctx, E.default_config(rows=120, cols=160, lanes=3, K=K, use_graph=0, fused_gn=fused, record_capacity=6))
+        for k in range(6):
+            eng.step(depth[k], rgb[k])
+        recs.append(eng.records())
+        eng.close()
+    for name in ("R", "t", "odo_cov", "status", "nu_int", "sigma_depthinv", "vis_odo"):
+        assert np.array_equal(recs[0][name], recs[1][name]), name
+
+
+def test_engine_fused_vs_oracle_full_res(ctx):
+    wr, wt = run_case(ctx, 480, 640, synth.TUM_K, n_lanes=2, n_frames=4, cfg_kw=dict(fused_gn=1), seq_kw=dict(), use_graph=1)
+    print("worst pose deviation fused engine vs oracle (640x480):", wr, wt)
 
 
 def test_engine_keyframe_switches(ctx):
