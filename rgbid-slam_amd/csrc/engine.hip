@@ -566,10 +566,9 @@ int enqueue_step(rgbid_engine* e, hipStream_t s) {
                                   e->sp, c.mestimator, M(f.gn));
           e->launches++;
         }
-        if (prof) hipEventRecord(e->prof_ev[e->prof_used++], s);
+        if (prof) { set_system_kernel_events(e->prof_ev[e->prof_used], e->prof_ev[e->prof_used + 1]); e->prof_used += 2; }
         nblk = launch_gn_fused(s, B, e->iD_kf[level], e->I_kf[level], e->gxD[level], e->gyD[level], e->gxI[level], e->gyI[level],
                                e->iD_curr[level], e->I_curr[level], e->wp, c.interp_mode, e->sp, e->partials, M(f.gn), level < 2 ? level : 2);
-        if (prof) hipEventRecord(e->prof_ev[e->prof_used++], s);
       } else {
         launch_warp_invdepth(s, B, e->iD_curr[level], e->iD_kf[level], e->wiD[level], nullptr, e->wp, M(f.gn));
         launch_warp_intensity(s, B, e->I_curr[level], e->wiD[level], e->wI[level], nullptr, e->wp, c.interp_mode, M(f.gn));
@@ -578,10 +577,9 @@ int enqueue_step(rgbid_engine* e, hipStream_t s) {
           launch_sigma_pair(s, B, e->wiD[level], e->iD_kf[level], e->wI[level], e->I_kf[level], c.nsamples, e->sp, c.mestimator, M(f.gn));
           e->launches++;
         }
-        if (prof) hipEventRecord(e->prof_ev[e->prof_used++], s);
+        if (prof) { set_system_kernel_events(e->prof_ev[e->prof_used], e->prof_ev[e->prof_used + 1]); e->prof_used += 2; }
         nblk = launch_build_system(s, B, e->iD_kf[level], e->I_kf[level], e->gxD[level], e->gyD[level], e->gxI[level], e->gyI[level],
                                    e->wiD[level], e->wI[level], nullptr, e->sp, e->partials, M(f.gn), level < 2 ? level : 2);
-        if (prof) hipEventRecord(e->prof_ev[e->prof_used++], s);
       }
       hipLaunchKernelGGL(k_solve_update, dim3(B), dim3(256), 0, s, e->partials, nblk, e->state, f, e->wp, sc, next_level);
       e->launches += 2;
@@ -595,18 +593,16 @@ int enqueue_step(rgbid_engine* e, hipStream_t s) {
     bool fuse_cov = c.fused_gn && !c.chi_square_stats;  // the chi-square statistics need W1 / I1 in memory
     int nblk;
     if (fuse_cov) {
-      if (prof) hipEventRecord(e->prof_ev[e->prof_used++], s);
+      if (prof) { set_system_kernel_events(e->prof_ev[e->prof_used], e->prof_ev[e->prof_used + 1]); e->prof_used += 2; }
       nblk = launch_gn_fused(s, B, e->iD_kf[fl], e->I_kf[fl], e->gxD_c[fl], e->gyD_c[fl], e->gxI_c[fl], e->gyI_c[fl],
                              e->iD_curr[fl], e->I_curr[fl], e->wp, c.interp_mode, e->sp, e->partials, M(f.gn), fl < 2 ? fl : 2);
-      if (prof) hipEventRecord(e->prof_ev[e->prof_used++], s);
       e->launches += 2;
     } else {
       launch_warp_invdepth(s, B, e->iD_curr[fl], e->iD_kf[fl], e->wiD[fl], nullptr, e->wp, M(f.gn));
       launch_warp_intensity(s, B, e->I_curr[fl], e->wiD[fl], e->wI[fl], nullptr, e->wp, c.interp_mode, M(f.gn));
-      if (prof) hipEventRecord(e->prof_ev[e->prof_used++], s);
+      if (prof) { set_system_kernel_events(e->prof_ev[e->prof_used], e->prof_ev[e->prof_used + 1]); e->prof_used += 2; }
       nblk = launch_build_system(s, B, e->iD_kf[fl], e->I_kf[fl], e->gxD_c[fl], e->gyD_c[fl], e->gxI_c[fl], e->gyI_c[fl],
                                  e->wiD[fl], e->wI[fl], nullptr, e->sp, e->partials, M(f.gn), fl < 2 ? fl : 2);
-      if (prof) hipEventRecord(e->prof_ev[e->prof_used++], s);
       e->launches += 4;
     }
     if (c.chi_square_stats) {  // :1411-1415 (results unused by the reference)
@@ -835,8 +831,7 @@ int rgbid_engine_profile_begin(rgbid_engine* e, int max_launches) {
   while ((int)e->prof_ev.size() < 2 * max_launches) {
     hipEvent_t ev;
     // no system-scope fence around the timed kernel: the events only order against work on this stream
-    hipError_t he = hipEventCreateWithFlags(&ev, hipEventDisableSystemFence);
-    if (he != hipSuccess) he = hipEventCreate(&ev);
+    hipError_t he = hipEventCreate(&ev);
     if (he != hipSuccess) return (int)he;
     e->prof_ev.push_back(ev);
   }

@@ -64,6 +64,8 @@ int launch_build_system(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB g
 // fused Gauss-Newton evaluation (engine): warp of the current frame + residual rows + 27-term reduction in one kernel
 int launch_gn_fused(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB Wcur, ImgB Icur,
                     const WarpParams* lane_wp, int interp_mode, const SysParams* lane_p, double* partials, LaneMask m, int level_tag);
+// the next launch_build_system / launch_gn_fused on this host thread is bracketed by these events (kernel duration)
+void set_system_kernel_events(hipEvent_t start, hipEvent_t stop);
 void launch_reduce_system(hipStream_t s, int B, const double* partials, int nblk, double* sums, LaneMask m);
 
 }  // namespace rgbid

@@ -326,9 +326,9 @@ struct FusedLatticeGetter {
   __device__ __forceinline__ float operator()(int i) const {
     int y = (i / lcols) * stride, x = (i - (i / lcols) * lcols) * stride;
     float w0 = px<float>(W0, lane, y, x);
-    float w1 = warp_invdepth_px(cur_iD, lane, x, y, w0, P);
+    float w1 = warp_invdepth_px(FMap(cur_iD, lane), x, y, w0, P);
     if (ch == 0) return w1 - w0;
-    return warp_intensity_px(cur_I, lane, x, y, w1, P, interp_mode) - px<float>(I0, lane, y, x);
+    return warp_intensity_px(FMap(cur_I, lane), x, y, w1, P, interp_mode) - px<float>(I0, lane, y, x);
   }
 };
 

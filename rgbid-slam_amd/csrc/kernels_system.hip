@@ -15,6 +15,7 @@
 // no floating-point atomics.  blockIdx is remapped so that the 8 XCDs each stream a contiguous slab.
 #include "kernels.h"
 #include "warp_device.h"
+#include <hip/hip_ext.h>
 
 namespace rgbid {
 
@@ -22,7 +23,7 @@ static constexpr int SYS_T = 256;
 static constexpr float TH_HUBER = 1.345f, TH_TUKEY = 4.685f, STUDENT_DOF = 5.f;
 
 struct SysConst {  // per-thread derived constants
-  float inv_fx, inv_fy, inv_sd, inv_si, be_d, be_i, wmul_d, wmul_i;
+  float inv_fx, inv_fy, cx_f, cy_f, inv_sd, inv_si, be_d, be_i, wmul_d, wmul_i, nud1, nui1;
 };
 
 __device__ __forceinline__ float m_weight(float e, int mest) {  // computeWeight estimate_VO.cu:141-167
@@ -35,53 +36,54 @@ __device__ __forceinline__ float m_weight(float e, int mest) {  // computeWeight
   return weight;
 }
 
-// one pixel: invDepthConstraint (:214-262) + intensityConstraint (:176-212) + the 27-term update (:408-418)
-__device__ __forceinline__ void accumulate_pixel(float acc[SYS_TERMS], float xf, float yf, float w0, float i0, float gwx, float gwy,
+// One pixel: invDepthConstraint (:214-262) + intensityConstraint (:176-212) + the 27-term update (:408-418).
+// Written as explicit FMAs with shared sub-expressions (about 150 VALU operations per pixel; the naive
+// `acc += a*J + d*J'` costs three operations per term without fast-math reassociation).  Invalid constraints
+// are neutralised by sanitising their INPUTS (so every row entry stays finite) and zeroing their weight: they
+// contribute exactly 0, as in the reference (weight 0 times a stale finite row).
+__device__ __forceinline__ void accumulate_pixel(float acc[SYS_TERMS], float px_, float py_, float pp_y, float w0, float i0, float gwx, float gwy,
                                                  float gix, float giy, float w1, float i1, const SysParams& P, const SysConst& C) {
-  float px_ = (xf - P.cx) * C.inv_fx, py_ = (yf - P.cy) * C.inv_fy;
+  const bool v0 = !isnan(w0);
+  const bool vd = v0 && !(isnan(w1) || isnan(gwx) || isnan(gwy));
+  const bool vi = v0 && !(isnan(i0) || isnan(i1) || isnan(gix) || isnan(giy));
+  w0 = v0 ? w0 : 1.f;
+  w1 = vd ? w1 : w0; gwx = vd ? gwx : 0.f; gwy = vd ? gwy : 0.f;
+  i1 = vi ? i1 : 0.f; i0 = vi ? i0 : 0.f; gix = vi ? gix : 0.f; giy = vi ? giy : 0.f;
   // ---- inverse-depth row
-  bool vd = !(isnan(w0) || isnan(w1) || isnan(gwx) || isnan(gwy));
   float gx = gwx * P.fx, gy = gwy * P.fy;
-  float gz = -(gx * px_ + gy * py_);
+  float gz = -fmaf(gx, px_, gy * py_);
   float iw0 = __builtin_amdgcn_rcpf(w0);
-  float nx = gx * iw0, ny = gy * iw0, nz = gz * iw0 + 1.f;
-  float ndp = nx * px_ + ny * py_ + nz;                               // n . p   (p.z = 1)
-  float nn = nx * nx + ny * ny + nz * nz, pp = px_ * px_ + py_ * py_ + 1.f;
+  float nx = gx * iw0, ny = gy * iw0, nz = fmaf(gz, iw0, 1.f);
+  float ndp = fmaf(nx, px_, fmaf(ny, py_, nz));                        // n . p   (p.z = 1)
+  float nn = fmaf(nx, nx, fmaf(ny, ny, nz * nz)), pp = fmaf(px_, px_, pp_y);
   float nfac = fabsf(ndp) * __builtin_amdgcn_rsqf(nn * pp);            // |n^ . p^|
+  float sd0 = w0 * C.inv_sd, gz1 = gz + w1;
   float Jd[6];
-  Jd[0] = gx * w0 * C.inv_sd;
-  Jd[1] = gy * w0 * C.inv_sd;
-  Jd[2] = (gz * w0 + w0 * w1) * C.inv_sd;
-  float gz1 = gz + w1;
-  Jd[3] = (gz1 * py_ - gy) * C.inv_sd;                                 // -(g x p).x
-  Jd[4] = (gx - gz1 * px_) * C.inv_sd;
-  Jd[5] = (gy * px_ - gx * py_) * C.inv_sd;
-  float ed = -(w1 - w0) * C.inv_sd;
+  Jd[0] = gx * sd0;
+  Jd[1] = gy * sd0;
+  Jd[2] = gz1 * sd0;                                                   // (gz*w0 + w0*w1)/sigma
+  Jd[3] = fmaf(gz1, py_, -gy) * C.inv_sd;                              // -(g' x p)
+  Jd[4] = fmaf(-gz1, px_, gx) * C.inv_sd;
+  Jd[5] = fmaf(gy, px_, -(gx * py_)) * C.inv_sd;
+  float ed = (w0 - w1) * C.inv_sd;
   float eu = ed - C.be_d;
-  float wd = P.student_nu ? (P.nu_d + 1.f) * __builtin_amdgcn_rcpf(P.nu_d + eu * eu) : m_weight(eu, P.mestimator);
-  wd *= C.wmul_d;
+  float wd = P.student_nu ? C.nud1 * __builtin_amdgcn_rcpf(fmaf(eu, eu, P.nu_d)) : m_weight(eu, P.mestimator);
+  wd = vd ? wd * C.wmul_d : 0.f;
   // ---- intensity row
-  bool vi = !(isnan(w0) || isnan(i0) || isnan(i1) || isnan(gix) || isnan(giy));
   float hx = gix * P.fx, hy = giy * P.fy;
-  float hz = -(hx * px_ + hy * py_);
+  float hz = -fmaf(hx, px_, hy * py_);
+  float si0 = w0 * C.inv_si;
   float Ji[6];
-  Ji[0] = hx * w0 * C.inv_si;
-  Ji[1] = hy * w0 * C.inv_si;
-  Ji[2] = hz * w0 * C.inv_si;
-  Ji[3] = (hz * py_ - hy) * C.inv_si;
-  Ji[4] = (hx - hz * px_) * C.inv_si;
-  Ji[5] = (hy * px_ - hx * py_) * C.inv_si;
-  float ei = -(i1 - i0) * C.inv_si;
+  Ji[0] = hx * si0;
+  Ji[1] = hy * si0;
+  Ji[2] = hz * si0;
+  Ji[3] = fmaf(hz, py_, -hy) * C.inv_si;
+  Ji[4] = fmaf(-hz, px_, hx) * C.inv_si;
+  Ji[5] = fmaf(hy, px_, -(hx * py_)) * C.inv_si;
+  float ei = (i0 - i1) * C.inv_si;
   float eiu = ei - C.be_i;
-  float wi = P.student_nu ? (P.nu_i + 1.f) * __builtin_amdgcn_rcpf(P.nu_i + eiu * eiu) : m_weight(eiu, P.mestimator);
-  wi *= C.wmul_i;
-  // invalid constraints contribute exactly nothing (reference: weight 0 times a stale finite row)
-  if (!vd) { wd = 0.f; nfac = 0.f; ed = 0.f;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) Jd[k] = 0.f; }
-  if (!vi) { wi = 0.f; ei = 0.f;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) Ji[k] = 0.f; }
+  float wi = P.student_nu ? C.nui1 * __builtin_amdgcn_rcpf(fmaf(eiu, eiu, P.nu_i)) : m_weight(eiu, P.mestimator);
+  wi = vi ? wi * C.wmul_i : 0.f;
   if (P.weighting == 1) wi = fminf(wd, wi);  // MIN_WEIGHT (:403-406)
   float sd = nfac * wd;
   int s = 0;
@@ -89,18 +91,20 @@ __device__ __forceinline__ void accumulate_pixel(float acc[SYS_TERMS], float xf,
   for (int r = 0; r < 6; ++r) {
     float a = wi * Ji[r], d = sd * Jd[r];
 #pragma unroll
-    for (int c = r; c < 6; ++c) acc[s++] += a * Ji[c] + d * Jd[c];
-    acc[s++] += a * ei + d * ed;
+    for (int c = r; c < 6; ++c) { acc[s] = fmaf(a, Ji[c], acc[s]); acc[s] = fmaf(d, Jd[c], acc[s]); ++s; }
+    acc[s] = fmaf(a, ei, acc[s]); acc[s] = fmaf(d, ed, acc[s]); ++s;
   }
 }
 
 __device__ __forceinline__ SysConst make_const(const SysParams& P) {
   SysConst C;
   C.inv_fx = 1.f / P.fx; C.inv_fy = 1.f / P.fy;
+  C.cx_f = P.cx; C.cy_f = P.cy;
   C.inv_sd = 1.f / P.sigma_d; C.inv_si = 1.f / P.sigma_i;
   C.be_d = P.bias_d / P.sigma_d; C.be_i = P.bias_i / P.sigma_i;
   C.wmul_d = (float)(1 - (P.weighting == 3));  // PHOT_ONLY
   C.wmul_i = (float)(1 - (P.weighting == 2));  // GEOM_ONLY
+  C.nud1 = P.nu_d + 1.f; C.nui1 = P.nu_i + 1.f;
   return C;
 }
 
@@ -122,6 +126,17 @@ __device__ __forceinline__ void block_reduce_store(float acc[SYS_TERMS], double*
   }
 }
 
+// 16-byte streaming load: every map is read exactly once per launch, so bypass-friendly (non-temporal) loads
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream4(const float* p) {
+#ifdef RGBID_SYS_NT_LOADS
+  f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *reinterpret_cast<const float4*>(p);
+#endif
+}
+
 // XCD-aware logical block id: hardware places block b on XCD b % 8; give every XCD a contiguous slab
 __device__ __forceinline__ int xcd_slab_block(int b, int n) {
   int per = n >> 3;
@@ -137,6 +152,11 @@ __device__ __forceinline__ int xcd_slab_block(int b, int n) {
 // instead of 56 B/px (12+12 for the two warp kernels, 32 for this one) and two launches disappear.
 struct FusedArgs { const WarpParams* wp; int interp_mode; };
 
+// optional event pair that brackets exactly the next normal-equation kernel dispatch (hipExtLaunchKernelGGL:
+// the events carry the dispatch's own start / end timestamps, i.e. the kernel duration a profiler reports)
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+void set_system_kernel_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = start; g_ev_stop = stop; }
+
 template <class PS, bool VEC, int LEVEL, bool FUSED>
 __global__ __launch_bounds__(SYS_T) void k_build_system(ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB W1, ImgB I1,
                                                         PS ps, double* partials, int nblk, int upt, LaneMask m, FusedArgs fa) {
@@ -149,6 +169,7 @@ __global__ __launch_bounds__(SYS_T) void k_build_system(ImgB W0, ImgB I0, ImgB g
   const SysConst C = make_const(P);
   WarpParams WP;
   if (FUSED) WP = fa.wp[lane];
+  const FMap Wc(W1, lane), Ic(I1, lane);  // FUSED: the current frame's maps travel in the W1 / I1 slots
   float acc[SYS_TERMS];
 #pragma unroll
   for (int k = 0; k < SYS_TERMS; ++k) acc[k] = 0.f;
@@ -162,27 +183,28 @@ __global__ __launch_bounds__(SYS_T) void k_build_system(ImgB W0, ImgB I0, ImgB g
       int u = u0 + j * SYS_T;
       if (u < units) {
         int y = u / upr, x = (u - y * upr) << 2;
-        float4 w0 = *reinterpret_cast<const float4*>(row_ptr<float>(W0, lane, y) + x);
-        float4 i0 = *reinterpret_cast<const float4*>(row_ptr<float>(I0, lane, y) + x);
-        float4 a = *reinterpret_cast<const float4*>(row_ptr<float>(gWx, lane, y) + x);
-        float4 b = *reinterpret_cast<const float4*>(row_ptr<float>(gWy, lane, y) + x);
-        float4 c = *reinterpret_cast<const float4*>(row_ptr<float>(gIx, lane, y) + x);
-        float4 d = *reinterpret_cast<const float4*>(row_ptr<float>(gIy, lane, y) + x);
+        float4 w0 = ld_stream4(row_ptr<float>(W0, lane, y) + x);
+        float4 i0 = ld_stream4(row_ptr<float>(I0, lane, y) + x);
+        float4 a = ld_stream4(row_ptr<float>(gWx, lane, y) + x);
+        float4 b = ld_stream4(row_ptr<float>(gWy, lane, y) + x);
+        float4 c = ld_stream4(row_ptr<float>(gIx, lane, y) + x);
+        float4 d = ld_stream4(row_ptr<float>(gIy, lane, y) + x);
         float4 w1, i1;
         if (FUSED) {
-          w1.x = warp_invdepth_px(W1, lane, x, y, w0.x, WP);     i1.x = warp_intensity_px(I1, lane, x, y, w1.x, WP, fa.interp_mode);
-          w1.y = warp_invdepth_px(W1, lane, x + 1, y, w0.y, WP); i1.y = warp_intensity_px(I1, lane, x + 1, y, w1.y, WP, fa.interp_mode);
-          w1.z = warp_invdepth_px(W1, lane, x + 2, y, w0.z, WP); i1.z = warp_intensity_px(I1, lane, x + 2, y, w1.z, WP, fa.interp_mode);
-          w1.w = warp_invdepth_px(W1, lane, x + 3, y, w0.w, WP); i1.w = warp_intensity_px(I1, lane, x + 3, y, w1.w, WP, fa.interp_mode);
+          w1.x = warp_invdepth_px(Wc, x, y, w0.x, WP);     i1.x = warp_intensity_px(Ic, x, y, w1.x, WP, fa.interp_mode);
+          w1.y = warp_invdepth_px(Wc, x + 1, y, w0.y, WP); i1.y = warp_intensity_px(Ic, x + 1, y, w1.y, WP, fa.interp_mode);
+          w1.z = warp_invdepth_px(Wc, x + 2, y, w0.z, WP); i1.z = warp_intensity_px(Ic, x + 2, y, w1.z, WP, fa.interp_mode);
+          w1.w = warp_invdepth_px(Wc, x + 3, y, w0.w, WP); i1.w = warp_intensity_px(Ic, x + 3, y, w1.w, WP, fa.interp_mode);
         } else {
-          w1 = *reinterpret_cast<const float4*>(row_ptr<float>(W1, lane, y) + x);
-          i1 = *reinterpret_cast<const float4*>(row_ptr<float>(I1, lane, y) + x);
+          w1 = ld_stream4(row_ptr<float>(W1, lane, y) + x);
+          i1 = ld_stream4(row_ptr<float>(I1, lane, y) + x);
         }
-        float yf = (float)y, xf = (float)x;
-        accumulate_pixel(acc, xf, yf, w0.x, i0.x, a.x, b.x, c.x, d.x, w1.x, i1.x, P, C);
-        accumulate_pixel(acc, xf + 1.f, yf, w0.y, i0.y, a.y, b.y, c.y, d.y, w1.y, i1.y, P, C);
-        accumulate_pixel(acc, xf + 2.f, yf, w0.z, i0.z, a.z, b.z, c.z, d.z, w1.z, i1.z, P, C);
-        accumulate_pixel(acc, xf + 3.f, yf, w0.w, i0.w, a.w, b.w, c.w, d.w, w1.w, i1.w, P, C);
+        float py_ = ((float)y - C.cy_f) * C.inv_fy, pp_y = fmaf(py_, py_, 1.f);
+        float px0 = ((float)x - C.cx_f) * C.inv_fx;
+        accumulate_pixel(acc, px0, py_, pp_y, w0.x, i0.x, a.x, b.x, c.x, d.x, w1.x, i1.x, P, C);
+        accumulate_pixel(acc, px0 + C.inv_fx, py_, pp_y, w0.y, i0.y, a.y, b.y, c.y, d.y, w1.y, i1.y, P, C);
+        accumulate_pixel(acc, fmaf(2.f, C.inv_fx, px0), py_, pp_y, w0.z, i0.z, a.z, b.z, c.z, d.z, w1.z, i1.z, P, C);
+        accumulate_pixel(acc, fmaf(3.f, C.inv_fx, px0), py_, pp_y, w0.w, i0.w, a.w, b.w, c.w, d.w, w1.w, i1.w, P, C);
       }
     }
   } else {
@@ -194,9 +216,10 @@ __global__ __launch_bounds__(SYS_T) void k_build_system(ImgB W0, ImgB I0, ImgB g
       if (u < units) {
         int y = u / cols, x = u - y * cols;
         float w0 = px<float>(W0, lane, y, x), w1, i1;
-        if (FUSED) { w1 = warp_invdepth_px(W1, lane, x, y, w0, WP); i1 = warp_intensity_px(I1, lane, x, y, w1, WP, fa.interp_mode); }
+        if (FUSED) { w1 = warp_invdepth_px(Wc, x, y, w0, WP); i1 = warp_intensity_px(Ic, x, y, w1, WP, fa.interp_mode); }
         else { w1 = px<float>(W1, lane, y, x); i1 = px<float>(I1, lane, y, x); }
-        accumulate_pixel(acc, (float)x, (float)y, w0, px<float>(I0, lane, y, x), px<float>(gWx, lane, y, x),
+        float py_ = ((float)y - C.cy_f) * C.inv_fy, pp_y = fmaf(py_, py_, 1.f);
+        accumulate_pixel(acc, ((float)x - C.cx_f) * C.inv_fx, py_, pp_y, w0, px<float>(I0, lane, y, x), px<float>(gWx, lane, y, x),
                          px<float>(gWy, lane, y, x), px<float>(gIx, lane, y, x), px<float>(gIy, lane, y, x), w1, i1, P, C);
       }
     }
@@ -206,15 +229,22 @@ __global__ __launch_bounds__(SYS_T) void k_build_system(ImgB W0, ImgB I0, ImgB g
 
 static inline bool vec_ok(const ImgB& a) { return ((a.pitch & 15) == 0) && ((a.lane_stride & 15) == 0) && ((((uintptr_t)a.base) & 15) == 0); }
 
-// launch plan: units per thread (upt) and blocks per lane
+// launch plan: units per thread (upt) and workgroups per lane.  The grid is sized to whole "rounds" of the
+// chip's resident capacity (256 CUs x 5 workgroups of 4 waves at <=102 VGPRs) so there is no partially
+// filled tail round; a thread's fp32 partial sums run over at most 16 units (64 px).
 static void system_plan(int rows, int cols, int B, bool vec, int* upt, int* nblk) {
-  long long units = vec ? (long long)rows * (cols / 4) : (long long)rows * cols;
-  int u = 1;
-  // grow the per-thread run while the launch still has >= 2048 workgroups (8 per CU); cap at 8 units
-  // (32 px) so the per-thread fp32 partial sums stay short
-  while (u < (vec ? 8 : 32) && (units * B) / ((long long)SYS_T * (u * 2)) >= 2048) u *= 2;
-  *upt = u;
-  *nblk = (int)((units + (long long)SYS_T * u - 1) / ((long long)SYS_T * u));
+  const long long units = vec ? (long long)rows * (cols / 4) : (long long)rows * cols;
+  const long long capacity = 256LL * 5;                      // resident workgroups
+  const long long max_upt = vec ? 16 : 64;
+  long long rounds = (units * B + capacity * SYS_T * max_upt - 1) / (capacity * SYS_T * max_upt);
+  long long nb = (rounds * capacity) / B;                    // workgroups per lane
+  long long nb_max = (units + SYS_T - 1) / SYS_T;
+  if (nb < 1) nb = 1;
+  if (nb > nb_max) nb = nb_max;
+  long long u = (units + nb * SYS_T - 1) / (nb * SYS_T);
+  nb = (units + u * SYS_T - 1) / (u * SYS_T);                // drop workgroups that would get no unit
+  *upt = (int)u;
+  *nblk = (int)nb;
 }
 
 int system_blocks_per_lane(int rows, int cols, int B) {
@@ -231,7 +261,7 @@ static int launch_system_impl(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, 
   int upt, nblk;
   system_plan(W0.rows, W0.cols, B, vec, &upt, &nblk);
   dim3 g(nblk * B), b(SYS_T);
-#define RGBID_SYS_LAUNCH(PSV, V, T, F) hipLaunchKernelGGL((k_build_system<decltype(PSV), V, T, F>), g, b, 0, s, W0, I0, gWx, gWy, gIx, gIy, W1, I1, PSV, partials, nblk, upt, m, fa)
+#define RGBID_SYS_LAUNCH(PSV, V, T, F) hipExtLaunchKernelGGL((k_build_system<decltype(PSV), V, T, F>), g, b, 0, s, g_ev_start, g_ev_stop, 0, W0, I0, gWx, gWy, gIx, gIy, W1, I1, PSV, partials, nblk, upt, m, fa)
 #define RGBID_SYS_LEVELS(PSV, V, F) do { if (level_tag == 0) RGBID_SYS_LAUNCH(PSV, V, 0, F); else if (level_tag == 1) RGBID_SYS_LAUNCH(PSV, V, 1, F); else RGBID_SYS_LAUNCH(PSV, V, 2, F); } while (0)
   if (lp) {
     ByLane<SysParams> p{lp};
@@ -243,6 +273,7 @@ static int launch_system_impl(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, 
   }
 #undef RGBID_SYS_LEVELS
 #undef RGBID_SYS_LAUNCH
+  g_ev_start = g_ev_stop = nullptr;
   return nblk;
 }
 

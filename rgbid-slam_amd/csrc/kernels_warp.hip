@@ -16,18 +16,23 @@
 
 namespace rgbid {
 
-static constexpr int TX = 64, TY = 4;
-static inline dim3 grid2d(int cols, int rows, int B) { return dim3(div_up(cols, TX), div_up(rows, TY), B); }
+static constexpr int TX = 64, TY = 4, RPB = 4;  // a workgroup sweeps RPB stacked 64x4 tiles (see kernels_prep.hip)
+static inline dim3 grid2d(int cols, int rows, int B) { return dim3(div_up(cols, TX), div_up(rows, TY * RPB), B); }
+static inline dim3 grid2d_full(int cols, int rows, int B) { return dim3(div_up(cols, TX), div_up(rows, TY), B); }
+#define RGBID_FOR_ROWS(yv) for (int it_ = 0, yv = blockIdx.y * (TY * RPB) + threadIdx.y; it_ < RPB; ++it_, yv += TY)
 
 // ---- trafo3DKernelInvDepthGridStride (:505-546) ---------------------------------------------------
 template <class PS>
 __global__ __launch_bounds__(256) void k_warp_invdepth(ImgB src, ImgB grid, ImgB dst, PS ps, LaneMask m) {
   int lane = blockIdx.z;
   if (!m.on(lane)) return;
-  int x = blockIdx.x * TX + threadIdx.x, y = blockIdx.y * TY + threadIdx.y;
-  if (x >= dst.cols || y >= dst.rows) return;
-  const WarpParams& P = ps.get(lane);
-  px<float>(dst, lane, y, x) = warp_invdepth_px(src, lane, x, y, px<float>(grid, lane, y, x), P);
+  int x = blockIdx.x * TX + threadIdx.x;
+  const WarpParams P = ps.get(lane);
+  const FMap S(src, lane);
+  RGBID_FOR_ROWS(y) {
+    if (x >= dst.cols || y >= dst.rows) continue;
+    px<float>(dst, lane, y, x) = warp_invdepth_px(S, x, y, px<float>(grid, lane, y, x), P);
+  }
 }
 void launch_warp_invdepth(hipStream_t s, int B, ImgB src, ImgB grid, ImgB dst, const WarpParams* hp, const WarpParams* lp, LaneMask m) {
   dim3 g = grid2d(dst.cols, dst.rows, B), b(TX, TY);
@@ -40,10 +45,13 @@ template <class PS>
 __global__ __launch_bounds__(256) void k_warp_intensity(ImgB src, ImgB grid, ImgB dst, PS ps, int interp_mode, LaneMask m) {
   int lane = blockIdx.z;
   if (!m.on(lane)) return;
-  int x = blockIdx.x * TX + threadIdx.x, y = blockIdx.y * TY + threadIdx.y;
-  if (x >= dst.cols || y >= dst.rows) return;
-  const WarpParams& P = ps.get(lane);
-  px<float>(dst, lane, y, x) = warp_intensity_px(src, lane, x, y, px<float>(grid, lane, y, x), P, interp_mode);
+  int x = blockIdx.x * TX + threadIdx.x;
+  const WarpParams P = ps.get(lane);
+  const FMap S(src, lane);
+  RGBID_FOR_ROWS(y) {
+    if (x >= dst.cols || y >= dst.rows) continue;
+    px<float>(dst, lane, y, x) = warp_intensity_px(S, x, y, px<float>(grid, lane, y, x), P, interp_mode);
+  }
 }
 void launch_warp_intensity(hipStream_t s, int B, ImgB src, ImgB grid, ImgB dst, const WarpParams* hp, const WarpParams* lp, int interp_mode, LaneMask m) {
   dim3 g = grid2d(dst.cols, dst.rows, B), b(TX, TY);
@@ -56,28 +64,30 @@ template <class PS>
 __global__ __launch_bounds__(256) void k_warp_invdepth_weighted(ImgB src, ImgB grid, ImgB dst, ImgB weight, PS ps, LaneMask m) {
   int lane = blockIdx.z;
   if (!m.on(lane)) return;
-  int x = blockIdx.x * TX + threadIdx.x, y = blockIdx.y * TY + threadIdx.y;
-  if (x >= dst.cols || y >= dst.rows) return;
-  const WarpParams& P = ps.get(lane);
-  float out = qnan();
-  float w = px<float>(grid, lane, y, x);
-  if (!isnan(w)) {
-    float xs, ys;
-    float w3 = register_pixel(xs, ys, x, y, w, P);
-    xs += 0.5f; ys += 0.5f;
-    if (in_bounds_rd(xs, ys, src.cols, src.rows)) {
-      float w2 = px<float>(src, lane, f2i_rd(ys), f2i_rd(xs));
-      float tz = P.t[2];
-      float v1_z = (1.f / w3 - tz) * w;
-      float w_factor = 1.f - w2 * tz;
-      float w_factor2 = w_factor * w_factor;
-      float weight_res = (w_factor2 * w_factor2) / (v1_z * v1_z);
-      float res = (v1_z / w_factor) * w2;
-      if (res > 0.f) out = res;
-      if (weight_res > 0.f) px<float>(weight, lane, y, x) = weight_res;  // untouched otherwise, as the reference
+  int x = blockIdx.x * TX + threadIdx.x;
+  const WarpParams P = ps.get(lane);
+  RGBID_FOR_ROWS(y) {
+    if (x >= dst.cols || y >= dst.rows) continue;
+    float out = qnan();
+    float w = px<float>(grid, lane, y, x);
+    if (!isnan(w)) {
+      float xs, ys;
+      float w3 = register_pixel(xs, ys, x, y, w, P);
+      xs += 0.5f; ys += 0.5f;
+      if (in_bounds_rd(xs, ys, src.cols, src.rows)) {
+        float w2 = px<float>(src, lane, f2i_rd(ys), f2i_rd(xs));
+        float tz = P.t[2];
+        float v1_z = (1.f / w3 - tz) * w;
+        float w_factor = 1.f - w2 * tz;
+        float w_factor2 = w_factor * w_factor;
+        float weight_res = (w_factor2 * w_factor2) / (v1_z * v1_z);
+        float res = (v1_z / w_factor) * w2;
+        if (res > 0.f) out = res;
+        if (weight_res > 0.f) px<float>(weight, lane, y, x) = weight_res;  // untouched otherwise, as the reference
+      }
     }
+    px<float>(dst, lane, y, x) = out;
   }
-  px<float>(dst, lane, y, x) = out;
 }
 void launch_warp_invdepth_weighted(hipStream_t s, int B, ImgB src, ImgB grid, ImgB dst, ImgB weight, const WarpParams* hp, const WarpParams* lp, LaneMask m) {
   dim3 g = grid2d(dst.cols, dst.rows, B), b(TX, TY);
@@ -89,20 +99,22 @@ void launch_warp_invdepth_weighted(hipStream_t s, int B, ImgB src, ImgB grid, Im
 __global__ __launch_bounds__(256) void k_integrate(ImgB warped, ImgB wweight, ImgB kf, ImgB kfw, LaneMask m) {
   int lane = blockIdx.z;
   if (!m.on(lane)) return;
-  int x = blockIdx.x * TX + threadIdx.x, y = blockIdx.y * TY + threadIdx.y;
-  if (x >= kf.cols || y >= kf.rows) return;
-  float w_sum = px<float>(warped, lane, y, x);
-  if (!isnan(w_sum)) {
-    float w_KF = px<float>(kf, lane, y, x);
-    float dw = fabsf(w_sum - w_KF);
-    if (isnan(w_KF)) {
-      px<float>(kf, lane, y, x) = w_sum;
-      px<float>(kfw, lane, y, x) = px<float>(wweight, lane, y, x);
-    } else if (dw < 3 * 0.0075f) {  // 3*DEPTHINV_INTEGR_TH (:80)
-      float q = px<float>(kfw, lane, y, x), qs = px<float>(wweight, lane, y, x);
-      float new_weight = q + qs;
-      px<float>(kf, lane, y, x) = (w_KF * q + w_sum * qs) / new_weight;
-      px<float>(kfw, lane, y, x) = new_weight;
+  int x = blockIdx.x * TX + threadIdx.x;
+  RGBID_FOR_ROWS(y) {
+    if (x >= kf.cols || y >= kf.rows) continue;
+    float w_sum = px<float>(warped, lane, y, x);
+    if (!isnan(w_sum)) {
+      float w_KF = px<float>(kf, lane, y, x);
+      float dw = fabsf(w_sum - w_KF);
+      if (isnan(w_KF)) {
+        px<float>(kf, lane, y, x) = w_sum;
+        px<float>(kfw, lane, y, x) = px<float>(wweight, lane, y, x);
+      } else if (dw < 3 * 0.0075f) {  // 3*DEPTHINV_INTEGR_TH (:80)
+        float q = px<float>(kfw, lane, y, x), qs = px<float>(wweight, lane, y, x);
+        float new_weight = q + qs;
+        px<float>(kf, lane, y, x) = (w_KF * q + w_sum * qs) / new_weight;
+        px<float>(kfw, lane, y, x) = new_weight;
+      }
     }
   }
 }
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(256) void k_vmap(ImgB depthinv, ImgB vmap, IntrP k,
   }
 }
 void launch_vmap(hipStream_t s, int B, ImgB depthinv, ImgB vmap, IntrP k, LaneMask m) {
-  hipLaunchKernelGGL(k_vmap, grid2d(depthinv.cols, depthinv.rows, B), dim3(TX, TY), 0, s, depthinv, vmap, k, m);
+  hipLaunchKernelGGL(k_vmap, grid2d_full(depthinv.cols, depthinv.rows, B), dim3(TX, TY), 0, s, depthinv, vmap, k, m);
 }
 
 // ---- computeNmapGradientsKernel (maps.cu:134-179) -------------------------------------------------
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(256) void k_nmap_grad(ImgB depthinv, ImgB gx_, ImgB
   px<float>(nmap, lane, v, u) = n0;
 }
 void launch_nmap_gradients(hipStream_t s, int B, ImgB depthinv, ImgB gx, ImgB gy, ImgB nmap, IntrP k, LaneMask m) {
-  hipLaunchKernelGGL(k_nmap_grad, grid2d(depthinv.cols, depthinv.rows, B), dim3(TX, TY), 0, s, depthinv, gx, gy, nmap, k, m);
+  hipLaunchKernelGGL(k_nmap_grad, grid2d_full(depthinv.cols, depthinv.rows, B), dim3(TX, TY), 0, s, depthinv, gx, gy, nmap, k, m);
 }
 
 // ---- ImageGenerator(RGB) (image_generator.cu:66-185) ----------------------------------------------
@@ -243,7 +255,7 @@ __global__ __launch_bounds__(256) void k_generate_image(ImgB vmap, ImgB nmap, Im
   d[0] = c0; d[1] = c1; d[2] = c2;
 }
 void launch_generate_image(hipStream_t s, int B, ImgB vmap, ImgB nmap, ImgB rgb, ImgB dst, const LightP* hl, const LightP* ll, LaneMask m) {
-  dim3 g = grid2d(dst.cols, dst.rows, B), b(TX, TY);
+  dim3 g = grid2d_full(dst.cols, dst.rows, B), b(TX, TY);
   if (ll) hipLaunchKernelGGL(k_generate_image<ByLane<LightP>>, g, b, 0, s, vmap, nmap, rgb, dst, ByLane<LightP>{ll}, m);
   else hipLaunchKernelGGL(k_generate_image<ByValue<LightP>>, g, b, 0, s, vmap, nmap, rgb, dst, ByValue<LightP>{*hl}, m);
 }

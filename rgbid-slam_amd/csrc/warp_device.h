@@ -1,15 +1,36 @@
 // warp_device.h -- per-pixel inverse warps shared by the stand-alone warp kernels (kernels_warp.hip), the fused
 // Gauss-Newton kernel (kernels_system.hip) and the lattice pre-pass of the sigma/nu kernel (kernels_sigma.hip).
-// All three therefore produce bit-identical W1 / I1 values.  fp contraction is off inside these functions so the
-// arithmetic is evaluated operation by operation exactly like the scalar oracle (see common.h register_pixel).
+// All three therefore produce bit-identical W1 / I1 values.
+//
+// Numerics: fp contraction is off inside these functions and the divisions are IEEE, so every value and every
+// floor()/rint() pixel selection is bit-identical to the scalar oracle.  Control flow: branch-free.  The CUDA
+// kernels nest three `if`s per pixel (valid iD, in bounds, res > 0); a wave64 would serialise all of them, so the
+// arithmetic runs unconditionally on sanitised inputs, every gather uses a clamped (always legal) address, and
+// the predicates only select the final value.  v_cvt_i32_f32 saturates and maps NaN to 0 -- exactly CUDA's
+// __float2int_rd/_rn semantics that registerPixel's callers rely on -- so the conversions need no range checks.
 #pragma once
 #include "common.h"
 
 namespace rgbid {
 
+__device__ __forceinline__ int cvt_rd(float x) { return __float2int_rd(x); }  // v_floor_f32 + v_cvt_i32_f32 (saturating)
+__device__ __forceinline__ bool inside(int ix, int iy, int cols, int rows) {
+  return ((unsigned)ix < (unsigned)cols) & ((unsigned)iy < (unsigned)rows);  // == !(ix<0 || iy<0 || ix>=cols || iy>=rows)
+}
+__device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi); }
+
+// lane-local element view of a float map: base pointer + pitch in elements (32-bit offsets)
+struct FMap {
+  const float* base;
+  int pitch, rows, cols;
+  __device__ __forceinline__ FMap(const ImgB& im, int lane)
+      : base(row_ptr<float>(im, lane, 0)), pitch((int)(im.pitch >> 2)), rows(im.rows), cols(im.cols) {}
+  __device__ __forceinline__ float at(int y, int x) const { return base[y * pitch + x]; }
+};
+
 // CUDA linear filtering at unnormalised coordinates with clamp addressing (what tex2D<float> computes for the
 // reference's cudaFilterModeLinear texture, warping_registration.cu:938-944); mode 1 = 1.8 fixed-point weights
-__device__ __forceinline__ float tex2d_linear(const ImgB& src, int lane, float xs, float ys, int mode) {
+__device__ __forceinline__ float tex2d_linear(const FMap& src, float xs, float ys, int mode) {
 #pragma clang fp contract(off)
   float xB = xs - 0.5f, yB = ys - 0.5f;
   float fx0 = floorf(xB), fy0 = floorf(yB);
@@ -18,50 +39,45 @@ __device__ __forceinline__ float tex2d_linear(const ImgB& src, int lane, float x
     a = rintf(a * 256.f) * 0.00390625f;
     b = rintf(b * 256.f) * 0.00390625f;
   }
-  int i0 = f2i_rd(fx0), j0 = f2i_rd(fy0);
-  int i1 = min(max(i0 + 1, 0), src.cols - 1), j1 = min(max(j0 + 1, 0), src.rows - 1);
-  i0 = min(max(i0, 0), src.cols - 1);
-  j0 = min(max(j0, 0), src.rows - 1);
-  const float* r0 = row_ptr<float>(src, lane, j0);
-  const float* r1 = row_ptr<float>(src, lane, j1);
-  float T00 = r0[i0], T10 = r0[i1], T01 = r1[i0], T11 = r1[i1];
+  int i0 = __float2int_rd(fx0), j0 = __float2int_rd(fy0);
+  int i1 = clampi(i0 + 1, src.cols - 1), j1 = clampi(j0 + 1, src.rows - 1);
+  i0 = clampi(i0, src.cols - 1);
+  j0 = clampi(j0, src.rows - 1);
+  int r0 = j0 * src.pitch, r1 = j1 * src.pitch;
+  float T00 = src.base[r0 + i0], T10 = src.base[r0 + i1], T01 = src.base[r1 + i0], T11 = src.base[r1 + i1];
   float oa = 1.f - a, ob = 1.f - b;
   return (oa * ob) * T00 + (a * ob) * T10 + (oa * b) * T01 + (a * b) * T11;
 }
 
 // trafo3DKernelInvDepthGridStride, warping_registration.cu:505-546 (one pixel; w = keyframe inverse depth)
-__device__ __forceinline__ float warp_invdepth_px(const ImgB& src, int lane, int x, int y, float w, const WarpParams& P) {
+__device__ __forceinline__ float warp_invdepth_px(const FMap& src, int x, int y, float w, const WarpParams& P) {
 #pragma clang fp contract(off)
-  float out = qnan();
-  if (!isnan(w)) {
-    float xs, ys;
-    float w3 = register_pixel(xs, ys, x, y, w, P);
-    xs += 0.5f; ys += 0.5f;
-    if (in_bounds_rd(xs, ys, src.cols, src.rows)) {
-      float w2 = px<float>(src, lane, f2i_rd(ys), f2i_rd(xs));
-      float tz = P.t[2];
-      float v1_z = (1.f / w3 - tz) * w;
-      float res = (v1_z / (1.f - w2 * tz)) * w2;
-      if (res > 0.f) out = res;
-    }
-  }
-  return out;
+  const bool valid = !isnan(w);
+  const float ws = valid ? w : 1.f;
+  float xs, ys;
+  float w3 = register_pixel(xs, ys, x, y, ws, P);
+  xs += 0.5f; ys += 0.5f;
+  int ix = cvt_rd(xs), iy = cvt_rd(ys);
+  const bool inb = inside(ix, iy, src.cols, src.rows);
+  float w2 = src.at(clampi(iy, src.rows - 1), clampi(ix, src.cols - 1));
+  float tz = P.t[2];
+  float v1_z = (1.f / w3 - tz) * ws;
+  float res = (v1_z / (1.f - w2 * tz)) * w2;
+  return (valid & inb & (res > 0.f)) ? res : qnan();
 }
 
 // trafo3DKernelIntensityWithInvDepthGridStride, warping_registration.cu:465-501 (one pixel; w = sampling-grid iD)
-__device__ __forceinline__ float warp_intensity_px(const ImgB& src, int lane, int x, int y, float w, const WarpParams& P, int interp_mode) {
+__device__ __forceinline__ float warp_intensity_px(const FMap& src, int x, int y, float w, const WarpParams& P, int interp_mode) {
 #pragma clang fp contract(off)
-  float res = qnan();
-  if (!isnan(w)) {
-    float xs, ys;
-    register_pixel(xs, ys, x, y, w, P);
-    xs += 0.5f; ys += 0.5f;
-    if (in_bounds_rd(xs, ys, src.cols, src.rows)) {
-      res = tex2d_linear(src, lane, xs, ys, interp_mode);
-      res = fmaxf(0.f, fminf(res, 255.f));  // NaN -> 255, as CUDA's min/max
-    }
-  }
-  return res;
+  const bool valid = !isnan(w);
+  const float ws = valid ? w : 1.f;
+  float xs, ys;
+  register_pixel(xs, ys, x, y, ws, P);
+  xs += 0.5f; ys += 0.5f;
+  const bool inb = inside(cvt_rd(xs), cvt_rd(ys), src.cols, src.rows);
+  float res = tex2d_linear(src, xs, ys, interp_mode);
+  res = fmaxf(0.f, fminf(res, 255.f));  // NaN -> 255, as CUDA's min/max
+  return (valid & inb) ? res : qnan();
 }
 
 }  // namespace rgbid
