@@ -45,6 +45,8 @@ def cpu_baseline(seq, rows, cols, K, budget_s=12.0):
     d = seq["depth"].cpu().numpy().astype(np.uint16)
     c = seq["rgb"].cpu().numpy()
     cfg = O.default_config(rows=rows, cols=cols, fx=K[0], fy=K[1], cx=K[2], cy=K[3])
+    # OpenMP over image rows stops scaling well before a 128-thread host is full (480 rows, fork/join per kernel): cap at 16
+    O.set_num_threads(min(os.cpu_count() or 1, 16))
     frames = 0
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
@@ -61,12 +63,28 @@ def cpu_baseline(seq, rows, cols, K, budget_s=12.0):
                       f"oracle C restatement with OpenMP on {O.num_threads()} host threads"}
 
 
+def pmc_traffic(lanes, rows, cols, fused):
+    """HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in separate
+    rocprofv3 --pmc runs by tools/profile_bench.sh, gfx950 corrections applied; committed under profiles/).  Counters
+    cannot be read from inside this process, so the figure is only reported when a committed PMC summary matches the
+    configuration being run; otherwise null."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if (d.get("lanes"), d.get("rows"), d.get("cols"), bool(d.get("fused_gn"))) == (lanes, rows, cols, bool(fused)):
+            return d["traffic_bytes_per_launch"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--lanes", type=int, default=64, help="independent RGB-D streams per GPU")
+    ap.add_argument("--lanes", type=int, default=128, help="independent RGB-D streams per GPU")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--levels", type=int, default=3)
@@ -156,7 +174,7 @@ def main():
                        "launches_per_step": eng.launches_per_step(), "engine_hbm_bytes": eng.bytes(),
                        "tracked_frames_rank0": tracked, "expected_rank0": B * Kst},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": pmc_traffic(B, rows, cols, args.fused),
                          "kernel": "rgbid::k_build_system<ByLane<SysParams>, true, 0> (level-0 residual + 27-term normal equations)",
                          "algorithmic_bytes_per_launch": k_bytes, "launches_timed": k_n, "avg_launch_us": avg_s * 1e6,
                          "timed_in": "timed region" if profile_in_timed else "separate eager pass"},

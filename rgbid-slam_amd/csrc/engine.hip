@@ -530,7 +530,7 @@ void enqueue_save_odo_kf(rgbid_engine* e, hipStream_t s) {
 }
 
 // the whole step as a launch sequence on stream s
-int enqueue_step(rgbid_engine* e, hipStream_t s) {
+int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   const rgbid_engine_config& c = e->cfg;
   const int B = e->B, L = e->L;
   const StepCfg sc = step_cfg(c);
@@ -550,8 +550,10 @@ int enqueue_step(rgbid_engine* e, hipStream_t s) {
   }
   hipLaunchKernelGGL(k_step_begin, dim3(gb), dim3(tb), 0, s, e->state, f, e->wp, e->sp, sc, B);
   e->launches++;
+  // The first step after reset() is host-known to be every lane's first frame (visodo.cpp:1994-2045): only the
+  // keyframe-creation part of the sequence below is enqueued (k_step_begin has set first / sw_odo / sw_int / maps).
   // ---- estimateVisualOdometry (visodo.cpp:1041-1281), PYR_FIRST
-  for (int level = L - 1; level >= c.finest_level; --level) {
+  for (int level = L - 1; !first && level >= c.finest_level; --level) {
     hipLaunchKernelGGL(k_set_sys, dim3(gb), dim3(tb), 0, s, e->sp, e->state, sc, level, 0, B);
     e->launches++;
     int iters = c.iters[level];
@@ -586,7 +588,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s) {
     }
   }
   // ---- covariance pass (visodo.cpp:1283-1409)
-  {
+  if (!first) {
     int fl = c.finest_level;
     hipLaunchKernelGGL(k_set_sys, dim3(gb), dim3(tb), 0, s, e->sp, e->state, sc, fl, 1, B);
     bool prof = e->prof_on && fl == 0 && e->prof_used + 2 <= (int)e->prof_ev.size();
@@ -618,19 +620,23 @@ int enqueue_step(rgbid_engine* e, hipStream_t s) {
     e->launches++;
   }
   // ---- covisibility with both keyframes (visodo.cpp:2172-2188), 4 ratio evaluations
-  hipMemsetAsync(e->counts, 0, sizeof(unsigned int) * 8 * B, s);
   ImgB none{nullptr, 0, 0, 0, 0};
-  launch_visibility(s, B, e->iD_curr[0], e->iD_kf[0], none, nullptr, e->vis_ab, e->counts + 0 * 2 * B, M(f.vis));
-  launch_visibility(s, B, e->iD_kf[0], e->iD_curr[0], none, nullptr, e->vis_ba, e->counts + 1 * 2 * B, M(f.vis));
-  launch_visibility(s, B, e->iD_curr[0], e->iD_integr_raw, none, nullptr, e->ivis_ab, e->counts + 2 * 2 * B, M(f.vis));
-  launch_visibility(s, B, e->iD_integr_raw, e->iD_curr[0], none, nullptr, e->ivis_ba, e->counts + 3 * 2 * B, M(f.vis));
-  hipLaunchKernelGGL(k_decide, dim3(gb), dim3(tb), 0, s, e->state, f, e->counts, e->fuse_wp, sc, B);
-  e->launches += 6;
+  if (!first) {
+    hipMemsetAsync(e->counts, 0, sizeof(unsigned int) * 8 * B, s);
+    launch_visibility(s, B, e->iD_curr[0], e->iD_kf[0], none, nullptr, e->vis_ab, e->counts + 0 * 2 * B, M(f.vis));
+    launch_visibility(s, B, e->iD_kf[0], e->iD_curr[0], none, nullptr, e->vis_ba, e->counts + 1 * 2 * B, M(f.vis));
+    launch_visibility(s, B, e->iD_curr[0], e->iD_integr_raw, none, nullptr, e->ivis_ab, e->counts + 2 * 2 * B, M(f.vis));
+    launch_visibility(s, B, e->iD_integr_raw, e->iD_curr[0], none, nullptr, e->ivis_ba, e->counts + 3 * 2 * B, M(f.vis));
+    hipLaunchKernelGGL(k_decide, dim3(gb), dim3(tb), 0, s, e->state, f, e->counts, e->fuse_wp, sc, B);
+    e->launches += 6;
+  }
   // ---- odometry keyframe switch
   enqueue_save_odo_kf(e, s);
   // ---- integration keyframe: computeOverlapping (:1517-1539) + saveCurrentImagesAsIntegrationKeyframes (:880-893) ...
-  hipMemsetAsync(e->counts, 0, sizeof(unsigned int) * 2 * B, s);
-  launch_visibility(s, B, e->iD_curr[0], e->iD_integr_raw, e->overlap_mask, nullptr, e->ivis_ab, e->counts, M(f.overlap));
+  if (!first) {
+    hipMemsetAsync(e->counts, 0, sizeof(unsigned int) * 2 * B, s);
+    launch_visibility(s, B, e->iD_curr[0], e->iD_integr_raw, e->overlap_mask, nullptr, e->ivis_ab, e->counts, M(f.overlap));
+  }
   launch_copy_bytes(s, B, e->iD_curr[0], e->iD_integr, 4, M(f.sw_int));
   launch_copy_bytes(s, B, e->iD_curr[0], e->iD_integr_raw, 4, M(f.sw_int));
   launch_copy_bytes(s, B, e->in_rgb, e->colors_integr, 3, M(f.sw_int));
@@ -638,8 +644,10 @@ int enqueue_step(rgbid_engine* e, hipStream_t s) {
   launch_fill(s, B, e->overlap_mask, 1, 0u, M(f.first));  // initialiseDeviceMemory2D(overlap_mask, 0) :2021
   e->launches += 7;
   // ... or integrateImagesIntoKeyframes (:1674-1764)
-  launch_warp_invdepth_weighted(s, B, e->iD_curr[0], e->iD_integr, e->warped_iD_integr, e->warped_w, nullptr, e->fuse_wp, M(f.fuse));
-  launch_integrate_warped(s, B, e->warped_iD_integr, e->warped_w, e->iD_integr, e->w_integr, M(f.fuse));
+  if (!first) {
+    launch_warp_invdepth_weighted(s, B, e->iD_curr[0], e->iD_integr, e->warped_iD_integr, e->warped_w, nullptr, e->fuse_wp, M(f.fuse));
+    launch_integrate_warped(s, B, e->warped_iD_integr, e->warped_w, e->iD_integr, e->w_integr, M(f.fuse));
+  }
   launch_vmap(s, B, e->iD_integr, e->vmap, K0, M(f.maps));
   launch_gradient(s, B, e->iD_integr, e->gxD_integr, e->gyD_integr, M(f.maps));
   launch_nmap_gradients(s, B, e->iD_integr, e->gxD_integr, e->gyD_integr, e->nmap, K0, M(f.maps));
@@ -761,25 +769,29 @@ int rgbid_engine_step(rgbid_engine* e, const void* depth_dev, const void* rgb_de
   he = hipMemcpy2DAsync(e->in_rgb.base, e->in_rgb.pitch, rgb_dev, (size_t)c.cols * 3, (size_t)c.cols * 3, (size_t)c.rows * e->B, hipMemcpyDeviceToDevice, s);
   if (he != hipSuccess) return (int)he;
   int r = RGBID_OK;
+  const bool first = (e->steps == 0);
   if (c.use_graph && !e->prof_on) {
     // the launch sequence is identical every step (flags live in device memory), so one captured graph is replayed
-    if (!e->graph_ready_next) {
+    // two graphs: the keyframe-creation sequence of the first frame, and every later frame
+    hipGraphExec_t& gx = first ? e->graph_first : e->graph_next;
+    bool& ready = first ? e->graph_ready_first : e->graph_ready_next;
+    if (!ready) {
       hipGraph_t g = nullptr;
       he = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
       if (he != hipSuccess) return (int)he;
-      r = enqueue_step(e, s);
+      r = enqueue_step(e, s, first);
       he = hipStreamEndCapture(s, &g);
       if (r) return r;
       if (he != hipSuccess) return (int)he;
-      he = hipGraphInstantiate(&e->graph_next, g, nullptr, nullptr, 0);
+      he = hipGraphInstantiate(&gx, g, nullptr, nullptr, 0);
       hipGraphDestroy(g);
       if (he != hipSuccess) return (int)he;
-      e->graph_ready_next = true;
+      ready = true;
     }
-    he = hipGraphLaunch(e->graph_next, s);
+    he = hipGraphLaunch(gx, s);
     if (he != hipSuccess) return (int)he;
   } else {
-    r = enqueue_step(e, s);
+    r = enqueue_step(e, s, first);
     if (r) return r;
   }
   int slot = e->steps % c.record_capacity;

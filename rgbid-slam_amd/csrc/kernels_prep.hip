@@ -151,12 +151,21 @@ void launch_fill(hipStream_t s, int B, ImgB dst, int elem_size, uint32_t bits, L
 // Gaussian weights exp(-d2/2), d2 in {0,1,2,4,5,8}, are evaluated with expf like the reference; the
 // validity rule `count > 12` and the tap order (cy outer, cx inner) are the reference's.
 static constexpr int PSX = 2 * TX + 3, PSY = 2 * TY + 3;
-__global__ __launch_bounds__(256) void k_pyr_down(ImgB src, ImgB dst, LaneMask m) {
+// exp(-d2/2) for the nine possible squared tap distances d2 = dx^2 + dy^2 in {0,1,2,4,5,8}: evaluated ONCE on the host
+// with expf (the reference evaluates __expf per tap: 25 transcendentals per output pixel)
+struct PyrWeights { float w[9]; };
+static const PyrWeights& pyr_weights() {
+  static const PyrWeights W = [] { PyrWeights t; for (int d2 = 0; d2 < 9; ++d2) t.w[d2] = expf(-((float)d2 * 0.5f)); return t; }();
+  return W;
+}
+__global__ __launch_bounds__(256) void k_pyr_down(ImgB src, ImgB dst, PyrWeights W, LaneMask m) {
   int lane = blockIdx.z;
   if (!m.on(lane)) return;
   __shared__ float tile[PSY][PSX + 1];
+  __shared__ float wt[9];
   int x0 = blockIdx.x * TX;
   int tid = threadIdx.y * TX + threadIdx.x;
+  if (tid < 9) wt[tid] = W.w[tid];
   RGBID_FOR_TILES(y0) {
     if (y0 >= dst.rows) break;
     int sx0 = 2 * x0 - 2, sy0 = 2 * y0 - 2;
@@ -179,8 +188,7 @@ __global__ __launch_bounds__(256) void k_pyr_down(ImgB src, ImgB dst, LaneMask m
       for (int cx = max(0, 2 * x - br); cx < tx_end; ++cx) {
         float val = tile[cy - sy0][cx - sx0];
         if (!isnan(val)) {
-          float space2 = (float)((2 * x - cx) * (2 * x - cx) + (2 * y - cy) * (2 * y - cy));
-          float weight = expf(-(space2 * 0.5f));
+          float weight = wt[(2 * x - cx) * (2 * x - cx) + (2 * y - cy) * (2 * y - cy)];
           sum1 += val * weight;
           sum2 += weight;
           ++count;
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(256) void k_pyr_down(ImgB src, ImgB dst, LaneMask m
   }
 }
 void launch_pyr_down(hipStream_t s, int B, ImgB src, ImgB dst, LaneMask m) {
-  hipLaunchKernelGGL(k_pyr_down, grid2d(dst.cols, dst.rows, B), dim3(TX, TY), 0, s, src, dst, m);
+  hipLaunchKernelGGL(k_pyr_down, grid2d(dst.cols, dst.rows, B), dim3(TX, TY), 0, s, src, dst, pyr_weights(), m);
 }
 
 // ---- bilateralKernel (filters.cu:86-135), clipped 5x5 window -------------------------------------

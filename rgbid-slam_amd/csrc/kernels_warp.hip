@@ -29,10 +29,17 @@ __global__ __launch_bounds__(256) void k_warp_invdepth(ImgB src, ImgB grid, ImgB
   int x = blockIdx.x * TX + threadIdx.x;
   const WarpParams P = ps.get(lane);
   const FMap S(src, lane);
-  RGBID_FOR_ROWS(y) {
-    if (x >= dst.cols || y >= dst.rows) continue;
-    px<float>(dst, lane, y, x) = warp_invdepth_px(S, x, y, px<float>(grid, lane, y, x), P);
-  }
+  if (x >= dst.cols) return;
+  // RPB independent pixels per thread: all grid loads first, then the RPB projection / gather chains (interleaved
+  // by the scheduler), then the stores -- the dependent chain load -> divide -> project -> gather is long
+  const int yb = blockIdx.y * (TY * RPB) + threadIdx.y;
+  float wv[RPB], out[RPB];
+#pragma unroll
+  for (int i = 0; i < RPB; ++i) { int y = yb + i * TY; wv[i] = (y < dst.rows) ? px<float>(grid, lane, y, x) : qnan(); }
+#pragma unroll
+  for (int i = 0; i < RPB; ++i) out[i] = warp_invdepth_px(S, x, yb + i * TY, wv[i], P);
+#pragma unroll
+  for (int i = 0; i < RPB; ++i) { int y = yb + i * TY; if (y < dst.rows) px<float>(dst, lane, y, x) = out[i]; }
 }
 void launch_warp_invdepth(hipStream_t s, int B, ImgB src, ImgB grid, ImgB dst, const WarpParams* hp, const WarpParams* lp, LaneMask m) {
   dim3 g = grid2d(dst.cols, dst.rows, B), b(TX, TY);
@@ -48,10 +55,15 @@ __global__ __launch_bounds__(256) void k_warp_intensity(ImgB src, ImgB grid, Img
   int x = blockIdx.x * TX + threadIdx.x;
   const WarpParams P = ps.get(lane);
   const FMap S(src, lane);
-  RGBID_FOR_ROWS(y) {
-    if (x >= dst.cols || y >= dst.rows) continue;
-    px<float>(dst, lane, y, x) = warp_intensity_px(S, x, y, px<float>(grid, lane, y, x), P, interp_mode);
-  }
+  if (x >= dst.cols) return;
+  const int yb = blockIdx.y * (TY * RPB) + threadIdx.y;
+  float wv[RPB], out[RPB];
+#pragma unroll
+  for (int i = 0; i < RPB; ++i) { int y = yb + i * TY; wv[i] = (y < dst.rows) ? px<float>(grid, lane, y, x) : qnan(); }
+#pragma unroll
+  for (int i = 0; i < RPB; ++i) out[i] = warp_intensity_px(S, x, yb + i * TY, wv[i], P, interp_mode);
+#pragma unroll
+  for (int i = 0; i < RPB; ++i) { int y = yb + i * TY; if (y < dst.rows) px<float>(dst, lane, y, x) = out[i]; }
 }
 void launch_warp_intensity(hipStream_t s, int B, ImgB src, ImgB grid, ImgB dst, const WarpParams* hp, const WarpParams* lp, int interp_mode, LaneMask m) {
   dim3 g = grid2d(dst.cols, dst.rows, B), b(TX, TY);
@@ -134,26 +146,32 @@ __global__ __launch_bounds__(256) void k_visibility(ImgB src, ImgB dst, ImgB mas
   if (!m.on(lane)) return;
   __shared__ unsigned int sm[2][4];
   const WarpParams P = ps.get(lane);
-  int x = blockIdx.x * TX + threadIdx.x;
+  const FMap D(dst, lane);
+  const int x = blockIdx.x * TX + threadIdx.x;
+  const bool xin = x < src.cols;
   unsigned int nvis = 0, nval = 0;
-  for (int yy = threadIdx.y; yy < VIS_ROWS; yy += TY) {
-    int y = blockIdx.y * VIS_ROWS + yy;
-    bool valid = false, visible = false;
-    if (x < src.cols && y < src.rows) {
-      float w = px<float>(src, lane, y, x);
-      if (!isnan(w)) {
-        float xd, yd;
-        float w_dst = register_pixel(xd, yd, x, y, w, P);
-        valid = true;
-        if ((xd > 0) && (xd < (float)(src.cols - 1)) && (yd > 0) && (yd < (float)(src.rows - 1))) {
-          int xi = f2i_rn(xd), yi = f2i_rn(yd);
-          if (fabsf(w_dst - px<float>(dst, lane, yi, xi)) < 0.020f) visible = true;
-        }
-        if (mask.base) px<uint8_t>(mask, lane, y, x) = visible ? 1 : 0;
-      }
+  for (int g = 0; g < VIS_ROWS / (TY * 4); ++g) {
+    // 4 independent pixels per thread and pass: loads, then 4 projection/gather chains, then the ballots
+    const int yb = blockIdx.y * VIS_ROWS + g * (TY * 4) + threadIdx.y;
+    float w[4];
+    bool valid[4], visible[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { int y = yb + i * TY; w[i] = (xin && y < src.rows) ? px<float>(src, lane, y, x) : qnan(); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      valid[i] = !isnan(w[i]);
+      float xd, yd;
+      float w_dst = register_pixel(xd, yd, x, yb + i * TY, valid[i] ? w[i] : 1.f, P);
+      bool inside_img = (xd > 0) && (xd < (float)(src.cols - 1)) && (yd > 0) && (yd < (float)(src.rows - 1));
+      int xi = clampi(__float2int_rn(xd), src.cols - 1), yi = clampi(__float2int_rn(yd), src.rows - 1);
+      visible[i] = valid[i] && inside_img && (fabsf(w_dst - D.at(yi, xi)) < 0.020f);
     }
-    nvis += (unsigned int)__popcll(__ballot(visible));  // wave-uniform
-    nval += (unsigned int)__popcll(__ballot(valid));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (mask.base && valid[i]) px<uint8_t>(mask, lane, yb + i * TY, x) = visible[i] ? 1 : 0;
+      nvis += (unsigned int)__popcll(__ballot(visible[i]));  // wave-uniform
+      nval += (unsigned int)__popcll(__ballot(valid[i]));
+    }
   }
   if (threadIdx.x == 0) { sm[0][threadIdx.y] = nvis; sm[1][threadIdx.y] = nval; }  // one wave per threadIdx.y (TX == 64)
   __syncthreads();
