@@ -63,6 +63,19 @@ enum { RGBID_INTERP_EXACT = 0, RGBID_INTERP_TEX8 = 1 };
 const char* rgbid_version(void);
 const char* rgbid_error_string(int err);
 int rgbid_device_count(int* n);
+/* what the reference reads from cudaDeviceProp (tools/RGBID_SLAMapp.cpp:385-387, src/cuda/device.hpp:166-187) */
+typedef struct rgbid_device_prop {
+  char name[256];
+  int multiProcessorCount;          /* compute units */
+  int maxThreadsPerMultiProcessor;
+  int warpSize;                     /* 64 on CDNA */
+  int clockRateKHz;
+  size_t totalGlobalMem;
+  size_t sharedMemPerBlock;         /* LDS per workgroup */
+  char gcnArchName[64];
+} rgbid_device_prop;
+int rgbid_get_device_prop(int device, rgbid_device_prop* prop);
+int rgbid_set_device(int device);   /* pcl::gpu::setDevice, ThirdParty/pcl_gpu_containers/src/initialization.cpp */
 /* stream: a hipStream_t to launch on (e.g. torch's current stream) or NULL for a private stream */
 int rgbid_ctx_create(rgbid_ctx** ctx, int device, void* stream);
 int rgbid_ctx_destroy(rgbid_ctx* ctx);

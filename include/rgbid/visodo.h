@@ -1,0 +1,220 @@
+// visodo.h -- VisodoTracker: the reference's dense RGB-iD visual-odometry front-end class (include/visodo.h,
+// src/visodo.cpp) re-implemented on the HIP bridge (rgbid/internal.h).  Same public surface -- constructor with the
+// 15 defaulted arguments, loadSettings / loadCalibration / start / trackNewFrame / operator() / intrinsics setters /
+// pose getters / getImage / visOdoIsLost / reset, and the public data members the application touches (rgb24_,
+// depth_, timestamps, mutex_, new_frame_cond_, flags, scene views).
+//
+// Differences forced by this image (no Eigen, Boost or PCL): poses use the tiny fixed-size types below
+// (row-major double, the reference's Matrix3ft is Eigen::RowMajor double, include/types.h:490-496), threads use
+// <thread>/<mutex>, and the KeyframeManager back-end (out of scope) is reached through the
+// TrackerSink interface, which receives exactly what the reference pushes: Pose, PoseConstraint and the keyframe
+// export record (src/visodo.cpp:1631-1652, 2154-2165).
+#pragma once
+#include <array>
+#include <condition_variable>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "internal.h"
+#include "settings.h"
+
+namespace RGBID_SLAM {
+
+struct PixelRGB { unsigned char r, g, b; };  // include/types.h:88-91
+typedef DeviceArray2D<PixelRGB> View;
+typedef DeviceArray2D<unsigned short> DepthMap;
+
+struct Matrix3ft {
+  double m[9];
+  static Matrix3ft Identity() { Matrix3ft r; for (int i = 0; i < 9; ++i) r.m[i] = (i % 4 == 0) ? 1.0 : 0.0; return r; }
+  double& operator()(int r, int c) { return m[r * 3 + c]; }
+  double operator()(int r, int c) const { return m[r * 3 + c]; }
+  double* data() { return m; }
+  const double* data() const { return m; }
+};
+struct Vector3ft {
+  double v[3];
+  static Vector3ft Zero() { Vector3ft r; r.v[0] = r.v[1] = r.v[2] = 0.0; return r; }
+  double& operator[](int i) { return v[i]; }
+  double operator[](int i) const { return v[i]; }
+  double* data() { return v; }
+  const double* data() const { return v; }
+};
+typedef std::array<double, 36> Matrix6d;  // row-major 6x6
+struct Affine3d {
+  Matrix3ft R; Vector3ft t;
+  Matrix3ft& linear() { return R; }
+  Vector3ft& translation() { return t; }
+  const Matrix3ft& linear() const { return R; }
+  const Vector3ft& translation() const { return t; }
+};
+struct Matrix3f { float m[9]; float* data() { return m; } const float* data() const { return m; } };
+
+// include/pose_graph_manager.h:54-108
+struct PoseConstraint {
+  enum { SEQ_ODO, SEQ_KF, LC_KF };
+  int ini_id_, end_id_, type_;
+  Matrix3ft rotation_; Vector3ft translation_;
+  Matrix6d covariance_;   // the reference stores information_ = covariance.inverse(); the sink may invert
+  float scale_;
+};
+struct Pose {
+  int id_; Matrix3ft rotation_; Vector3ft translation_; float scale_;
+  Affine3d getAffine() const { Affine3d a; a.R = rotation_; for (int i = 0; i < 9; ++i) a.R.m[i] *= scale_; a.t = translation_; return a; }
+};
+// what resetIntegrationKeyframe hands to the back-end (include/keyframe.h:45-70, src/visodo.cpp:1631-1641)
+struct KeyframeRecord {
+  Matrix3f K; float kd[5];
+  Matrix3ft rotation; Vector3ft translation;          // global pose of the keyframe
+  Matrix3ft rotation_rel; Vector3ft translation_rel;  // delta to the next keyframe
+  int id, cols, rows;
+  std::vector<unsigned char> overlap_mask_;
+  std::vector<PixelRGB> colors_;
+  std::vector<float> depthinv_;
+  std::vector<float> normals_;   // 3*rows x cols planar
+};
+// stands in for KeyframeManager (keyframe_manager.h:77-104): poses_, constraints_, buffer_keyframes_.try_push
+struct TrackerSink {
+  virtual ~TrackerSink() {}
+  virtual void pushPose(const Pose&) {}
+  virtual void pushConstraint(const PoseConstraint&) {}
+  virtual bool tryPushKeyframe(std::shared_ptr<KeyframeRecord>) { return true; }
+};
+
+class VisodoTracker {
+ public:
+  enum { LEVELS = 3 };  // include/visodo.h:52; `levels` below is the run-time value (config 5 uses 4)
+
+  VisodoTracker(int optim_dim = 6, int Mestimator = device::DEFAULT_MESTIMATOR, int motion_model = device::DEFAULT_MOTION_MODEL,
+                int sigma_estimator = device::SIGMA_PDF, int weighting = device::DEFAULT_WEIGHTING, int warping = device::WARP_FIRST,
+                int max_odoKF_count = device::DEFAULT_ODO_KF_COUNT, int finest_level = 0, int termination = device::DEFAULT_TERMINATION,
+                float visratio_odo = device::DEFAULT_VISRATIO_ODO, int image_filtering = device::DEFAULT_IMAGE_FILTERING,
+                float visratio_integr = device::DEFAULT_VISRATIO_INTEGR, int max_integrKF_count = device::DEFAULT_INTEGR_KF_COUNT,
+                int Nsamples = 10000, int rows = 480, int cols = 640, int levels = LEVELS);
+  ~VisodoTracker();
+
+  void loadSettings(Settings& settings);
+  void loadCalibration(std::string const& calib_file);
+  void start();
+  bool trackNewFrame();
+  int cols() { return cols_; }
+  int rows() { return rows_; }
+  bool operator()();
+
+  void setRGBIntrinsics(float fx, float fy, float cx = -1, float cy = -1, float k1 = 0.f, float k2 = 0.f, float k3 = 0.f, float k4 = 0.f, float k5 = 0.f);
+  void setDepthIntrinsics(float fxd, float fyd, float cxd = -1, float cyd = -1);
+  void setSharedCameraPose(const Affine3d& pose);
+  Affine3d getCameraPose(int time = -1) const;
+  float getVisOdoTime(int time = -1) const;
+  int64_t getTimestamp(int time = -1) const;
+  Affine3d getSharedCameraPose();
+  size_t getNumberOfPoses() const { return rmats_.size(); }
+  Matrix3f getCalibMatrix(int level_index = 0) const;
+  void getImage(std::vector<PixelRGB>& scene_view, std::vector<float>& intensity_view, std::vector<float>& depthinv_view);
+  bool visOdoIsLost() { return lost_; }
+  void reset();
+
+  // extras of this implementation
+  void setIterations(const int* iters, int n);           // visodo_iterations_ (visodo.cpp:65)
+  void setFactorDepth(float f) { factor_depth_ = f; }
+  void setInterpMode(int mode);                           // RGBID_INTERP_EXACT / RGBID_INTERP_TEX8
+  void setPreview(bool on) { preview_ = on; }             // getImage + 3 D2H per frame (visodo.cpp:2237-2241)
+  void setVerbose(bool on) { verbose_ = on; }
+  const std::vector<Matrix3ft>& odoRotations() const { return odo_rmats_; }
+  const std::vector<Vector3ft>& odoTranslations() const { return odo_tvecs_; }
+  const std::vector<Matrix6d>& odoCovariances() const { return odo_covmats_; }
+  const device::DepthMapf& integrationKeyframeDepthinv() const { return depthinv_integrKF_; }
+  const DeviceArray2D<float>& integrationKeyframeWeight() const { return weight_integrKF_; }
+  struct LastFrameInfo { bool odo_kf_switched, integr_kf_switched; float visratio_odo, visratio_integr, sigma_int, sigma_depthinv, nu_int, nu_depthinv; };
+  LastFrameInfo lastInfo() const { return last_info_; }
+
+  // public data members the application touches (include/visodo.h:110-147)
+  bool newKF_;
+  std::vector<Matrix3ft> rmatsKF_;
+  std::vector<Vector3ft> tvecsKF_;
+  View rgb24_;
+  DepthMap depth_;
+  uint64_t timestamp_rgb_curr_, timestamp_depth_curr_, timestamp_ini_;
+  std::mutex mutex_;
+  std::condition_variable new_frame_cond_;
+  std::mutex created_aux_mutex_;
+  std::condition_variable created_cond_;
+  bool compute_deltat_flag_, real_time_flag_, exit_;
+  TrackerSink* keyframe_manager_ptr_;
+  std::vector<float> kf_times_;
+  std::mutex mutex_shared_camera_pose_;
+  Affine3d shared_camera_pose_;
+  bool camera_pose_has_changed_, odometry_success_;
+  std::mutex mutex_scene_view_;
+  std::vector<PixelRGB> scene_view_;
+  std::vector<float> intensity_view_, depthinv_view_;
+  bool scene_view_has_changed_;
+
+ private:
+  float computeInterframeTime();
+  void allocateBuffers(int rows_arg, int cols_arg);
+  void prepareImages(const DepthMap& depth_raw, const View& colors_raw);
+  bool estimateVisualOdometry(Matrix3ft& resulting_rotation, Vector3ft& resulting_translation, Matrix6d& resulting_covariance);
+  float computeCovisibility(const Matrix3ft& rotation_AtoB, const Vector3ft& translation_AtoB, const device::DepthMapf& depthinvA, const device::DepthMapf& depthinvB);
+  float computeOverlapping(const Matrix3ft& rotation_AtoB, const Vector3ft& translation_AtoB, const device::DepthMapf& depthinvA,
+                           const device::DepthMapf& depthinvB, device::BinaryMap& overlap_maskB);
+  void resetOdometryKeyframe();
+  void resetIntegrationKeyframe();
+  void integrateImagesIntoKeyframes(device::DepthMapf& depthinv_src, Matrix3ft delta_rotation, Vector3ft delta_translation);
+  void saveCurrentImagesAsOdoKeyframes();
+  void saveCurrentImagesAsIntegrationKeyframes(const View& colors);
+  void warpAtLevel(int level, const Matrix3ft& R, const Vector3ft& t);
+  device::Intr intr() const { return device::Intr(fx_, fy_, cx_, cy_, k1_, k2_, k3_, k4_, k5_); }
+
+  int rows_, cols_, levels_, global_time_;
+  float fx_, fy_, cx_, cy_, k1_, k2_, k3_, k4_, k5_, factor_depth_;
+  float fxd_, fyd_, cxd_, cyd_;
+  int custom_registration_;
+  Matrix3ft init_Rcam_; Vector3ft init_tcam_;
+  int visodo_iterations_[8];
+  std::vector<device::DepthMapf> depthinvs_curr_, depthinvs_odoKF_, depthinvs_odoKF_filtered_, warped_depthinvs_curr_;
+  std::vector<device::IntensityMapf> intensities_curr_, intensities_odoKF_, intensities_odoKF_filtered_, warped_intensities_curr_;
+  std::vector<device::GradientMap> xGradsInt_odoKF_, yGradsInt_odoKF_, xGradsDepthinv_odoKF_, yGradsDepthinv_odoKF_;
+  std::vector<device::GradientMap> xGradsInt_odoKF_covOnly_, yGradsInt_odoKF_covOnly_, xGradsDepthinv_odoKF_covOnly_, yGradsDepthinv_odoKF_covOnly_;
+  std::vector<DeviceArray<float> > res_intensities_, res_depthinvs_;
+  device::DepthMapf depthinv_integrKF_, depthinv_integrKF_raw_, warped_depthinv_integr_curr_;
+  View colors_integrKF_;
+  device::BinaryMap overlap_mask_integrKF_;
+  device::IntensityMapf r_curr_, g_curr_, b_curr_;
+  DeviceArray2D<float> warped_weight_curr_, weight_integrKF_;
+  device::MapArr vertices_integrKF_, normals_integrKF_;
+  device::GradientMap xGradsDepthinv_integrKF_, yGradsDepthinv_integrKF_;
+  DeviceArray2D<device::float_type> gbuf_;
+  DeviceArray<device::float_type> sumbuf_;
+  std::vector<Matrix3ft> rmats_, odo_rmats_;
+  std::vector<Vector3ft> tvecs_, odo_tvecs_;
+  std::vector<Matrix6d> odo_covmats_;
+  std::vector<float> vis_odo_times_;
+  std::vector<int64_t> timestamps_;
+  bool lost_;
+  Matrix3ft last_estimated_rotation_; Vector3ft last_estimated_translation_;
+  int odoKF_count_, integrKF_count_, last_odoKF_index_, last_integrKF_index_;
+  float delta_t_;
+  Vector3ft velocity_, omega_;
+  int optim_dim_, Mestimator_, motion_model_, sigma_estimator_, weighting_, warping_, max_odoKF_count_, finest_level_, termination_;
+  float visibility_ratio_odo_threshold_;
+  int image_filtering_;
+  float visibility_ratio_integr_threshold_;
+  int max_integrKF_count_, Nsamples_;
+  std::shared_ptr<std::thread> visodo_thread_;
+  Matrix3ft delta_rotation_; Vector3ft delta_translation_; Matrix6d delta_covariance_;
+  Matrix3ft last_odoKF_global_rotation_; Vector3ft last_odoKF_global_translation_;
+  Matrix3ft last_integrKF_global_rotation_; Vector3ft last_integrKF_global_translation_;
+  Matrix3ft delta_rotation_odo2integr_last_; Vector3ft delta_translation_odo2integr_last_; Matrix6d delta_covariance_odo2integr_last_;
+  Matrix3ft delta_rotation_odo2integr_next_; Vector3ft delta_translation_odo2integr_next_; Matrix6d delta_covariance_odo2integr_next_;
+  float kf_time_accum_;
+  bool preview_, verbose_;
+  LastFrameInfo last_info_;
+  TrackerSink null_sink_;
+};
+
+}  // namespace RGBID_SLAM

@@ -1,0 +1,65 @@
+/*
+ * rgbid_host.h -- C-ABI of the host-side library (librgbid_host.so): the VisodoTracker mirror
+ * (include/rgbid/visodo.h; reference include/visodo.h + src/visodo.cpp), the SE(3) helpers
+ * (reference src/util_funcs.cpp:31-155) and the INI settings parser (reference src/settings.cpp).
+ * The C++ classes themselves are the drop-in surface; this C layer exists so tests and other languages
+ * can drive them without a C++ compiler.
+ */
+#ifndef RGBID_HOST_H_
+#define RGBID_HOST_H_
+
+#include "rgbid.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* util_funcs.cpp: expMapRot :124-148, expMap :86-122, logMap :31-83 (twist = v, omega), forceOrthogonalisation :150-155 */
+void rgbid_expmap_rot(const double w[3], double R[9]);
+void rgbid_expmap(const double w[3], const double v[3], double R[9], double t[3]);
+void rgbid_logmap(const double R[9], const double t[3], double twist[6]);
+void rgbid_force_orthogonal(const double M[9], double R[9]);
+/* Eigen A.llt().solve(b) (visodo.cpp:1249) and A.inverse() (visodo.cpp:1409) */
+void rgbid_llt_solve6(const double A[36], const double b[6], double x[6]);
+void rgbid_inverse6(const double A[36], double Ainv[36]);
+
+/* Settings::getSection + Section::getEntry (settings.cpp); returns the value length or <0 */
+int rgbid_settings_get(const char* ini_path, const char* section, const char* key, char* out, int cap);
+
+typedef struct rgbid_tracker rgbid_tracker;
+/* the VisodoTracker constructor arguments (include/visodo.h:54-68) + calibration */
+typedef struct rgbid_tracker_config {
+  int rows, cols, levels;
+  int iters[8];
+  int mestimator, motion_model, sigma_estimator, weighting, warping;
+  int max_odoKF_count, finest_level, termination;
+  float visratio_odo;
+  int image_filtering;
+  float visratio_integr;
+  int max_integrKF_count, nsamples;
+  float fx, fy, cx, cy, factor_depth;
+  int interp_mode, preview;
+} rgbid_tracker_config;
+typedef struct rgbid_tracker_info {
+  int lost, odo_kf_switched, integr_kf_switched;
+  float visratio_odo, visratio_integr, sigma_int, sigma_depthinv, nu_int, nu_depthinv;
+} rgbid_tracker_info;
+
+void rgbid_tracker_default_config(rgbid_tracker_config* c);  /* ctor defaults + shipped ini + factory calibration */
+int rgbid_tracker_create(rgbid_tracker** t, const rgbid_tracker_config* c, int device);
+int rgbid_tracker_destroy(rgbid_tracker* t);
+int rgbid_tracker_load_settings(rgbid_tracker* t, const char* ini_path);      /* VisodoTracker::loadSettings */
+int rgbid_tracker_load_calibration(rgbid_tracker* t, const char* ini_path);   /* VisodoTracker::loadCalibration */
+/* uploads depth (u16 mm, rows x cols) and rgb (u8 r,g,b) from HOST memory and runs trackNewFrame */
+int rgbid_tracker_track(rgbid_tracker* t, const uint16_t* depth_mm_host, const uint8_t* rgb_host, int* tracked);
+int rgbid_tracker_num_poses(const rgbid_tracker* t);
+int rgbid_tracker_get_pose(const rgbid_tracker* t, int i, double R[9], double tv[3]);
+int rgbid_tracker_num_odo(const rgbid_tracker* t);
+int rgbid_tracker_get_odo(const rgbid_tracker* t, int i, double R[9], double tv[3], double cov[36]);
+int rgbid_tracker_last_info(const rgbid_tracker* t, rgbid_tracker_info* info);
+int rgbid_tracker_keyframe_maps(rgbid_tracker* t, float* depthinv_host, float* weight_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -40,6 +40,28 @@ int rgbid_device_count(int* n) {
   return RGBID_OK;
 }
 
+int rgbid_get_device_prop(int device, rgbid_device_prop* prop) {
+  if (!prop) return RGBID_E_INVALID;
+  hipDeviceProp_t p;
+  hipError_t e = hipGetDeviceProperties(&p, device);
+  if (e != hipSuccess) return RGBID_E_NODEV;
+  memset(prop, 0, sizeof(*prop));
+  strncpy(prop->name, p.name, sizeof(prop->name) - 1);
+  prop->multiProcessorCount = p.multiProcessorCount;
+  prop->maxThreadsPerMultiProcessor = p.maxThreadsPerMultiProcessor;
+  prop->warpSize = p.warpSize;
+  prop->clockRateKHz = p.clockRate;
+  prop->totalGlobalMem = p.totalGlobalMem;
+  prop->sharedMemPerBlock = p.sharedMemPerBlock;
+  strncpy(prop->gcnArchName, p.gcnArchName, sizeof(prop->gcnArchName) - 1);
+  return RGBID_OK;
+}
+
+int rgbid_set_device(int device) {
+  hipError_t e = hipSetDevice(device);
+  return e == hipSuccess ? RGBID_OK : RGBID_E_NODEV;
+}
+
 int rgbid_ctx_create(rgbid_ctx** out, int device, void* stream) {
   if (!out) return RGBID_E_INVALID;
   *out = nullptr;

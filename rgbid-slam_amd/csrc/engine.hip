@@ -10,7 +10,7 @@
 #include "../../include/rgbid_engine.h"
 #include "ctx.h"
 #include "kernels.h"
-#include "se3.h"
+#include "../../include/rgbid/se3.h"
 
 #include <cstdio>
 #include <cstring>

@@ -1,0 +1,128 @@
+// host_capi.cpp -- C-ABI over the host-side C++ (VisodoTracker, SE(3) helpers, settings) so tests and other languages can
+// drive it (declared in include/rgbid_host.h).
+#include "../../include/rgbid_host.h"
+
+#include <cstring>
+#include <fstream>
+#include <new>
+
+#include "../../include/rgbid/se3.h"
+#include "../../include/rgbid/visodo.h"
+
+namespace RGBID_SLAM { namespace device { DeviceProp dev_prop; int dev_id = 0; } }
+
+using namespace RGBID_SLAM;
+namespace se3 = rgbid::se3;
+
+struct rgbid_tracker { VisodoTracker* t; };
+
+extern "C" {
+
+void rgbid_expmap_rot(const double w[3], double R[9]) { se3::expmap_rot(w, R); }
+void rgbid_expmap(const double w[3], const double v[3], double R[9], double t[3]) { se3::expmap(w, v, R, t); }
+void rgbid_logmap(const double R[9], const double t[3], double twist[6]) { se3::logmap(R, t, twist); }
+void rgbid_force_orthogonal(const double M[9], double R[9]) { se3::force_orthogonal(M, R); }
+void rgbid_llt_solve6(const double A[36], const double b[6], double x[6]) { se3::llt_solve6(A, b, x); }
+void rgbid_inverse6(const double A[36], double Ainv[36]) { se3::inverse6(A, Ainv); }
+
+int rgbid_settings_get(const char* path, const char* section, const char* key, char* out, int cap) {
+  std::ifstream f(path);
+  if (!f.is_open()) return -1;
+  Settings s(f, false);
+  Section sec;
+  if (!s.getSection(section, sec)) return -2;
+  Entry e;
+  if (!sec.getEntry(key, e)) return -3;
+  std::string v = e.getValue();
+  if ((int)v.size() + 1 > cap) return -4;
+  std::memcpy(out, v.c_str(), v.size() + 1);
+  return (int)v.size();
+}
+
+void rgbid_tracker_default_config(rgbid_tracker_config* c) {
+  std::memset(c, 0, sizeof(*c));
+  c->rows = 480; c->cols = 640; c->levels = 3;
+  c->iters[0] = 10; c->iters[1] = 5; c->iters[2] = 3;
+  c->mestimator = RGBID_STUDENT; c->motion_model = RGBID_CONSTANT_VELOCITY; c->sigma_estimator = RGBID_SIGMA_PDF;
+  c->weighting = RGBID_INDEPENDENT; c->warping = RGBID_PYR_FIRST; c->max_odoKF_count = 9999999; c->finest_level = 0;
+  c->termination = RGBID_ALL_ITERS; c->visratio_odo = 0.9f; c->image_filtering = RGBID_NO_FILTERS; c->visratio_integr = 0.7f;
+  c->max_integrKF_count = 9999999; c->nsamples = 10000;
+  c->fx = 525.f; c->fy = 525.f; c->cx = 319.5f; c->cy = 239.5f; c->factor_depth = 1.f;
+  c->interp_mode = RGBID_INTERP_TEX8; c->preview = 0;
+}
+
+int rgbid_tracker_create(rgbid_tracker** out, const rgbid_tracker_config* c, int device) {
+  if (!out || !c) return RGBID_E_INVALID;
+  int n = 0;
+  if (rgbid_device_count(&n) != RGBID_OK || device < 0 || device >= n) return RGBID_E_NODEV;
+  pcl::gpu::setDevice(device);
+  rgbid_tracker* h = new (std::nothrow) rgbid_tracker();
+  if (!h) return RGBID_E_NOMEM;
+  h->t = new VisodoTracker(6, c->mestimator, c->motion_model, c->sigma_estimator, c->weighting, c->warping, c->max_odoKF_count, c->finest_level,
+                           c->termination, c->visratio_odo, c->image_filtering, c->visratio_integr, c->max_integrKF_count, c->nsamples, c->rows,
+                           c->cols, c->levels);
+  h->t->setRGBIntrinsics(c->fx, c->fy, c->cx, c->cy);
+  h->t->setFactorDepth(c->factor_depth);
+  h->t->setIterations(c->iters, c->levels);
+  h->t->setInterpMode(c->interp_mode);
+  h->t->setPreview(c->preview != 0);
+  *out = h;
+  return RGBID_OK;
+}
+
+int rgbid_tracker_destroy(rgbid_tracker* h) { if (h) { delete h->t; delete h; } return RGBID_OK; }
+int rgbid_tracker_load_settings(rgbid_tracker* h, const char* ini_path) {
+  if (!h || !ini_path) return RGBID_E_INVALID;
+  std::ifstream f(ini_path);
+  if (!f.is_open()) return RGBID_E_INVALID;
+  Settings s(f, false);
+  h->t->loadSettings(s);
+  return RGBID_OK;
+}
+int rgbid_tracker_load_calibration(rgbid_tracker* h, const char* ini_path) {
+  if (!h || !ini_path) return RGBID_E_INVALID;
+  h->t->loadCalibration(ini_path);
+  return RGBID_OK;
+}
+int rgbid_tracker_track(rgbid_tracker* h, const uint16_t* depth_mm_host, const uint8_t* rgb_host, int* tracked) {
+  if (!h || !depth_mm_host || !rgb_host) return RGBID_E_INVALID;
+  VisodoTracker& t = *h->t;
+  // what the application's grabber does (tools/RGBID_SLAMapp.cpp:187-188): H2D upload of depth_ and rgb24_
+  t.depth_.upload(depth_mm_host, (size_t)t.cols() * 2, t.rows(), t.cols());
+  t.rgb24_.upload(rgb_host, (size_t)t.cols() * 3, t.rows(), t.cols());
+  bool ok = t.trackNewFrame();
+  if (tracked) *tracked = ok ? 1 : 0;
+  return RGBID_OK;
+}
+int rgbid_tracker_num_poses(const rgbid_tracker* h) { return h ? (int)h->t->getNumberOfPoses() : 0; }
+int rgbid_tracker_get_pose(const rgbid_tracker* h, int i, double R[9], double tv[3]) {
+  if (!h || i < 0 || i >= (int)h->t->getNumberOfPoses()) return RGBID_E_INVALID;
+  Affine3d a = h->t->getCameraPose(i);
+  std::memcpy(R, a.R.m, sizeof(a.R.m)); std::memcpy(tv, a.t.v, sizeof(a.t.v));
+  return RGBID_OK;
+}
+int rgbid_tracker_num_odo(const rgbid_tracker* h) { return h ? (int)h->t->odoRotations().size() : 0; }
+int rgbid_tracker_get_odo(const rgbid_tracker* h, int i, double R[9], double tv[3], double cov[36]) {
+  if (!h || i < 0 || i >= (int)h->t->odoRotations().size()) return RGBID_E_INVALID;
+  std::memcpy(R, h->t->odoRotations()[i].m, 72); std::memcpy(tv, h->t->odoTranslations()[i].v, 24);
+  std::memcpy(cov, h->t->odoCovariances()[i].data(), 288);
+  return RGBID_OK;
+}
+int rgbid_tracker_last_info(const rgbid_tracker* h, rgbid_tracker_info* info) {
+  if (!h || !info) return RGBID_E_INVALID;
+  VisodoTracker::LastFrameInfo l = h->t->lastInfo();
+  info->lost = h->t->visOdoIsLost() ? 1 : 0;
+  info->odo_kf_switched = l.odo_kf_switched; info->integr_kf_switched = l.integr_kf_switched;
+  info->visratio_odo = l.visratio_odo; info->visratio_integr = l.visratio_integr;
+  info->sigma_int = l.sigma_int; info->sigma_depthinv = l.sigma_depthinv; info->nu_int = l.nu_int; info->nu_depthinv = l.nu_depthinv;
+  return RGBID_OK;
+}
+int rgbid_tracker_keyframe_maps(rgbid_tracker* h, float* depthinv_host, float* weight_host) {
+  if (!h) return RGBID_E_INVALID;
+  VisodoTracker& t = *h->t;
+  if (depthinv_host) t.integrationKeyframeDepthinv().download(depthinv_host, (size_t)t.cols() * 4);
+  if (weight_host) t.integrationKeyframeWeight().download(weight_host, (size_t)t.cols() * 4);
+  return RGBID_OK;
+}
+
+}  // extern "C"

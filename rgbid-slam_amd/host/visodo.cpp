@@ -1,0 +1,725 @@
+// visodo.cpp -- VisodoTracker on the HIP bridge: the per-frame driver of the reference (src/visodo.cpp) with the same
+// control flow, written against include/rgbid/internal.h (same bridge function names as the reference) and
+// include/rgbid/se3.h (Eigen-free SE(3) / 6x6 algebra).  Every block cites the reference lines it follows.
+// This is the host-driven, one-stream-of-frames path (the drop-in for the existing pipeline); the batched
+// device-resident engine (csrc/engine.hip) runs the same algorithm for many streams without host round trips.
+#include "../../include/rgbid/visodo.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "../../include/rgbid/se3.h"
+
+using namespace RGBID_SLAM::device;
+namespace se3 = rgbid::se3;
+
+namespace RGBID_SLAM {
+
+namespace {
+inline Matrix6d zero6() { Matrix6d z; z.fill(0.0); return z; }
+inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// K R K^-1, K t in float (Eigen float expression `K*R.cast<float>()*K.inverse()`), as Mat33 rows / float3
+inline void project(const Matrix3f& K, const Matrix3ft& R, const Vector3ft& t, Mat33& Rp, float3& tp) {
+  float Rf[9], tf[3];
+  se3::project_trafo(K.m[0], K.m[4], K.m[2], K.m[5], R.m, t.v, Rf, tf);
+  for (int i = 0; i < 3; ++i) { Rp.data[i].x = Rf[i * 3]; Rp.data[i].y = Rf[i * 3 + 1]; Rp.data[i].z = Rf[i * 3 + 2]; }
+  tp.x = tf[0]; tp.y = tf[1]; tp.z = tf[2];
+}
+}  // namespace
+
+VisodoTracker::VisodoTracker(int optim_dim, int Mestimator, int motion_model, int sigma_estimator, int weighting, int warping,
+                             int max_odoKF_count, int finest_level, int termination, float visratio_odo, int image_filtering,
+                             float visratio_integr, int max_integrKF_count, int Nsamples, int rows, int cols, int levels)
+    : rows_(rows), cols_(cols), levels_(levels), global_time_(0), lost_(false), optim_dim_(optim_dim), Mestimator_(Mestimator),
+      motion_model_(motion_model), sigma_estimator_(sigma_estimator), weighting_(weighting), warping_(warping),
+      max_odoKF_count_(max_odoKF_count), finest_level_(finest_level), termination_(termination),
+      visibility_ratio_odo_threshold_(visratio_odo), image_filtering_(image_filtering),
+      visibility_ratio_integr_threshold_(visratio_integr), max_integrKF_count_(max_integrKF_count), Nsamples_(Nsamples) {
+  // src/visodo.cpp:49-97
+  k1_ = k2_ = k3_ = k4_ = k5_ = 0.f;
+  setRGBIntrinsics(FOCAL_LENGTH, FOCAL_LENGTH, CENTER_X, CENTER_Y);
+  setDepthIntrinsics(FOCAL_LENGTH, FOCAL_LENGTH_DEPTH, CENTER_X, CENTER_Y);
+  init_Rcam_ = Matrix3ft::Identity();
+  init_tcam_ = Vector3ft::Zero();
+  custom_registration_ = 0;
+  const int iters[] = {10, 5, 3, 3, 3, 3, 3, 3};  // {10,5,3} for the reference's 3 levels (:65); extra levels get 3
+  for (int i = 0; i < 8; ++i) visodo_iterations_[i] = iters[i];
+  real_time_flag_ = false;
+  compute_deltat_flag_ = false;
+  exit_ = false;
+  preview_ = true;
+  verbose_ = false;
+  keyframe_manager_ptr_ = &null_sink_;
+  timestamp_rgb_curr_ = timestamp_depth_curr_ = timestamp_ini_ = 0;
+  kf_time_accum_ = 0.f;
+  odometry_success_ = false;
+  last_info_ = LastFrameInfo();
+  allocateBuffers(rows, cols);
+  scene_view_.resize((size_t)cols_ * rows_);
+  intensity_view_.resize((size_t)cols_ * rows_, 0.f);
+  depthinv_view_.resize((size_t)cols_ * rows_);
+  newKF_ = false;
+  scene_view_has_changed_ = false;
+  camera_pose_has_changed_ = false;
+  factor_depth_ = 1.f;
+  reset();
+}
+
+VisodoTracker::~VisodoTracker() {
+  if (visodo_thread_ && visodo_thread_->joinable()) {
+    { std::unique_lock<std::mutex> lock(mutex_); exit_ = true; }
+    new_frame_cond_.notify_one();
+    visodo_thread_->join();
+  }
+}
+
+void VisodoTracker::setIterations(const int* iters, int n) { for (int i = 0; i < n && i < 8; ++i) visodo_iterations_[i] = iters[i]; }
+void VisodoTracker::setInterpMode(int mode) { rgbidSafeCall(rgbid_ctx_set_interp_mode(default_ctx(), mode)); }
+
+void VisodoTracker::loadCalibration(std::string const& calib_file) {
+  // src/visodo.cpp:99-181 ([CALIBRATION] / [RGB_CALIBRATION]: fx fy cx cy kd factor_depth)
+  std::ifstream filestream(calib_file.c_str());
+  if (!filestream.is_open()) { std::cout << "Could not open configuration file " << calib_file << std::endl; return; }
+  Settings settings(filestream, verbose_);
+  Section calibration;
+  if (settings.getSection("CALIBRATION", calibration) || settings.getSection("RGB_CALIBRATION", calibration)) {
+    Entry entry;
+    if (calibration.getEntry("fx", entry)) { std::stringstream ss(entry.getValue()); ss >> fx_; fxd_ = fx_; }
+    if (calibration.getEntry("fy", entry)) { fy_ = (float)atof(entry.getValue().c_str()); fyd_ = fy_; }
+    if (calibration.getEntry("cx", entry)) { cx_ = (float)atof(entry.getValue().c_str()); cxd_ = cx_; }
+    if (calibration.getEntry("cy", entry)) { cy_ = (float)atof(entry.getValue().c_str()); cyd_ = cy_; }
+    if (calibration.getEntry("kd", entry)) { std::stringstream ss(entry.getValue()); ss >> k1_ >> k2_ >> k3_ >> k4_ >> k5_; }
+    if (calibration.getEntry("factor_depth", entry)) factor_depth_ = (float)atof(entry.getValue().c_str());
+  }
+  if (settings.getSection("DEPTH_CALIBRATION", calibration)) {
+    Entry entry;
+    if (calibration.getEntry("custom_registration", entry)) {
+      std::stringstream ss(entry.getValue());
+      ss >> custom_registration_;
+      if (custom_registration_) {
+        // the custom-calibration front-end (undistortion + depth registration) is not part of this build
+        std::cout << "custom_registration=1 is not supported by this build (the reference's README advises against it); ignoring" << std::endl;
+        custom_registration_ = 0;
+      }
+    }
+  }
+}
+
+void VisodoTracker::loadSettings(Settings& settings) {
+  // src/visodo.cpp:321-435 ([VISODO])
+  Section s;
+  if (!settings.getSection("VISODO", s)) return;
+  Entry e;
+  if (s.getEntry("M_ESTIMATOR", e)) {
+    std::string v = e.getValue();
+    if (v == "Student") Mestimator_ = STUDENT;
+    if (v == "LeastSquares") Mestimator_ = LSQ;
+    if (v == "Tukey") Mestimator_ = TUKEY;
+    if (v == "Huber") Mestimator_ = HUBER;
+  }
+  if (s.getEntry("MOTION_MODEL", e)) {
+    if (e.getValue() == "none") motion_model_ = NO_MM;
+    if (e.getValue() == "constVelocity") motion_model_ = CONSTANT_VELOCITY;
+  }
+  if (s.getEntry("WARP_ORDER", e)) {
+    if (e.getValue() == "warpFirst") warping_ = WARP_FIRST;
+    if (e.getValue() == "pyrFirst") warping_ = PYR_FIRST;
+  }
+  if (s.getEntry("IMAGE_FILTERING", e)) {
+    if (e.getValue() == "none") image_filtering_ = NO_FILTERS;
+    if (e.getValue() == "gradients") image_filtering_ = FILTER_GRADS;
+  }
+  if (s.getEntry("SIGMA_ESTIMATOR", e)) {
+    if (e.getValue() == "sigmaMAD") sigma_estimator_ = SIGMA_MAD;
+    if (e.getValue() == "sigmaML") sigma_estimator_ = SIGMA_PDF;
+    if (e.getValue() == "sigmaConst") sigma_estimator_ = SIGMA_CONS;
+  }
+  if (s.getEntry("INTEGRATION_VISRATIO_THRESHOLD", e)) visibility_ratio_integr_threshold_ = (float)atof(e.getValue().c_str());
+  if (s.getEntry("ODOMETRY_VISRATIO_THRESHOLD", e)) visibility_ratio_odo_threshold_ = (float)atof(e.getValue().c_str());
+  if (s.getEntry("FINEST_PYR_LEVEL", e)) finest_level_ = (int)atof(e.getValue().c_str());
+}
+
+void VisodoTracker::start() {
+  // src/visodo.cpp:437-445
+  std::unique_lock<std::mutex> lock(created_aux_mutex_);
+  visodo_thread_.reset(new std::thread([this]() { (*this)(); }));
+  created_cond_.wait(lock);
+}
+
+bool VisodoTracker::operator()() {
+  // src/visodo.cpp:2249-2267
+  std::unique_lock<std::mutex> lock(mutex_);
+  exit_ = false;
+  { std::unique_lock<std::mutex> l2(created_aux_mutex_); created_cond_.notify_one(); }
+  while (!exit_) {
+    new_frame_cond_.wait(lock);
+    if (exit_) break;
+    trackNewFrame();
+  }
+  return true;
+}
+
+void VisodoTracker::setRGBIntrinsics(float fx, float fy, float cx, float cy, float k1, float k2, float k3, float k4, float k5) {
+  // src/visodo.cpp:448-462
+  fx_ = fx; fy_ = fy;
+  cx_ = (cx == -1) ? cols_ / 2 - 0.5f : cx;
+  cy_ = (cy == -1) ? rows_ / 2 - 0.5f : cy;
+  k1_ = k1; k2_ = k2; k3_ = k3; k4_ = k4; k5_ = k5;
+  lost_ = false;
+}
+void VisodoTracker::setDepthIntrinsics(float fxd, float fyd, float cxd, float cyd) {
+  fxd_ = fxd; fyd_ = fyd;
+  cxd_ = (cxd == -1) ? cols_ / 2 - 0.5f : cxd;
+  cyd_ = (cyd == -1) ? rows_ / 2 - 0.5f : cyd;
+}
+void VisodoTracker::setSharedCameraPose(const Affine3d& pose) {
+  std::lock_guard<std::mutex> lock(mutex_shared_camera_pose_);
+  shared_camera_pose_ = pose;
+  camera_pose_has_changed_ = true;
+}
+Affine3d VisodoTracker::getSharedCameraPose() {
+  std::lock_guard<std::mutex> lock(mutex_shared_camera_pose_);
+  camera_pose_has_changed_ = false;
+  return shared_camera_pose_;
+}
+Affine3d VisodoTracker::getCameraPose(int time) const {
+  if (time > (int)rmats_.size() || time < 0) time = (int)rmats_.size() - 1;
+  Affine3d a; a.R = rmats_[time]; a.t = tvecs_[time];
+  return a;
+}
+float VisodoTracker::getVisOdoTime(int time) const {
+  if (time > (int)vis_odo_times_.size() || time < 0) time = (int)vis_odo_times_.size() - 1;
+  return vis_odo_times_[time];
+}
+int64_t VisodoTracker::getTimestamp(int time) const {
+  if (timestamps_.empty()) return 0;
+  if (time > (int)timestamps_.size() || time < 0) time = (int)timestamps_.size() - 1;
+  return timestamps_[time];
+}
+Matrix3f VisodoTracker::getCalibMatrix(int level_index) const {
+  // src/visodo.cpp:1885-1900
+  int div = 1 << level_index;
+  Matrix3f K;
+  float v[9] = {fx_ / div, 0.f, cx_ / div, 0.f, fy_ / div, cy_ / div, 0.f, 0.f, 1.f};
+  for (int i = 0; i < 9; ++i) K.m[i] = v[i];
+  return K;
+}
+
+void VisodoTracker::getImage(std::vector<PixelRGB>& scene_view, std::vector<float>& intensity_view, std::vector<float>& depthinv_view) {
+  // src/visodo.cpp:559-580
+  LightSource light;
+  light.number = 1;
+  light.pos[0].x = (float)last_integrKF_global_translation_[0];
+  light.pos[0].y = (float)last_integrKF_global_translation_[1];
+  light.pos[0].z = (float)last_integrKF_global_translation_[2];
+  View scene_view_dev;
+  scene_view_dev.create(rows_, cols_);
+  PtrStepSz<uchar3> rgb(rows_, cols_, (uchar3*)colors_integrKF_.ptr(), colors_integrKF_.step());
+  PtrStepSz<uchar3> dst(rows_, cols_, (uchar3*)scene_view_dev.ptr(), scene_view_dev.step());
+  generateImageRGB(vertices_integrKF_, normals_integrKF_, rgb, light, dst);
+  device::sync();
+  int c;
+  scene_view_dev.download(scene_view, c);
+  intensities_curr_[0].download(intensity_view, c);
+  depthinv_integrKF_.download(depthinv_view, c);
+}
+
+void VisodoTracker::allocateBuffers(int rows, int cols) {
+  // src/visodo.cpp:584-691 (only the buffers that live code touches)
+  const int L = levels_;
+  depthinvs_curr_.resize(L); intensities_curr_.resize(L); depthinvs_odoKF_.resize(L); intensities_odoKF_.resize(L);
+  depthinvs_odoKF_filtered_.resize(L); intensities_odoKF_filtered_.resize(L);
+  xGradsInt_odoKF_.resize(L); yGradsInt_odoKF_.resize(L); xGradsDepthinv_odoKF_.resize(L); yGradsDepthinv_odoKF_.resize(L);
+  xGradsInt_odoKF_covOnly_.resize(L); yGradsInt_odoKF_covOnly_.resize(L); xGradsDepthinv_odoKF_covOnly_.resize(L); yGradsDepthinv_odoKF_covOnly_.resize(L);
+  warped_depthinvs_curr_.resize(L); warped_intensities_curr_.resize(L);
+  res_intensities_.resize(L); res_depthinvs_.resize(L);
+  rgb24_.create(rows, cols); depth_.create(rows, cols);
+  warped_weight_curr_.create(rows, cols);
+  initialiseDeviceMemory2D<float>(warped_weight_curr_, 0.f);  // the reference leaves it uninitialised; defined as 0 here
+  warped_depthinv_integr_curr_.create(rows, cols);
+  depthinv_integrKF_.create(rows, cols); weight_integrKF_.create(rows, cols); overlap_mask_integrKF_.create(rows, cols);
+  depthinv_integrKF_raw_.create(rows, cols);
+  vertices_integrKF_.create(3 * rows, cols); normals_integrKF_.create(3 * rows, cols);
+  xGradsDepthinv_integrKF_.create(rows, cols); yGradsDepthinv_integrKF_.create(rows, cols);
+  colors_integrKF_.create(rows, cols);
+  r_curr_.create(rows, cols); g_curr_.create(rows, cols); b_curr_.create(rows, cols);
+  for (int i = 0; i < L; ++i) {
+    int pr = rows >> i, pc = cols >> i;
+    intensities_curr_[i].create(pr, pc); depthinvs_curr_[i].create(pr, pc);
+    intensities_odoKF_[i].create(pr, pc); depthinvs_odoKF_[i].create(pr, pc);
+    intensities_odoKF_filtered_[i].create(pr, pc); depthinvs_odoKF_filtered_[i].create(pr, pc);
+    xGradsInt_odoKF_[i].create(pr, pc); yGradsInt_odoKF_[i].create(pr, pc);
+    xGradsDepthinv_odoKF_[i].create(pr, pc); yGradsDepthinv_odoKF_[i].create(pr, pc);
+    xGradsInt_odoKF_covOnly_[i].create(pr, pc); yGradsInt_odoKF_covOnly_[i].create(pr, pc);
+    xGradsDepthinv_odoKF_covOnly_[i].create(pr, pc); yGradsDepthinv_odoKF_covOnly_[i].create(pr, pc);
+    warped_depthinvs_curr_[i].create(pr, pc); warped_intensities_curr_[i].create(pr, pc);
+    res_intensities_[i].create((size_t)pr * pc); res_depthinvs_[i].create((size_t)pr * pc);
+  }
+}
+
+void VisodoTracker::reset() {
+  // src/visodo.cpp:519-553
+  global_time_ = 0;
+  rmats_.clear(); tvecs_.clear(); vis_odo_times_.clear(); timestamps_.clear();
+  odo_rmats_.clear(); odo_tvecs_.clear(); odo_covmats_.clear();
+  rmats_.push_back(init_Rcam_); tvecs_.push_back(init_tcam_); vis_odo_times_.push_back(0.f);
+  last_estimated_rotation_ = Matrix3ft::Identity();
+  last_estimated_translation_ = Vector3ft::Zero();
+  velocity_ = Vector3ft::Zero(); omega_ = Vector3ft::Zero();
+  lost_ = false;
+}
+
+void VisodoTracker::prepareImages(const DepthMap& depth_raw, const View& colors_raw) {
+  // src/visodo.cpp:760-773
+  PtrStepSz<uchar3> colors(rows_, cols_, (uchar3*)colors_raw.ptr(), colors_raw.step());
+  computeIntensity(colors, intensities_curr_[0]);
+  decomposeRGBInChannels(colors, r_curr_, g_curr_, b_curr_);
+  convertDepth2InvDepth(depth_raw, depthinvs_curr_[0], factor_depth_);
+  for (int i = 1; i < levels_; ++i) {
+    pyrDownIntensity(intensities_curr_[i - 1], intensities_curr_[i]);
+    pyrDownDepth(depthinvs_curr_[i - 1], depthinvs_curr_[i]);
+  }
+}
+
+void VisodoTracker::saveCurrentImagesAsOdoKeyframes() {
+  // src/visodo.cpp:826-878
+  const float sigma_int_ref = 3.f, sigma_depthinv_ref = 0.0025f;
+  for (int i = 0; i < levels_; ++i) copyImages(depthinvs_curr_[i], intensities_curr_[i], depthinvs_odoKF_[i], intensities_odoKF_[i]);
+  bilateralFilter(depthinvs_odoKF_[0], depthinvs_odoKF_filtered_[0], 2.f * sigma_depthinv_ref);
+  bilateralFilter(intensities_odoKF_[0], intensities_odoKF_filtered_[0], sigma_int_ref);
+  computeGradientIntensity(intensities_odoKF_filtered_[0], xGradsInt_odoKF_covOnly_[0], yGradsInt_odoKF_covOnly_[0]);
+  computeGradientDepth(depthinvs_odoKF_filtered_[0], xGradsDepthinv_odoKF_covOnly_[0], yGradsDepthinv_odoKF_covOnly_[0]);
+  for (int i = 1; i < levels_; ++i) {
+    pyrDownDepth(depthinvs_odoKF_filtered_[i - 1], depthinvs_odoKF_filtered_[i]);
+    pyrDownIntensity(intensities_odoKF_filtered_[i - 1], intensities_odoKF_filtered_[i]);
+    computeGradientIntensity(intensities_odoKF_filtered_[i], xGradsInt_odoKF_covOnly_[i], yGradsInt_odoKF_covOnly_[i]);
+    computeGradientDepth(depthinvs_odoKF_filtered_[i], xGradsDepthinv_odoKF_covOnly_[i], yGradsDepthinv_odoKF_covOnly_[i]);
+  }
+  for (int i = 0; i < levels_; ++i) {
+    if (image_filtering_ == FILTER_GRADS) {
+      copyImages(xGradsInt_odoKF_covOnly_[i], yGradsInt_odoKF_covOnly_[i], xGradsInt_odoKF_[i], yGradsInt_odoKF_[i]);
+      copyImages(xGradsDepthinv_odoKF_covOnly_[i], yGradsDepthinv_odoKF_covOnly_[i], xGradsDepthinv_odoKF_[i], yGradsDepthinv_odoKF_[i]);
+    } else {
+      computeGradientIntensity(intensities_odoKF_[i], xGradsInt_odoKF_[i], yGradsInt_odoKF_[i]);
+      computeGradientDepth(depthinvs_odoKF_[i], xGradsDepthinv_odoKF_[i], yGradsDepthinv_odoKF_[i]);
+    }
+  }
+}
+
+void VisodoTracker::saveCurrentImagesAsIntegrationKeyframes(const View& colors) {
+  // src/visodo.cpp:880-893
+  copyImage(depthinvs_curr_[0], depthinv_integrKF_);
+  copyImage(depthinvs_curr_[0], depthinv_integrKF_raw_);
+  colors.copyTo(colors_integrKF_);
+  initialiseWeightKeyframe(depthinvs_curr_[0], weight_integrKF_);
+  createVMap(intr()(0), depthinv_integrKF_, vertices_integrKF_);
+  computeGradientDepth(depthinv_integrKF_, xGradsDepthinv_integrKF_, yGradsDepthinv_integrKF_);
+  createNMapGradients(intr()(0), depthinv_integrKF_, xGradsDepthinv_integrKF_, yGradsDepthinv_integrKF_, normals_integrKF_);
+}
+
+void VisodoTracker::warpAtLevel(int level, const Matrix3ft& R, const Vector3ft& t) {
+  // src/visodo.cpp:1066-1067, 1108-1126: inverse pose, projected with K(level); the intensity warp samples on the WARPED iD
+  Matrix3ft Ri; Vector3ft ti;
+  se3::m3_inv(R.m, Ri.m);
+  se3::m3_mulv(Ri.m, t.v, ti.v);
+  for (int i = 0; i < 3; ++i) ti.v[i] = -ti.v[i];
+  Mat33 Rp; float3 tp;
+  project(getCalibMatrix(level), Ri, ti, Rp, tp);
+  warpInvDepthWithTrafo3D(depthinvs_curr_[level], warped_depthinvs_curr_[level], depthinvs_odoKF_[level], Rp, tp, intr()(level));
+  warpIntensityWithTrafo3DInvDepth(intensities_curr_[level], warped_intensities_curr_[level], warped_depthinvs_curr_[level], Rp, tp, intr()(level));
+}
+
+bool VisodoTracker::estimateVisualOdometry(Matrix3ft& resulting_rotation, Vector3ft& resulting_translation, Matrix6d& resulting_covariance) {
+  // src/visodo.cpp:944-1479
+  if (real_time_flag_) visodo_iterations_[0] = 5;  // :961-964
+  double A_total[36], b_total[6];
+  const float sigma_int_ref = 5.f, sigma_depthinv_ref = 0.0025f;
+  float sigma_int = 40.f, sigma_depthinv = 5.f, bias_int = 0.f, bias_depthinv = 0.f, nu_int = 5.f, nu_depthinv = 5.f;
+  float chi_test = 1.f, chi_square = 1.f, Ndof = 640.f * 480.f, RMSE = 9999.f, RMSE_prev = 9999.f;
+  Matrix3ft cam_rot_incremental_inv, cam_rot_incremental; Vector3ft cam_trans_incremental;
+  float3 zero3 = {0.f, 0.f, 0.f};
+  Matrix3ft previous_rotation = resulting_rotation; Vector3ft previous_translation = resulting_translation;
+  Matrix3ft current_rotation; Vector3ft current_translation;
+  if ((global_time_ > 1) && (motion_model_ == CONSTANT_VELOCITY) && (!lost_)) {  // :1016-1027
+    double vt[3], wt[3], dR[9], dt[3], tmp[3];
+    for (int i = 0; i < 3; ++i) { vt[i] = velocity_[i] * delta_t_; wt[i] = omega_[i] * delta_t_; }
+    se3::expmap(wt, vt, dR, dt);
+    se3::m3_mulv(previous_rotation.m, dt, tmp);
+    for (int i = 0; i < 3; ++i) current_translation[i] = tmp[i] + previous_translation[i];
+    se3::m3_mul(previous_rotation.m, dR, current_rotation.m);
+  } else { current_rotation = previous_rotation; current_translation = previous_translation; }
+  double t_start = now_ms();
+
+  for (int level_index = levels_ - 1; level_index >= finest_level_; --level_index) {
+    int iter_num = visodo_iterations_[level_index];
+    for (int iter = 0; iter < iter_num; ++iter) {
+      if (warping_ == WARP_FIRST) {  // :1078-1105
+        warpAtLevel(0, current_rotation, current_translation);
+        for (int i = 1; i < level_index + 1; ++i) {
+          pyrDownIntensity(warped_intensities_curr_[i - 1], warped_intensities_curr_[i]);
+          pyrDownDepth(warped_depthinvs_curr_[i - 1], warped_depthinvs_curr_[i]);
+        }
+      } else warpAtLevel(level_index, current_rotation, current_translation);
+      if ((termination_ == CHI_SQUARED) && (iter != 0)) {  // :1134-1164
+        computeErrorGridStride(warped_intensities_curr_[0], intensities_odoKF_[0], res_intensities_[0]);
+        computeErrorGridStride(warped_depthinvs_curr_[0], depthinvs_odoKF_[0], res_depthinvs_[0]);
+        computeChiSquare(res_intensities_[0], res_depthinvs_[0], sigma_int_ref, sigma_depthinv_ref, Mestimator_, chi_square, chi_test, Ndof);
+        RMSE = std::sqrt(chi_square) / std::sqrt(Ndof);
+        if (iter != 1) {
+          if (RMSE > RMSE_prev) {  // undo the previous increment and end this level
+            double d[3], tmp[3];
+            for (int i = 0; i < 3; ++i) d[i] = current_translation[i] - cam_trans_incremental[i];
+            se3::m3_mulv(cam_rot_incremental_inv.m, d, tmp);
+            for (int i = 0; i < 3; ++i) current_translation[i] = tmp[i];
+            se3::m3_mul(cam_rot_incremental_inv.m, current_rotation.m, current_rotation.m);
+            break;
+          }
+        }
+        RMSE_prev = RMSE;
+      }
+      sigma_int = 5.f; sigma_depthinv = 0.0025f; bias_int = 0.f; bias_depthinv = 0.f; nu_int = 5.f; nu_depthinv = 5.f;  // :1168-1173
+      if (sigma_estimator_ == SIGMA_PDF) {  // :1175-1186
+        computeErrorGridStride(warped_intensities_curr_[level_index], intensities_odoKF_[level_index], res_intensities_[level_index], Nsamples_);
+        computeErrorGridStride(warped_depthinvs_curr_[level_index], depthinvs_odoKF_[level_index], res_depthinvs_[level_index], Nsamples_);
+        computeSigmaAndNuStudent(res_intensities_[level_index], bias_int, sigma_int, nu_int, Mestimator_);
+        computeSigmaAndNuStudent(res_depthinvs_[level_index], bias_depthinv, sigma_depthinv, nu_depthinv, Mestimator_);
+        nu_int = std::max(nu_int, nu_depthinv);
+      } else if (sigma_estimator_ == SIGMA_CONS) {
+        sigma_int = (float)std::exp(std::log((double)sigma_int_ref));
+        sigma_depthinv = (float)std::exp(std::log((double)sigma_depthinv_ref));
+      }
+      buildSystemStudentNuGridStride(zero3, zero3, depthinvs_odoKF_[level_index], intensities_odoKF_[level_index],
+                                     xGradsDepthinv_odoKF_[level_index], yGradsDepthinv_odoKF_[level_index], xGradsInt_odoKF_[level_index],
+                                     yGradsInt_odoKF_[level_index], warped_depthinvs_curr_[level_index], warped_intensities_curr_[level_index],
+                                     Mestimator_, weighting_, sigma_depthinv, sigma_int, bias_depthinv, bias_int, nu_depthinv, nu_int,
+                                     intr()(level_index), B_SIZE, gbuf_, sumbuf_, A_total, b_total);
+      double x[6];
+      se3::llt_solve6(A_total, b_total, x);  // A.llt().solve(b) :1249
+      // :1252-1263
+      se3::expmap_rot(x + 3, cam_rot_incremental_inv.m);
+      se3::m3_inv(cam_rot_incremental_inv.m, cam_rot_incremental.m);
+      se3::m3_mulv(cam_rot_incremental.m, x, cam_trans_incremental.v);
+      for (int i = 0; i < 3; ++i) cam_trans_incremental[i] = -cam_trans_incremental[i];
+      double tmp[3];
+      se3::m3_mulv(cam_rot_incremental.m, current_translation.v, tmp);
+      for (int i = 0; i < 3; ++i) current_translation[i] = tmp[i] + cam_trans_incremental[i];
+      se3::m3_mul(cam_rot_incremental.m, current_rotation.m, current_rotation.m);
+      if (se3::has_nan(current_rotation.m, current_translation.v)) {  // :1265-1274
+        resulting_translation = previous_translation;
+        resulting_rotation = previous_rotation;
+        resulting_covariance = zero6();
+        for (int i = 0; i < 6; ++i) resulting_covariance[i * 7] = 100.0;
+        vis_odo_times_.push_back((float)(now_ms() - t_start));
+        return false;
+      }
+    }
+  }
+  last_info_.sigma_int = sigma_int; last_info_.sigma_depthinv = sigma_depthinv; last_info_.nu_int = nu_int; last_info_.nu_depthinv = nu_depthinv;
+  {
+    // covariance pass :1283-1417
+    int fl = finest_level_;
+    warpAtLevel(fl, current_rotation, current_translation);
+    sigma_int = (float)std::exp(std::log((double)sigma_int_ref));
+    sigma_depthinv = (float)std::exp(std::log((double)sigma_depthinv_ref));
+    buildSystemGridStride(zero3, zero3, depthinvs_odoKF_[fl], intensities_odoKF_[fl], xGradsDepthinv_odoKF_covOnly_[fl],
+                          yGradsDepthinv_odoKF_covOnly_[fl], xGradsInt_odoKF_covOnly_[fl], yGradsInt_odoKF_covOnly_[fl],
+                          warped_depthinvs_curr_[fl], warped_intensities_curr_[fl], STUDENT, weighting_, sigma_depthinv, sigma_int, 0.f, 0.f,
+                          intr()(fl), B_SIZE, gbuf_, sumbuf_, A_total, b_total);
+    resulting_rotation = current_rotation;
+    resulting_translation = current_translation;
+    se3::inverse6(A_total, resulting_covariance.data());
+    // :1411-1415 -- full-resolution residuals + chi-square; the reference only writes locals with the result
+    computeErrorGridStride(warped_intensities_curr_[fl], intensities_odoKF_[fl], res_intensities_[fl]);
+    computeErrorGridStride(warped_depthinvs_curr_[fl], depthinvs_odoKF_[fl], res_depthinvs_[fl]);
+    computeChiSquare(res_intensities_[fl], res_depthinvs_[fl], sigma_int_ref, sigma_depthinv_ref, Mestimator_, chi_square, chi_test, Ndof);
+  }
+  {
+    // :1459-1468
+    double pT[9], dR[9], d[3], dt[3], twist[6];
+    se3::m3_T(previous_rotation.m, pT);
+    se3::m3_mul(pT, current_rotation.m, dR);
+    for (int i = 0; i < 3; ++i) d[i] = current_translation[i] - previous_translation[i];
+    se3::m3_mulv(pT, d, dt);
+    se3::logmap(dR, dt, twist);
+    float inv_dt = 1.f / delta_t_;
+    for (int i = 0; i < 3; ++i) { velocity_[i] = twist[i] * (double)inv_dt; omega_[i] = twist[3 + i] * (double)inv_dt; }
+  }
+  return true;
+}
+
+float VisodoTracker::computeCovisibility(const Matrix3ft& R_AtoB, const Vector3ft& t_AtoB, const DepthMapf& depthinvA, const DepthMapf& depthinvB) {
+  // src/visodo.cpp:1481-1514
+  const float geom_tol = 0.05f / (2.f * 2.f);
+  float visibility_ratio_AtoB = 1.f, visibility_ratio_BtoA = 1.f;
+  Matrix3f K = getCalibMatrix(0);
+  Mat33 Rab, Rba; float3 tab, tba, dummy;
+  project(K, R_AtoB, t_AtoB, Rab, tab);
+  Matrix3ft Ri; Vector3ft zero = Vector3ft::Zero();
+  se3::m3_inv(R_AtoB.m, Ri.m);
+  project(K, Ri, zero, Rba, dummy);
+  {
+    // translation_BtoA_f = -K*Rinv.cast<float>()*t.cast<float>() in float
+    float Rf[9], T[9], tf[3] = {(float)t_AtoB[0], (float)t_AtoB[1], (float)t_AtoB[2]}, out[3];
+    for (int i = 0; i < 9; ++i) Rf[i] = (float)Ri.m[i];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T[i * 3 + j] = -K.m[i * 3] * Rf[j] + -K.m[i * 3 + 1] * Rf[3 + j] + -K.m[i * 3 + 2] * Rf[6 + j];
+    for (int i = 0; i < 3; ++i) out[i] = T[i * 3] * tf[0] + T[i * 3 + 1] * tf[1] + T[i * 3 + 2] * tf[2];
+    tba.x = out[0]; tba.y = out[1]; tba.z = out[2];
+  }
+  getVisibilityRatio(depthinvB, depthinvA, Rab, tab, intr()(0), visibility_ratio_BtoA, geom_tol);
+  getVisibilityRatio(depthinvA, depthinvB, Rba, tba, intr()(0), visibility_ratio_AtoB, geom_tol);
+  return std::min(visibility_ratio_AtoB, visibility_ratio_BtoA);
+}
+
+float VisodoTracker::computeOverlapping(const Matrix3ft& R_AtoB, const Vector3ft& t_AtoB, const DepthMapf& depthinvA, const DepthMapf& depthinvB,
+                                        BinaryMap& overlap_maskB) {
+  // src/visodo.cpp:1517-1539
+  float ratio = 1.f;
+  Mat33 Rab; float3 tab;
+  project(getCalibMatrix(0), R_AtoB, t_AtoB, Rab, tab);
+  getVisibilityRatioWithOverlapMask(depthinvB, depthinvA, Rab, tab, intr()(0), ratio, 0.0125f, overlap_maskB);
+  return ratio;
+}
+
+static void propagate_next(Matrix3ft& next_R, Vector3ft& next_t, Matrix6d& next_cov, const Matrix3ft& dR, const Vector3ft& dt, const Matrix6d& dcov) {
+  // shared head of resetOdometryKeyframe / resetIntegrationKeyframe (src/visodo.cpp:1553-1567, 1594-1607)
+  double J[36], tn[3], S[9];
+  se3::m6_zero(J);
+  se3::m6_set_block(J, 0, 0, next_R.m, 1.0);
+  se3::m6_set_block(J, 3, 3, next_R.m, 1.0);
+  se3::m3_mulv(next_R.m, dt.v, tn);
+  se3::skew(tn, S);
+  se3::m6_set_block(J, 0, 3, S, 1.0);
+  se3::m6_JCJt_add(J, dcov.data(), next_cov.data());
+  for (int i = 0; i < 3; ++i) next_t[i] = tn[i] + next_t[i];
+  se3::m3_mul(next_R.m, dR.m, next_R.m);
+}
+
+void VisodoTracker::resetOdometryKeyframe() {
+  // src/visodo.cpp:1541-1575
+  odoKF_count_ = 0;
+  propagate_next(delta_rotation_odo2integr_next_, delta_translation_odo2integr_next_, delta_covariance_odo2integr_next_, delta_rotation_,
+                 delta_translation_, delta_covariance_);
+  last_odoKF_index_ = global_time_;
+  last_odoKF_global_rotation_ = last_estimated_rotation_;
+  last_odoKF_global_translation_ = last_estimated_translation_;
+  delta_rotation_ = Matrix3ft::Identity();
+  delta_translation_ = Vector3ft::Zero();
+  delta_covariance_ = zero6();
+}
+
+void VisodoTracker::resetIntegrationKeyframe() {
+  // src/visodo.cpp:1577-1672
+  integrKF_count_ = 0;
+  rmatsKF_.push_back(last_integrKF_global_rotation_);
+  tvecsKF_.push_back(last_integrKF_global_translation_);
+  propagate_next(delta_rotation_odo2integr_next_, delta_translation_odo2integr_next_, delta_covariance_odo2integr_next_, delta_rotation_,
+                 delta_translation_, delta_covariance_);
+  // T{k-1,k} = inv(T{odo,k-1})*T{odo,k} and its covariance (:1612-1629)
+  Matrix3ft lastT, delta_rotation_kf; Vector3ft delta_translation_kf;
+  se3::m3_T(delta_rotation_odo2integr_last_.m, lastT.m);
+  se3::m3_mul(lastT.m, delta_rotation_odo2integr_next_.m, delta_rotation_kf.m);
+  double d[3];
+  for (int i = 0; i < 3; ++i) d[i] = delta_translation_odo2integr_next_[i] - delta_translation_odo2integr_last_[i];
+  se3::m3_mulv(lastT.m, d, delta_translation_kf.v);
+  double Jn[36], Jl[36], S[9], SR[9];
+  se3::m6_zero(Jn); se3::m6_set_block(Jn, 0, 0, lastT.m, 1.0); se3::m6_set_block(Jn, 3, 3, lastT.m, 1.0);
+  se3::m6_zero(Jl); se3::m6_set_block(Jl, 0, 0, lastT.m, -1.0); se3::m6_set_block(Jl, 3, 3, lastT.m, -1.0);
+  se3::skew(delta_translation_kf.v, S); se3::m3_mul(S, lastT.m, SR); se3::m6_set_block(Jl, 0, 3, SR, 1.0);
+  Matrix6d delta_covariance_kf = zero6();
+  se3::m6_JCJt_add(Jl, delta_covariance_odo2integr_last_.data(), delta_covariance_kf.data());
+  se3::m6_JCJt_add(Jn, delta_covariance_odo2integr_next_.data(), delta_covariance_kf.data());
+  {
+    // keyframe export record :1631-1652 (4 D2H downloads)
+    std::shared_ptr<KeyframeRecord> kf(new KeyframeRecord());
+    kf->K = getCalibMatrix(0);
+    kf->kd[0] = k1_; kf->kd[1] = k2_; kf->kd[2] = k3_; kf->kd[3] = k4_; kf->kd[4] = k5_;
+    kf->rotation = last_integrKF_global_rotation_; kf->translation = last_integrKF_global_translation_;
+    kf->rotation_rel = delta_rotation_kf; kf->translation_rel = delta_translation_kf;
+    kf->id = last_integrKF_index_; kf->cols = cols_; kf->rows = rows_;
+    int c;
+    overlap_mask_integrKF_.download(kf->overlap_mask_, c);
+    colors_integrKF_.download(kf->colors_, c);
+    depthinv_integrKF_.download(kf->depthinv_, c);
+    normals_integrKF_.download(kf->normals_, c);
+    if (keyframe_manager_ptr_->tryPushKeyframe(kf)) {
+      PoseConstraint kf_constr;
+      kf_constr.ini_id_ = last_integrKF_index_; kf_constr.end_id_ = global_time_; kf_constr.type_ = PoseConstraint::SEQ_KF;
+      kf_constr.rotation_ = delta_rotation_kf; kf_constr.translation_ = delta_translation_kf; kf_constr.scale_ = 1.f;
+      kf_constr.covariance_ = delta_covariance_kf;
+      keyframe_manager_ptr_->pushConstraint(kf_constr);
+    }
+  }
+  kf_times_.push_back(1000.f * kf_time_accum_);
+  kf_time_accum_ = 0.f;
+  last_integrKF_index_ = global_time_;
+  last_integrKF_global_rotation_ = last_estimated_rotation_;
+  last_integrKF_global_translation_ = last_estimated_translation_;
+  delta_rotation_odo2integr_last_ = delta_rotation_;
+  delta_translation_odo2integr_last_ = delta_translation_;
+  delta_covariance_odo2integr_last_ = delta_covariance_;
+  delta_rotation_odo2integr_next_ = Matrix3ft::Identity();
+  delta_translation_odo2integr_next_ = Vector3ft::Zero();
+  delta_covariance_odo2integr_next_ = zero6();
+}
+
+void VisodoTracker::integrateImagesIntoKeyframes(DepthMapf& depthinv_src, Matrix3ft dR, Vector3ft dt) {
+  // src/visodo.cpp:1674-1764: K R K^-1 in DOUBLE, inverted, then cast to float
+  double K[9] = {(double)fx_, 0, (double)cx_, 0, (double)fy_, (double)cy_, 0, 0, 1}, Ki[9], T[9], Rp[9], tp[3], Rpi[9], tpi[3];
+  se3::m3_inv(K, Ki);
+  se3::m3_mul(K, dR.m, T); se3::m3_mul(T, Ki, Rp);
+  se3::m3_mulv(K, dt.v, tp);
+  se3::m3_inv(Rp, Rpi);
+  se3::m3_mulv(Rpi, tp, tpi);
+  Mat33 Rd; float3 td;
+  for (int i = 0; i < 3; ++i) { Rd.data[i].x = (float)Rpi[i * 3]; Rd.data[i].y = (float)Rpi[i * 3 + 1]; Rd.data[i].z = (float)Rpi[i * 3 + 2]; }
+  td.x = (float)(-tpi[0]); td.y = (float)(-tpi[1]); td.z = (float)(-tpi[2]);
+  warpInvDepthWithTrafo3DWeighted(depthinv_src, warped_depthinv_integr_curr_, depthinv_integrKF_, warped_weight_curr_, Rd, td, intr()(0));
+  integrateWarpedFrame(warped_depthinv_integr_curr_, warped_weight_curr_, depthinv_integrKF_, weight_integrKF_);
+  createVMap(intr()(0), depthinv_integrKF_, vertices_integrKF_);
+  computeGradientDepth(depthinv_integrKF_, xGradsDepthinv_integrKF_, yGradsDepthinv_integrKF_);
+  createNMapGradients(intr()(0), depthinv_integrKF_, xGradsDepthinv_integrKF_, yGradsDepthinv_integrKF_, normals_integrKF_);
+}
+
+float VisodoTracker::computeInterframeTime() {
+  // src/visodo.cpp:1929-1964
+  float dt = 0.03333f;
+  if (!compute_deltat_flag_) { timestamp_rgb_curr_ = 0; timestamp_depth_curr_ = 0; return dt; }
+  if (global_time_ == 0) timestamp_ini_ = (timestamp_rgb_curr_ <= timestamp_depth_curr_) ? timestamp_rgb_curr_ : timestamp_depth_curr_;
+  uint64_t timestamp_rgb_curr_zeroed = timestamp_rgb_curr_ - timestamp_ini_;
+  timestamps_.push_back((int64_t)timestamp_rgb_curr_zeroed);
+  if (global_time_ > 0) dt = (float)(1e-9 * (double)(timestamp_rgb_curr_zeroed - (uint64_t)timestamps_[global_time_ - 1]));
+  return dt;
+}
+
+bool VisodoTracker::trackNewFrame() {
+  // src/visodo.cpp:1967-2247
+  delta_t_ = computeInterframeTime();
+  kf_time_accum_ += delta_t_;
+  double t1 = now_ms();
+  last_info_ = LastFrameInfo();
+  prepareImages(depth_, rgb24_);
+  device::sync();
+  TrackerSink* sink = keyframe_manager_ptr_ ? keyframe_manager_ptr_ : &null_sink_;
+  keyframe_manager_ptr_ = sink;
+  if (global_time_ == 0) {  // :1994-2045
+    ++global_time_;
+    odoKF_count_ = 0; last_odoKF_index_ = 0;
+    last_odoKF_global_rotation_ = rmats_[0]; last_odoKF_global_translation_ = tvecs_[0];
+    integrKF_count_ = 0; last_integrKF_index_ = 0;
+    last_integrKF_global_rotation_ = Matrix3ft::Identity(); last_integrKF_global_translation_ = Vector3ft::Zero();
+    delta_rotation_ = Matrix3ft::Identity(); delta_translation_ = Vector3ft::Zero(); delta_covariance_ = zero6();
+    odo_rmats_.push_back(delta_rotation_); odo_tvecs_.push_back(delta_translation_); odo_covmats_.push_back(delta_covariance_);
+    delta_rotation_odo2integr_last_ = Matrix3ft::Identity(); delta_translation_odo2integr_last_ = Vector3ft::Zero(); delta_covariance_odo2integr_last_ = zero6();
+    delta_rotation_odo2integr_next_ = Matrix3ft::Identity(); delta_translation_odo2integr_next_ = Vector3ft::Zero(); delta_covariance_odo2integr_next_ = zero6();
+    saveCurrentImagesAsOdoKeyframes();
+    saveCurrentImagesAsIntegrationKeyframes(rgb24_);
+    initialiseDeviceMemory2D<unsigned char>(overlap_mask_integrKF_, 0);
+    kf_time_accum_ = 0.f;
+    Pose pose_new; pose_new.id_ = 0; pose_new.rotation_ = Matrix3ft::Identity(); pose_new.translation_ = Vector3ft::Zero(); pose_new.scale_ = 1.f;
+    sink->pushPose(pose_new);
+    setSharedCameraPose(pose_new.getAffine());
+    last_info_.odo_kf_switched = last_info_.integr_kf_switched = true;
+    return false;
+  }
+  Matrix3ft delta_rotation_prev = delta_rotation_; Vector3ft delta_translation_prev = delta_translation_; Matrix6d delta_covariance_prev = delta_covariance_;
+  auto compose_global = [&]() {
+    double tmp[3];
+    se3::m3_mulv(last_odoKF_global_rotation_.m, delta_translation_.v, tmp);
+    for (int i = 0; i < 3; ++i) last_estimated_translation_[i] = last_odoKF_global_translation_[i] + tmp[i];
+    se3::m3_mul(last_odoKF_global_rotation_.m, delta_rotation_.m, last_estimated_rotation_.m);
+    rmats_.push_back(last_estimated_rotation_); tvecs_.push_back(last_estimated_translation_);
+  };
+  if (!lost_) {
+    odometry_success_ = estimateVisualOdometry(delta_rotation_, delta_translation_, delta_covariance_);
+    compose_global();
+    if (!odometry_success_) {  // :2066-2117
+      lost_ = true;
+      PoseConstraint dummy; dummy.ini_id_ = global_time_ - 1; dummy.end_id_ = global_time_; dummy.type_ = PoseConstraint::SEQ_ODO;
+      dummy.rotation_ = Matrix3ft::Identity(); dummy.translation_ = Vector3ft::Zero(); dummy.scale_ = 1.f; dummy.covariance_ = zero6();
+      for (int i = 0; i < 6; ++i) dummy.covariance_[i * 7] = 100.0;
+      sink->pushConstraint(dummy);
+      Pose p; p.id_ = global_time_; p.rotation_ = last_estimated_rotation_; p.translation_ = last_estimated_translation_; p.scale_ = 1.f;
+      sink->pushPose(p);
+      resetOdometryKeyframe();
+      resetIntegrationKeyframe();
+      saveCurrentImagesAsOdoKeyframes();
+      saveCurrentImagesAsIntegrationKeyframes(rgb24_);
+      ++global_time_;
+      last_info_.odo_kf_switched = last_info_.integr_kf_switched = true;
+      if (verbose_) std::cout << "I am LOST!!!" << std::endl;
+      return false;
+    }
+  } else {
+    odometry_success_ = estimateVisualOdometry(delta_rotation_, delta_translation_, delta_covariance_);
+    if (odometry_success_) { lost_ = false; compose_global(); }
+    else {
+      saveCurrentImagesAsOdoKeyframes();
+      saveCurrentImagesAsIntegrationKeyframes(rgb24_);
+      return false;
+    }
+  }
+  device::sync();
+  odoKF_count_++; integrKF_count_++;
+  {
+    // sequential constraint + covariance :2128-2165
+    Matrix3ft pT, Rseq; Vector3ft tseq; double d[3], Jn[36], Jl[36], S[9], SR[9];
+    se3::m3_T(delta_rotation_prev.m, pT.m);
+    se3::m3_mul(pT.m, delta_rotation_.m, Rseq.m);
+    for (int i = 0; i < 3; ++i) d[i] = delta_translation_[i] - delta_translation_prev[i];
+    se3::m3_mulv(pT.m, d, tseq.v);
+    se3::m6_zero(Jn); se3::m6_set_block(Jn, 0, 0, pT.m, 1.0); se3::m6_set_block(Jn, 3, 3, pT.m, 1.0);
+    se3::m6_zero(Jl); se3::m6_set_block(Jl, 0, 0, pT.m, -1.0); se3::m6_set_block(Jl, 3, 3, pT.m, -1.0);
+    se3::skew(tseq.v, S); se3::m3_mul(S, pT.m, SR); se3::m6_set_block(Jl, 0, 3, SR, 1.0);
+    Matrix6d cseq = zero6();
+    se3::m6_JCJt_add(Jl, delta_covariance_prev.data(), cseq.data());
+    se3::m6_JCJt_add(Jn, delta_covariance_.data(), cseq.data());
+    odo_rmats_.push_back(Rseq); odo_tvecs_.push_back(tseq); odo_covmats_.push_back(cseq);
+    PoseConstraint c; c.ini_id_ = global_time_ - 1; c.end_id_ = global_time_; c.type_ = PoseConstraint::SEQ_ODO;
+    c.rotation_ = Rseq; c.translation_ = tseq; c.scale_ = 1.f; c.covariance_ = cseq;
+    sink->pushConstraint(c);
+    Pose p; p.id_ = global_time_; p.rotation_ = last_estimated_rotation_; p.translation_ = last_estimated_translation_; p.scale_ = 1.f;
+    sink->pushPose(p);
+    setSharedCameraPose(p.getAffine());
+  }
+  // odometry keyframe :2172-2180
+  float visibility_ratio_odo = computeCovisibility(delta_rotation_, delta_translation_, depthinvs_odoKF_[0], depthinvs_curr_[0]);
+  last_info_.visratio_odo = visibility_ratio_odo;
+  if ((odoKF_count_ >= max_odoKF_count_) || (visibility_ratio_odo < visibility_ratio_odo_threshold_)) {
+    resetOdometryKeyframe();
+    saveCurrentImagesAsOdoKeyframes();
+    last_info_.odo_kf_switched = true;
+  }
+  // integration keyframe :2182-2211
+  Matrix3ft iRi, delta_integr_rotation; Vector3ft delta_integr_translation; double d[3];
+  se3::m3_inv(last_integrKF_global_rotation_.m, iRi.m);
+  se3::m3_mul(iRi.m, last_estimated_rotation_.m, delta_integr_rotation.m);
+  for (int i = 0; i < 3; ++i) d[i] = last_estimated_translation_[i] - last_integrKF_global_translation_[i];
+  se3::m3_mulv(iRi.m, d, delta_integr_translation.v);
+  float visibility_ratio_integr = computeCovisibility(delta_integr_rotation, delta_integr_translation, depthinv_integrKF_raw_, depthinvs_curr_[0]);
+  last_info_.visratio_integr = visibility_ratio_integr;
+  if ((integrKF_count_ >= max_integrKF_count_) || (visibility_ratio_integr < visibility_ratio_integr_threshold_)) {
+    resetIntegrationKeyframe();
+    computeOverlapping(delta_integr_rotation, delta_integr_translation, depthinv_integrKF_raw_, depthinvs_curr_[0], overlap_mask_integrKF_);
+    saveCurrentImagesAsIntegrationKeyframes(rgb24_);
+    newKF_ = true;
+    last_info_.integr_kf_switched = true;
+  } else {
+    integrateImagesIntoKeyframes(depthinvs_curr_[0], delta_integr_rotation, delta_integr_translation);
+  }
+  vis_odo_times_.push_back((float)(now_ms() - t1));
+  if (preview_) {
+    std::lock_guard<std::mutex> lock(mutex_scene_view_);
+    getImage(scene_view_, intensity_view_, depthinv_view_);
+    scene_view_has_changed_ = true;
+  }
+  device::sync();
+  ++global_time_;
+  return true;
+}
+
+}  // namespace RGBID_SLAM

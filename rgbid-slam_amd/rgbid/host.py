@@ -1,0 +1,163 @@
+"""ctypes binding of librgbid_host.so (include/rgbid_host.h): the C++ VisodoTracker mirror, SE(3) helpers, INI settings."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+HOST_LIB = os.path.join(os.path.dirname(_lib.LIB_PATH), "librgbid_host.so")
+HOST_SRC = os.path.join(os.path.dirname(os.path.dirname(_lib.LIB_PATH)), "host")
+
+
+class TrackerConfig(C.Structure):
+    _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("levels", C.c_int), ("iters", C.c_int * 8),
+                ("mestimator", C.c_int), ("motion_model", C.c_int), ("sigma_estimator", C.c_int), ("weighting", C.c_int), ("warping", C.c_int),
+                ("max_odoKF_count", C.c_int), ("finest_level", C.c_int), ("termination", C.c_int), ("visratio_odo", C.c_float),
+                ("image_filtering", C.c_int), ("visratio_integr", C.c_float), ("max_integrKF_count", C.c_int), ("nsamples", C.c_int),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("factor_depth", C.c_float),
+                ("interp_mode", C.c_int), ("preview", C.c_int)]
+
+
+class TrackerInfo(C.Structure):
+    _fields_ = [("lost", C.c_int), ("odo_kf_switched", C.c_int), ("integr_kf_switched", C.c_int), ("visratio_odo", C.c_float),
+                ("visratio_integr", C.c_float), ("sigma_int", C.c_float), ("sigma_depthinv", C.c_float), ("nu_int", C.c_float), ("nu_depthinv", C.c_float)]
+
+
+_h = None
+
+
+def build(force=False):
+    if force or not os.path.exists(HOST_LIB):
+        subprocess.check_call(["make", "-C", HOST_SRC, "-j8"])
+    return HOST_LIB
+
+
+def lib():
+    global _h
+    if _h is None:
+        _lib.lib()  # librgbid_hip.so first (RTLD_GLOBAL not needed: rpath $ORIGIN)
+        if not os.path.exists(HOST_LIB):
+            raise _lib.RgbidError(f"{HOST_LIB} is missing: run __graft_entry__.build()")
+        _h = C.CDLL(HOST_LIB)
+    return _h
+
+
+def _d(a, n):
+    return np.ascontiguousarray(a, np.float64).reshape(n)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def expmap_rot(w):
+    w = _d(w, 3); R = np.empty(9)
+    lib().rgbid_expmap_rot(_p(w), _p(R))
+    return R.reshape(3, 3)
+
+
+def expmap(w, v):
+    w, v = _d(w, 3), _d(v, 3); R = np.empty(9); t = np.empty(3)
+    lib().rgbid_expmap(_p(w), _p(v), _p(R), _p(t))
+    return R.reshape(3, 3), t
+
+
+def logmap(R, t):
+    R, t = _d(R, 9), _d(t, 3); tw = np.empty(6)
+    lib().rgbid_logmap(_p(R), _p(t), _p(tw))
+    return tw
+
+
+def force_orthogonal(M):
+    M = _d(M, 9); R = np.empty(9)
+    lib().rgbid_force_orthogonal(_p(M), _p(R))
+    return R.reshape(3, 3)
+
+
+def llt_solve6(A, b):
+    A, b = _d(A, 36), _d(b, 6); x = np.empty(6)
+    lib().rgbid_llt_solve6(_p(A), _p(b), _p(x))
+    return x
+
+
+def inverse6(A):
+    A = _d(A, 36); out = np.empty(36)
+    lib().rgbid_inverse6(_p(A), _p(out))
+    return out.reshape(6, 6)
+
+
+def settings_get(path, section, key):
+    buf = C.create_string_buffer(4096)
+    n = lib().rgbid_settings_get(path.encode(), section.encode(), key.encode(), buf, 4096)
+    return None if n < 0 else buf.value.decode()
+
+
+def default_config(**kw):
+    c = TrackerConfig()
+    lib().rgbid_tracker_default_config(C.byref(c))
+    for k, v in kw.items():
+        if k == "iters":
+            for i, it in enumerate(v):
+                c.iters[i] = int(it)
+        else:
+            setattr(c, k, v)
+    return c
+
+
+class Tracker:
+    """RGBID_SLAM::VisodoTracker (C++, host-driven) on device `device`; frames are passed as host numpy arrays."""
+
+    def __init__(self, cfg=None, device=0, **kw):
+        self.cfg = cfg if cfg is not None else default_config(**kw)
+        self._h = C.c_void_p()
+        check(lib().rgbid_tracker_create(C.byref(self._h), C.byref(self.cfg), int(device)))
+
+    def close(self):
+        if self._h:
+            lib().rgbid_tracker_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_settings(self, path):
+        check(lib().rgbid_tracker_load_settings(self._h, path.encode()))
+
+    def load_calibration(self, path):
+        check(lib().rgbid_tracker_load_calibration(self._h, path.encode()))
+
+    def track(self, depth_u16, rgb_u8):
+        d = np.ascontiguousarray(depth_u16, np.uint16); r = np.ascontiguousarray(rgb_u8, np.uint8)
+        ok = C.c_int()
+        check(lib().rgbid_tracker_track(self._h, _p(d), _p(r), C.byref(ok)))
+        return bool(ok.value)
+
+    def poses(self):
+        n = lib().rgbid_tracker_num_poses(self._h)
+        Rs, ts = np.empty((n, 9)), np.empty((n, 3))
+        for i in range(n):
+            check(lib().rgbid_tracker_get_pose(self._h, i, _p(Rs[i]), _p(ts[i])))
+        return Rs.reshape(n, 3, 3), ts
+
+    def odometry(self):
+        n = lib().rgbid_tracker_num_odo(self._h)
+        Rs, ts, cs = np.empty((n, 9)), np.empty((n, 3)), np.empty((n, 36))
+        for i in range(n):
+            check(lib().rgbid_tracker_get_odo(self._h, i, _p(Rs[i]), _p(ts[i]), _p(cs[i])))
+        return Rs.reshape(n, 3, 3), ts, cs.reshape(n, 6, 6)
+
+    def last_info(self):
+        info = TrackerInfo()
+        check(lib().rgbid_tracker_last_info(self._h, C.byref(info)))
+        return info
+
+    def keyframe_maps(self):
+        d = np.empty((self.cfg.rows, self.cfg.cols), np.float32); w = np.empty_like(d)
+        check(lib().rgbid_tracker_keyframe_maps(self._h, _p(d), _p(w)))
+        return d, w

@@ -1,0 +1,77 @@
+"""GPU parity of the C++ VisodoTracker mirror (librgbid_host.so, host-driven through the bridge API of
+include/rgbid/internal.h) against the CPU oracle tracker: pose < 1e-4 rad / 1e-4 m per frame (north star),
+identical keyframe decisions, for the shipped configuration and for the non-default modes the engine does not run."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from rgbid import host, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rot_angle(Ra, Rb):
+    return float(np.arccos(np.clip((np.trace(Ra.T @ Rb) - 1) / 2, -1, 1)))
+
+
+def run(rows, cols, K, n_frames, cfg_kw, seq_kw):
+    seq = synth.make_sequence(n_frames, K=K, rows=rows, cols=cols, device="cuda", **seq_kw)
+    d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+    kw = dict(rows=rows, cols=cols, fx=K[0], fy=K[1], cx=K[2], cy=K[3], **cfg_kw)
+    trk = host.Tracker(host.default_config(**kw))
+    orc = O.Tracker(O.default_config(**kw))
+    for k in range(n_frames):
+        a, b = trk.track(d[k], c[k]), orc.track(d[k], c[k])
+        assert a == b, k
+        if k:
+            ia, ib = trk.last_info(), orc.last_info()
+            assert bool(ia.odo_kf_switched) == bool(ib.odo_kf_switched) and bool(ia.integr_kf_switched) == bool(ib.integr_kf_switched), k
+            assert abs(ia.visratio_odo - ib.visratio_odo) < 2e-4 and ia.nu_depthinv == ib.nu_depthinv
+    Ra, ta = trk.poses(); Rb, tb = orc.poses()
+    assert len(Ra) == len(Rb) == n_frames
+    for k in range(n_frames):
+        assert rot_angle(Ra[k], Rb[k]) < 1e-4 and np.linalg.norm(ta[k] - tb[k]) < 1e-4, (k, rot_angle(Ra[k], Rb[k]), np.linalg.norm(ta[k] - tb[k]))
+    oa, ota, ca = trk.odometry(); ob, otb, cb = orc.odometry()
+    for k in range(1, n_frames):
+        sc = np.sqrt(np.outer(np.diag(cb[k]), np.diag(cb[k]))) + 1e-30
+        assert (np.abs(ca[k] - cb[k]) / sc).max() < 1e-2
+    kd, kw_ = trk.keyframe_maps()
+    od = orc.kf_depthinv()
+    assert np.count_nonzero(np.isnan(kd) != np.isnan(od)) <= 2e-3 * od.size
+    m = ~np.isnan(kd) & ~np.isnan(od)
+    assert np.quantile(np.abs(kd[m] - od[m]) / od[m], 0.999) < 1e-4
+    trk.close(); orc.close()
+
+
+SMALL_K = (131.25, 131.25, 79.5, 59.5)
+SLOW = dict(trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8))
+
+
+def test_cpp_tracker_shipped_config():
+    run(120, 160, SMALL_K, 6, dict(), SLOW)
+
+
+def test_cpp_tracker_warp_first():
+    run(120, 160, SMALL_K, 4, dict(warping=O.WARP_FIRST), SLOW)
+
+
+def test_cpp_tracker_filter_grads_and_min_weight():
+    run(120, 160, SMALL_K, 4, dict(image_filtering=O.FILTER_GRADS, weighting=O.MIN_WEIGHT), SLOW)
+
+
+def test_cpp_tracker_sigma_const_no_motion_model():
+    run(120, 160, SMALL_K, 4, dict(sigma_estimator=O.SIGMA_CONS, motion_model=O.NO_MM), SLOW)
+
+
+def test_cpp_tracker_keyframe_switches():
+    run(120, 160, SMALL_K, 8, dict(visratio_odo=0.985, visratio_integr=0.97), dict(trans_step=(0.01, 0.02), rot_step_deg=(0.5, 1.0)))
+
+
+def test_cpp_tracker_full_res():
+    run(480, 640, synth.TUM_K, 4, dict(), dict())
+
+
+def test_cpp_tracker_four_levels_1280x960():
+    """BASELINE config 5: 1280x960 upsampled synthetic stream, 4-level pyramid."""
+    K = (1050.0, 1050.0, 639.5, 479.5)
+    run(960, 1280, K, 3, dict(levels=4, iters=[10, 5, 3, 3]), dict())
