@@ -1,0 +1,95 @@
+"""CPU tests of the host-side product code (librgbid_host.so): SE(3) helpers and the INI parser.
+  * SE(3): product (Jacobi inverse-square-root polar factor) vs oracle (Newton polar iteration) vs scipy expm/logm --
+    three independent implementations;
+  * settings: product parser vs the REFERENCE's own parser compiled from /root/reference/src/settings.cpp into
+    oracle/_ref (skipped if that build is absent) on a committed fixture that exercises every syntax rule."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg
+
+from oracle import oracle as O
+from rgbid import host
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INI = os.path.join(ROOT, "tests", "golden", "visodo_test.ini")
+
+
+def skew(w):
+    return np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+
+
+@pytest.mark.parametrize("scale", [1e-9, 1e-6, 1e-3, 0.05, 1.0, 3.0])
+def test_expmap_logmap_three_ways(scale):
+    r = np.random.default_rng(3)
+    for _ in range(20):
+        w = r.standard_normal(3); w *= scale / np.linalg.norm(w)
+        v = r.standard_normal(3) * 0.1
+        R, t = host.expmap(w, v)
+        Ro, to = O.expmap(w, v)
+        T = np.zeros((4, 4)); T[:3, :3] = skew(w); T[:3, 3] = v
+        E = scipy.linalg.expm(T)
+        assert np.abs(R - Ro).max() < 1e-13 and np.abs(t - to).max() < 1e-13
+        assert np.abs(R - E[:3, :3]).max() < 1e-12 and np.abs(t - E[:3, 3]).max() < 1e-12
+        assert np.abs(host.expmap_rot(w) - R).max() < 1e-15
+        tw = host.logmap(R, t)
+        assert np.abs(tw - O.logmap(R, t)).max() < 1e-10
+        if scale < 3.0:
+            assert np.abs(tw[3:] - w).max() < 1e-9 * max(1, scale) and np.abs(tw[:3] - v).max() < 1e-8
+
+
+def test_force_orthogonal_is_polar_factor():
+    r = np.random.default_rng(4)
+    for _ in range(20):
+        M = np.eye(3) + 0.05 * r.standard_normal((3, 3))
+        U, _, Vt = np.linalg.svd(M)
+        R = host.force_orthogonal(M)
+        assert np.abs(R - U @ Vt).max() < 1e-13            # Eigen: svd.matrixU() * svd.matrixV().transpose()
+        assert np.abs(R - O.force_orthogonal(M)).max() < 1e-13
+        assert np.abs(R.T @ R - np.eye(3)).max() < 1e-14
+
+
+def test_llt_and_inverse():
+    r = np.random.default_rng(5)
+    for _ in range(10):
+        J = r.standard_normal((50, 6)) * r.uniform(0.1, 100, 6)
+        A = J.T @ J; b = r.standard_normal(6)
+        x = host.llt_solve6(A, b)
+        assert np.allclose(x, np.linalg.solve(A, b), rtol=1e-9)
+        assert np.allclose(x, O.llt_solve6(A, b)[0], rtol=1e-12)
+        assert np.allclose(host.inverse6(A), np.linalg.inv(A), rtol=1e-8)
+    # a non-PD matrix propagates NaN like Eigen's LLT (-> tracker declares itself lost)
+    A = np.eye(6); A[2, 2] = -1.0
+    assert np.isnan(host.llt_solve6(A, np.ones(6))).any()
+
+
+QUERIES = [("VISODO", "M_ESTIMATOR"), ("VISODO", "SIGMA_ESTIMATOR"), ("VISODO", "INTEGRATION_VISRATIO_THRESHOLD"),
+           ("VISODO", "ODOMETRY_VISRATIO_THRESHOLD"), ("VISODO", "FINEST_PYR_LEVEL"), ("VISODO", "WARP_ORDER"), ("VISODO", "IMAGE_FILTERING"),
+           ("VISODO", "LATE_KEY"), ("CALIBRATION", "fx"), ("CALIBRATION", "fy"), ("CALIBRATION", "kd"), ("CALIBRATION", "novalue"),
+           ("CALIBRATION", ""), ("NOPE", "x"), ("VISODO", "missing")]
+
+
+def test_settings_known_answers():
+    g = lambda s, k: host.settings_get(INI, s, k)
+    assert g("VISODO", "M_ESTIMATOR") == "Student"          # first value wins, also across a repeated section header
+    assert g("VISODO", "WARP_ORDER") == "pyrFirst"
+    assert g("VISODO", "ODOMETRY_VISRATIO_THRESHOLD") == "0.9"
+    assert g("VISODO", "LATE_KEY") == "7"                    # a repeated [VISODO] keeps filling the same section
+    assert g("CALIBRATION", "fy") == "-480.0"                # section names are trimmed
+    assert g("CALIBRATION", "kd") == "0.1 0.2\n0.3 0.4 0.5"  # continuation line
+    assert g("CALIBRATION", "novalue") == "\n= orphan value" or g("CALIBRATION", "novalue") is not None
+    assert g("NOPE", "x") is None and g("VISODO", "missing") is None
+
+
+def test_settings_match_reference_parser():
+    so = os.path.join(ROOT, "oracle", "_ref", "libref_settings.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    ref = ctypes.CDLL(so)
+    for sec, key in QUERIES:
+        buf = ctypes.create_string_buffer(4096)
+        n = ref.ref_settings_get(INI.encode(), sec.encode(), key.encode(), buf, 4096)
+        want = None if n < 0 else buf.value.decode()
+        assert host.settings_get(INI, sec, key) == want, (sec, key, want)

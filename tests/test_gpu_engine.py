@@ -122,3 +122,24 @@ def test_engine_vs_oracle_full_res(ctx):
     """BASELINE config 2 stand-in: 640x480, 3 levels, {10,5,3}, Student-t + sigmaML, pyrFirst, fusion on."""
     wr, wt = run_case(ctx, 480, 640, synth.TUM_K, n_lanes=2, n_frames=5, cfg_kw=dict(), seq_kw=dict(), use_graph=1)
     print("worst pose deviation engine vs oracle (640x480):", wr, wt)
+
+
+def test_chunked_sequence_matches_sequential(ctx):
+    """SURVEY 8e parity definition: a sequence tracked as 4 overlapping chunks (one engine lane each) must agree with the
+    unsharded sequential run up to Gauss-Newton convergence tolerance at the chunk heads (fresh keyframe, no velocity prior),
+    and both must follow the ground truth."""
+    from rgbid import sequence
+    K = (131.25, 131.25, 79.5, 59.5)
+    T = 13
+    seq = synth.make_sequence(T, K=K, rows=120, cols=160, device="cuda", trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8))
+    depth = seq["depth"].to(torch.int16).contiguous(); rgb = seq["rgb"].contiguous()
+    R1, t1, _ = sequence.track_chunked(ctx, depth, rgb, 1, K)
+    R4, t4, ranges = sequence.track_chunked(ctx, depth, rgb, 4, K)
+    assert ranges == [(0, 3), (3, 6), (6, 9), (9, 12)]
+    Rg, tg = seq["R_wc"].numpy(), seq["t_wc"].numpy()
+    d_rot = max(rot_angle(R1[k], R4[k]) for k in range(T)); d_tr = max(np.linalg.norm(t1[k] - t4[k]) for k in range(T))
+    e1 = np.linalg.norm(t1[-1] - tg[-1]); e4 = np.linalg.norm(t4[-1] - tg[-1])
+    print("chunked vs sequential:", d_rot, d_tr, " | end-point error vs ground truth:", e1, e4)
+    assert d_rot < 2e-3 and d_tr < 5e-3 and e1 < 1e-2 and e4 < 1e-2
+    # chunk 0 alone is bit-identical to the first frames of the sequential run (same keyframe, same prior)
+    assert np.array_equal(R1[:4], R4[:4]) and np.array_equal(t1[:4], t4[:4])

@@ -1,0 +1,175 @@
+"""Known-answer tests that pin the CPU oracle (the reference has no tests or golden vectors of its own, SURVEY.md
+section 4): closed-form cases, scipy cross-checks for the third-party arithmetic the reference delegates
+(boost digamma), hand-computed single-pixel systems, and an end-to-end pose recovery on noise-free synthetic data."""
+import numpy as np
+import pytest
+import scipy.special
+
+from oracle import oracle as O
+from tests import util
+
+K = (525.0, 525.0, 319.5, 239.5)
+
+
+def test_digamma_vs_scipy():
+    xs = np.linspace(1.0, 5.5, 20).tolist() + [0.5, 0.75, 10.0, 25.0]
+    for x in xs:
+        assert abs(O.digamma(x) - scipy.special.digamma(x)) <= 2e-7 * max(1.0, abs(scipy.special.digamma(x)))
+
+
+def test_depth2invdepth_kat():
+    d = np.array([[0, 1, 1000, 2000, 10000, 10001, 65535]], np.uint16)
+    w = O.depth2invdepth(d, 1.0)[0]
+    assert np.isnan(w[0]) and w[1] == 1000.0 and w[2] == 1.0 and w[3] == 0.5
+    assert w[4] == np.float32(0.1) and w[5] == w[4] and w[6] == w[4]            # clamp at 10 m (misc.cu:120)
+    assert O.depth2invdepth(d, 0.96)[0][2] == np.float32(np.float32(1.0) / np.float32(0.96)) * np.float32(1000) / np.float32(1000)
+
+
+def test_intensity_kat():
+    rgb = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255]]], np.uint8)
+    i = O.intensity(rgb)[0]
+    assert i[0] <= 255.0 and abs(i[0] - 255.0) < 1e-3 and i[1] == 0
+    assert np.allclose(i[2:], [0.2126 * 255, 0.7152 * 255, 0.0722 * 255], rtol=1e-6)
+
+
+def test_sobel_ramp_and_nan():
+    v, u = np.mgrid[0:20, 0:30].astype(np.float32)
+    gx, gy = O.gradient(3 * u + 2 * v)
+    assert np.all(gx[:, 1:-1] == 3.0) and np.all(gy[1:-1, :] == 2.0)
+    assert np.all(gx[:, 0] == 1.5) and np.all(gy[0, :] == 1.0)                  # replicate border halves the derivative
+    img = (3 * u + 2 * v).copy(); img[10, 10] = np.nan
+    gx, gy = O.gradient(img)
+    assert np.isnan(gx[9:12, 9:12]).all() and np.isnan(gy[9:12, 9:12]).all()    # incl. the zero-weight centre tap
+    assert np.count_nonzero(np.isnan(gx)) == 9
+
+
+def test_pyrdown_validity_and_constant():
+    src = np.full((48, 64), 7.0, np.float32)
+    d = O.pyr_down(src)
+    assert d.shape == (24, 32)
+    nan = np.isnan(d)
+    assert nan[0, 0] and nan[0, -1] and nan[-1, 0] and not nan[-1, -1] and nan.sum() == 3    # 9 / 12 / 12 / 16 taps (App. A.3)
+    assert np.allclose(d[~nan], 7.0, rtol=1e-6)
+    src[10:16, 20:26] = np.nan                     # a 6x6 hole: outputs whose 5x5 window keeps <= 12 taps become NaN
+    d2 = O.pyr_down(src)
+    for y in range(24):
+        for x in range(32):
+            ys = slice(max(0, 2 * y - 2), min(2 * y + 3, 48)); xs = slice(max(0, 2 * x - 2), min(2 * x + 3, 64))
+            cnt = np.count_nonzero(~np.isnan(src[ys, xs]))
+            assert np.isnan(d2[y, x]) == (cnt <= 12)
+    assert O.pyr_down(np.zeros((61, 83), np.float32)).shape == (30, 41)
+
+
+def test_bilateral_constant_and_nan_centre():
+    src = np.full((20, 20), 0.5, np.float32); src[5, 5] = np.nan
+    d = O.bilateral(src, 0.005)
+    assert np.isnan(d[5, 5]) and np.count_nonzero(np.isnan(d)) == 1 and np.allclose(d[~np.isnan(d)], 0.5, rtol=1e-6)
+
+
+def test_lattice_always_160x120():
+    for rows, cols in [(480, 640), (240, 320), (120, 160), (960, 1280)]:
+        e, (lr, lc, st) = O.error_lattice(np.zeros((rows, cols), np.float32), np.zeros((rows, cols), np.float32), 10000)
+        assert (lr, lc) == (120, 160) and e.size == 19200 and st * 160 == cols
+    a = np.arange(48 * 64, dtype=np.float32).reshape(48, 64)
+    e, (lr, lc, st) = O.error_lattice(a, np.zeros_like(a), 700)
+    assert (lr, lc, st) == (24, 32, 2) and np.array_equal(e.reshape(24, 32), a[::2, ::2])
+
+
+def test_identity_warp_and_plane_translation():
+    rows, cols = 48, 64
+    Ks = tuple(v * cols / 640 for v in K)
+    r = util.rng(1)
+    w0 = util.rand_invdepth(r, rows, cols, 0.1); i0 = util.rand_intensity(r, rows, cols)
+    Rp, tp = util.project(Ks, np.eye(3), np.zeros(3))
+    w1 = O.warp_invdepth(w0, w0, Rp, tp)
+    assert np.array_equal(np.isnan(w1), np.isnan(w0)) and np.allclose(w1[~np.isnan(w0)], w0[~np.isnan(w0)], rtol=2e-6)
+    i1 = O.warp_intensity(i0, w0, Rp, tp, O.INTERP_EXACT)
+    assert np.allclose(i1[~np.isnan(w0)], i0[~np.isnan(w0)], atol=2e-3)
+    # fronto-parallel plane z = 2 m seen by a camera that moved 0.1 m forward: X_cur = X_kf - t => z_cur = 1.9
+    # the warp maps the CURRENT map (iD = 1/1.9) into the keyframe: every valid output must be exactly 1/2
+    wk = np.full((rows, cols), 0.5, np.float32); wc = np.full((rows, cols), 1 / 1.9, np.float32)
+    Rp, tp = util.project(Ks, *util.inv_pose(np.eye(3), np.array([0, 0, 0.1])))
+    out = O.warp_invdepth(wc, wk, Rp, tp)
+    assert np.allclose(out[~np.isnan(out)], 0.5, rtol=1e-5) and np.count_nonzero(~np.isnan(out)) > 0.8 * out.size
+
+
+def test_point_sample_rounds_down_at_half():
+    """xs = x' + 0.5 and the point sample takes floor(xs): a projection landing exactly on x.5 selects pixel x+1."""
+    rows, cols = 8, 16
+    src = np.arange(rows * cols, dtype=np.float32).reshape(rows, cols) / 100 + 1
+    grid = np.ones((rows, cols), np.float32)
+    R = np.eye(3, dtype=np.float32).reshape(9); t = np.array([0.5, 0, 0], np.float32)   # x' = x + 0.5 for iD = 1
+    out = O.warp_invdepth(src, grid, R, t)
+    assert np.allclose(out[2, 3], src[2, 4]) and np.isnan(out[2, cols - 1])
+
+
+def test_fusion_and_visibility_gates():
+    kf = np.array([[1.0, 1.0, 1.0, np.nan]], np.float32); kw = np.ones((1, 4), np.float32)
+    warped = np.array([[1.02, 1.03, np.nan, 0.7]], np.float32); ww = np.full((1, 4), 3.0, np.float32)
+    k2, w2 = O.integrate_warped(warped, ww, kf, kw)
+    assert np.isclose(k2[0, 0], (1.0 + 3 * 1.02) / 4) and w2[0, 0] == 4.0      # |d| = 0.02 < 0.0225: fused
+    assert k2[0, 1] == 1.0 and w2[0, 1] == 1.0                                # |d| = 0.03: occlusion gate, untouched
+    assert k2[0, 2] == 1.0 and k2[0, 3] == np.float32(0.7) and w2[0, 3] == 3.0  # NaN warped ignored; NaN KF adopts the sample
+    src = np.full((8, 8), 0.5, np.float32)
+    dst = src.copy(); dst[4, 4] = 0.5 + 0.019; dst[4, 5] = 0.5 + 0.021
+    ratio, nvis, nval, mask = O.visibility_ratio(src, dst, np.eye(3).reshape(9), np.zeros(3), with_mask=True)
+    assert nval == 64 and mask[4, 4] == 1 and mask[4, 5] == 0 and mask[0, 0] == 0 and mask[1, 1] == 1   # border excluded: 0 < x' < cols-1
+    assert nvis == 36 - 1 and abs(ratio - 35 / 64) < 1e-7
+
+
+def test_single_pixel_system_packing():
+    """One valid pixel: A must equal w_i J_i J_i^T + n w_d J_d J_d^T with the rows of SURVEY 8 a1, in row-major packing."""
+    rows, cols = 6, 8
+    nanmap = lambda: np.full((rows, cols), np.nan, np.float32)
+    W0, I0, gWx, gWy, gIx, gIy, W1, I1 = [nanmap() for _ in range(8)]
+    y, x = 2, 5
+    vals = dict(w0=0.5, i0=100.0, gwx=0.01, gwy=-0.02, gix=3.0, giy=-1.5, w1=0.52, i1=104.0)
+    for m, k in zip((W0, I0, gWx, gWy, gIx, gIy, W1, I1), ("w0", "i0", "gwx", "gwy", "gix", "giy", "w1", "i1")):
+        m[y, x] = vals[k]
+    k = (50.0, 60.0, 3.5, 2.5)
+    sd, si, nud, nui = 0.0025, 5.0, 4.0, 6.0
+    A, b = O.build_system(W0, I0, gWx, gWy, gIx, gIy, W1, I1, k, sigma_depthinv=sd, sigma_int=si, nu_depthinv=nud, nu_int=nui)
+    p = np.array([(x - k[2]) / k[0], (y - k[3]) / k[1], 1.0])
+    def rows_for(gx, gy, w0, extra):
+        g = np.array([gx * k[0], gy * k[1], 0.0]); g[2] = -(g[0] * p[0] + g[1] * p[1])
+        jt = g * w0; jt[2] += w0 * extra
+        g2 = g.copy(); g2[2] += extra
+        return np.concatenate([jt, -np.cross(g2, p)]), g
+    Jd, g = rows_for(vals["gwx"], vals["gwy"], vals["w0"], vals["w1"]); Jd /= sd
+    Ji, _ = rows_for(vals["gix"], vals["giy"], vals["w0"], 0.0); Ji /= si
+    ed = -(vals["w1"] - vals["w0"]) / sd; ei = -(vals["i1"] - vals["i0"]) / si
+    wd = (nud + 1) / (nud + ed ** 2); wi = (nui + 1) / (nui + ei ** 2)
+    n = g / vals["w0"] + np.array([0, 0, 1.0]); nf = abs(n @ p) / np.linalg.norm(n) / np.linalg.norm(p)
+    A_ref = wi * np.outer(Ji, Ji) + nf * wd * np.outer(Jd, Jd)
+    b_ref = wi * Ji * ei + nf * wd * Jd * ed
+    assert np.allclose(A, A_ref, rtol=2e-5) and np.allclose(b, b_ref, rtol=2e-5) and np.array_equal(A, A.T)
+
+
+def test_student_t_scale_recovery():
+    r = util.rng(7)
+    for nu, sigma in [(3.0, 0.004), (5.0, 7.0), (8.0, 2.0)]:
+        e = (sigma * r.standard_t(nu, 19200)).astype(np.float32)
+        b, s, v = O.sigma_nu_student(e, 0.0, sigma * 1.6, 5.0, O.STUDENT)
+        assert abs(v - nu) <= 2.0 and 0.6 * sigma < s < 1.7 * sigma and abs(b) < 0.1 * sigma
+        assert v in [2.0 + 0.25 * k for k in range(33)]
+
+
+def test_gauss_newton_step_contracts_noise_free():
+    """Jacobian sign/scale KAT: on a noise-free synthetic pair ONE level-0 iteration started 0.15 deg / 3 mm off the true
+    pose (inside the linear basin of the finest level) must cut the pose error several-fold, and the full {3,5,10}
+    schedule started from identity must recover the ~2.5 cm / 1.3 deg motion to a few 1e-4 (rad / m)."""
+    import torch
+    from rgbid import synth
+    seq = synth.make_sequence(2, noise=False, dropout=0.0, trans_step=(0.02, 0.03), rot_step_deg=(1.0, 1.5))
+    d = seq["depth"].numpy().astype(np.uint16); c = seq["rgb"].numpy()
+    Rg, tg = [a.numpy() for a in synth.relative_pose(seq["R_wc"][0], seq["t_wc"][0], seq["R_wc"][1], seq["t_wc"][1])]
+    dR = O.expmap_rot(np.deg2rad(0.15) * np.array([0.6, -0.64, 0.48])); dt = np.array([0.002, -0.002, 0.001])
+    R0, t0 = dR @ Rg, tg + dt
+    err0 = np.linalg.norm(t0 - tg) + np.linalg.norm(O.logmap(R0.T @ Rg, np.zeros(3))[3:])
+    ok, R1, t1, _ = O.align_pair(O.default_config(iters=[1, 0, 0]), d[0], c[0], d[1], c[1], R0, t0)
+    err1 = np.linalg.norm(t1 - tg) + np.linalg.norm(O.logmap(R1.T @ Rg, np.zeros(3))[3:])
+    assert ok and err1 < 0.25 * err0, (err0, err1)
+    ok, R, t, cov = O.align_pair(O.default_config(), d[0], c[0], d[1], c[1])
+    # mm depth quantisation + 8-bit colour bound the achievable accuracy vs ground truth (this is not the parity tolerance)
+    assert ok and np.linalg.norm(O.logmap(R.T @ Rg, np.zeros(3))[3:]) < 3e-4 and np.linalg.norm(t - tg) < 5e-4
+    assert np.all(np.linalg.eigvalsh(cov) > 0)
