@@ -389,3 +389,13 @@ def align_pair(cfg, depth0, rgb0, depth1, rgb1, R0=None, t0=None):
     d1 = np.ascontiguousarray(depth1, np.uint16); r1 = np.ascontiguousarray(rgb1, np.uint8)
     ok = lib().orc_align_pair(C.byref(cfg), _p(d0), _p(r0), _p(d1), _p(r1), _p(R), _p(t), _p(cov))
     return bool(ok), R.reshape(3, 3), t, cov.reshape(6, 6)
+
+
+def keyframe_align(depthinv_ini, grey_ini, depthinv_end, grey_end, k, interp_mode=INTERP_TEX8, R0=None, t0=None):
+    a, b = _f(depthinv_ini), _f(depthinv_end)
+    ga = np.ascontiguousarray(grey_ini, np.uint8); gb = np.ascontiguousarray(grey_end, np.uint8)
+    R = np.eye(3).reshape(9).copy() if R0 is None else _d(R0, 9).copy()
+    t = np.zeros(3) if t0 is None else _d(t0, 3).copy()
+    cov = np.zeros(36)
+    lib().orc_keyframe_align(a.shape[0], a.shape[1], _p(a), _p(ga), _p(b), _p(gb), _intr(k), int(interp_mode), _p(R), _p(t), _p(cov))
+    return R.reshape(3, 3), t, cov.reshape(6, 6)

@@ -160,6 +160,10 @@ int orc_align_pair(const orc_tracker_config* c, const uint16_t* depth0, const ui
                    const uint16_t* depth1, const uint8_t* rgb1, double R[9], double t[3],
                    double cov[36]);
 
+/* KeyframeAlign::alignKeyframes, src/keyframe_align.cpp:115-357 (4 levels, iterations {5,5,3,0}); grey is 8-bit */
+int orc_keyframe_align(int rows, int cols, const float* depthinv_ini, const uint8_t* grey_ini, const float* depthinv_end,
+                       const uint8_t* grey_end, orc_intr k, int interp_mode, double R[9], double t[3], double cov[36]);
+
 /* number of OpenMP threads the oracle will use (1 when built without -fopenmp) */
 int orc_num_threads(void);
 void orc_set_num_threads(int n);

@@ -728,3 +728,65 @@ int orc_align_pair(const orc_tracker_config* c, const uint16_t* depth0, const ui
   orc_tracker_destroy(t);
   return ok;
 }
+
+int orc_keyframe_align(int rows, int cols, const float* depthinv_ini, const uint8_t* grey_ini, const float* depthinv_end,
+                       const uint8_t* grey_end, orc_intr k, int interp_mode, double R[9], double tv[3], double cov[36]) {
+  /* src/keyframe_align.cpp:115-357 */
+  enum { L = 4 };
+  const int iters[L] = { 5, 5, 3, 0 };
+  float *iDa[L], *iDb[L], *Ia[L], *Ib[L], *gxD[L], *gyD[L], *gxI[L], *gyI[L], *wD[L], *wI[L];
+  size_t n0 = (size_t)rows * cols;
+  for (int l = 0; l < L; ++l) {
+    size_t n = (size_t)(rows >> l) * (cols >> l);
+    iDa[l] = falloc(n); iDb[l] = falloc(n); Ia[l] = falloc(n); Ib[l] = falloc(n);
+    gxD[l] = falloc(n); gyD[l] = falloc(n); gxI[l] = falloc(n); gyI[l] = falloc(n); wD[l] = falloc(n); wI[l] = falloc(n);
+  }
+  float* resD = falloc(n0); float* resI = falloc(n0);
+  memcpy(iDa[0], depthinv_ini, n0 * sizeof(float)); memcpy(iDb[0], depthinv_end, n0 * sizeof(float));
+  for (size_t i = 0; i < n0; ++i) { Ia[0][i] = (float)grey_ini[i]; Ib[0][i] = (float)grey_end[i]; }
+  for (int l = 1; l < L; ++l) {
+    orc_pyr_down(iDa[l - 1], rows >> (l - 1), cols >> (l - 1), iDa[l]); orc_pyr_down(iDb[l - 1], rows >> (l - 1), cols >> (l - 1), iDb[l]);
+    orc_pyr_down(Ia[l - 1], rows >> (l - 1), cols >> (l - 1), Ia[l]); orc_pyr_down(Ib[l - 1], rows >> (l - 1), cols >> (l - 1), Ib[l]);
+  }
+  for (int l = 0; l < L; ++l) {
+    orc_gradient(iDa[l], rows >> l, cols >> l, gxD[l], gyD[l]);
+    orc_gradient(Ia[l], rows >> l, cols >> l, gxI[l], gyI[l]);
+  }
+  double curR[9], curt[3], A[36], b[6];
+  memcpy(curR, R, sizeof(curR)); memcpy(curt, tv, sizeof(curt));
+  orc_tracker_config cfg;
+  orc_tracker_default_config(&cfg);
+  cfg.fx = k.fx; cfg.fy = k.fy; cfg.cx = k.cx; cfg.cy = k.cy;
+  for (int level = L - 1; level >= 0; --level) {
+    int r = rows >> level, cc = cols >> level;
+    for (int it = 0; it < iters[level]; ++it) {
+      double Ri[9], ti[3];
+      m3_inv(curR, Ri); m3_mulv(Ri, curt, ti);
+      ti[0] = -ti[0]; ti[1] = -ti[1]; ti[2] = -ti[2];
+      float Rp[9], tp[3];
+      project_trafo(&cfg, level, Ri, ti, Rp, tp);
+      orc_warp_invdepth(iDb[level], iDa[level], r, cc, Rp, tp, wD[level]);
+      orc_warp_intensity(Ib[level], iDa[level], r, cc, Rp, tp, interp_mode, wI[level]);
+      int nD = orc_error_lattice(wD[level], iDa[level], r, cc, 19200, resD, NULL, NULL, NULL);
+      int nI = orc_error_lattice(wI[level], Ia[level], r, cc, 19200, resI, NULL, NULL, NULL);
+      float nu_d = 5.f, nu_i = 5.f;
+      orc_nu_student(resD, nD, 0.f, 0.0025f, &nu_d);
+      orc_nu_student(resI, nI, 0.f, 5.f, &nu_i);
+      orc_build_system(iDa[level], Ia[level], gxD[level], gyD[level], gxI[level], gyI[level], wD[level], wI[level], r, cc, 1, ORC_STUDENT,
+                       ORC_INDEPENDENT, 0.0025f, 5.f, 0.f, 0.f, nu_d, nu_d, orc_intr_level(k, level), A, b);
+      double x[6], inc_inv[9], inc[9], tinc[3], tmp[3];
+      orc_llt_solve6(A, b, x);
+      orc_expmap_rot(x + 3, inc_inv);
+      m3_inv(inc_inv, inc);
+      m3_mulv(inc, x, tinc);
+      m3_mulv(inc, curt, tmp);
+      for (int i = 0; i < 3; ++i) curt[i] = tmp[i] - tinc[i];
+      m3_mul(inc, curR, curR);
+    }
+  }
+  memcpy(R, curR, sizeof(curR)); memcpy(tv, curt, sizeof(curt));
+  orc_inverse6(A, cov);
+  for (int l = 0; l < L; ++l) { free(iDa[l]); free(iDb[l]); free(Ia[l]); free(Ib[l]); free(gxD[l]); free(gyD[l]); free(gxI[l]); free(gyI[l]); free(wD[l]); free(wI[l]); }
+  free(resD); free(resI);
+  return 1;
+}

@@ -7,6 +7,7 @@
 #include <new>
 
 #include "../../include/rgbid/se3.h"
+#include "../../include/rgbid/keyframe_align.h"
 #include "../../include/rgbid/visodo.h"
 
 namespace RGBID_SLAM { namespace device { DeviceProp dev_prop; int dev_id = 0; } }
@@ -122,6 +123,21 @@ int rgbid_tracker_keyframe_maps(rgbid_tracker* h, float* depthinv_host, float* w
   VisodoTracker& t = *h->t;
   if (depthinv_host) t.integrationKeyframeDepthinv().download(depthinv_host, (size_t)t.cols() * 4);
   if (weight_host) t.integrationKeyframeWeight().download(weight_host, (size_t)t.cols() * 4);
+  return RGBID_OK;
+}
+
+int rgbid_keyframe_align(int device, int rows, int cols, const float* depthinv_ini, const unsigned char* grey_ini, const float* depthinv_end,
+                         const unsigned char* grey_end, float fx, float fy, float cx, float cy, double R[9], double t[3], double cov[36]) {
+  if (!depthinv_ini || !grey_ini || !depthinv_end || !grey_end || !R || !t || !cov) return RGBID_E_INVALID;
+  int n = 0;
+  if (rgbid_device_count(&n) != RGBID_OK || device < 0 || device >= n) return RGBID_E_NODEV;
+  pcl::gpu::setDevice(device);
+  KeyframeAlign ka(rows, cols);
+  KeyframeImages a = {depthinv_ini, grey_ini, fx, fy, cx, cy}, b = {depthinv_end, grey_end, fx, fy, cx, cy};
+  Matrix3ft Rm; Vector3ft tv; Matrix6d c;
+  std::memcpy(Rm.m, R, 72); std::memcpy(tv.v, t, 24);
+  ka.alignKeyframes(a, b, Rm, tv, c);
+  std::memcpy(R, Rm.m, 72); std::memcpy(t, tv.v, 24); std::memcpy(cov, c.data(), 288);
   return RGBID_OK;
 }
 

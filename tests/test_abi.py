@@ -56,3 +56,13 @@ def test_lattice_geometry_host_logic():
         a = np.zeros((rows, cols), np.float32)
         e, geo = O.error_lattice(a, a, ns)
         assert device.error_lattice_size(rows, cols, ns) == (e.size, geo[0], geo[1], geo[2])
+
+
+def test_host_library_exports_every_declared_symbol():
+    """librgbid_host.so (C++ VisodoTracker / KeyframeAlign / settings / SE(3)) exports all of include/rgbid_host.h."""
+    from rgbid import host
+    L = host.lib()
+    names = _declared("rgbid_host.h")
+    assert len(names) >= 15
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing

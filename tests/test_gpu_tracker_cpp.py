@@ -75,3 +75,18 @@ def test_cpp_tracker_four_levels_1280x960():
     """BASELINE config 5: 1280x960 upsampled synthetic stream, 4-level pyramid."""
     K = (1050.0, 1050.0, 639.5, 479.5)
     run(960, 1280, K, 3, dict(levels=4, iters=[10, 5, 3, 3]), dict())
+
+
+def test_keyframe_align_vs_oracle():
+    """KeyframeAlign (second consumer of the kernels: 4 levels, computeNuStudent, KF-iD sampling grid)."""
+    seq = synth.make_sequence(4, device="cuda", trans_step=(0.01, 0.02), rot_step_deg=(0.5, 1.0))
+    d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+    iD = [O.depth2invdepth(d[k]) for k in (0, 3)]
+    grey = [np.clip(np.rint(O.intensity(c[k])), 0, 255).astype(np.uint8) for k in (0, 3)]
+    Rg, tg = [a.numpy() for a in synth.relative_pose(seq["R_wc"][0], seq["t_wc"][0], seq["R_wc"][3], seq["t_wc"][3])]
+    R, t, cov = host.keyframe_align(iD[0], grey[0], iD[1], grey[1], synth.TUM_K)
+    Ro, to, covo = O.keyframe_align(iD[0], grey[0], iD[1], grey[1], synth.TUM_K)
+    assert rot_angle(R, Ro) < 1e-4 and np.linalg.norm(t - to) < 1e-4, (rot_angle(R, Ro), np.linalg.norm(t - to))
+    sc = np.sqrt(np.outer(np.diag(covo), np.diag(covo)))
+    assert (np.abs(cov - covo) / sc).max() < 1e-2
+    assert rot_angle(R, Rg) < 3e-3 and np.linalg.norm(t - tg) < 1e-2     # and it finds the true relative pose
