@@ -64,6 +64,25 @@ int rgbid_keyframe_align(int device, int rows, int cols, const float* depthinv_i
                          const float* depthinv_end, const unsigned char* grey_end, float fx, float fy, float cx, float cy,
                          double R[9], double t[3], double cov[36]);
 
+/* ---- dataset I/O (tools/evaluation.cpp:122-351,380-439): PNG codec, TUM/ICL association files, trajectory writer ---- */
+int rgbid_png_info(const char* path, int* rows, int* cols, int* channels, int* bit_depth);
+int rgbid_png_read(const char* path, void* dst, size_t dst_bytes);             /* interleaved, host-endian samples */
+int rgbid_png_write(const char* path, const void* data, int rows, int cols, int channels, int bit_depth);
+typedef struct rgbid_dataset rgbid_dataset;
+/* folder with depth_associated.txt + rgb_associated.txt, or match_file (may be NULL/"") = 4-column association file */
+int rgbid_dataset_open(rgbid_dataset** out, const char* folder, const char* match_file);
+void rgbid_dataset_close(rgbid_dataset* d);
+int rgbid_dataset_size(const rgbid_dataset* d);
+double rgbid_dataset_stamp(const rgbid_dataset* d, int i);
+/* Evaluation::grab(i, depth, rgb): depth = PNG x 0.2 (mm, u16), rgb = r,g,b bytes; *grabbed = 0 if the pair is unreadable */
+int rgbid_dataset_grab(rgbid_dataset* d, int i, uint16_t* depth_mm, uint8_t* rgb, int rows, int cols, int* grabbed);
+/* "stamp tx ty tz qx qy qz qw" (fixed, 6 decimals; Eigen::Quaternionf of the float rotation); returns length or <0 */
+int rgbid_format_pose_line(double stamp, const double R[9], const double t[3], char* dst, size_t dst_bytes);
+/* Evaluation::saveAllPoses / saveTimeLogFiles for a tracker driven over the dataset */
+int rgbid_tracker_save_poses(const rgbid_tracker* t, const rgbid_dataset* d, int frame_number, const char* poses_logfile,
+                             const char* misc_logfile);
+int rgbid_tracker_save_kf_times(const rgbid_tracker* t, const rgbid_dataset* d, const char* kftimes_logfile);
+
 #ifdef __cplusplus
 }
 #endif

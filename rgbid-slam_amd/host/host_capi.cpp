@@ -2,11 +2,13 @@
 // drive it (declared in include/rgbid_host.h).
 #include "../../include/rgbid_host.h"
 
+#include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <new>
 
 #include "../../include/rgbid/se3.h"
+#include "../../include/rgbid/evaluation.h"
 #include "../../include/rgbid/keyframe_align.h"
 #include "../../include/rgbid/visodo.h"
 
@@ -138,6 +140,74 @@ int rgbid_keyframe_align(int device, int rows, int cols, const float* depthinv_i
   std::memcpy(Rm.m, R, 72); std::memcpy(tv.v, t, 24);
   ka.alignKeyframes(a, b, Rm, tv, c);
   std::memcpy(R, Rm.m, 72); std::memcpy(t, tv.v, 24); std::memcpy(cov, c.data(), 288);
+  return RGBID_OK;
+}
+
+struct rgbid_dataset { Evaluation* e; };
+
+int rgbid_png_info(const char* path, int* rows, int* cols, int* channels, int* bit_depth) {
+  if (!path) return RGBID_E_INVALID;
+  try {
+    PngImage im = read_png(path);
+    if (rows) *rows = im.rows;
+    if (cols) *cols = im.cols;
+    if (channels) *channels = im.channels;
+    if (bit_depth) *bit_depth = im.bit_depth;
+  } catch (const std::exception& ex) { std::fprintf(stderr, "%s\n", ex.what()); return RGBID_E_INVALID; }
+  return RGBID_OK;
+}
+int rgbid_png_read(const char* path, void* dst, size_t dst_bytes) {
+  if (!path || !dst) return RGBID_E_INVALID;
+  try {
+    PngImage im = read_png(path);
+    if (im.bytes.size() > dst_bytes) return RGBID_E_INVALID;
+    std::memcpy(dst, im.bytes.data(), im.bytes.size());
+  } catch (const std::exception& ex) { std::fprintf(stderr, "%s\n", ex.what()); return RGBID_E_INVALID; }
+  return RGBID_OK;
+}
+int rgbid_png_write(const char* path, const void* data, int rows, int cols, int channels, int bit_depth) {
+  if (!path || !data) return RGBID_E_INVALID;
+  try { write_png(path, data, rows, cols, channels, bit_depth); }
+  catch (const std::exception& ex) { std::fprintf(stderr, "%s\n", ex.what()); return RGBID_E_INVALID; }
+  return RGBID_OK;
+}
+int rgbid_dataset_open(rgbid_dataset** out, const char* folder, const char* match_file) {
+  if (!out || !folder) return RGBID_E_INVALID;
+  *out = nullptr;
+  try { *out = new rgbid_dataset{new Evaluation(folder, match_file ? match_file : "")}; }
+  catch (const std::exception&) { return RGBID_E_INVALID; }
+  return RGBID_OK;
+}
+void rgbid_dataset_close(rgbid_dataset* d) { if (d) { delete d->e; delete d; } }
+int rgbid_dataset_size(const rgbid_dataset* d) { return d ? (int)d->e->size() : 0; }
+double rgbid_dataset_stamp(const rgbid_dataset* d, int i) { return (d && i >= 0 && i < (int)d->e->size()) ? d->e->stamp(i) : 0.0; }
+int rgbid_dataset_grab(rgbid_dataset* d, int i, uint16_t* depth_mm, uint8_t* rgb, int rows, int cols, int* grabbed) {
+  if (!d || !depth_mm || !rgb || !grabbed) return RGBID_E_INVALID;
+  ImageWrapper<unsigned short> dw; ImageWrapper<PixelRGB> cw;
+  *grabbed = 0;
+  try { if (!d->e->grab(i, dw, cw)) return RGBID_OK; }
+  catch (const std::exception& ex) { std::fprintf(stderr, "%s\n", ex.what()); return RGBID_E_INVALID; }
+  if (dw.rows != rows || dw.cols != cols || cw.rows != rows || cw.cols != cols) return RGBID_E_INVALID;
+  std::memcpy(depth_mm, dw.data, (size_t)rows * cols * 2);
+  std::memcpy(rgb, cw.data, (size_t)rows * cols * 3);
+  *grabbed = 1;
+  return RGBID_OK;
+}
+int rgbid_format_pose_line(double stamp, const double R[9], const double t[3], char* dst, size_t dst_bytes) {
+  if (!R || !t || !dst) return RGBID_E_INVALID;
+  std::string s = format_pose_line(stamp, R, t);
+  if (s.size() + 1 > dst_bytes) return RGBID_E_INVALID;
+  std::memcpy(dst, s.c_str(), s.size() + 1);
+  return (int)s.size();
+}
+int rgbid_tracker_save_poses(const rgbid_tracker* t, const rgbid_dataset* d, int frame_number, const char* poses_logfile, const char* misc_logfile) {
+  if (!t || !d || !poses_logfile || !misc_logfile) return RGBID_E_INVALID;
+  d->e->saveAllPoses(*t->t, frame_number, poses_logfile, misc_logfile);
+  return RGBID_OK;
+}
+int rgbid_tracker_save_kf_times(const rgbid_tracker* t, const rgbid_dataset* d, const char* kftimes_logfile) {
+  if (!t || !d || !kftimes_logfile) return RGBID_E_INVALID;
+  d->e->saveTimeLogFiles(*t->t, std::vector<float>(), kftimes_logfile);
   return RGBID_OK;
 }
 

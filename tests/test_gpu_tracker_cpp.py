@@ -90,3 +90,43 @@ def test_keyframe_align_vs_oracle():
     sc = np.sqrt(np.outer(np.diag(covo), np.diag(covo)))
     assert (np.abs(cov - covo) / sc).max() < 1e-2
     assert rot_angle(R, Rg) < 3e-3 and np.linalg.norm(t - tg) < 1e-2     # and it finds the true relative pose
+
+
+def test_cli_eval_harness_on_tum_layout(tmp_path):
+    """a TUM-layout dataset on disk (16-bit PNG depth x5000, 8-bit RGB PNG, association files) played through
+    the `rgbid_slam_eval -eval` harness gives the oracle tracker's trajectory in the TUM trajectory format."""
+    import os
+    import subprocess
+    from rgbid import tum, _lib
+    n = 5
+    seq = synth.make_sequence(n, device="cuda")
+    d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+    root = tmp_path / "synth_desk"
+    os.makedirs(root / "depth"); os.makedirs(root / "rgb")
+    hdr = "# line 1\n# line 2\n# timestamp filename\n"
+    dl, cl = [], []
+    for k in range(n):
+        st = 1305031102.175304 + k / 30.0
+        tum.write_png(str(root / "depth" / f"{st:.6f}.png"), (d[k].astype(np.uint32) * 5).astype(np.uint16))
+        tum.write_png(str(root / "rgb" / f"{st:.6f}.png"), c[k])
+        dl.append(f"{st:.6f} depth/{st:.6f}.png"); cl.append(f"{st:.6f} rgb/{st:.6f}.png")
+    (root / "depth_associated.txt").write_text(hdr + "\n".join(dl) + "\n")
+    (root / "rgb_associated.txt").write_text(hdr + "\n".join(cl) + "\n")
+    exe = os.path.join(os.path.dirname(os.path.dirname(_lib.LIB_PATH)), "bin", "rgbid_slam_eval")
+    out = subprocess.run([exe, "-eval", str(root) + "/", "-out", str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    poses = np.loadtxt(tmp_path / "synth_desk_poses.txt")
+    assert poses.shape == (n, 8)
+    orc = O.Tracker(O.default_config())
+    for k in range(n):
+        orc.track(d[k], c[k])
+    Rb, tb = orc.poses()
+    lines = (tmp_path / "synth_desk_poses.txt").read_text().strip().split("\n")
+    from scipy.spatial.transform import Rotation
+    for k in range(n):
+        assert lines[k].split(" ")[0] == "%.6f" % (1305031102.175304 + k / 30.0)
+        assert np.linalg.norm(poses[k, 1:4] - tb[k]) < 1e-4
+        assert rot_angle(Rotation.from_quat(poses[k, 4:]).as_matrix(), Rb[k]) < 1e-4
+    misc = (tmp_path / "synth_desk_misc.txt").read_text().split("\n")
+    assert misc[0].startswith("Mean time per frame: ") and misc[2].startswith("Max time per frame: ") and len(misc) >= 3 + n
+    assert (tmp_path / "synth_desk_kf_times.txt").read_text().startswith("ObtainKeyframe ProcessKeyframeTotal Segmentation DescriptionBoW LoopDetection PoseGraphOptim\n")
