@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--lanes", type=int, default=128, help="independent RGB-D streams per GPU")
+    ap.add_argument("--lanes", type=int, default=512, help="independent RGB-D streams per GPU")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--levels", type=int, default=3)

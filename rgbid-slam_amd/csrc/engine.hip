@@ -539,10 +539,8 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   e->launches = 0;
   Flags& f = e->flags;
   // ---- prepareImages (visodo.cpp:760-773)
-  launch_intensity(s, B, e->in_rgb, e->I_curr[0], ALL);
-  launch_decompose_rgb(s, B, e->in_rgb, e->r_curr, e->g_curr, e->b_curr, ALL);
-  launch_depth_to_invdepth(s, B, e->in_depth, e->iD_curr[0], c.factor_depth, ALL);
-  e->launches += 3;
+  launch_prep_frame(s, B, e->in_depth, e->in_rgb, e->iD_curr[0], e->I_curr[0], e->r_curr, e->g_curr, e->b_curr, c.factor_depth, ALL);
+  e->launches += 1;
   for (int i = 1; i < L; ++i) {
     launch_pyr_down(s, B, e->I_curr[i - 1], e->I_curr[i], ALL);
     launch_pyr_down(s, B, e->iD_curr[i - 1], e->iD_curr[i], ALL);

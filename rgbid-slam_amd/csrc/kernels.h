@@ -23,6 +23,8 @@ void launch_depth_to_invdepth(hipStream_t s, int B, ImgB src_u16, ImgB dst, floa
 void launch_intensity(hipStream_t s, int B, ImgB rgb, ImgB dst, LaneMask m);
 void launch_decompose_rgb(hipStream_t s, int B, ImgB rgb, ImgB r, ImgB g, ImgB b, LaneMask m);
 void launch_gradient(hipStream_t s, int B, ImgB src, ImgB gx, ImgB gy, LaneMask m);
+// depth->iD + rgb->luma + rgb->r,g,b planes in one pass (engine); falls back to the three kernels when not 16-byte aligned
+void launch_prep_frame(hipStream_t s, int B, ImgB depth_u16, ImgB rgb, ImgB iD, ImgB I, ImgB r, ImgB g, ImgB b, float factor_depth, LaneMask m);
 void launch_copy_bytes(hipStream_t s, int B, ImgB src, ImgB dst, int elem_size, LaneMask m);  // row-wise D2D copy kernel
 void launch_fill(hipStream_t s, int B, ImgB dst, int elem_size, uint32_t bits, LaneMask m);
 void launch_pyr_down(hipStream_t s, int B, ImgB src, ImgB dst, LaneMask m);

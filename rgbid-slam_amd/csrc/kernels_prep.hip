@@ -70,6 +70,53 @@ void launch_decompose_rgb(hipStream_t s, int B, ImgB rgb, ImgB r, ImgB g, ImgB b
   hipLaunchKernelGGL(k_decompose, grid2d(r.cols, r.rows, B), dim3(TX, TY), 0, s, rgb, r, g, b, m);
 }
 
+// ---- engine frame preparation: the three converters above in ONE pass, 4 pixels per thread -------------------
+// reads the u16 depth (8 B) and the packed rgb (12 B) of a 4-pixel group once, writes five 16-byte vectors
+// (iD, luma, r, g, b planes).  Same per-pixel arithmetic as k_depth_to_invdepth / k_intensity / k_decompose.
+static inline bool vec4_ok(const ImgB& a, int elem) {
+  return ((a.pitch & 15) == 0) && ((a.lane_stride & 15) == 0) && ((((uintptr_t)a.base) & 15) == 0) && (((size_t)a.cols * elem) % (4 * elem) == 0);
+}
+__global__ __launch_bounds__(256) void k_prep_frame4(ImgB depth, ImgB rgb, ImgB iD, ImgB I, ImgB r, ImgB g, ImgB b, float factor_depth, int cols4, int units, LaneMask m) {
+  int lane = blockIdx.y;
+  if (!m.on(lane)) return;
+  const float scale = (1.f / factor_depth) * 1000.f;
+  for (int u = blockIdx.x * 256 + threadIdx.x; u < units; u += gridDim.x * 256) {
+    int y = u / cols4, x = (u - y * cols4) * 4;
+    uint2 dq = *reinterpret_cast<const uint2*>(row_ptr<uint16_t>(depth, lane, y) + x);
+    const uint32_t* cp = reinterpret_cast<const uint32_t*>(row_ptr<uint8_t>(rgb, lane, y) + 3 * x);
+    uint32_t c0 = cp[0], c1 = cp[1], c2 = cp[2];
+    int dv[4] = {(int)(dq.x & 0xffffu), (int)(dq.x >> 16), (int)(dq.y & 0xffffu), (int)(dq.y >> 16)};
+    float R[4] = {(float)(c0 & 255u), (float)(c0 >> 24), (float)((c1 >> 16) & 255u), (float)((c2 >> 8) & 255u)};
+    float G[4] = {(float)((c0 >> 8) & 255u), (float)(c1 & 255u), (float)(c1 >> 24), (float)((c2 >> 16) & 255u)};
+    float Bl[4] = {(float)((c0 >> 16) & 255u), (float)((c1 >> 8) & 255u), (float)(c2 & 255u), (float)(c2 >> 24)};
+    float w[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      w[i] = dv[i] > 0 ? scale / (float)min(dv[i], 10000) : qnan();
+      float v = 0.2126f * R[i] + 0.7152f * G[i] + 0.0722f * Bl[i];
+      l[i] = fmaxf(0.f, fminf(v, 255.f));
+    }
+    *reinterpret_cast<float4*>(row_ptr<float>(iD, lane, y) + x) = make_float4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<float4*>(row_ptr<float>(I, lane, y) + x) = make_float4(l[0], l[1], l[2], l[3]);
+    *reinterpret_cast<float4*>(row_ptr<float>(r, lane, y) + x) = make_float4(R[0], R[1], R[2], R[3]);
+    *reinterpret_cast<float4*>(row_ptr<float>(g, lane, y) + x) = make_float4(G[0], G[1], G[2], G[3]);
+    *reinterpret_cast<float4*>(row_ptr<float>(b, lane, y) + x) = make_float4(Bl[0], Bl[1], Bl[2], Bl[3]);
+  }
+}
+void launch_prep_frame(hipStream_t s, int B, ImgB depth, ImgB rgb, ImgB iD, ImgB I, ImgB r, ImgB g, ImgB b, float factor_depth, LaneMask m) {
+  bool vec = (iD.cols % 4 == 0) && vec4_ok(iD, 4) && vec4_ok(I, 4) && vec4_ok(r, 4) && vec4_ok(g, 4) && vec4_ok(b, 4) &&
+             ((depth.pitch & 7) == 0) && ((depth.lane_stride & 7) == 0) && ((((uintptr_t)depth.base) & 7) == 0) &&
+             ((rgb.pitch & 3) == 0) && ((rgb.lane_stride & 3) == 0) && ((((uintptr_t)rgb.base) & 3) == 0);
+  if (!vec) {
+    launch_intensity(s, B, rgb, I, m);
+    launch_decompose_rgb(s, B, rgb, r, g, b, m);
+    launch_depth_to_invdepth(s, B, depth, iD, factor_depth, m);
+    return;
+  }
+  int cols4 = iD.cols / 4, units = cols4 * iD.rows;
+  hipLaunchKernelGGL(k_prep_frame4, dim3(div_up(units, 256 * 2), B), dim3(256), 0, s, depth, rgb, iD, I, r, g, b, factor_depth, cols4, units, m);
+}
+
 // ---- gradientKernel (misc.cu:176-220): 3x3 Sobel/8, replicate border -----------------------------
 // LDS tile (TY+2)x(TX+2): one coalesced load of the halo'd tile, 9 taps from LDS.  Accumulation order
 // is the reference's (dx outer, dy inner) so the oracle comparison is exact.
@@ -104,7 +151,53 @@ __global__ __launch_bounds__(256) void k_gradient(ImgB src, ImgB gx, ImgB gy, La
     px<float>(gy, lane, y, x) = res_vert / 8.f;
   }
 }
+// 4 pixels per thread with a rolling 3-row window in registers: per output row one 16-byte load plus the two
+// neighbour columns (cache hits), two 16-byte stores.  No LDS, no barriers; tap order and arithmetic as above.
+static constexpr int GR_ROWS = 8;  // output rows per thread
+__device__ __forceinline__ void sobel_load_row(const ImgB& src, int lane, int y, int x, int xl, int xr, float r[6]) {
+  const float* rp = row_ptr<float>(src, lane, y);
+  float4 v = *reinterpret_cast<const float4*>(rp + x);
+  r[0] = rp[xl]; r[1] = v.x; r[2] = v.y; r[3] = v.z; r[4] = v.w; r[5] = rp[xr];
+}
+__global__ __launch_bounds__(256) void k_gradient4(ImgB src, ImgB gx, ImgB gy, int cols4, int strips, LaneMask m) {
+  int lane = blockIdx.y;
+  if (!m.on(lane)) return;
+  int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= cols4 * strips) return;
+  int strip = u / cols4, x = (u - strip * cols4) * 4;
+  int y_begin = strip * GR_ROWS, y_end = min(y_begin + GR_ROWS, src.rows);
+  int xl = max(x - 1, 0), xr = min(x + 4, src.cols - 1);
+  float a[6], b[6], c[6];  // rows y-1, y, y+1 (replicated at the border)
+  sobel_load_row(src, lane, max(y_begin - 1, 0), x, xl, xr, a);
+  sobel_load_row(src, lane, y_begin, x, xl, xr, b);
+  for (int y = y_begin; y < y_end; ++y) {
+    sobel_load_row(src, lane, min(y + 1, src.rows - 1), x, xl, xr, c);
+    float h[4], v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float res_hor = 0.f, res_vert = 0.f;
+#pragma unroll
+      for (int dx = -1; dx < 2; dx++)
+#pragma unroll
+        for (int dy = -1; dy < 2; dy++) {
+          float t = dy < 0 ? a[i + 1 + dx] : (dy == 0 ? b[i + 1 + dx] : c[i + 1 + dx]);
+          res_hor += t * (float)(dx * (2 - dy * dy));
+          res_vert += t * (float)(dy * (2 - dx * dx));
+        }
+      h[i] = res_hor / 8.f; v[i] = res_vert / 8.f;
+    }
+    *reinterpret_cast<float4*>(row_ptr<float>(gx, lane, y) + x) = make_float4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<float4*>(row_ptr<float>(gy, lane, y) + x) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { a[i] = b[i]; b[i] = c[i]; }
+  }
+}
 void launch_gradient(hipStream_t s, int B, ImgB src, ImgB gx, ImgB gy, LaneMask m) {
+  if ((src.cols % 4 == 0) && vec4_ok(src, 4) && vec4_ok(gx, 4) && vec4_ok(gy, 4)) {
+    int cols4 = src.cols / 4, strips = div_up(src.rows, GR_ROWS);
+    hipLaunchKernelGGL(k_gradient4, dim3(div_up(cols4 * strips, 256), B), dim3(256), 0, s, src, gx, gy, cols4, strips, m);
+    return;
+  }
   hipLaunchKernelGGL(k_gradient, grid2d(src.cols, src.rows, B), dim3(TX, TY), 0, s, src, gx, gy, m);
 }
 
@@ -147,60 +240,63 @@ void launch_fill(hipStream_t s, int B, ImgB dst, int elem_size, uint32_t bits, L
 }
 
 // ---- pyrDownKernelGridStridef (pyrdown.cu:84-132) -------------------------------------------------
-// dst tile 64x4 <- src tile (2*64+3) x (2*4+3) staged in LDS (window [2x-2, 2x+2] clipped).  The 5x5
-// Gaussian weights exp(-d2/2), d2 in {0,1,2,4,5,8}, are evaluated with expf like the reference; the
-// validity rule `count > 12` and the tap order (cy outer, cx inner) are the reference's.
-static constexpr int PSX = 2 * TX + 3, PSY = 2 * TY + 3;
-// exp(-d2/2) for the nine possible squared tap distances d2 = dx^2 + dy^2 in {0,1,2,4,5,8}: evaluated ONCE on the host
-// with expf (the reference evaluates __expf per tap: 25 transcendentals per output pixel)
+// 5x5 window [2x-2, 2x+2] x [2y-2, 2y+2] clipped to the image, NaN taps skipped, `count > 12` validity rule, tap order
+// cy outer / cx inner -- all as in the reference.  The Gaussian weights exp(-d2/2), d2 = dx^2+dy^2 in {0,1,2,4,5,8}, are
+// evaluated ONCE on the host with expf (the reference evaluates __expf per tap: 25 transcendentals per output pixel)
+// and reach the kernel as scalar arguments.
 struct PyrWeights { float w[9]; };
 static const PyrWeights& pyr_weights() {
   static const PyrWeights W = [] { PyrWeights t; for (int d2 = 0; d2 < 9; ++d2) t.w[d2] = expf(-((float)d2 * 0.5f)); return t; }();
   return W;
 }
-__global__ __launch_bounds__(256) void k_pyr_down(ImgB src, ImgB dst, PyrWeights W, LaneMask m) {
-  int lane = blockIdx.z;
+// A thread owns one output column and walks PD_ROWS output rows downwards, keeping the 5x5 source window in registers
+// (two new source rows = ten cached loads per output; out-of-image taps become NaN).  No LDS, no barriers.
+static constexpr int PD_ROWS = 8;
+__device__ __forceinline__ void pyr_load_row(const ImgB& src, int lane, int cy, const int cx[5], const bool cin[5], float r[5]) {
+  const bool row_in = cy >= 0 && cy < src.rows;
+  const float* rp = row_ptr<float>(src, lane, row_in ? cy : 0);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) { float v = rp[cx[i]]; r[i] = (row_in && cin[i]) ? v : qnan(); }
+}
+__global__ __launch_bounds__(256) void k_pyr_down_roll(ImgB src, ImgB dst, PyrWeights W, int strips, LaneMask m) {
+  int lane = blockIdx.y;
   if (!m.on(lane)) return;
-  __shared__ float tile[PSY][PSX + 1];
-  __shared__ float wt[9];
-  int x0 = blockIdx.x * TX;
-  int tid = threadIdx.y * TX + threadIdx.x;
-  if (tid < 9) wt[tid] = W.w[tid];
-  RGBID_FOR_TILES(y0) {
-    if (y0 >= dst.rows) break;
-    int sx0 = 2 * x0 - 2, sy0 = 2 * y0 - 2;
-    __syncthreads();
-    for (int i = tid; i < PSY * PSX; i += TX * TY) {
-      int ty = i / PSX, tx = i - ty * PSX;
-      int cx = sx0 + tx, cy = sy0 + ty;
-      float v = qnan();
-      if (cx >= 0 && cy >= 0 && cx < src.cols && cy < src.rows) v = px<float>(src, lane, cy, cx);
-      tile[ty][tx] = v;
-    }
-    __syncthreads();
-    int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
-    if (x >= dst.cols || y >= dst.rows) continue;
-    const int br = 2;
-    int tx_end = min(2 * x + br + 1, src.cols), ty_end = min(2 * y + br + 1, src.rows);
+  int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= dst.cols * strips) return;
+  int strip = u / dst.cols, x = u - strip * dst.cols;
+  int y_begin = strip * PD_ROWS, y_end = min(y_begin + PD_ROWS, dst.rows);
+  int cx[5]; bool cin[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) { int c = 2 * x - 2 + i; cin[i] = c >= 0 && c < src.cols; cx[i] = min(max(c, 0), src.cols - 1); }
+  float win[5][5];  // source rows 2y-2 .. 2y+2
+#pragma unroll
+  for (int r = 0; r < 3; ++r) pyr_load_row(src, lane, 2 * y_begin - 2 + r, cx, cin, win[r + 2]);
+  for (int y = y_begin; y < y_end; ++y) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int i = 0; i < 5; ++i) win[r][i] = win[r + 2][i];
+    pyr_load_row(src, lane, 2 * y + 1, cx, cin, win[3]);
+    pyr_load_row(src, lane, 2 * y + 2, cx, cin, win[4]);
     float sum1 = 0.f, sum2 = 0.f;
     int count = 0;
-    for (int cy = max(0, 2 * y - br); cy < ty_end; ++cy)
-      for (int cx = max(0, 2 * x - br); cx < tx_end; ++cx) {
-        float val = tile[cy - sy0][cx - sx0];
-        if (!isnan(val)) {
-          float weight = wt[(2 * x - cx) * (2 * x - cx) + (2 * y - cy) * (2 * y - cy)];
-          sum1 += val * weight;
-          sum2 += weight;
-          ++count;
-        }
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) {
+        const float val = win[dy][dx];
+        const float weight = W.w[(dx - 2) * (dx - 2) + (dy - 2) * (dy - 2)];
+        const bool ok = !isnan(val);
+        sum1 = ok ? sum1 + val * weight : sum1;
+        sum2 = ok ? sum2 + weight : sum2;
+        count += ok ? 1 : 0;
       }
-    float res = qnan();
-    if (count > 12) res = sum1 / sum2;
-    px<float>(dst, lane, y, x) = res;
+    px<float>(dst, lane, y, x) = count > 12 ? sum1 / sum2 : qnan();
   }
 }
 void launch_pyr_down(hipStream_t s, int B, ImgB src, ImgB dst, LaneMask m) {
-  hipLaunchKernelGGL(k_pyr_down, grid2d(dst.cols, dst.rows, B), dim3(TX, TY), 0, s, src, dst, pyr_weights(), m);
+  int strips = div_up(dst.rows, PD_ROWS);
+  hipLaunchKernelGGL(k_pyr_down_roll, dim3(div_up(dst.cols * strips, 256), B), dim3(256), 0, s, src, dst, pyr_weights(), strips, m);
 }
 
 // ---- bilateralKernel (filters.cu:86-135), clipped 5x5 window -------------------------------------
@@ -209,39 +305,41 @@ __global__ __launch_bounds__(256) void k_bilateral(ImgB src, ImgB dst, float sig
   int lane = blockIdx.z;
   if (!m.on(lane)) return;
   __shared__ float tile[TY + 2 * BR][TX + 2 * BR + 1];
-  int x0 = blockIdx.x * TX;
-  int tid = threadIdx.y * TX + threadIdx.x;
+  const int x0 = blockIdx.x * TX;
+  const float sigma_space = 5.f;
+  const float s2ih = (float)(0.5 / (double)(sigma_space * sigma_space));
   RGBID_FOR_TILES(y0) {
     if (y0 >= src.rows) break;
     __syncthreads();
-    for (int i = tid; i < (TY + 2 * BR) * (TX + 2 * BR); i += TX * TY) {
-      int ty = i / (TX + 2 * BR), tx = i - ty * (TX + 2 * BR);
-      int cx = x0 + tx - BR, cy = y0 + ty - BR;
-      float v = qnan();
-      if (cx >= 0 && cy >= 0 && cx < src.cols && cy < src.rows) v = px<float>(src, lane, cy, cx);
-      tile[ty][tx] = v;
+    for (int ty = threadIdx.y; ty < TY + 2 * BR; ty += TY) {
+      const int cy = y0 + ty - BR;
+      const bool row_in = cy >= 0 && cy < src.rows;
+      const float* rp = row_ptr<float>(src, lane, row_in ? cy : 0);
+      for (int tx = threadIdx.x; tx < TX + 2 * BR; tx += TX) {
+        const int cx = x0 + tx - BR;
+        tile[ty][tx] = (row_in && cx >= 0 && cx < src.cols) ? rp[cx] : qnan();
+      }
     }
     __syncthreads();
-    int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
+    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
     if (x >= src.cols || y >= src.rows) continue;
-    float value = tile[threadIdx.y + BR][threadIdx.x + BR];
+    const float value = tile[threadIdx.y + BR][threadIdx.x + BR];
     if (isnan(value)) { px<float>(dst, lane, y, x) = qnan(); continue; }
-    int tx_end = min(x + BR + 1, src.cols), ty_end = min(y + BR + 1, src.rows);
     float sum1 = 0.f, sum2 = 0.f;
-    const float sigma_space = 5.f;
-    const float s2ih = (float)(0.5 / (double)(sigma_space * sigma_space));
-    for (int cy = max(y - BR, 0); cy < ty_end; ++cy)
-      for (int cx = max(x - BR, 0); cx < tx_end; ++cx) {
-        float tmp = tile[cy - y0 + BR][cx - x0 + BR];
-        if (!isnan(tmp)) {
-          float space2 = (float)((x - cx) * (x - cx) + (y - cy) * (y - cy));
-          float fn = (value - tmp) / sigma_floatmap;
-          // the source mixes float and double here (`0.5*fn*fn`): keep the double evaluation
-          double arg = (double)(s2ih * space2) + (0.5 * (double)fn) * (double)fn;
-          float weight = expf((float)(-arg));
-          sum1 += tmp * weight;
-          sum2 += weight;
-        }
+    // clipped window == full window over the NaN-padded tile (NaN taps are skipped either way); tap order cy outer, cx inner
+#pragma unroll
+    for (int dy = -BR; dy <= BR; ++dy)
+#pragma unroll
+      for (int dx = -BR; dx <= BR; ++dx) {
+        const float tmp = tile[threadIdx.y + BR + dy][threadIdx.x + BR + dx];
+        const float space2 = (float)(dx * dx + dy * dy);
+        const float fn = (value - tmp) / sigma_floatmap;
+        // the source mixes float and double here (`0.5*fn*fn`): keep the double evaluation
+        const double arg = (double)(s2ih * space2) + (0.5 * (double)fn) * (double)fn;
+        const float weight = expf((float)(-arg));
+        const bool ok = !isnan(tmp);
+        sum1 = ok ? sum1 + tmp * weight : sum1;
+        sum2 = ok ? sum2 + weight : sum2;
       }
     px<float>(dst, lane, y, x) = sum1 / sum2;
   }

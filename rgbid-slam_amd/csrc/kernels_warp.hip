@@ -130,7 +130,40 @@ __global__ __launch_bounds__(256) void k_integrate(ImgB warped, ImgB wweight, Im
     }
   }
 }
+// 4 pixels per thread (16-byte accesses); pixels that keep their value are simply written back unchanged
+static inline bool vec4_ok(const ImgB& a) { return ((a.pitch & 15) == 0) && ((a.lane_stride & 15) == 0) && ((((uintptr_t)a.base) & 15) == 0) && (a.cols % 4 == 0); }
+__device__ __forceinline__ void integrate_px(float w_sum, float qs, float& w_KF, float& q) {
+  if (!isnan(w_sum)) {
+    float dw = fabsf(w_sum - w_KF);
+    if (isnan(w_KF)) { w_KF = w_sum; q = qs; }
+    else if (dw < 3 * 0.0075f) {
+      float new_weight = q + qs;
+      w_KF = (w_KF * q + w_sum * qs) / new_weight;
+      q = new_weight;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_integrate4(ImgB warped, ImgB wweight, ImgB kf, ImgB kfw, int cols4, int units, LaneMask m) {
+  int lane = blockIdx.y;
+  if (!m.on(lane)) return;
+  for (int u = blockIdx.x * 256 + threadIdx.x; u < units; u += gridDim.x * 256) {
+    int y = u / cols4, x = (u - y * cols4) * 4;
+    float4 ws = *reinterpret_cast<const float4*>(row_ptr<float>(warped, lane, y) + x);
+    float4 qs = *reinterpret_cast<const float4*>(row_ptr<float>(wweight, lane, y) + x);
+    float4* kp = reinterpret_cast<float4*>(row_ptr<float>(kf, lane, y) + x);
+    float4* qp = reinterpret_cast<float4*>(row_ptr<float>(kfw, lane, y) + x);
+    float4 k = *kp, q = *qp;
+    integrate_px(ws.x, qs.x, k.x, q.x); integrate_px(ws.y, qs.y, k.y, q.y);
+    integrate_px(ws.z, qs.z, k.z, q.z); integrate_px(ws.w, qs.w, k.w, q.w);
+    *kp = k; *qp = q;
+  }
+}
 void launch_integrate_warped(hipStream_t s, int B, ImgB warped, ImgB wweight, ImgB kf, ImgB kfw, LaneMask m) {
+  if (vec4_ok(warped) && vec4_ok(wweight) && vec4_ok(kf) && vec4_ok(kfw)) {
+    int cols4 = kf.cols / 4, units = cols4 * kf.rows;
+    hipLaunchKernelGGL(k_integrate4, dim3(div_up(units, 256 * 2), B), dim3(256), 0, s, warped, wweight, kf, kfw, cols4, units, m);
+    return;
+  }
   hipLaunchKernelGGL(k_integrate, grid2d(kf.cols, kf.rows, B), dim3(TX, TY), 0, s, warped, wweight, kf, kfw, m);
 }
 
