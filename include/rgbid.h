@@ -121,6 +121,19 @@ int rgbid_pyr_down(rgbid_ctx*, const rgbid_img* src, const rgbid_img* dst, float
 /* ---- bilateral (src/cuda/filters.cu:139-162) --------------------------------------------- */
 int rgbid_bilateral_filter(rgbid_ctx*, const rgbid_img* src, const rgbid_img* dst, float sigma_floatmap, float* ms);
 
+/* ---- custom-calibration front-end (src/cuda/undistortion.cu, warping_registration.cu:720-822); custom_registration=1 only */
+typedef struct rgbid_intr_k { float fx, fy, cx, cy, k1, k2, k3, k4, k5; } rgbid_intr_k;            /* Intr, src/internal.h:119-140 */
+typedef struct rgbid_depth_dist { float c1, c0, q0[9], q1[9]; int xshift, yshift; } rgbid_depth_dist; /* DepthDist, :142-161 */
+/* undistortIntensity undistortion.cu:214-243 (bilinear fetch, filter model = ctx interp mode) */
+int rgbid_undistort_intensity(rgbid_ctx*, const rgbid_img* src, const rgbid_img* dst, const rgbid_intr_k* intr, float* ms);
+/* undistortDepthInv undistortion.cu:246-312: src_corr receives the depth-distortion-corrected map, dst its undistortion */
+int rgbid_undistort_depthinv(rgbid_ctx*, const rgbid_img* src, const rgbid_img* src_corr, const rgbid_img* dst,
+                             const rgbid_intr_k* intr_depth, const rgbid_depth_dist* dp, float* ms);
+/* registerDepthinv warping_registration.cu:720-822: intermediate (float) and intermediate_as_int (int32) are the enlarged
+ * (3 rows x 3 cols in the reference) scratch images of the translation splat */
+int rgbid_register_depthinv(rgbid_ctx*, const rgbid_img* src, const rgbid_img* intermediate, const rgbid_img* intermediate_as_int,
+                            const rgbid_img* dst, const float dRc_proj[9], const float t_dc_proj[3], const float cRd_proj[9], float* ms);
+
 /* ---- warps, fusion, visibility (src/cuda/warping_registration.cu) ------------------------ */
 /* warpInvDepthWithTrafo3D :971-1019 */
 int rgbid_warp_invdepth(rgbid_ctx*, const rgbid_img* src, const rgbid_img* dst, const rgbid_img* depthinv_prev,

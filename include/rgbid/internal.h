@@ -91,10 +91,29 @@ struct Intr {
   }
 };
 
+// depth-sensor distortion model (src/internal.h:142-161)
+struct DepthDist {
+  float c1, c0;
+  float q00, q01, q02, q03, q04, q05, q06, q07, q08;
+  float q10, q11, q12, q13, q14, q15, q16, q17, q18;
+  int xshift, yshift;
+  DepthDist() {}
+  DepthDist(float c1_, float c0_, float q00_ = 0.f, float q01_ = 0.f, float q02_ = 0.f, float q03_ = 0.f, float q04_ = 0.f, float q05_ = 0.f,
+            float q06_ = 0.f, float q07_ = 0.f, float q08_ = 0.f, float q10_ = 1.f, float q11_ = 0.f, float q12_ = 0.f, float q13_ = 0.f,
+            float q14_ = 0.f, float q15_ = 0.f, float q16_ = 0.f, float q17_ = 0.f, float q18_ = 0.f, int xshift_ = 4, int yshift_ = 4)
+      : c1(c1_), c0(c0_), q00(q00_), q01(q01_), q02(q02_), q03(q03_), q04(q04_), q05(q05_), q06(q06_), q07(q07_), q08(q08_),
+        q10(q10_), q11(q11_), q12(q12_), q13(q13_), q14(q14_), q15(q15_), q16(q16_), q17(q17_), q18(q18_), xshift(xshift_), yshift(yshift_) {}
+};
 struct Mat33 { float3 data[3]; };      // three rows (src/internal.h:166-169)
 struct LightSource { float3 pos[1]; int number; };
 
 inline rgbid_intr c_intr(const Intr& k) { rgbid_intr r = {k.fx, k.fy, k.cx, k.cy}; return r; }
+inline rgbid_intr_k c_intr_k(const Intr& k) { rgbid_intr_k r = {k.fx, k.fy, k.cx, k.cy, k.k1, k.k2, k.k3, k.k4, k.k5}; return r; }
+inline rgbid_depth_dist c_depth_dist(const DepthDist& d) {
+  rgbid_depth_dist r = {d.c1, d.c0, {d.q00, d.q01, d.q02, d.q03, d.q04, d.q05, d.q06, d.q07, d.q08},
+                        {d.q10, d.q11, d.q12, d.q13, d.q14, d.q15, d.q16, d.q17, d.q18}, d.xshift, d.yshift};
+  return r;
+}
 template <class T> inline rgbid_img c_img(const DeviceArray2D<T>& a) { return a.img(); }
 template <class T> inline rgbid_img c_img(const PtrStepSz<T>& a) { rgbid_img i; i.data = (void*)a.data; i.step = a.step; i.rows = a.rows; i.cols = a.cols; return i; }
 
@@ -239,6 +258,26 @@ inline float warpIntensityWithTrafo3DInvDepth(IntensityMapf& src, IntensityMapf&
   (void)intr; (void)numSMs;
   float ms; rgbid_img a = c_img(src), b = c_img(dst), c = c_img(depthinv_prev);
   rgbidSafeCall(rgbid_warp_intensity(default_ctx(), &a, &b, &c, &inv_rotation.data[0].x, &inv_translation.x, &ms));
+  return ms;
+}
+// ---- custom-calibration front-end (src/internal.h:354-356,437-440)
+inline float undistortIntensity(IntensityMapf& src, IntensityMapf& dst, const Intr& intr_int, int numSMs = -1) {
+  (void)numSMs;
+  float ms; rgbid_img a = c_img(src), b = c_img(dst); rgbid_intr_k k = c_intr_k(intr_int);
+  rgbidSafeCall(rgbid_undistort_intensity(default_ctx(), &a, &b, &k, &ms));
+  return ms;
+}
+inline float undistortDepthInv(const DepthMapf& src, DepthMapf& src_corr, DepthMapf& dst, const Intr& intr_depth, const DepthDist& dp, int numSMs = -1) {
+  (void)numSMs;
+  float ms; rgbid_img a = c_img(src), b = c_img(src_corr), c = c_img(dst); rgbid_intr_k k = c_intr_k(intr_depth); rgbid_depth_dist d = c_depth_dist(dp);
+  rgbidSafeCall(rgbid_undistort_depthinv(default_ctx(), &a, &b, &c, &k, &d, &ms));
+  return ms;
+}
+inline float registerDepthinv(const DepthMapf& src, DepthMapf& intermediate, DeviceArray2D<int>& intermediate_as_int, DepthMapf& dst, const Mat33 dRc_proj,
+                              float3 t_dc_proj, const Mat33 cRd_proj, int numSMs = -1) {
+  (void)numSMs;
+  float ms; rgbid_img a = c_img(src), b = c_img(intermediate), c = c_img(intermediate_as_int), d = c_img(dst);
+  rgbidSafeCall(rgbid_register_depthinv(default_ctx(), &a, &b, &c, &d, &dRc_proj.data[0].x, &t_dc_proj.x, &cRd_proj.data[0].x, &ms));
   return ms;
 }
 inline float warpInvDepthWithTrafo3D(DepthMapf& src, DepthMapf& dst, const DepthMapf& depth_prev, Mat33 inv_rotation, float3 inv_translation,

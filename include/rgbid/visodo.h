@@ -106,7 +106,15 @@ class VisodoTracker {
   bool operator()();
 
   void setRGBIntrinsics(float fx, float fy, float cx = -1, float cy = -1, float k1 = 0.f, float k2 = 0.f, float k3 = 0.f, float k4 = 0.f, float k5 = 0.f);
-  void setDepthIntrinsics(float fxd, float fyd, float cxd = -1, float cyd = -1);
+  void setDepthIntrinsics(float fxd, float fyd, float cxd = -1, float cyd = -1, float k1d = 0.f, float k2d = 0.f, float k3d = 0.f, float k4d = 0.f,
+                          float k5d = 0.f, float c0 = 0.f, float c1 = 1.f, float q00 = 0.f, float q01 = 0.f, float q02 = 0.f, float q03 = 0.f,
+                          float q04 = 0.f, float q05 = 0.f, float q06 = 0.f, float q07 = 0.f, float q08 = 0.f, float q10 = 0.f, float q11 = 0.f,
+                          float q12 = 0.f, float q13 = 0.f, float q14 = 0.f, float q15 = 0.f, float q16 = 0.f, float q17 = 0.f, float q18 = 0.f);
+  void setDepthToRGBExtrinsics(const float dRc[9], const float t_dc[3]);   // dRc_, t_dc_ ([STEREO_DEPTH2RGB], visodo.cpp:288-316)
+  void setCustomRegistration(bool on) { custom_registration_ = on ? 1 : 0; }
+  Matrix3f getCalibMatrixDepth(int level_index = 0) const;
+  const device::DepthMapf& currentDepthinv(int level = 0) const { return depthinvs_curr_[level]; }
+  const device::IntensityMapf& currentIntensity(int level = 0) const { return intensities_curr_[level]; }
   void setSharedCameraPose(const Affine3d& pose);
   Affine3d getCameraPose(int time = -1) const;
   float getVisOdoTime(int time = -1) const;
@@ -158,6 +166,7 @@ class VisodoTracker {
   float computeInterframeTime();
   void allocateBuffers(int rows_arg, int cols_arg);
   void prepareImages(const DepthMap& depth_raw, const View& colors_raw);
+  void prepareImagesCustomCalibration(const DepthMap& depth_raw, const View& colors_raw);
   bool estimateVisualOdometry(Matrix3ft& resulting_rotation, Vector3ft& resulting_translation, Matrix6d& resulting_covariance);
   float computeCovisibility(const Matrix3ft& rotation_AtoB, const Vector3ft& translation_AtoB, const device::DepthMapf& depthinvA, const device::DepthMapf& depthinvB);
   float computeOverlapping(const Matrix3ft& rotation_AtoB, const Vector3ft& translation_AtoB, const device::DepthMapf& depthinvA,
@@ -172,8 +181,12 @@ class VisodoTracker {
 
   int rows_, cols_, levels_, global_time_;
   float fx_, fy_, cx_, cy_, k1_, k2_, k3_, k4_, k5_, factor_depth_;
-  float fxd_, fyd_, cxd_, cyd_;
+  float fxd_, fyd_, cxd_, cyd_, k1d_, k2d_, k3d_, k4d_, k5d_, c0_, c1_, q0_[9], q1_[9];
+  float dRc_[9], t_dc_[3];                 // depth -> rgb extrinsics (Matrix3f / Vector3f in the reference)
   int custom_registration_;
+  device::DepthMapf depthinv_distorted_, depthinv_corr_distorted_, depthinv_preregister_, depthinv_register_trans_;
+  device::IntensityMapf intensity_distorted_;
+  DeviceArray2D<int> depthinv_register_trans_as_int_;
   Matrix3ft init_Rcam_; Vector3ft init_tcam_;
   int visodo_iterations_[8];
   std::vector<device::DepthMapf> depthinvs_curr_, depthinvs_odoKF_, depthinvs_odoKF_filtered_, warped_depthinvs_curr_;

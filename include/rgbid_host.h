@@ -59,6 +59,9 @@ int rgbid_tracker_get_odo(const rgbid_tracker* t, int i, double R[9], double tv[
 int rgbid_tracker_last_info(const rgbid_tracker* t, rgbid_tracker_info* info);
 int rgbid_tracker_keyframe_maps(rgbid_tracker* t, float* depthinv_host, float* weight_host);
 
+/* level-0 inverse depth / intensity of the last prepared frame (after undistortion + registration when custom_registration=1), to host */
+int rgbid_tracker_current_maps(const rgbid_tracker* t, float* depthinv, float* intensity);
+
 /* KeyframeAlign::alignKeyframes (src/keyframe_align.cpp:115-357): host inputs, R/t in-out (initial guess -> result) */
 int rgbid_keyframe_align(int device, int rows, int cols, const float* depthinv_ini, const unsigned char* grey_ini,
                          const float* depthinv_end, const unsigned char* grey_end, float fx, float fy, float cx, float cy,

@@ -365,6 +365,20 @@ class Tracker:
         buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
         return np.frombuffer(buf, dtype=dtype).reshape(shape).copy()
 
+    def set_custom_calibration(self, rgb_k, depth_k, dist, dRc, t_dc):
+        """prepareImagesCustomCalibration path (custom_registration=1); dist = oracle.depth_dist(...)"""
+        cc = CustomCalib(IntrK(*[float(v) for v in rgb_k]), IntrK(*[float(v) for v in depth_k]), dist,
+                         (C.c_float * 9)(*[float(v) for v in np.asarray(dRc).reshape(9)]), (C.c_float * 3)(*[float(v) for v in t_dc]))
+        lib().orc_tracker_set_custom_calibration(self._h, C.byref(cc))
+
+    def cur_depthinv(self):
+        lib().orc_tracker_cur_depthinv.restype = C.c_void_p
+        return self._map(lib().orc_tracker_cur_depthinv, (self.cfg.rows, self.cfg.cols), np.float32)
+
+    def cur_intensity(self):
+        lib().orc_tracker_cur_intensity.restype = C.c_void_p
+        return self._map(lib().orc_tracker_cur_intensity, (self.cfg.rows, self.cfg.cols), np.float32)
+
     def kf_depthinv(self):
         return self._map(lib().orc_tracker_kf_depthinv, (self.cfg.rows, self.cfg.cols), np.float32)
 
@@ -399,3 +413,40 @@ def keyframe_align(depthinv_ini, grey_ini, depthinv_end, grey_end, k, interp_mod
     cov = np.zeros(36)
     lib().orc_keyframe_align(a.shape[0], a.shape[1], _p(a), _p(ga), _p(b), _p(gb), _intr(k), int(interp_mode), _p(R), _p(t), _p(cov))
     return R.reshape(3, 3), t, cov.reshape(6, 6)
+
+
+# ---- custom-calibration front-end
+class IntrK(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("fx", "fy", "cx", "cy", "k1", "k2", "k3", "k4", "k5")]
+
+
+class DepthDist(C.Structure):
+    _fields_ = [("c1", C.c_float), ("c0", C.c_float), ("q0", C.c_float * 9), ("q1", C.c_float * 9), ("xshift", C.c_int), ("yshift", C.c_int)]
+
+
+class CustomCalib(C.Structure):
+    _fields_ = [("rgb", IntrK), ("depth", IntrK), ("dist", DepthDist), ("dRc", C.c_float * 9), ("t_dc", C.c_float * 3)]
+
+
+def depth_dist(c1=1.0, c0=0.0, q0=(0,) * 9, q1=(1,) + (0,) * 8, xshift=4, yshift=4):
+    return DepthDist(c1, c0, (C.c_float * 9)(*q0), (C.c_float * 9)(*q1), xshift, yshift)
+
+
+def undistort_intensity(src, k, interp_mode=INTERP_TEX8):
+    s = _f(src); out = np.empty_like(s)
+    lib().orc_undistort_intensity(_p(s), s.shape[0], s.shape[1], IntrK(*[float(v) for v in k]), int(interp_mode), _p(out))
+    return out
+
+
+def undistort_depthinv(src, k, dd):
+    s = _f(src); corr = np.empty_like(s); out = np.empty_like(s)
+    lib().orc_undistort_depthinv(_p(s), s.shape[0], s.shape[1], IntrK(*[float(v) for v in k]), dd, _p(corr), _p(out))
+    return corr, out
+
+
+def register_depthinv(src, dRc_proj, t_dc_proj, cRd_proj, scale=3):
+    s = _f(src)
+    inter = np.empty((scale * s.shape[0], scale * s.shape[1]), np.float32); out = np.empty_like(s)
+    a, b, c = _f(np.asarray(dRc_proj).reshape(9)), _f(np.asarray(t_dc_proj).reshape(3)), _f(np.asarray(cRd_proj).reshape(9))
+    lib().orc_register_depthinv(_p(s), s.shape[0], s.shape[1], inter.shape[0], inter.shape[1], _p(a), _p(b), _p(c), _p(inter), _p(out))
+    return inter, out

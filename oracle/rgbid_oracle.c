@@ -414,6 +414,122 @@ void orc_generate_image_rgb(const float* vmap, const float* nmap, const uint8_t*
 }
 
 /* ------------------------------------------------------------------ sigmaFuncs.cu */
+/* ================================================================== custom-calibration front-end (f-5) */
+static inline void distort_pixel(float uu, float vu, float* ud, float* vd, orc_intr_k k) {
+  /* distortPixel undistortion.cu:96-112 */
+  float r2 = uu * uu + vu * vu;
+  float r4 = r2 * r2;
+  float r6 = r2 * r4;
+  float factor_r = 1.f + k.k1 * r2 + k.k2 * r4 + k.k5 * r6;
+  float a = factor_r * uu;
+  a += 2.f * k.k3 * uu * vu + k.k4 * (r2 + 2.f * uu * uu);
+  float b = factor_r * vu;
+  b += 2.f * k.k4 * uu * vu + k.k3 * (r2 + 2.f * vu * vu);
+  *ud = a; *vd = b;
+}
+
+static void undistort_image(const float* src, int rows, int cols, orc_intr_k k, int linear, int interp_mode, float* dst) {
+  /* undistortKernel undistortion.cu:145-176 */
+#pragma omp parallel for
+  for (int yu = 0; yu < rows; ++yu)
+    for (int xu = 0; xu < cols; ++xu) {
+      float res = ORC_NAN;
+      float uu = ((float)xu - k.cx) * (1.f / k.fx);
+      float vu = ((float)yu - k.cy) * (1.f / k.fy);
+      float ud, vd;
+      distort_pixel(uu, vu, &ud, &vd, k);
+      float xd = k.fx * ud + k.cx + 0.5f;
+      float yd = k.fy * vd + k.cy + 0.5f;
+      if (!((xd <= 0) || (yd <= 0) || (xd >= (float)cols) || (yd >= (float)rows))) {
+        if (linear) res = tex2d_linear(src, rows, cols, xd, yd, interp_mode);
+        else res = src[(size_t)imin(imax(f2i_rd(yd), 0), rows - 1) * cols + imin(imax(f2i_rd(xd), 0), cols - 1)];
+      }
+      dst[(size_t)yu * cols + xu] = res;
+    }
+}
+
+void orc_undistort_intensity(const float* src, int rows, int cols, orc_intr_k k, int interp_mode, float* dst) {
+  undistort_image(src, rows, cols, k, 1, interp_mode, dst);
+}
+
+void orc_undistort_depthinv(const float* src, int rows, int cols, orc_intr_k k, orc_depth_dist dp, float* src_corr, float* dst) {
+  float* corr = src_corr ? src_corr : (float*)malloc((size_t)rows * cols * sizeof(float));
+  /* depthinvCorrectionKernel undistortion.cu:179-211, correctDepthinv :131-142, undistortDepthinv :114-129 */
+#pragma omp parallel for
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x) {
+      float res = ORC_NAN;
+      int xs = x - dp.xshift, ys = y - dp.yshift;
+      if ((xs > 0) && (ys > 0)) {
+        float u = ((float)x - k.cx) * (1.f / k.fx);
+        float v = ((float)y - k.cy) * (1.f / k.fy);
+        float val = src[(size_t)ys * cols + xs];
+        float wd = dp.c1 * val + dp.c0;
+        float r2 = u * u + v * v;
+        float r4 = r2 * r2;
+        float r6 = r2 * r4;
+        float uv = u * v;
+        float u2v = u * u * v;
+        float uv2 = u * v * v;
+        float D0 = dp.q0[0] + dp.q0[1] * r2 + dp.q0[2] * r4 + dp.q0[3] * r6 + dp.q0[4] * u + dp.q0[5] * v + dp.q0[6] * uv + dp.q0[7] * u2v + dp.q0[8] * uv2;
+        float D1 = dp.q1[0] + dp.q1[1] * r2 + dp.q1[2] * r4 + dp.q1[3] * r6 + dp.q1[4] * u + dp.q1[5] * v + dp.q1[6] * uv + dp.q1[7] * u2v + dp.q1[8] * uv2;
+        res = (1.f + D1) * wd + D0;
+      }
+      corr[(size_t)y * cols + x] = res;
+    }
+  undistort_image(corr, rows, cols, k, 0, 0, dst);
+  if (!src_corr) free(corr);
+}
+
+void orc_register_depthinv(const float* src, int rows, int cols, int irows, int icols, const float dRc_proj[9], const float t[3],
+                           const float cRd_proj[9], float* intermediate, float* dst) {
+  int offset_x = (icols - cols) / 2, offset_y = (irows - rows) / 2;
+  size_t ni = (size_t)irows * icols;
+  int32_t* zbuf = (int32_t*)calloc(ni, sizeof(int32_t));        /* initialiseRegistrationKernel :168-183 */
+  for (size_t i = 0; i < ni; ++i) intermediate[i] = ORC_NAN;
+  /* depthinvRegistrationTranslationWithDilationKernel :241-288 (serial: the max is order independent) */
+  for (int yd = 0; yd < rows; ++yd)
+    for (int xd = 0; xd < cols; ++xd) {
+      float wd = src[(size_t)yd * cols + xd];
+      if (wd != wd) continue;
+      float zd = 1.f / wd;                                        /* registerPixelTranslationOnly :148-165 */
+      float X0 = (float)xd * zd - t[0], X1 = (float)yd * zd - t[1], X2 = zd - t[2];
+      float wc = 1.f / X2;
+      float xc = X0 * wc, yc = X1 * wc;
+      if (wc > 0.01f) {
+        float dilation = wc / wd;
+        int32_t bits; memcpy(&bits, &wc, 4);
+        int xmin = f2i_rn(xc - 0.5f * dilation) + offset_x, xmax = f2i_rn(xc + 0.5f * dilation) + offset_x;
+        int ymin = f2i_rn(yc - 0.5f * dilation) + offset_y, ymax = f2i_rn(yc + 0.5f * dilation) + offset_y;
+        for (int x = imax(0, xmin); x < imin(xmax + 1, icols); x++)
+          for (int y = imax(0, ymin); y < imin(ymax + 1, irows); y++)
+            if (zbuf[(size_t)y * icols + x] < bits) zbuf[(size_t)y * icols + x] = bits;   /* dst is all-NaN during this kernel */
+      }
+    }
+  for (size_t i = 0; i < ni; ++i)                                  /* conversionRegistrationKernel :186-204 */
+    if (zbuf[i] != 0) memcpy(&intermediate[i], &zbuf[i], 4);
+  free(zbuf);
+  /* homographyKernelInvDepthGridStride :597-635 with srcHdst = dRc_proj, dstHsrc = cRd_proj */
+#pragma omp parallel for
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x) {
+      float out = ORC_NAN;
+      float pd[3] = { (float)x, (float)y, 1.f }, ps[3];
+      for (int r = 0; r < 3; ++r) ps[r] = dot3(dRc_proj + 3 * r, pd);
+      float iz = 1.f / ps[2];
+      ps[0] *= iz; ps[1] *= iz; ps[2] *= iz;
+      float x_src = ps[0] + 0.5f + (float)offset_x;
+      float y_src = ps[1] + 0.5f + (float)offset_y;
+      if (!(f2i_rd(x_src) < 0 || f2i_rd(y_src) < 0 || f2i_rd(x_src) >= icols || f2i_rd(y_src) >= irows)) {
+        float w_src = intermediate[(size_t)imin(imax(f2i_rd(y_src), 0), irows - 1) * icols + imin(imax(f2i_rd(x_src), 0), icols - 1)];
+        float pz = dot3(cRd_proj + 6, ps);
+        float res = w_src / pz;
+        if (res > 0.f) out = res;
+      }
+      dst[(size_t)y * cols + x] = out;
+    }
+}
+
 int orc_error_lattice(const float* im1, const float* im0, int rows, int cols, int min_nsamples,
                       float* err, int* out_rows, int* out_cols, int* out_stride) {
   /* computeErrorGridStride sigmaFuncs.cu:701-765 + errorHandler :90-135 */

@@ -81,6 +81,18 @@ void orc_nmap_gradients(const float* depthinv, const float* gx, const float* gy,
 void orc_generate_image_rgb(const float* vmap, const float* nmap, const uint8_t* rgb,
                             const float light[3], int rows, int cols, uint8_t* dst);
 
+/* ---- custom-calibration front-end (src/cuda/undistortion.cu, warping_registration.cu:148-288,597-635,720-822) ---- */
+typedef struct { float fx, fy, cx, cy, k1, k2, k3, k4, k5; } orc_intr_k;              /* src/internal.h:119-140 */
+typedef struct { float c1, c0, q0[9], q1[9]; int xshift, yshift; } orc_depth_dist;   /* src/internal.h:142-161 (xshift=yshift=4) */
+/* undistortIntensity undistortion.cu:195-243: bilinear texture fetch at the distorted position */
+void orc_undistort_intensity(const float* src, int rows, int cols, orc_intr_k k, int interp_mode, float* dst);
+/* undistortDepthInv :246-312: depthinvCorrectionKernel into src_corr (nullable), then point-sampled undistortion */
+void orc_undistort_depthinv(const float* src, int rows, int cols, orc_intr_k k, orc_depth_dist dp, float* src_corr, float* dst);
+/* registerDepthinv warping_registration.cu:720-822: translation splat with dilation (z-buffer by atomicMax on the float bits)
+ * into the (irows x icols) intermediate, then the rotation homography with point sampling */
+void orc_register_depthinv(const float* src, int rows, int cols, int irows, int icols, const float dRc_proj[9], const float t_dc_proj[3],
+                           const float cRd_proj[9], float* intermediate, float* dst);
+
 /* ---- residual lattice + scale estimation (src/cuda/sigmaFuncs.cu) ---- */
 /* returns number of samples written to err; lattice geometry in out_* (sigmaFuncs.cu:701-765) */
 int  orc_error_lattice(const float* im1, const float* im0, int rows, int cols, int min_nsamples,
@@ -139,6 +151,17 @@ void orc_tracker_get_pose(const orc_tracker* t, int i, double R[9], double tv[3]
 /* sequential odometry i (odo_rmats_/odo_tvecs_/odo_covmats_) */
 int  orc_tracker_num_odo(const orc_tracker* t);
 void orc_tracker_get_odo(const orc_tracker* t, int i, double R[9], double tv[3], double cov[36]);
+/* prepareImagesCustomCalibration (visodo.cpp:775-824) instead of prepareImages: rgb intrinsics with distortion, depth intrinsics,
+ * depth distortion model, depth->rgb extrinsics (loadCalibration :183-318) */
+typedef struct {
+  orc_intr_k rgb, depth;
+  orc_depth_dist dist;
+  float dRc[9], t_dc[3];
+} orc_custom_calib;
+void orc_tracker_set_custom_calibration(orc_tracker* t, const orc_custom_calib* cc);
+/* level-0 maps of the current frame after preparation (for tests) */
+const float* orc_tracker_cur_depthinv(const orc_tracker* t);
+const float* orc_tracker_cur_intensity(const orc_tracker* t);
 /* diagnostics of the last tracked frame */
 typedef struct {
   int lost, odo_kf_switched, integr_kf_switched, odometry_success;

@@ -201,6 +201,7 @@ static void m6_ABAt_add(const double J[36], const double C[36], double out[36]) 
 
 struct orc_tracker {
   orc_tracker_config c;
+  int custom_registration; orc_custom_calib cc;   /* prepareImagesCustomCalibration instead of prepareImages */
   int global_time, lost;
   int odoKF_count, integrKF_count, last_odoKF_index, last_integrKF_index;
   double velocity[3], omega[3];
@@ -333,9 +334,47 @@ static void project_trafo(const orc_tracker_config* c, int level, const double R
 
 static orc_intr cfg_intr(const orc_tracker_config* c) { orc_intr k = { c->fx, c->fy, c->cx, c->cy }; return k; }
 
+static void m3f_mul(const float A[9], const float B[9], float C[9]) {
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+static void m3f_inv(const float A[9], float I[9]) {
+  /* Eigen Matrix3f::inverse(): cofactors / determinant, in float */
+  float c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+  float det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+  float id = 1.f / det;
+  I[0] = c00 * id; I[1] = (A[2] * A[7] - A[1] * A[8]) * id; I[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+  I[3] = c01 * id; I[4] = (A[0] * A[8] - A[2] * A[6]) * id; I[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+  I[6] = c02 * id; I[7] = (A[1] * A[6] - A[0] * A[7]) * id; I[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+}
+
 static void prepare_images(orc_tracker* t, const uint16_t* depth, const uint8_t* rgb) {
   /* prepareImages visodo.cpp:760-773 */
   const orc_tracker_config* c = &t->c;
+  if (t->custom_registration) {
+    /* prepareImagesCustomCalibration visodo.cpp:775-824 */
+    const orc_custom_calib* cc = &t->cc;
+    size_t n = (size_t)c->rows * c->cols;
+    float* I_dist = falloc(n); float* iD_dist = falloc(n); float* iD_pre = falloc(n); float* inter = falloc(9 * n);
+    orc_intensity(rgb, I_dist, c->rows, c->cols);
+    orc_decompose_rgb(rgb, t->r_curr, t->g_curr, t->b_curr, c->rows, c->cols);
+    orc_depth2invdepth(depth, iD_dist, c->rows, c->cols, c->factor_depth);
+    orc_undistort_intensity(I_dist, c->rows, c->cols, cc->rgb, c->interp_mode, t->I_curr[0]);
+    orc_undistort_depthinv(iD_dist, c->rows, c->cols, cc->depth, cc->dist, NULL, iD_pre);
+    /* Kd*dRc*Kc^-1, Kd*t_dc, inverse: all Eigen float (:792-801); Kc from getCalibMatrix(0) = tracker fx.. (no distortion) */
+    float Kc[9] = { c->fx, 0, c->cx, 0, c->fy, c->cy, 0, 0, 1 }, Kd[9] = { cc->depth.fx, 0, cc->depth.cx, 0, cc->depth.fy, cc->depth.cy, 0, 0, 1 };
+    float Kci[9], T[9], dRc_proj[9], cRd_proj[9], t_proj[3];
+    m3f_inv(Kc, Kci);
+    m3f_mul(Kd, cc->dRc, T); m3f_mul(T, Kci, dRc_proj);
+    for (int i = 0; i < 3; ++i) t_proj[i] = Kd[i * 3] * cc->t_dc[0] + Kd[i * 3 + 1] * cc->t_dc[1] + Kd[i * 3 + 2] * cc->t_dc[2];
+    m3f_inv(dRc_proj, cRd_proj);
+    orc_register_depthinv(iD_pre, c->rows, c->cols, 3 * c->rows, 3 * c->cols, dRc_proj, t_proj, cRd_proj, inter, t->iD_curr[0]);
+    free(I_dist); free(iD_dist); free(iD_pre); free(inter);
+    for (int i = 1; i < c->levels; ++i) {
+      orc_pyr_down(t->I_curr[i - 1], c->rows >> (i - 1), c->cols >> (i - 1), t->I_curr[i]);
+      orc_pyr_down(t->iD_curr[i - 1], c->rows >> (i - 1), c->cols >> (i - 1), t->iD_curr[i]);
+    }
+    return;
+  }
   orc_intensity(rgb, t->I_curr[0], c->rows, c->cols);
   orc_decompose_rgb(rgb, t->r_curr, t->g_curr, t->b_curr, c->rows, c->cols);
   orc_depth2invdepth(depth, t->iD_curr[0], c->rows, c->cols, c->factor_depth);
@@ -711,6 +750,9 @@ void orc_tracker_get_odo(const orc_tracker* t, int i, double R[9], double tv[3],
   memcpy(cov, t->odo_cov + 36 * i, 36 * sizeof(double));
 }
 void orc_tracker_last_info(const orc_tracker* t, orc_frame_info* info) { *info = t->info; }
+void orc_tracker_set_custom_calibration(orc_tracker* t, const orc_custom_calib* cc) { t->custom_registration = cc != NULL; if (cc) t->cc = *cc; }
+const float* orc_tracker_cur_depthinv(const orc_tracker* t) { return t->iD_curr[0]; }
+const float* orc_tracker_cur_intensity(const orc_tracker* t) { return t->I_curr[0]; }
 const float* orc_tracker_kf_depthinv(const orc_tracker* t) { return t->iD_integr; }
 const float* orc_tracker_kf_weight(const orc_tracker* t) { return t->w_integr; }
 const float* orc_tracker_kf_normals(const orc_tracker* t) { return t->nmap; }

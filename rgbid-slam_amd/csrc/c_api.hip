@@ -289,6 +289,35 @@ int rgbid_bilateral_filter(rgbid_ctx* c, const rgbid_img* src, const rgbid_img* 
   return t.finish();
 }
 
+// ---- custom-calibration front-end --------------------------------------------------------------------
+static IntrK to_k(const rgbid_intr_k* k) { return IntrK{k->fx, k->fy, k->cx, k->cy, k->k1, k->k2, k->k3, k->k4, k->k5}; }
+int rgbid_undistort_intensity(rgbid_ctx* c, const rgbid_img* src, const rgbid_img* dst, const rgbid_intr_k* intr, float* ms) {
+  if (!c || !ok_img(src) || !ok_img(dst) || !intr || !same_size(src, dst) || src->data == dst->data) return RGBID_E_INVALID;
+  Timed t(c, ms);
+  launch_undistort(c->stream, 1, B1(src), B1(dst), to_k(intr), true, c->interp_mode, ALL);
+  return t.finish();
+}
+int rgbid_undistort_depthinv(rgbid_ctx* c, const rgbid_img* src, const rgbid_img* src_corr, const rgbid_img* dst, const rgbid_intr_k* intr,
+                             const rgbid_depth_dist* dp, float* ms) {
+  if (!c || !ok_img(src) || !ok_img(src_corr) || !ok_img(dst) || !intr || !dp || !same_size(src, dst) || !same_size(src, src_corr) ||
+      src->data == src_corr->data || src_corr->data == dst->data) return RGBID_E_INVALID;
+  DepthDistP d;
+  d.c1 = dp->c1; d.c0 = dp->c0; d.xshift = dp->xshift; d.yshift = dp->yshift;
+  for (int i = 0; i < 9; ++i) { d.q0[i] = dp->q0[i]; d.q1[i] = dp->q1[i]; }
+  Timed t(c, ms);
+  launch_depthinv_correction(c->stream, 1, B1(src), B1(src_corr), to_k(intr), d, ALL);
+  launch_undistort(c->stream, 1, B1(src_corr), B1(dst), to_k(intr), false, 0, ALL);
+  return t.finish();
+}
+int rgbid_register_depthinv(rgbid_ctx* c, const rgbid_img* src, const rgbid_img* inter, const rgbid_img* inter_i, const rgbid_img* dst,
+                            const float dRc_proj[9], const float t_dc_proj[3], const float cRd_proj[9], float* ms) {
+  if (!c || !ok_img(src) || !ok_img(inter) || !ok_img(inter_i) || !ok_img(dst) || !dRc_proj || !t_dc_proj || !cRd_proj || !same_size(inter, inter_i) ||
+      inter->rows < src->rows || inter->cols < src->cols || src->data == dst->data) return RGBID_E_INVALID;
+  Timed t(c, ms);
+  launch_register_depthinv(c->stream, 1, B1(src), B1(inter), B1(inter_i), B1(dst), dRc_proj, t_dc_proj, cRd_proj, ALL);
+  return t.finish();
+}
+
 // ---- warps / fusion / visibility ----------------------------------------------------------------------
 int rgbid_warp_invdepth(rgbid_ctx* c, const rgbid_img* src, const rgbid_img* dst, const rgbid_img* prev, const float R[9], const float tv[3], float* ms) {
   if (!c || !ok_img(src) || !ok_img(dst) || !ok_img(prev) || !R || !tv || !same_size(src, dst) || !same_size(src, prev)) return RGBID_E_INVALID;

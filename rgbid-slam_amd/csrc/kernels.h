@@ -15,8 +15,16 @@ struct SysParams {     // inputs of constraintsHandler (estimate_VO.cu:95-139)
 struct SigmaIO { float bias, sigma, nu; };
 struct IntrP { float fx, fy, cx, cy; };
 struct LightP { float x, y, z; };
+struct IntrK { float fx, fy, cx, cy, k1, k2, k3, k4, k5; };                      // Intr with distortion, src/internal.h:119-140
+struct DepthDistP { float c1, c0, q0[9], q1[9]; int xshift, yshift; };          // DepthDist, src/internal.h:142-161
 
 enum { SYS_TERMS = 27 };
+
+// ---- custom-calibration front-end (kernels_calib.hip) -------------------------------------------
+void launch_undistort(hipStream_t s, int B, ImgB src, ImgB dst, IntrK k, bool linear, int interp_mode, LaneMask m);
+void launch_depthinv_correction(hipStream_t s, int B, ImgB src, ImgB dst, IntrK k, DepthDistP dp, LaneMask m);
+void launch_register_depthinv(hipStream_t s, int B, ImgB src, ImgB inter_f, ImgB inter_i, ImgB dst, const float dRc_proj[9], const float t_dc_proj[3],
+                              const float cRd_proj[9], LaneMask m);
 
 // ---- prep (kernels_prep.hip) -------------------------------------------------------------------
 void launch_depth_to_invdepth(hipStream_t s, int B, ImgB src_u16, ImgB dst, float factor_depth, LaneMask m);

@@ -128,6 +128,15 @@ int rgbid_tracker_keyframe_maps(rgbid_tracker* h, float* depthinv_host, float* w
   return RGBID_OK;
 }
 
+int rgbid_tracker_current_maps(const rgbid_tracker* h, float* depthinv, float* intensity) {
+  if (!h) return RGBID_E_INVALID;
+  const VisodoTracker& t = *h->t;
+  int cols = const_cast<VisodoTracker&>(t).cols();
+  if (depthinv) t.currentDepthinv(0).download(depthinv, (size_t)cols * 4);
+  if (intensity) t.currentIntensity(0).download(intensity, (size_t)cols * 4);
+  return RGBID_OK;
+}
+
 int rgbid_keyframe_align(int device, int rows, int cols, const float* depthinv_ini, const unsigned char* grey_ini, const float* depthinv_end,
                          const unsigned char* grey_end, float fx, float fy, float cx, float cy, double R[9], double t[3], double cov[36]) {
   if (!depthinv_ini || !grey_ini || !depthinv_end || !grey_end || !R || !t || !cov) return RGBID_E_INVALID;

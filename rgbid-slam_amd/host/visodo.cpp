@@ -47,6 +47,8 @@ VisodoTracker::VisodoTracker(int optim_dim, int Mestimator, int motion_model, in
   init_Rcam_ = Matrix3ft::Identity();
   init_tcam_ = Vector3ft::Zero();
   custom_registration_ = 0;
+  const float eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, zero3[3] = {0, 0, 0};
+  setDepthToRGBExtrinsics(eye, zero3);  // dRc_ = I, t_dc_ = 0 (:59-60)
   const int iters[] = {10, 5, 3, 3, 3, 3, 3, 3};  // {10,5,3} for the reference's 3 levels (:65); extra levels get 3
   for (int i = 0; i < 8; ++i) visodo_iterations_[i] = iters[i];
   real_time_flag_ = false;
@@ -96,17 +98,77 @@ void VisodoTracker::loadCalibration(std::string const& calib_file) {
     if (calibration.getEntry("kd", entry)) { std::stringstream ss(entry.getValue()); ss >> k1_ >> k2_ >> k3_ >> k4_ >> k5_; }
     if (calibration.getEntry("factor_depth", entry)) factor_depth_ = (float)atof(entry.getValue().c_str());
   }
-  if (settings.getSection("DEPTH_CALIBRATION", calibration)) {
+  if (settings.getSection("DEPTH_CALIBRATION", calibration)) {  // :183-286
     Entry entry;
-    if (calibration.getEntry("custom_registration", entry)) {
-      std::stringstream ss(entry.getValue());
-      ss >> custom_registration_;
-      if (custom_registration_) {
-        // the custom-calibration front-end (undistortion + depth registration) is not part of this build
-        std::cout << "custom_registration=1 is not supported by this build (the reference's README advises against it); ignoring" << std::endl;
-        custom_registration_ = 0;
-      }
-    }
+    if (calibration.getEntry("custom_registration", entry)) { std::stringstream ss(entry.getValue()); ss >> custom_registration_; }
+    if (calibration.getEntry("fx", entry)) { std::stringstream ss(entry.getValue()); ss >> fxd_; }
+    if (calibration.getEntry("fy", entry)) fyd_ = (float)atof(entry.getValue().c_str());
+    if (calibration.getEntry("cx", entry)) cxd_ = (float)atof(entry.getValue().c_str());
+    if (calibration.getEntry("cy", entry)) cyd_ = (float)atof(entry.getValue().c_str());
+    if (calibration.getEntry("kd", entry)) { std::stringstream ss(entry.getValue()); ss >> k1d_ >> k2d_ >> k3d_ >> k4d_ >> k5d_; }
+    if (calibration.getEntry("c0", entry)) { std::stringstream ss(entry.getValue()); ss >> c0_; }
+    if (calibration.getEntry("c1", entry)) { std::stringstream ss(entry.getValue()); ss >> c1_; }
+    if (calibration.getEntry("q0", entry)) { std::stringstream ss(entry.getValue()); for (int i = 0; i < 9; ++i) ss >> q0_[i]; }
+    if (calibration.getEntry("q1", entry)) { std::stringstream ss(entry.getValue()); for (int i = 0; i < 9; ++i) ss >> q1_[i]; }
+  }
+  if (settings.getSection("STEREO_DEPTH2RGB", calibration)) {  // :288-316
+    Entry entry;
+    if (calibration.getEntry("dRc", entry)) { std::stringstream ss(entry.getValue()); for (int i = 0; i < 9; ++i) ss >> dRc_[i]; }
+    if (calibration.getEntry("t_dc", entry)) { std::stringstream ss(entry.getValue()); ss >> t_dc_[0] >> t_dc_[1] >> t_dc_[2]; }
+  }
+}
+
+namespace {
+// Eigen Matrix3f products / inverse of prepareImagesCustomCalibration (:792-801), float, cofactor inverse
+void m3f_mul(const float* A, const float* B, float* C) {
+  float T[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+  for (int i = 0; i < 9; ++i) C[i] = T[i];
+}
+void m3f_inv(const float* A, float* I) {
+  float c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+  float det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+  float id = 1.f / det;
+  float T[9] = {c00 * id, (A[2] * A[7] - A[1] * A[8]) * id, (A[1] * A[5] - A[2] * A[4]) * id,
+                c01 * id, (A[0] * A[8] - A[2] * A[6]) * id, (A[2] * A[3] - A[0] * A[5]) * id,
+                c02 * id, (A[1] * A[6] - A[0] * A[7]) * id, (A[0] * A[4] - A[1] * A[3]) * id};
+  for (int i = 0; i < 9; ++i) I[i] = T[i];
+}
+}  // namespace
+
+void VisodoTracker::prepareImagesCustomCalibration(const DepthMap& depth_raw, const View& colors_raw) {
+  // src/visodo.cpp:775-824: undistort both images, correct the depth-sensor distortion, register depth onto the RGB camera
+  if (depthinv_distorted_.rows() != rows_) {  // allocateBuffers :619-624 (only needed on this path)
+    depthinv_distorted_.create(rows_, cols_); intensity_distorted_.create(rows_, cols_);
+    depthinv_corr_distorted_.create(rows_, cols_); depthinv_preregister_.create(rows_, cols_);
+    depthinv_register_trans_.create(3 * rows_, 3 * cols_); depthinv_register_trans_as_int_.create(3 * rows_, 3 * cols_);
+  }
+  PtrStepSz<uchar3> colors(rows_, cols_, (uchar3*)colors_raw.ptr(), colors_raw.step());
+  Intr rgb_intrinsics = intr();
+  Intr depth_intrinsics(fxd_, fyd_, cxd_, cyd_, k1d_, k2d_, k3d_, k4d_, k5d_);
+  DepthDist depth_spdist(c1_, c0_, q0_[0], q0_[1], q0_[2], q0_[3], q0_[4], q0_[5], q0_[6], q0_[7], q0_[8], q1_[0], q1_[1], q1_[2], q1_[3], q1_[4],
+                         q1_[5], q1_[6], q1_[7], q1_[8]);
+  computeIntensity(colors, intensity_distorted_);
+  decomposeRGBInChannels(colors, r_curr_, g_curr_, b_curr_);
+  convertDepth2InvDepth(depth_raw, depthinv_distorted_, factor_depth_);
+  undistortIntensity(intensity_distorted_, intensities_curr_[0], rgb_intrinsics);
+  undistortDepthInv(depthinv_distorted_, depthinv_corr_distorted_, depthinv_preregister_, depth_intrinsics, depth_spdist);
+  Matrix3f Kc = getCalibMatrix(0), Kd = getCalibMatrixDepth(0);
+  float Kci[9], T[9], dRc_proj[9], cRd_proj[9], t_dc_proj[3];
+  m3f_inv(Kc.m, Kci);
+  m3f_mul(Kd.m, dRc_, T); m3f_mul(T, Kci, dRc_proj);
+  for (int i = 0; i < 3; ++i) t_dc_proj[i] = Kd.m[i * 3] * t_dc_[0] + Kd.m[i * 3 + 1] * t_dc_[1] + Kd.m[i * 3 + 2] * t_dc_[2];
+  m3f_inv(dRc_proj, cRd_proj);
+  Mat33 dRc_dev, cRd_dev; float3 t_dev;
+  for (int i = 0; i < 3; ++i) {
+    dRc_dev.data[i].x = dRc_proj[i * 3]; dRc_dev.data[i].y = dRc_proj[i * 3 + 1]; dRc_dev.data[i].z = dRc_proj[i * 3 + 2];
+    cRd_dev.data[i].x = cRd_proj[i * 3]; cRd_dev.data[i].y = cRd_proj[i * 3 + 1]; cRd_dev.data[i].z = cRd_proj[i * 3 + 2];
+  }
+  t_dev.x = t_dc_proj[0]; t_dev.y = t_dc_proj[1]; t_dev.z = t_dc_proj[2];
+  registerDepthinv(depthinv_preregister_, depthinv_register_trans_, depthinv_register_trans_as_int_, depthinvs_curr_[0], dRc_dev, t_dev, cRd_dev);
+  for (int i = 1; i < levels_; ++i) {
+    pyrDownIntensity(intensities_curr_[i - 1], intensities_curr_[i]);
+    pyrDownDepth(depthinvs_curr_[i - 1], depthinvs_curr_[i]);
   }
 }
 
@@ -172,10 +234,27 @@ void VisodoTracker::setRGBIntrinsics(float fx, float fy, float cx, float cy, flo
   k1_ = k1; k2_ = k2; k3_ = k3; k4_ = k4; k5_ = k5;
   lost_ = false;
 }
-void VisodoTracker::setDepthIntrinsics(float fxd, float fyd, float cxd, float cyd) {
+void VisodoTracker::setDepthIntrinsics(float fxd, float fyd, float cxd, float cyd, float k1d, float k2d, float k3d, float k4d, float k5d, float c0,
+                                       float c1, float q00, float q01, float q02, float q03, float q04, float q05, float q06, float q07, float q08,
+                                       float q10, float q11, float q12, float q13, float q14, float q15, float q16, float q17, float q18) {
+  // src/visodo.cpp:464-505
   fxd_ = fxd; fyd_ = fyd;
   cxd_ = (cxd == -1) ? cols_ / 2 - 0.5f : cxd;
   cyd_ = (cyd == -1) ? rows_ / 2 - 0.5f : cyd;
+  k1d_ = k1d; k2d_ = k2d; k3d_ = k3d; k4d_ = k4d; k5d_ = k5d;
+  c0_ = c0; c1_ = c1;
+  const float a[9] = {q00, q01, q02, q03, q04, q05, q06, q07, q08}, b[9] = {q10, q11, q12, q13, q14, q15, q16, q17, q18};
+  for (int i = 0; i < 9; ++i) { q0_[i] = a[i]; q1_[i] = b[i]; }
+}
+void VisodoTracker::setDepthToRGBExtrinsics(const float dRc[9], const float t_dc[3]) {
+  for (int i = 0; i < 9; ++i) dRc_[i] = dRc[i];
+  for (int i = 0; i < 3; ++i) t_dc_[i] = t_dc[i];
+}
+Matrix3f VisodoTracker::getCalibMatrixDepth(int level_index) const {
+  // src/visodo.cpp:1904-1919
+  int div = 1 << level_index;
+  Matrix3f K = {{fxd_ / div, 0.f, cxd_ / div, 0.f, fyd_ / div, cyd_ / div, 0.f, 0.f, 1.f}};
+  return K;
 }
 void VisodoTracker::setSharedCameraPose(const Affine3d& pose) {
   std::lock_guard<std::mutex> lock(mutex_shared_camera_pose_);
@@ -602,7 +681,8 @@ bool VisodoTracker::trackNewFrame() {
   kf_time_accum_ += delta_t_;
   double t1 = now_ms();
   last_info_ = LastFrameInfo();
-  prepareImages(depth_, rgb24_);
+  if (custom_registration_) prepareImagesCustomCalibration(depth_, rgb24_);  // :1982-1989
+  else prepareImages(depth_, rgb24_);
   device::sync();
   TrackerSink* sink = keyframe_manager_ptr_ ? keyframe_manager_ptr_ : &null_sink_;
   keyframe_manager_ptr_ = sink;

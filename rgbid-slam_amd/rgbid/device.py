@@ -23,6 +23,19 @@ NO_FILTERS, FILTER_GRADS = range(2)
 INTERP_EXACT, INTERP_TEX8 = range(2)
 
 
+class IntrK(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("fx", "fy", "cx", "cy", "k1", "k2", "k3", "k4", "k5")]
+
+
+class DepthDist(C.Structure):
+    _fields_ = [("c1", C.c_float), ("c0", C.c_float), ("q0", C.c_float * 9), ("q1", C.c_float * 9), ("xshift", C.c_int), ("yshift", C.c_int)]
+
+
+def depth_dist(c1=1.0, c0=0.0, q0=(0,) * 9, q1=(1,) + (0,) * 8, xshift=4, yshift=4):
+    """DepthDist with the constructor defaults of src/internal.h:150-159"""
+    return DepthDist(c1, c0, (C.c_float * 9)(*q0), (C.c_float * 9)(*q1), xshift, yshift)
+
+
 def img(t):
     """rgbid_img view of a CUDA tensor: [rows, cols] (any 1/2/4-byte dtype) or [rows, cols, 3] uint8."""
     if not t.is_cuda:
@@ -117,6 +130,26 @@ class Context:
     def bilateralFilter(self, src, dst, sigma_floatmap):
         ms = C.c_float()
         check(self.L.rgbid_bilateral_filter(self._h, C.byref(img(src)), C.byref(img(dst)), C.c_float(sigma_floatmap), C.byref(ms)))
+        return ms.value
+
+    # ---- custom-calibration front-end (undistortion.cu, warping_registration.cu:720-822) ----
+    def undistortIntensity(self, src, dst, intr_k):
+        ms = C.c_float()
+        k = IntrK(*[float(v) for v in intr_k])
+        check(self.L.rgbid_undistort_intensity(self._h, C.byref(img(src)), C.byref(img(dst)), C.byref(k), C.byref(ms)))
+        return ms.value
+
+    def undistortDepthInv(self, src, src_corr, dst, intr_k, depth_dist):
+        ms = C.c_float()
+        k = IntrK(*[float(v) for v in intr_k])
+        check(self.L.rgbid_undistort_depthinv(self._h, C.byref(img(src)), C.byref(img(src_corr)), C.byref(img(dst)), C.byref(k),
+                                              C.byref(depth_dist), C.byref(ms)))
+        return ms.value
+
+    def registerDepthinv(self, src, intermediate, intermediate_as_int, dst, dRc_proj, t_dc_proj, cRd_proj):
+        ms = C.c_float()
+        check(self.L.rgbid_register_depthinv(self._h, C.byref(img(src)), C.byref(img(intermediate)), C.byref(img(intermediate_as_int)),
+                                             C.byref(img(dst)), _fa(dRc_proj, 9), _fa(t_dc_proj, 3), _fa(cRd_proj, 9), C.byref(ms)))
         return ms.value
 
     # ---- warps / fusion / visibility ----

@@ -132,6 +132,12 @@ class Tracker:
     def load_calibration(self, path):
         check(lib().rgbid_tracker_load_calibration(self._h, path.encode()))
 
+    def current_maps(self):
+        """level-0 (inverse depth, intensity) of the last prepared frame"""
+        d = np.empty((self.cfg.rows, self.cfg.cols), np.float32); i = np.empty_like(d)
+        check(lib().rgbid_tracker_current_maps(self._h, _p(d), _p(i)))
+        return d, i
+
     def track(self, depth_u16, rgb_u8):
         d = np.ascontiguousarray(depth_u16, np.uint16); r = np.ascontiguousarray(rgb_u8, np.uint8)
         ok = C.c_int()

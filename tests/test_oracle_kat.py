@@ -173,3 +173,32 @@ def test_gauss_newton_step_contracts_noise_free():
     # mm depth quantisation + 8-bit colour bound the achievable accuracy vs ground truth (this is not the parity tolerance)
     assert ok and np.linalg.norm(O.logmap(R.T @ Rg, np.zeros(3))[3:]) < 3e-4 and np.linalg.norm(t - tg) < 5e-4
     assert np.all(np.linalg.eigvalsh(cov) > 0)
+
+
+def test_calibration_front_end_kats():
+    """SURVEY 8 f-5 oracle pins: zero distortion is the identity map; the default depth model (c1=1, c0=0, q=0) only shifts by
+    (xshift, yshift); identity extrinsics with equal intrinsics register a fronto-parallel plane onto itself; a pure +z offset of
+    the depth camera rescales inverse depth by 1/(1 - w tz)."""
+    r = util.rng(41)
+    rows, cols = 60, 80
+    I = util.rand_intensity(r, rows, cols)
+    k0 = (105.0, 105.0, 39.5, 29.5, 0, 0, 0, 0, 0)
+    out = O.undistort_intensity(I, k0)
+    ok = np.isfinite(out)
+    assert ok[1:-1, 1:-1].all()
+    np.testing.assert_allclose(out[ok], I[ok], atol=2e-3)
+    w = util.rand_invdepth(r, rows, cols, nan_frac=0.0)
+    corr, und = O.undistort_depthinv(w, k0, O.depth_dist(q1=(0,) * 9))
+    np.testing.assert_array_equal(corr[5:, 5:], w[1:-4, 1:-4])       # res(y, x) = src(y - 4, x - 4), strict > 0
+    assert np.isnan(corr[:5]).all() and np.isnan(corr[:, :5]).all()
+    plane = np.full((rows, cols), 0.5, np.float32)
+    eye = np.eye(3, dtype=np.float32)
+    inter, reg = O.register_depthinv(plane, eye, np.zeros(3, np.float32), eye)
+    np.testing.assert_array_equal(reg, plane)
+    assert np.isnan(inter[:rows - 1]).all() and np.isfinite(inter[rows:2 * rows, cols:2 * cols]).all()   # centred in the 3x canvas
+    K = np.array([[105.0, 0, 39.5], [0, 105.0, 29.5], [0, 0, 1]], np.float32)
+    tz = 0.2
+    _, reg = O.register_depthinv(plane, eye, K @ np.array([0, 0, tz], np.float32), eye)
+    ok = np.isfinite(reg)
+    assert ok.mean() > 0.5
+    np.testing.assert_allclose(reg[ok], 0.5 / (1 - 0.5 * tz), rtol=1e-6)
