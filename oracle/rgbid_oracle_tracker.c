@@ -558,6 +558,9 @@ static int estimate_visual_odometry(orc_tracker* t, double R_io[9], double t_io[
   }
   float sigma_int = 40.f, sigma_depthinv = 5.f, bias_int = 0.f, bias_depthinv = 0.f, nu_int = 5.f, nu_depthinv = 5.f;
   double A[36], b[6];
+  float RMSE = 9999.f, RMSE_prev = 9999.f;   /* :1041 (declared once, carried across levels) */
+  double last_inc_inv[9], last_tinc[3];
+  m3_id(last_inc_inv); memset(last_tinc, 0, sizeof(last_tinc));
   int iters0 = c->iters[0];
   for (int level = c->levels - 1; level >= c->finest_level; --level) {
     int iter_num = level == 0 ? iters0 : c->iters[level];
@@ -572,6 +575,26 @@ static int estimate_visual_odometry(orc_tracker* t, double R_io[9], double t_io[
         }
       } else {
         warp_level(t, level, curR, curt);
+      }
+      if ((c->termination == ORC_CHI_SQUARED) && (iter != 0)) {
+        /* :1134-1164: full-lattice residuals of the LEVEL-0 warped maps (fresh only with WARP_FIRST; with PYR_FIRST the reference
+         * reads whatever the last level-0 warp left there), RMSE must not grow, else undo the last increment and end the level */
+        float chi_square, chi_test, ndof;
+        int nI = orc_error_lattice(t->wI[0], t->I_kf[0], c->rows, c->cols, 9999999, t->res_I, NULL, NULL, NULL);
+        orc_error_lattice(t->wiD[0], t->iD_kf[0], c->rows, c->cols, 9999999, t->res_D, NULL, NULL, NULL);
+        orc_chi_square(t->res_I, t->res_D, nI, sigma_int_ref, sigma_depthinv_ref, c->mestimator, &chi_square, &chi_test, &ndof);
+        RMSE = sqrtf(chi_square) / sqrtf(ndof);
+        if (iter != 1) {
+          if (RMSE > RMSE_prev) {
+            double d[3], tmp2[3];
+            for (int i = 0; i < 3; ++i) d[i] = curt[i] - last_tinc[i];
+            m3_mulv(last_inc_inv, d, tmp2);
+            memcpy(curt, tmp2, sizeof(tmp2));
+            m3_mul(last_inc_inv, curR, curR);
+            break;
+          }
+        }
+        RMSE_prev = RMSE;
       }
       sigma_int = 5.f; sigma_depthinv = 0.0025f; bias_int = 0.f; bias_depthinv = 0.f; nu_int = 5.f; nu_depthinv = 5.f; /* :1168-1173 */
       if (c->sigma_estimator == ORC_SIGMA_PDF) {
@@ -598,6 +621,7 @@ static int estimate_visual_odometry(orc_tracker* t, double R_io[9], double t_io[
       m3_mulv(inc, curt, tmp);
       for (int i = 0; i < 3; ++i) curt[i] = tmp[i] + tinc[i];
       m3_mul(inc, curR, curR);
+      memcpy(last_inc_inv, inc_inv, sizeof(last_inc_inv)); memcpy(last_tinc, tinc, sizeof(last_tinc));
       if (has_nan3(curR, curt)) { /* :1265-1274 */
         memcpy(R_io, prevR, sizeof(prevR)); memcpy(t_io, prevt, sizeof(prevt));
         m6_zero(cov); for (int i = 0; i < 6; ++i) cov[i * 7] = 100.0;

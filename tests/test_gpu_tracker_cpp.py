@@ -63,6 +63,23 @@ def test_cpp_tracker_sigma_const_no_motion_model():
     run(120, 160, SMALL_K, 4, dict(sigma_estimator=O.SIGMA_CONS, motion_model=O.NO_MM), SLOW)
 
 
+def test_cpp_tracker_chi_squared_termination():
+    """termination = CHI_SQUARED (visodo.cpp:1134-1164): a level ends, and the last increment is undone, as soon as the full-lattice
+    RMSE grows.  Run with WARP_FIRST, where the level-0 warped maps the test reads are fresh at every level."""
+    kw = dict(warping=O.WARP_FIRST, termination=O.CHI_SQUARED)
+    run(120, 160, SMALL_K, 5, kw, SLOW)
+    # the early exit really fires on this sequence: the oracle's trajectory differs from the all-iterations one
+    seq = synth.make_sequence(5, K=SMALL_K, rows=120, cols=160, device="cuda", **SLOW)
+    d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+    out = []
+    for term in (O.CHI_SQUARED, O.ALL_ITERS):
+        t = O.Tracker(O.default_config(rows=120, cols=160, fx=SMALL_K[0], fy=SMALL_K[1], cx=SMALL_K[2], cy=SMALL_K[3], warping=O.WARP_FIRST, termination=term))
+        for k in range(5):
+            t.track(d[k], c[k])
+        out.append(t.poses()[1])
+    assert np.abs(out[0] - out[1]).max() > 1e-7
+
+
 def test_cpp_tracker_keyframe_switches():
     run(120, 160, SMALL_K, 8, dict(visratio_odo=0.985, visratio_integr=0.97), dict(trans_step=(0.01, 0.02), rot_step_deg=(0.5, 1.0)))
 
