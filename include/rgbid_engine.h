@@ -39,6 +39,7 @@ typedef struct rgbid_engine_config {
   int chi_square_stats;      /* also run the (unused-by-the-reference) full-res chi-square of visodo.cpp:1411-1415 */
   int preview;               /* also render the Phong preview (getImage, visodo.cpp:559-580) each step */
   int record_capacity;       /* steps of pose records kept on the device (ring) */
+  int warping;               /* RGBID_PYR_FIRST (default) or RGBID_WARP_FIRST: warp at level 0 and pyrDown the warped maps (visodo.cpp:1078-1105) */
 } rgbid_engine_config;
 
 #define RGBID_ST_TRACKED    1   /* trackNewFrame returned true */

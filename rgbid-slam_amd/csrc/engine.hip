@@ -52,6 +52,7 @@ struct StepCfg {  // by-value kernel argument with what the scalar kernels need
   int levels, finest_level, motion_model, max_odoKF_count, max_integrKF_count;
   float visratio_odo, visratio_integr, delta_t;
   int mestimator, weighting;
+  int start_warp_level;  // pyramid level whose intrinsics project the first warp of a frame
 };
 
 __device__ void set_warp_from_pose(const StepCfg& c, int level, const double* R, const double* t, WarpParams& wp) {
@@ -146,7 +147,7 @@ __global__ void k_step_begin(LaneState* st, Flags f, WarpParams* wp, SysParams* 
     se3::m3_copy(s.prev_R, s.cur_R);
     for (int i = 0; i < 3; ++i) s.cur_t[i] = s.prev_t[i];
   }
-  set_warp_from_pose(c, c.levels - 1, s.cur_R, s.cur_t, wp[lane]);
+  set_warp_from_pose(c, c.start_warp_level, s.cur_R, s.cur_t, wp[lane]);
   (void)sp;
 }
 
@@ -492,6 +493,11 @@ StepCfg step_cfg(const rgbid_engine_config& c) {
   s.max_odoKF_count = c.max_odoKF_count; s.max_integrKF_count = c.max_integrKF_count;
   s.visratio_odo = c.visratio_odo; s.visratio_integr = c.visratio_integr; s.delta_t = c.delta_t;
   s.mestimator = c.mestimator; s.weighting = c.weighting;
+  // first level (coarse to fine) that runs at least one iteration; the covariance pass warps at the finest level
+  s.start_warp_level = c.finest_level;
+  bool any_gn = false;
+  for (int l = c.levels - 1; l >= c.finest_level; --l) if (c.iters[l] > 0) { s.start_warp_level = l; any_gn = true; break; }
+  if (c.warping == RGBID_WARP_FIRST && any_gn) s.start_warp_level = 0;  // warp-first warps the level-0 frame in every GN iteration
   return s;
 }
 
@@ -557,7 +563,16 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
     int iters = c.iters[level];
     for (int it = 0; it < iters; ++it) {
       bool last_of_level = (it == iters - 1);
-      int next_level = last_of_level ? (level > c.finest_level ? level - 1 : c.finest_level) : level;
+      // level whose intrinsics project the NEXT warp: same level, the next lower level that iterates, or (after the very last
+      // iteration) the finest level for the covariance pass; warp-first always warps at level 0 inside the GN loop
+      int next_level = level;
+      if (last_of_level) {
+        next_level = c.finest_level;
+        for (int l = level - 1; l >= c.finest_level; --l) if (c.iters[l] > 0) { next_level = l; break; }
+      }
+      bool more_gn = !last_of_level;
+      for (int l = level - 1; l >= c.finest_level && !more_gn; --l) more_gn = c.iters[l] > 0;
+      if (c.warping == RGBID_WARP_FIRST) next_level = more_gn ? 0 : c.finest_level;
       bool prof = e->prof_on && level == 0 && e->prof_used + 2 <= (int)e->prof_ev.size();
       int nblk;
       if (c.fused_gn) {
@@ -570,9 +585,22 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
         nblk = launch_gn_fused(s, B, e->iD_kf[level], e->I_kf[level], e->gxD[level], e->gyD[level], e->gxI[level], e->gyI[level],
                                e->iD_curr[level], e->I_curr[level], e->wp, c.interp_mode, e->sp, e->partials, M(f.gn), level < 2 ? level : 2);
       } else {
-        launch_warp_invdepth(s, B, e->iD_curr[level], e->iD_kf[level], e->wiD[level], nullptr, e->wp, M(f.gn));
-        launch_warp_intensity(s, B, e->I_curr[level], e->wiD[level], e->wI[level], nullptr, e->wp, c.interp_mode, M(f.gn));
-        e->launches += 2;
+        if (c.warping == RGBID_WARP_FIRST) {
+          // :1078-1105: warp the full-resolution frame, then reduce the WARPED maps down to the working level
+          // (k_step_begin / k_solve_update project the pose with the level-0 intrinsics in this mode)
+          launch_warp_invdepth(s, B, e->iD_curr[0], e->iD_kf[0], e->wiD[0], nullptr, e->wp, M(f.gn));
+          launch_warp_intensity(s, B, e->I_curr[0], e->wiD[0], e->wI[0], nullptr, e->wp, c.interp_mode, M(f.gn));
+          e->launches += 2;
+          for (int i = 1; i <= level; ++i) {
+            launch_pyr_down(s, B, e->wI[i - 1], e->wI[i], M(f.gn));
+            launch_pyr_down(s, B, e->wiD[i - 1], e->wiD[i], M(f.gn));
+            e->launches += 2;
+          }
+        } else {
+          launch_warp_invdepth(s, B, e->iD_curr[level], e->iD_kf[level], e->wiD[level], nullptr, e->wp, M(f.gn));
+          launch_warp_intensity(s, B, e->I_curr[level], e->wiD[level], e->wI[level], nullptr, e->wp, c.interp_mode, M(f.gn));
+          e->launches += 2;
+        }
         if (c.sigma_estimator == RGBID_SIGMA_PDF) {
           launch_sigma_pair(s, B, e->wiD[level], e->iD_kf[level], e->wI[level], e->I_kf[level], c.nsamples, e->sp, c.mestimator, M(f.gn));
           e->launches++;
@@ -678,6 +706,7 @@ void rgbid_engine_default_config(rgbid_engine_config* c) {
   c->delta_t = 0.03333f;
   c->use_graph = 1; c->fused_gn = 0; c->chi_square_stats = 0; c->preview = 0;
   c->record_capacity = 64;
+  c->warping = RGBID_PYR_FIRST;
 }
 
 int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_config* cfg) {
@@ -685,7 +714,8 @@ int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_c
   *out = nullptr;
   if (cfg->rows <= 0 || cfg->cols <= 0 || cfg->levels < 1 || cfg->levels > MAXL || cfg->lanes < 1 || cfg->finest_level < 0 ||
       cfg->finest_level >= cfg->levels || (cfg->rows >> (cfg->levels - 1)) < 4 || (cfg->cols >> (cfg->levels - 1)) < 4 ||
-      cfg->record_capacity < 1) return RGBID_E_INVALID;
+      cfg->record_capacity < 1 || (cfg->warping != RGBID_PYR_FIRST && cfg->warping != RGBID_WARP_FIRST) ||
+      (cfg->warping == RGBID_WARP_FIRST && cfg->fused_gn)) return RGBID_E_INVALID;
   rgbid_engine* e = new (std::nothrow) rgbid_engine();
   if (!e) return RGBID_E_NOMEM;
   e->ctx = ctx; e->cfg = *cfg; e->B = cfg->lanes; e->L = cfg->levels;

@@ -90,6 +90,18 @@ def test_engine_vs_oracle_small(ctx, use_graph):
     print("worst pose deviation engine vs oracle:", wr, wt)
 
 
+def test_engine_warp_first(ctx):
+    """warping = WARP_FIRST (visodo.cpp:1078-1105): warp the level-0 frame, pyrDown the warped maps to the working level."""
+    K = (synth.TUM_K[0] / 4, synth.TUM_K[1] / 4, (synth.TUM_K[2] + 0.5) / 4 - 0.5, (synth.TUM_K[3] + 0.5) / 4 - 0.5)
+    run_case(ctx, 120, 160, K, n_lanes=2, n_frames=5, cfg_kw=dict(warping=O.WARP_FIRST), seq_kw=dict(trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8)), use_graph=0)
+
+
+def test_engine_skips_levels_without_iterations(ctx):
+    """iterations {3, 0, 4}: the middle level runs no iteration, so the coarse level hands its pose straight to level 0."""
+    K = (synth.TUM_K[0] / 4, synth.TUM_K[1] / 4, (synth.TUM_K[2] + 0.5) / 4 - 0.5, (synth.TUM_K[3] + 0.5) / 4 - 0.5)
+    run_case(ctx, 120, 160, K, n_lanes=2, n_frames=4, cfg_kw=dict(iters=[3, 0, 4]), seq_kw=dict(trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8)), use_graph=0)
+
+
 def test_engine_fused_gn_is_bit_identical(ctx):
     """The fused warp+residual+JTJ kernel computes W1/I1 with the same per-pixel device functions and accumulates in the
     same per-thread order as the unfused kernels: poses must be IDENTICAL, not merely close."""
