@@ -56,6 +56,9 @@ class Context:
     """rgbid_ctx bound to a device and (by default) torch's current stream on that device."""
 
     def __init__(self, device=0, use_torch_stream=True):
+        # use_torch_stream: adopt torch's CURRENT stream when it is a real stream object; torch's default stream is the null
+        # stream (handle 0), in which case the context creates its own non-blocking stream -- order against it with
+        # Context.sync() / Engine.records(), or create the Context inside `with torch.cuda.stream(s):` to share stream s.
         L = _lib.lib()
         self._h = C.c_void_p()
         stream = None

@@ -155,3 +155,53 @@ def test_chunked_sequence_matches_sequential(ctx):
     assert d_rot < 2e-3 and d_tr < 5e-3 and e1 < 1e-2 and e4 < 1e-2
     # chunk 0 alone is bit-identical to the first frames of the sequential run (same keyframe, same prior)
     assert np.array_equal(R1[:4], R4[:4]) and np.array_equal(t1[:4], t4[:4])
+
+
+def test_engine_reset_and_streamed_inputs_are_bit_identical():
+    """reset() restores the exact initial state (a second run over the same frames reproduces every record bit for bit), and
+    frames streamed from pinned host memory on a copy stream -- double-buffered against the engine's own stream with events, the
+    way bench.py --h2d does -- give the same records as device-resident inputs."""
+    from rgbid import device
+    dev = torch.device("cuda", 0)
+    K = (synth.TUM_K[0] / 4, synth.TUM_K[1] / 4, (synth.TUM_K[2] + 0.5) / 4 - 0.5, (synth.TUM_K[3] + 0.5) / 4 - 0.5)
+    T, B = 6, 4
+    seqs, depth, rgb = make_lanes(B, T, 120, 160, K)
+    work = torch.cuda.Stream(dev)
+    with torch.cuda.stream(work):
+        ctx = device.Context(0)          # the context adopts the (non-null) torch stream that is current at creation
+    ctx.set_async(1)
+    eng = E.Engine(ctx, E.default_config(rows=120, cols=160, lanes=B, K=K, use_graph=0, record_capacity=T))
+    torch.cuda.synchronize()
+
+    def resident():
+        for k in range(T):
+            eng.step(depth[k], rgb[k])
+        return eng.records(0, T).copy()
+
+    a = resident(); eng.reset(); b = resident()
+    assert a.tobytes() == b.tobytes()
+    depth_h, rgb_h = depth.cpu().pin_memory(), rgb.cpu().pin_memory()
+    bufs = [(torch.empty_like(depth[0]), torch.empty_like(rgb[0])) for _ in range(2)]
+    copy_stream = torch.cuda.Stream(dev)
+    ready = [torch.cuda.Event() for _ in range(2)]; free = [torch.cuda.Event() for _ in range(2)]
+
+    def upload(k, slot):
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(free[slot])
+            bufs[slot][0].copy_(depth_h[k], non_blocking=True); bufs[slot][1].copy_(rgb_h[k], non_blocking=True)
+            ready[slot].record(copy_stream)
+
+    eng.reset()
+    for ev in free:
+        ev.record(work)
+    upload(0, 0)
+    for k in range(T):
+        slot = k % 2
+        if k + 1 < T:
+            upload(k + 1, 1 - slot)
+        work.wait_event(ready[slot])
+        eng.step(bufs[slot][0], bufs[slot][1])
+        free[slot].record(work)
+    c = eng.records(0, T).copy()
+    assert a.tobytes() == c.tobytes()
+    eng.close(); ctx.close()
