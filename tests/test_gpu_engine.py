@@ -53,7 +53,8 @@ def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph):
             assert bool(st & E.ST_INTEGR_KF) == bool(info.integr_kf_switched), (l, k, st, rec[k, l]["vis_integr"], info.visratio_integr)
             assert abs(rec[k, l]["vis_odo"] - info.visratio_odo) < 2e-4 and abs(rec[k, l]["vis_integr"] - info.visratio_integr) < 2e-4
             assert rec[k, l]["nu_depthinv"] == info.nu_depthinv and rec[k, l]["nu_int"] == info.nu_int, (l, k)
-            assert abs(rec[k, l]["sigma_int"] - info.sigma_int) < 1e-4 * info.sigma_int
+            # sigma is the scale of the residuals AT the current pose estimate, which itself agrees to ~1e-5: 1e-3 relative
+            assert abs(rec[k, l]["sigma_int"] - info.sigma_int) < 1e-3 * info.sigma_int, (l, k, rec[k, l]["sigma_int"], info.sigma_int)
         Rs, ts = trk.poses()
         oR, ot, ocov = trk.odometry()
         for k in range(1, n_frames):
@@ -88,6 +89,15 @@ def test_engine_vs_oracle_small(ctx, use_graph):
     K = (K[0], K[1], (synth.TUM_K[2] + 0.5) / 4 - 0.5, (synth.TUM_K[3] + 0.5) / 4 - 0.5)
     wr, wt = run_case(ctx, 120, 160, K, n_lanes=3, n_frames=7, cfg_kw=dict(), seq_kw=dict(trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8)), use_graph=use_graph)
     print("worst pose deviation engine vs oracle:", wr, wt)
+
+
+def test_engine_long_sequence(ctx):
+    """40 frames per lane with keyframe switches and fusion: the engine must not drift away from the oracle tracker (every frame is
+    still held to 1e-4 rad / 1e-4 m and to identical keyframe decisions)."""
+    K = (synth.TUM_K[0] / 4, synth.TUM_K[1] / 4, (synth.TUM_K[2] + 0.5) / 4 - 0.5, (synth.TUM_K[3] + 0.5) / 4 - 0.5)
+    wr, wt = run_case(ctx, 120, 160, K, n_lanes=2, n_frames=40, cfg_kw=dict(visratio_odo=0.97, visratio_integr=0.93),
+                      seq_kw=dict(trans_step=(0.004, 0.012), rot_step_deg=(0.2, 0.8)), use_graph=0)
+    print("worst pose deviation over 40 frames:", wr, wt)
 
 
 def test_engine_warp_first(ctx):
