@@ -224,51 +224,137 @@ void launch_visibility(hipStream_t s, int B, ImgB src, ImgB dst, ImgB mask, cons
 __global__ __launch_bounds__(256) void k_vmap(ImgB depthinv, ImgB vmap, IntrP k, LaneMask m) {
   int lane = blockIdx.z;
   if (!m.on(lane)) return;
-  int u = blockIdx.x * TX + threadIdx.x, v = blockIdx.y * TY + threadIdx.y;
-  if (u >= depthinv.cols || v >= depthinv.rows) return;
+  int u = blockIdx.x * TX + threadIdx.x;
   int rows = depthinv.rows;
   float fx_inv = 1.f / k.fx, fy_inv = 1.f / k.fy;
-  float z = 1.f / px<float>(depthinv, lane, v, u);
-  if (!isnan(z)) {
-    px<float>(vmap, lane, v, u) = z * ((float)u - k.cx) * fx_inv;
-    px<float>(vmap, lane, v + rows, u) = z * ((float)v - k.cy) * fy_inv;
-    px<float>(vmap, lane, v + 2 * rows, u) = z;
-  } else {
-    px<float>(vmap, lane, v, u) = qnan();
+  RGBID_FOR_ROWS(v) {
+    if (u >= depthinv.cols || v >= rows) continue;
+    float z = 1.f / px<float>(depthinv, lane, v, u);
+    if (!isnan(z)) {
+      px<float>(vmap, lane, v, u) = z * ((float)u - k.cx) * fx_inv;
+      px<float>(vmap, lane, v + rows, u) = z * ((float)v - k.cy) * fy_inv;
+      px<float>(vmap, lane, v + 2 * rows, u) = z;
+    } else {
+      px<float>(vmap, lane, v, u) = qnan();
+    }
+  }
+}
+// 4 pixels per thread, 16-byte stores.  The reference leaves planes 1/2 untouched at invalid pixels: a group with an invalid pixel
+// reads the old vector back and blends (read-modify-write), every group then stores full vectors.
+__device__ __forceinline__ float4 blend4(float4 oldv, const float n[4], const bool keep[4]) {
+  return make_float4(keep[0] ? n[0] : oldv.x, keep[1] ? n[1] : oldv.y, keep[2] ? n[2] : oldv.z, keep[3] ? n[3] : oldv.w);
+}
+__global__ __launch_bounds__(256) void k_vmap4(ImgB depthinv, ImgB vmap, IntrP k, int cols4, int units, LaneMask m) {
+  int lane = blockIdx.y;
+  if (!m.on(lane)) return;
+  const int rows = depthinv.rows;
+  const float fx_inv = 1.f / k.fx, fy_inv = 1.f / k.fy;
+  for (int un = blockIdx.x * 256 + threadIdx.x; un < units; un += gridDim.x * 256) {
+    int v = un / cols4, u = (un - v * cols4) * 4;
+    float4 w = *reinterpret_cast<const float4*>(row_ptr<float>(depthinv, lane, v) + u);
+    float wi[4] = {w.x, w.y, w.z, w.w}, X[4], Y[4], Z[4];
+    bool ok[4], all = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float z = 1.f / wi[i];
+      ok[i] = !isnan(z);
+      all = all && ok[i];
+      X[i] = ok[i] ? z * ((float)(u + i) - k.cx) * fx_inv : qnan();
+      Y[i] = z * ((float)v - k.cy) * fy_inv;
+      Z[i] = z;
+    }
+    float4* p0 = reinterpret_cast<float4*>(row_ptr<float>(vmap, lane, v) + u);
+    float4* p1 = reinterpret_cast<float4*>(row_ptr<float>(vmap, lane, v + rows) + u);
+    float4* p2 = reinterpret_cast<float4*>(row_ptr<float>(vmap, lane, v + 2 * rows) + u);
+    float4 y4 = make_float4(Y[0], Y[1], Y[2], Y[3]), z4 = make_float4(Z[0], Z[1], Z[2], Z[3]);
+    if (!all) { y4 = blend4(*p1, Y, ok); z4 = blend4(*p2, Z, ok); }
+    *p0 = make_float4(X[0], X[1], X[2], X[3]);
+    *p1 = y4;
+    *p2 = z4;
   }
 }
 void launch_vmap(hipStream_t s, int B, ImgB depthinv, ImgB vmap, IntrP k, LaneMask m) {
-  hipLaunchKernelGGL(k_vmap, grid2d_full(depthinv.cols, depthinv.rows, B), dim3(TX, TY), 0, s, depthinv, vmap, k, m);
+  if (vec4_ok(depthinv) && vec4_ok(vmap)) {
+    int cols4 = depthinv.cols / 4, units = cols4 * depthinv.rows;
+    hipLaunchKernelGGL(k_vmap4, dim3(div_up(units, 256 * 2), B), dim3(256), 0, s, depthinv, vmap, k, cols4, units, m);
+    return;
+  }
+  hipLaunchKernelGGL(k_vmap, grid2d(depthinv.cols, depthinv.rows, B), dim3(TX, TY), 0, s, depthinv, vmap, k, m);
 }
 
 // ---- computeNmapGradientsKernel (maps.cu:134-179) -------------------------------------------------
 __global__ __launch_bounds__(256) void k_nmap_grad(ImgB depthinv, ImgB gx_, ImgB gy_, ImgB nmap, IntrP k, LaneMask m) {
   int lane = blockIdx.z;
   if (!m.on(lane)) return;
-  int u = blockIdx.x * TX + threadIdx.x, v = blockIdx.y * TY + threadIdx.y;
-  if (u >= depthinv.cols || v >= depthinv.rows) return;
+  int u = blockIdx.x * TX + threadIdx.x;
   int rows = depthinv.rows;
-  float w = px<float>(depthinv, lane, v, u), gx = px<float>(gx_, lane, v, u), gy = px<float>(gy_, lane, v, u);
-  float n0 = qnan();
-  if (!(isnan(w) || isnan(gx) || isnan(gy))) {
-    float nx = gx * k.fx, ny = gy * k.fy, nz = gx * (k.cx - (float)u) + gy * (k.cy - (float)v) + w;
-    float rn = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz);
-    nx *= rn; ny *= rn; nz *= rn;
-    float z = 1.f / w;
-    float vx = z * ((float)u - k.cx) * (1.f / k.fx), vy = z * ((float)v - k.cy) * (1.f / k.fy), vz = z;
-    float rv = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
-    vx *= rv; vy *= rv; vz *= rv;
-    float acos_vn = vx * nx + vy * ny + vz * nz;
-    if ((double)acos_vn > 0.1) {
-      n0 = nx;
-      px<float>(nmap, lane, v + rows, u) = ny;
-      px<float>(nmap, lane, v + 2 * rows, u) = nz;
+  RGBID_FOR_ROWS(v) {
+    if (u >= depthinv.cols || v >= rows) continue;
+    float w = px<float>(depthinv, lane, v, u), gx = px<float>(gx_, lane, v, u), gy = px<float>(gy_, lane, v, u);
+    float n0 = qnan();
+    if (!(isnan(w) || isnan(gx) || isnan(gy))) {
+      float nx = gx * k.fx, ny = gy * k.fy, nz = gx * (k.cx - (float)u) + gy * (k.cy - (float)v) + w;
+      float rn = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz);
+      nx *= rn; ny *= rn; nz *= rn;
+      float z = 1.f / w;
+      float vx = z * ((float)u - k.cx) * (1.f / k.fx), vy = z * ((float)v - k.cy) * (1.f / k.fy), vz = z;
+      float rv = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
+      vx *= rv; vy *= rv; vz *= rv;
+      float acos_vn = vx * nx + vy * ny + vz * nz;
+      if ((double)acos_vn > 0.1) {
+        n0 = nx;
+        px<float>(nmap, lane, v + rows, u) = ny;
+        px<float>(nmap, lane, v + 2 * rows, u) = nz;
+      }
     }
+    px<float>(nmap, lane, v, u) = n0;
   }
-  px<float>(nmap, lane, v, u) = n0;
+}
+__global__ __launch_bounds__(256) void k_nmap_grad4(ImgB depthinv, ImgB gx_, ImgB gy_, ImgB nmap, IntrP k, int cols4, int units, LaneMask m) {
+  int lane = blockIdx.y;
+  if (!m.on(lane)) return;
+  const int rows = depthinv.rows;
+  for (int un = blockIdx.x * 256 + threadIdx.x; un < units; un += gridDim.x * 256) {
+    int v = un / cols4, u = (un - v * cols4) * 4;
+    float4 w4 = *reinterpret_cast<const float4*>(row_ptr<float>(depthinv, lane, v) + u);
+    float4 gx4 = *reinterpret_cast<const float4*>(row_ptr<float>(gx_, lane, v) + u);
+    float4 gy4 = *reinterpret_cast<const float4*>(row_ptr<float>(gy_, lane, v) + u);
+    float wi[4] = {w4.x, w4.y, w4.z, w4.w}, gxi[4] = {gx4.x, gx4.y, gx4.z, gx4.w}, gyi[4] = {gy4.x, gy4.y, gy4.z, gy4.w};
+    float N0[4], N1[4], N2[4];
+    bool keep[4], all = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float w = wi[i], gx = gxi[i], gy = gyi[i];
+      float uu = (float)(u + i);
+      float nx = gx * k.fx, ny = gy * k.fy, nz = gx * (k.cx - uu) + gy * (k.cy - (float)v) + w;
+      float rn = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz);
+      nx *= rn; ny *= rn; nz *= rn;
+      float z = 1.f / w;
+      float vx = z * (uu - k.cx) * (1.f / k.fx), vy = z * ((float)v - k.cy) * (1.f / k.fy), vz = z;
+      float rv = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
+      vx *= rv; vy *= rv; vz *= rv;
+      float acos_vn = vx * nx + vy * ny + vz * nz;
+      keep[i] = !(isnan(w) || isnan(gx) || isnan(gy)) && ((double)acos_vn > 0.1);
+      all = all && keep[i];
+      N0[i] = keep[i] ? nx : qnan(); N1[i] = ny; N2[i] = nz;
+    }
+    float4* p0 = reinterpret_cast<float4*>(row_ptr<float>(nmap, lane, v) + u);
+    float4* p1 = reinterpret_cast<float4*>(row_ptr<float>(nmap, lane, v + rows) + u);
+    float4* p2 = reinterpret_cast<float4*>(row_ptr<float>(nmap, lane, v + 2 * rows) + u);
+    float4 a = make_float4(N1[0], N1[1], N1[2], N1[3]), b = make_float4(N2[0], N2[1], N2[2], N2[3]);
+    if (!all) { a = blend4(*p1, N1, keep); b = blend4(*p2, N2, keep); }
+    *p0 = make_float4(N0[0], N0[1], N0[2], N0[3]);
+    *p1 = a;
+    *p2 = b;
+  }
 }
 void launch_nmap_gradients(hipStream_t s, int B, ImgB depthinv, ImgB gx, ImgB gy, ImgB nmap, IntrP k, LaneMask m) {
-  hipLaunchKernelGGL(k_nmap_grad, grid2d_full(depthinv.cols, depthinv.rows, B), dim3(TX, TY), 0, s, depthinv, gx, gy, nmap, k, m);
+  if (vec4_ok(depthinv) && vec4_ok(gx) && vec4_ok(gy) && vec4_ok(nmap)) {
+    int cols4 = depthinv.cols / 4, units = cols4 * depthinv.rows;
+    hipLaunchKernelGGL(k_nmap_grad4, dim3(div_up(units, 256 * 2), B), dim3(256), 0, s, depthinv, gx, gy, nmap, k, cols4, units, m);
+    return;
+  }
+  hipLaunchKernelGGL(k_nmap_grad, grid2d(depthinv.cols, depthinv.rows, B), dim3(TX, TY), 0, s, depthinv, gx, gy, nmap, k, m);
 }
 
 // ---- ImageGenerator(RGB) (image_generator.cu:66-185) ----------------------------------------------
