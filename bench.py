@@ -112,7 +112,25 @@ def main():
     s = cols / 640.0
     K = (525.0 * s, 525.0 * s, (319.5 + 0.5) * s - 0.5, (239.5 + 0.5) * s - 0.5)
     T = 1 + W + Kst
-    seqs, depth, rgb = make_inputs(B, T, rows, cols, K, dev)
+    # frames resident in HBM: at most 48 per lane; longer runs walk the sequence forwards and backwards (a reversed camera path is
+    # an equally valid sequence for the tracker), so --steps can be large without the inputs outgrowing the GPU
+    TF = min(T, 48)
+    seqs, depth_f, rgb_f = make_inputs(B, TF, rows, cols, K, dev)
+
+    class _PingPong:
+        def __init__(self, a):
+            self.a = a
+
+        def __getitem__(self, k):
+            if TF == 1:
+                return self.a[0]
+            p = k % (2 * (TF - 1))
+            return self.a[p if p < TF else 2 * (TF - 1) - p]
+
+        def cpu_frames(self):
+            return torch.stack([self[k].cpu() for k in range(T)])
+
+    depth, rgb = _PingPong(depth_f), _PingPong(rgb_f)
 
     work = torch.cuda.Stream(dev)                 # the engine's HIP stream (a torch stream so torch events can order against it)
     with torch.cuda.stream(work):
@@ -163,7 +181,7 @@ def main():
     pcie = None
     if args.h2d:
         # PCIe-inclusive leg: frames start in pinned host memory; frame k+1 is uploaded on a copy stream while step k computes
-        depth_h, rgb_h = depth.cpu().pin_memory(), rgb.cpu().pin_memory()
+        depth_h, rgb_h = depth.cpu_frames().pin_memory(), rgb.cpu_frames().pin_memory()
         bufs = [(torch.empty_like(depth[0]), torch.empty_like(rgb[0])) for _ in range(2)]
         copy_stream = torch.cuda.Stream(dev)
         ready = [torch.cuda.Event() for _ in range(2)]
