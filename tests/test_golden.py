@@ -78,3 +78,61 @@ def test_trackers_reproduce_golden_trajectory(ctx):
             ang = np.arccos(np.clip((np.trace(Rk.T @ GOLD["traj_R"][k]) - 1) / 2, -1, 1))
             assert ang < 1e-4 and np.linalg.norm(tk - GOLD["traj_t"][k]) < 1e-4
     trk.close(); eng.close()
+
+
+# ---- golden_v2: the "next" rows of SURVEY 8 (f-1 KeyframeAlign, f-4 dataset I/O, f-5 custom calibration) -----------------------
+from tests.golden import make_golden_v2 as G2  # noqa: E402
+
+GOLD2 = np.load(os.path.join(ROOT, "tests", "golden", "golden_v2.npz"))
+TUM_MINI = os.path.join(ROOT, "tests", "golden", "tum_mini")
+
+
+def test_oracle_reproduces_golden_v2():
+    for k, v in G2.calib_outputs().items():
+        assert np.array_equal(np.asarray(v), GOLD2["cal_" + k], equal_nan=True), k
+    ka = G2.kfalign_outputs()
+    for k in ("ka_iD0", "ka_iD1", "ka_grey0", "ka_grey1"):
+        assert np.array_equal(ka[k], GOLD2[k], equal_nan=True), k
+    assert np.allclose(ka["ka_R"], GOLD2["ka_R"], atol=1e-12) and np.allclose(ka["ka_t"], GOLD2["ka_t"], atol=1e-12)
+    assert np.allclose(ka["ka_cov"], GOLD2["ka_cov"], rtol=1e-9)
+
+
+def test_tum_mini_fixture_decodes_to_golden():
+    """the committed PNG / association files (written by an independent encoder) through the product's dataset reader and
+    trajectory formatter (host code only: no GPU needed)"""
+    from rgbid import tum
+    ds = tum.Dataset(TUM_MINI)
+    n = len(GOLD2["tum_stamps"])
+    assert len(ds) == n
+    for k in range(n):
+        assert ds.stamp(k) == GOLD2["tum_stamps"][k]
+        d, c = ds.grab(k, 24, 32)
+        assert np.array_equal(d, GOLD2["tum_depth_mm"][k]) and np.array_equal(c, GOLD2["tum_rgb"][k])
+        assert tum.format_pose_line(ds.stamp(k), GOLD2["tum_R"][k], GOLD2["tum_t"][k]) == str(GOLD2["tum_lines"][k])
+
+
+@pytest.mark.gpu
+def test_hip_calibration_kernels_reproduce_golden_v2(ctx):
+    import torch
+    from rgbid import device
+    d = G1_inputs = G.inputs()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    new = lambda r=G.ROWS, c=G.COLS: torch.full((r, c), float("nan"), device="cuda")
+    g = lambda k: GOLD2["cal_" + k]
+    out = new(); ctx.undistortIntensity(dev(d["I0"]), out, G2.KRGB); util.assert_bits(out.cpu().numpy(), g("und_I"), 0, "undistort I")
+    corr, und = new(), new(); ctx.undistortDepthInv(dev(d["W0"]), corr, und, G2.KDEPTH, device.depth_dist(**G2.DIST))
+    util.assert_bits(corr.cpu().numpy(), g("corr_W"), 0, "depth correction"); util.assert_bits(und.cpu().numpy(), g("und_W"), 0, "undistort iD")
+    inter = new(3 * G.ROWS, 3 * G.COLS); inter_i = torch.zeros((3 * G.ROWS, 3 * G.COLS), dtype=torch.int32, device="cuda"); reg = new()
+    ctx.registerDepthinv(dev(d["W0"]), inter, inter_i, reg, g("dRc_proj").reshape(9), g("t_proj"), g("cRd_proj").reshape(9))
+    util.assert_bits(inter.cpu().numpy(), g("reg_inter"), 0, "registration canvas"); util.assert_bits(reg.cpu().numpy(), g("reg_W"), 0, "registered iD")
+
+
+@pytest.mark.gpu
+def test_keyframe_align_reproduces_golden_v2():
+    from rgbid import host
+    Ks = (131.25, 131.25, 79.5, 59.5)
+    R, t, cov = host.keyframe_align(GOLD2["ka_iD0"], GOLD2["ka_grey0"], GOLD2["ka_iD1"], GOLD2["ka_grey1"], Ks)
+    ang = float(np.arccos(np.clip((np.trace(R.T @ GOLD2["ka_R"]) - 1) / 2, -1, 1)))
+    assert ang < 1e-4 and np.linalg.norm(t - GOLD2["ka_t"]) < 1e-4
+    sc = np.sqrt(np.outer(np.diag(GOLD2["ka_cov"]), np.diag(GOLD2["ka_cov"])))
+    assert (np.abs(cov - GOLD2["ka_cov"]) / sc).max() < 1e-2
