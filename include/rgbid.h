@@ -152,6 +152,17 @@ int rgbid_visibility_ratio(rgbid_ctx*, const rgbid_img* depthinv_src, const rgbi
                            const float R_proj[9], const float t_proj[3], const rgbid_img* overlap_mask,
                            float* visibility_ratio, float* ms);
 
+/* ---- bridge functions the reference defines but its tracker no longer calls (kept so the C++ surface is complete) ---- */
+/* convertDepth2Float misc.cu:353-362 (u16 mm -> metres) ; convertFloat2RGB misc.cu:514-523 (grey visualisation, NaN/inf colour coded) */
+int rgbid_depth_to_float(rgbid_ctx*, const rgbid_img* depth_u16, const rgbid_img* dst);
+int rgbid_float_to_rgb(rgbid_ctx*, const rgbid_img* src, const rgbid_img* dst_u8x3);
+/* createNMap maps.cu:346-393 (normals = normalised cross product of forward differences of the vertex map) */
+int rgbid_create_nmap(rgbid_ctx*, const rgbid_img* vmap, const rgbid_img* nmap);
+/* integrateWarpedRGB warping_registration.cu:1097-1129 (inverse-depth + colour fusion, gate 0.0075 each way) */
+int rgbid_integrate_warped_rgb(rgbid_ctx*, const rgbid_img* warped_depthinv, const rgbid_img* r, const rgbid_img* g, const rgbid_img* b,
+                               const rgbid_img* warped_weight, const rgbid_img* depthinv_dst, const rgbid_img* colors_dst_u8x3,
+                               const rgbid_img* weight_dst, float* ms);
+
 /* ---- vertex / normal maps (src/cuda/maps.cu:300-344, 396-443); planar 3*rows x cols ------ */
 int rgbid_create_vmap(rgbid_ctx*, rgbid_intr intr, const rgbid_img* depthinv, const rgbid_img* vmap);
 int rgbid_create_nmap_gradients(rgbid_ctx*, rgbid_intr intr, const rgbid_img* depthinv, const rgbid_img* grad_x,

@@ -324,6 +324,35 @@ inline void createVMap(const Intr& intr, const DepthMapf& depth, MapArr& vmap, i
   rgbid_img a = c_img(depth), b = c_img(vmap);
   rgbidSafeCall(rgbid_create_vmap(default_ctx(), c_intr(intr), &a, &b));
 }
+// bridge functions the reference defines but its tracker does not call any more (src/internal.h:217-221,362-365,384-385)
+inline void convertDepth2Float(const DepthMap& src, DepthMapf& dst) {
+  rgbid_img a = c_img(src), b = c_img(dst);
+  rgbidSafeCall(rgbid_depth_to_float(default_ctx(), &a, &b));
+}
+inline void convertFloat2RGB(const IntensityMapf& src, PtrStepSz<uchar3> dst) {
+  rgbid_img a = c_img(src), b = c_img(dst);
+  rgbidSafeCall(rgbid_float_to_rgb(default_ctx(), &a, &b));
+}
+inline void createNMap(const MapArr& vmap, MapArr& nmap, int numSMs = -1) {
+  (void)numSMs;
+  nmap.create(vmap.rows(), vmap.cols());  // maps.cu:349
+  rgbid_img a = c_img(vmap), b = c_img(nmap);
+  rgbidSafeCall(rgbid_create_nmap(default_ctx(), &a, &b));
+}
+inline float integrateWarpedRGB(const DepthMapf& depth_warped_src, const IntensityMapf& r_warped_src, const IntensityMapf& g_warped_src,
+                                const IntensityMapf& b_warped_src, const DeviceArray2D<float>& weight_warped_src, DepthMapf& depth_dst,
+                                PtrStepSz<uchar3> colors_dst, DeviceArray2D<float>& weight_dst, int numSMs = -1) {
+  (void)numSMs;
+  float ms; rgbid_img a = c_img(depth_warped_src), r = c_img(r_warped_src), g = c_img(g_warped_src), b = c_img(b_warped_src), w = c_img(weight_warped_src),
+                      d = c_img(depth_dst), c = c_img(colors_dst), q = c_img(weight_dst);
+  rgbidSafeCall(rgbid_integrate_warped_rgb(default_ctx(), &a, &r, &g, &b, &w, &d, &c, &q, &ms));
+  return ms;
+}
+// device_cast (src/internal.h:459-463): bit-copy between layout-compatible host and device PODs (e.g. a row-major float[9] -> Mat33)
+template <class D, class S> inline D device_cast(const S& source) {
+  static_assert(sizeof(D) <= sizeof(S), "device_cast: destination larger than source");
+  D d; std::memcpy(&d, &source, sizeof(D)); return d;
+}
 inline void createNMapGradients(const Intr& intr, const DepthMapf& depth_inv, const GradientMap& grad_x, const GradientMap& grad_y, MapArr& nmap,
                                 int numSMs = -1) {
   (void)numSMs;

@@ -450,3 +450,30 @@ def register_depthinv(src, dRc_proj, t_dc_proj, cRd_proj, scale=3):
     a, b, c = _f(np.asarray(dRc_proj).reshape(9)), _f(np.asarray(t_dc_proj).reshape(3)), _f(np.asarray(cRd_proj).reshape(9))
     lib().orc_register_depthinv(_p(s), s.shape[0], s.shape[1], inter.shape[0], inter.shape[1], _p(a), _p(b), _p(c), _p(inter), _p(out))
     return inter, out
+
+
+# ---- bridge functions the reference defines but does not call any more
+def nmap_cross(vmap_):
+    v = _f(vmap_); out = np.zeros_like(v)
+    lib().orc_nmap_cross(_p(v), v.shape[0] // 3, v.shape[1], _p(out))
+    return out
+
+
+def integrate_warped_rgb(warped, r, g, b, warped_weight, kf, colors, kf_weight):
+    a, rr, gg, bb, w = _f(warped), _f(r), _f(g), _f(b), _f(warped_weight)
+    k, kw = _f(kf).copy(), _f(kf_weight).copy()
+    c = np.ascontiguousarray(colors, np.uint8).copy()
+    lib().orc_integrate_warped_rgb(_p(a), _p(rr), _p(gg), _p(bb), _p(w), _p(k), _p(c), _p(kw), k.shape[0], k.shape[1])
+    return k, c, kw
+
+
+def depth2float(depth_u16):
+    d = np.ascontiguousarray(depth_u16, np.uint16); out = np.empty(d.shape, np.float32)
+    lib().orc_depth2float(_p(d), _p(out), d.shape[0], d.shape[1])
+    return out
+
+
+def float2rgb(src):
+    s_ = _f(src); out = np.empty(s_.shape + (3,), np.uint8)
+    lib().orc_float2rgb(_p(s_), _p(out), s_.shape[0], s_.shape[1])
+    return out

@@ -386,6 +386,72 @@ void orc_nmap_gradients(const float* depthinv, const float* gx_, const float* gy
     }
 }
 
+void orc_nmap_cross(const float* vmap, int rows, int cols, float* nmap) {
+  /* computeNmapKernel maps.cu:92-133 (normalized = v * rsqrt(dot), cross utils.hpp:153-162) */
+  for (int v = 0; v < rows; ++v)
+    for (int u = 0; u < cols; ++u) {
+      nmap[(size_t)v * cols + u] = ORC_NAN;
+      if (u == cols - 1 || v == rows - 1) continue;
+      float ax = vmap[(size_t)v * cols + u], bx = vmap[(size_t)v * cols + u + 1], cx = vmap[(size_t)(v + 1) * cols + u];
+      if (!isnan(ax) && !isnan(bx) && !isnan(cx)) {
+        float ay = vmap[(size_t)(v + rows) * cols + u], by = vmap[(size_t)(v + rows) * cols + u + 1], cy = vmap[(size_t)(v + 1 + rows) * cols + u];
+        float az = vmap[(size_t)(v + 2 * rows) * cols + u], bz = vmap[(size_t)(v + 2 * rows) * cols + u + 1], cz = vmap[(size_t)(v + 1 + 2 * rows) * cols + u];
+        float d1x = bx - ax, d1y = by - ay, d1z = bz - az, d2x = cx - ax, d2y = cy - ay, d2z = cz - az;
+        float rx = d1y * d2z - d1z * d2y, ry = d1z * d2x - d1x * d2z, rz = d1x * d2y - d1y * d2x;
+        float inv = rsqrt_f(rx * rx + ry * ry + rz * rz);
+        nmap[(size_t)v * cols + u] = rx * inv;
+        nmap[(size_t)(v + rows) * cols + u] = ry * inv;
+        nmap[(size_t)(v + 2 * rows) * cols + u] = rz * inv;
+      }
+    }
+}
+
+void orc_integrate_warped_rgb(const float* warped, const float* r, const float* g, const float* b, const float* wweight,
+                              float* kf, uint8_t* colors, float* kfw, int rows, int cols) {
+  /* integrateWarpedRGBKernel warping_registration.cu:673-708 */
+  const float TH = 0.0075f;
+  for (size_t i = 0; i < (size_t)rows * cols; ++i) {
+    if (isnan(warped[i]) || isnan(r[i]) || isnan(g[i]) || isnan(b[i])) continue;
+    uint8_t* c = colors + 3 * i;
+    if (isnan(kf[i])) {
+      kf[i] = warped[i];
+      c[0] = (uint8_t)f2i_rn(r[i]); c[1] = (uint8_t)f2i_rn(g[i]); c[2] = (uint8_t)f2i_rn(b[i]);
+      kfw[i] = wweight[i];
+    } else if (((kf[i] - warped[i]) < TH) && ((warped[i] - kf[i]) < TH)) {
+      float new_weight = kfw[i] + wweight[i];
+      float q = kfw[i];
+      kf[i] = (kf[i] * q + warped[i] * wweight[i]) / new_weight;
+      c[0] = (uint8_t)f2i_rn(((float)c[0] * q + r[i] * wweight[i]) / new_weight);
+      c[1] = (uint8_t)f2i_rn(((float)c[1] * q + g[i] * wweight[i]) / new_weight);
+      c[2] = (uint8_t)f2i_rn(((float)c[2] * q + b[i] * wweight[i]) / new_weight);
+      kfw[i] = new_weight;
+    }
+  }
+}
+
+void orc_depth2float(const uint16_t* src, float* dst, int rows, int cols) {
+  /* depth2floatKernel misc.cu:86-102 */
+  for (size_t i = 0; i < (size_t)rows * cols; ++i) {
+    int value = src[i];
+    dst[i] = value > 0 ? (float)imax(0, imin(value, 10000)) / 1000.f : ORC_NAN;
+  }
+}
+
+void orc_float2rgb(const float* src, uint8_t* dst, int rows, int cols) {
+  /* float2ucharKernel misc.cu:289-324 */
+  const float min_val = 0.f, max_val = 255.f;
+  for (size_t i = 0; i < (size_t)rows * cols; ++i) {
+    float v = src[i];
+    uint8_t* c = dst + 3 * i;
+    if (isnan(v)) { c[0] = 200; c[1] = 150; c[2] = 150; }
+    else if (isinf(v)) { c[0] = 150; c[1] = 150; c[2] = 250; }
+    else {
+      uint8_t grey = (uint8_t)imax(0, imin(f2i_rn(255 * (v - min_val) / (max_val - min_val)), 255));
+      c[0] = c[1] = c[2] = grey;
+    }
+  }
+}
+
 void orc_generate_image_rgb(const float* vmap, const float* nmap, const uint8_t* rgb,
                             const float light[3], int rows, int cols, uint8_t* dst) {
   /* ImageGeneratorRGB image_generator.cu:122-180, light.number == 1 (visodo.cpp:563-565) */

@@ -77,6 +77,13 @@ float orc_visibility_ratio(const float* src, const float* dst, int rows, int col
 void orc_vmap(const float* depthinv, int rows, int cols, orc_intr k, float* vmap);
 void orc_nmap_gradients(const float* depthinv, const float* gx, const float* gy,
                         int rows, int cols, orc_intr k, float* nmap);
+/* bridge functions the reference defines but no longer calls: computeNmapKernel maps.cu:92-133, integrateWarpedRGBKernel
+ * warping_registration.cu:673-708, depth2floatKernel misc.cu:86-102, float2ucharKernel misc.cu:289-324 */
+void orc_nmap_cross(const float* vmap, int rows, int cols, float* nmap);
+void orc_integrate_warped_rgb(const float* warped, const float* r, const float* g, const float* b, const float* warped_weight,
+                              float* kf, uint8_t* colors, float* kf_weight, int rows, int cols);
+void orc_depth2float(const uint16_t* src, float* dst, int rows, int cols);
+void orc_float2rgb(const float* src, uint8_t* dst, int rows, int cols);
 /* preview (src/cuda/image_generator.cu:122-180) */
 void orc_generate_image_rgb(const float* vmap, const float* nmap, const uint8_t* rgb,
                             const float light[3], int rows, int cols, uint8_t* dst);

@@ -374,6 +374,33 @@ int rgbid_create_vmap(rgbid_ctx* c, rgbid_intr k, const rgbid_img* depthinv, con
   launch_vmap(c->stream, 1, B1(depthinv), B1(vmap), IntrP{k.fx, k.fy, k.cx, k.cy}, ALL);
   return t.finish();
 }
+int rgbid_depth_to_float(rgbid_ctx* c, const rgbid_img* src, const rgbid_img* dst) {
+  if (!c || !ok_img(src) || !ok_img(dst) || !same_size(src, dst)) return RGBID_E_INVALID;
+  Timed t(c, nullptr);
+  launch_depth_to_float(c->stream, 1, B1(src), B1(dst), ALL);
+  return t.finish();
+}
+int rgbid_float_to_rgb(rgbid_ctx* c, const rgbid_img* src, const rgbid_img* dst) {
+  if (!c || !ok_img(src) || !ok_img(dst) || !same_size(src, dst)) return RGBID_E_INVALID;
+  Timed t(c, nullptr);
+  launch_float_to_rgb(c->stream, 1, B1(src), B1(dst), ALL);
+  return t.finish();
+}
+int rgbid_create_nmap(rgbid_ctx* c, const rgbid_img* vmap, const rgbid_img* nmap) {
+  if (!c || !ok_img(vmap) || !ok_img(nmap) || !same_size(vmap, nmap) || vmap->rows % 3 != 0 || vmap->data == nmap->data) return RGBID_E_INVALID;
+  Timed t(c, nullptr);
+  launch_nmap_cross(c->stream, 1, B1(vmap), B1(nmap), ALL);
+  return t.finish();
+}
+int rgbid_integrate_warped_rgb(rgbid_ctx* c, const rgbid_img* warped, const rgbid_img* r, const rgbid_img* g, const rgbid_img* b, const rgbid_img* wweight,
+                               const rgbid_img* kf, const rgbid_img* colors, const rgbid_img* kfw, float* ms) {
+  if (!c || !ok_img(warped) || !ok_img(r) || !ok_img(g) || !ok_img(b) || !ok_img(wweight) || !ok_img(kf) || !ok_img(colors) || !ok_img(kfw) ||
+      !same_size(warped, r) || !same_size(warped, g) || !same_size(warped, b) || !same_size(warped, wweight) || !same_size(warped, kf) ||
+      !same_size(warped, colors) || !same_size(warped, kfw)) return RGBID_E_INVALID;
+  Timed t(c, ms);
+  launch_integrate_warped_rgb(c->stream, 1, B1(warped), B1(r), B1(g), B1(b), B1(wweight), B1(kf), B1(colors), B1(kfw), ALL);
+  return t.finish();
+}
 int rgbid_create_nmap_gradients(rgbid_ctx* c, rgbid_intr k, const rgbid_img* depthinv, const rgbid_img* gx, const rgbid_img* gy, const rgbid_img* nmap) {
   if (!c || !ok_img(depthinv) || !ok_img(gx) || !ok_img(gy) || !ok_img(nmap) || !same_size(depthinv, gx) || !same_size(depthinv, gy) ||
       nmap->rows != 3 * depthinv->rows || nmap->cols != depthinv->cols) return RGBID_E_INVALID;

@@ -29,6 +29,10 @@ void launch_register_depthinv(hipStream_t s, int B, ImgB src, ImgB inter_f, ImgB
 // ---- prep (kernels_prep.hip) -------------------------------------------------------------------
 void launch_depth_to_invdepth(hipStream_t s, int B, ImgB src_u16, ImgB dst, float factor_depth, LaneMask m);
 void launch_intensity(hipStream_t s, int B, ImgB rgb, ImgB dst, LaneMask m);
+void launch_depth_to_float(hipStream_t s, int B, ImgB src_u16, ImgB dst, LaneMask m);
+void launch_float_to_rgb(hipStream_t s, int B, ImgB src, ImgB dst_rgb, LaneMask m);
+void launch_nmap_cross(hipStream_t s, int B, ImgB vmap, ImgB nmap, LaneMask m);
+void launch_integrate_warped_rgb(hipStream_t s, int B, ImgB warped, ImgB r, ImgB g, ImgB b, ImgB wweight, ImgB kf, ImgB colors, ImgB kfw, LaneMask m);
 void launch_decompose_rgb(hipStream_t s, int B, ImgB rgb, ImgB r, ImgB g, ImgB b, LaneMask m);
 void launch_gradient(hipStream_t s, int B, ImgB src, ImgB gx, ImgB gy, LaneMask m);
 // depth->iD + rgb->luma + rgb->r,g,b planes in one pass (engine); falls back to the three kernels when not 16-byte aligned

@@ -36,6 +36,44 @@ void launch_depth_to_invdepth(hipStream_t s, int B, ImgB src, ImgB dst, float fa
   hipLaunchKernelGGL(k_depth_to_invdepth, grid2d(dst.cols, dst.rows, B), dim3(TX, TY), 0, s, src, dst, factor_depth, m);
 }
 
+// ---- depth2floatKernel (misc.cu:86-102): u16 millimetres -> metres (bridge function convertDepth2Float, unused by the tracker)
+__global__ __launch_bounds__(256) void k_depth_to_float(ImgB src, ImgB dst, LaneMask m) {
+  int lane = blockIdx.z;
+  if (!m.on(lane)) return;
+  int x = blockIdx.x * TX + threadIdx.x;
+  RGBID_FOR_TILES(y0) {
+    int y = y0 + threadIdx.y;
+    if (x >= dst.cols || y >= dst.rows) continue;
+    int value = px<uint16_t>(src, lane, y, x);
+    px<float>(dst, lane, y, x) = value > 0 ? (float)max(0, min(value, 10000)) / 1000.f : qnan();
+  }
+}
+void launch_depth_to_float(hipStream_t s, int B, ImgB src, ImgB dst, LaneMask m) {
+  hipLaunchKernelGGL(k_depth_to_float, grid2d(dst.cols, dst.rows, B), dim3(TX, TY), 0, s, src, dst, m);
+}
+// ---- float2ucharKernel (misc.cu:289-324): grey visualisation of a float map, NaN / inf colour coded (convertFloat2RGB)
+__global__ __launch_bounds__(256) void k_float_to_rgb(ImgB src, ImgB dst, LaneMask m) {
+  int lane = blockIdx.z;
+  if (!m.on(lane)) return;
+  int x = blockIdx.x * TX + threadIdx.x;
+  RGBID_FOR_TILES(y0) {
+    int y = y0 + threadIdx.y;
+    if (x >= src.cols || y >= src.rows) continue;
+    float v = px<float>(src, lane, y, x);
+    uint8_t* c = row_ptr<uint8_t>(dst, lane, y) + 3 * x;
+    const float min_val = 0.f, max_val = 255.f;
+    if (isnan(v)) { c[0] = 200; c[1] = 150; c[2] = 150; }
+    else if (isinf(v)) { c[0] = 150; c[1] = 150; c[2] = 250; }
+    else {
+      uint8_t grey = (uint8_t)max(0, min(f2i_rn(255 * (v - min_val) / (max_val - min_val)), 255));
+      c[0] = grey; c[1] = grey; c[2] = grey;
+    }
+  }
+}
+void launch_float_to_rgb(hipStream_t s, int B, ImgB src, ImgB dst, LaneMask m) {
+  hipLaunchKernelGGL(k_float_to_rgb, grid2d(src.cols, src.rows, B), dim3(TX, TY), 0, s, src, dst, m);
+}
+
 // ---- computeIntensity (misc.cu:128-147) / decomposeRGBInChannels (misc.cu:151-172) --------------
 __global__ __launch_bounds__(256) void k_intensity(ImgB rgb, ImgB dst, LaneMask m) {
   int lane = blockIdx.z;

@@ -167,6 +167,39 @@ void launch_integrate_warped(hipStream_t s, int B, ImgB warped, ImgB wweight, Im
   hipLaunchKernelGGL(k_integrate, grid2d(kf.cols, kf.rows, B), dim3(TX, TY), 0, s, warped, wweight, kf, kfw, m);
 }
 
+// ---- integrateWarpedRGBKernel (:673-708): colour + inverse-depth fusion (bridge function; the reference's only caller,
+// visodo.cpp:1826, sits in a routine trackNewFrame no longer invokes) ---------------------------------------------
+__global__ __launch_bounds__(256) void k_integrate_rgb(ImgB warped, ImgB r_w, ImgB g_w, ImgB b_w, ImgB wweight, ImgB kf, ImgB colors, ImgB kfw, LaneMask m) {
+  int lane = blockIdx.z;
+  if (!m.on(lane)) return;
+  int x = blockIdx.x * TX + threadIdx.x;
+  const float TH = 0.0075f;  // DEPTHINV_INTEGR_TH (:80)
+  RGBID_FOR_ROWS(y) {
+    if (x >= kf.cols || y >= kf.rows) continue;
+    float ws = px<float>(warped, lane, y, x), r = px<float>(r_w, lane, y, x), g = px<float>(g_w, lane, y, x), b = px<float>(b_w, lane, y, x);
+    if (isnan(ws) || isnan(r) || isnan(g) || isnan(b)) continue;
+    float wk = px<float>(kf, lane, y, x);
+    uint8_t* c = row_ptr<uint8_t>(colors, lane, y) + 3 * x;
+    float qs = px<float>(wweight, lane, y, x);
+    if (isnan(wk)) {
+      px<float>(kf, lane, y, x) = ws;
+      c[0] = (uint8_t)f2i_rn(r); c[1] = (uint8_t)f2i_rn(g); c[2] = (uint8_t)f2i_rn(b);
+      px<float>(kfw, lane, y, x) = qs;
+    } else if (((wk - ws) < TH) && ((ws - wk) < TH)) {
+      float q = px<float>(kfw, lane, y, x);
+      float new_weight = q + qs;
+      px<float>(kf, lane, y, x) = (wk * q + ws * qs) / new_weight;
+      c[0] = (uint8_t)f2i_rn(((float)c[0] * q + r * qs) / new_weight);
+      c[1] = (uint8_t)f2i_rn(((float)c[1] * q + g * qs) / new_weight);
+      c[2] = (uint8_t)f2i_rn(((float)c[2] * q + b * qs) / new_weight);
+      px<float>(kfw, lane, y, x) = new_weight;
+    }
+  }
+}
+void launch_integrate_warped_rgb(hipStream_t s, int B, ImgB warped, ImgB r, ImgB g, ImgB b, ImgB wweight, ImgB kf, ImgB colors, ImgB kfw, LaneMask m) {
+  hipLaunchKernelGGL(k_integrate_rgb, grid2d(kf.cols, kf.rows, B), dim3(TX, TY), 0, s, warped, r, g, b, wweight, kf, colors, kfw, m);
+}
+
 // ---- partialVisibility(WithOverlapMask)Kernel (:297-437) -----------------------------------------
 // The reference reduces float counters through shared memory + a second kernel + a per-call malloc.
 // Here a workgroup sweeps a 64 x 32 pixel strip; every wave ballots its predicates, popcounts into scalar
@@ -280,6 +313,36 @@ void launch_vmap(hipStream_t s, int B, ImgB depthinv, ImgB vmap, IntrP k, LaneMa
     return;
   }
   hipLaunchKernelGGL(k_vmap, grid2d(depthinv.cols, depthinv.rows, B), dim3(TX, TY), 0, s, depthinv, vmap, k, m);
+}
+
+// ---- computeNmapKernel (maps.cu:92-133): normals from the cross product of forward differences of the vertex map ----
+__global__ __launch_bounds__(256) void k_nmap_cross(ImgB vmap, ImgB nmap, int rows, LaneMask m) {
+  int lane = blockIdx.z;
+  if (!m.on(lane)) return;
+  int u = blockIdx.x * TX + threadIdx.x;
+  int cols = vmap.cols;
+  RGBID_FOR_ROWS(v) {
+    if (u >= cols || v >= rows) continue;
+    float n0 = qnan();
+    if (!(u == cols - 1 || v == rows - 1)) {
+      float ax = px<float>(vmap, lane, v, u), bx = px<float>(vmap, lane, v, u + 1), cx = px<float>(vmap, lane, v + 1, u);
+      if (!isnan(ax) && !isnan(bx) && !isnan(cx)) {
+        float ay = px<float>(vmap, lane, v + rows, u), by = px<float>(vmap, lane, v + rows, u + 1), cy = px<float>(vmap, lane, v + 1 + rows, u);
+        float az = px<float>(vmap, lane, v + 2 * rows, u), bz = px<float>(vmap, lane, v + 2 * rows, u + 1), cz = px<float>(vmap, lane, v + 1 + 2 * rows, u);
+        float d1x = bx - ax, d1y = by - ay, d1z = bz - az, d2x = cx - ax, d2y = cy - ay, d2z = cz - az;
+        float rx = d1y * d2z - d1z * d2y, ry = d1z * d2x - d1x * d2z, rz = d1x * d2y - d1y * d2x;
+        float inv = 1.0f / sqrtf(rx * rx + ry * ry + rz * rz);
+        n0 = rx * inv;
+        px<float>(nmap, lane, v + rows, u) = ry * inv;
+        px<float>(nmap, lane, v + 2 * rows, u) = rz * inv;
+      }
+    }
+    px<float>(nmap, lane, v, u) = n0;
+  }
+}
+void launch_nmap_cross(hipStream_t s, int B, ImgB vmap, ImgB nmap, LaneMask m) {
+  int rows = vmap.rows / 3;
+  hipLaunchKernelGGL(k_nmap_cross, grid2d(vmap.cols, rows, B), dim3(TX, TY), 0, s, vmap, nmap, rows, m);
 }
 
 // ---- computeNmapGradientsKernel (maps.cu:134-179) -------------------------------------------------

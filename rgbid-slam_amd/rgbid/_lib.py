@@ -61,6 +61,7 @@ EXPORTS = [
     "rgbid_ctx_set_stream", "rgbid_ctx_set_async", "rgbid_ctx_set_interp_mode", "rgbid_ctx_sync", "rgbid_mem_info",
     "rgbid_malloc", "rgbid_malloc_pitch", "rgbid_free", "rgbid_memcpy_h2d", "rgbid_memcpy_d2h", "rgbid_memcpy_d2d",
     "rgbid_memcpy2d_h2d", "rgbid_memcpy2d_d2h", "rgbid_memcpy2d_d2d",
+    "rgbid_depth_to_float", "rgbid_float_to_rgb", "rgbid_create_nmap", "rgbid_integrate_warped_rgb",
     "rgbid_undistort_intensity", "rgbid_undistort_depthinv", "rgbid_register_depthinv",
     "rgbid_depth_to_invdepth", "rgbid_compute_intensity", "rgbid_decompose_rgb", "rgbid_compute_gradient",
     "rgbid_copy_images", "rgbid_copy_image", "rgbid_copy_image_rgb", "rgbid_init_weight_keyframe", "rgbid_fill_2d",

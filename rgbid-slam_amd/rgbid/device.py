@@ -135,6 +135,23 @@ class Context:
         check(self.L.rgbid_bilateral_filter(self._h, C.byref(img(src)), C.byref(img(dst)), C.c_float(sigma_floatmap), C.byref(ms)))
         return ms.value
 
+    # ---- bridge functions the reference defines but no longer calls ----
+    def convertDepth2Float(self, src, dst):
+        check(self.L.rgbid_depth_to_float(self._h, C.byref(img(src)), C.byref(img(dst))))
+
+    def convertFloat2RGB(self, src, dst):
+        check(self.L.rgbid_float_to_rgb(self._h, C.byref(img(src)), C.byref(img(dst))))
+
+    def createNMap(self, vmap, nmap):
+        check(self.L.rgbid_create_nmap(self._h, C.byref(img(vmap)), C.byref(img(nmap))))
+
+    def integrateWarpedRGB(self, warped, r, g, b, warped_weight, depth_dst, colors_dst, weight_dst):
+        ms = C.c_float()
+        check(self.L.rgbid_integrate_warped_rgb(self._h, C.byref(img(warped)), C.byref(img(r)), C.byref(img(g)), C.byref(img(b)),
+                                                C.byref(img(warped_weight)), C.byref(img(depth_dst)), C.byref(img(colors_dst)),
+                                                C.byref(img(weight_dst)), C.byref(ms)))
+        return ms.value
+
     # ---- custom-calibration front-end (undistortion.cu, warping_registration.cu:720-822) ----
     def undistortIntensity(self, src, dst, intr_k):
         ms = C.c_float()

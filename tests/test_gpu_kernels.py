@@ -349,3 +349,41 @@ def test_invalid_arguments(ctx):
         ctx.copyImage(a, b)
     with pytest.raises(RgbidError):
         ctx.bilateralFilter(a, a, 1.0)  # in-place is not allowed
+
+
+# ---- bridge functions the reference defines but its tracker no longer calls (kept for a complete C++ surface) -----------------
+@pytest.mark.parametrize("rows,cols", SIZES)
+def test_unused_bridge_functions(ctx, rows, cols):
+    r = util.rng(51)
+    K = K_for(rows, cols)
+    # convertDepth2Float / convertFloat2RGB
+    d = r.integers(0, 12000, (rows, cols)).astype(np.uint16); d[r.random((rows, cols)) < 0.1] = 0
+    out = new(rows, cols); ctx.convertDepth2Float(dev(d.view(np.int16)), out)
+    assert_bits(out.cpu().numpy(), O.depth2float(d), 0, "depth2float")
+    f = util.rand_intensity(r, rows, cols, nan_frac=0.05); f[1, 1] = np.inf; f[2, 2] = -7.3; f[3, 3] = 300.2; f[4, 4] = 127.5
+    rgb = torch.zeros((rows, cols, 3), dtype=torch.uint8, device="cuda"); ctx.convertFloat2RGB(dev(f), rgb)
+    assert np.array_equal(rgb.cpu().numpy(), O.float2rgb(f))
+    # createNMap on a vertex map with holes
+    w = util.rand_invdepth(r, rows, cols)
+    vm = O.vmap(w, K)
+    nm = new(3 * rows, cols); nm[:] = 0
+    ctx.createNMap(dev(vm), nm)
+    ref = O.nmap_cross(vm)
+    got = nm.cpu().numpy()
+    assert_bits(got[:rows], ref[:rows], 0, "nmap plane 0")
+    ok = np.isfinite(ref[:rows])
+    for p in (1, 2):
+        assert np.array_equal(got[p * rows:(p + 1) * rows][ok], ref[p * rows:(p + 1) * rows][ok])
+    n2 = got[:rows][ok] ** 2 + got[rows:2 * rows][ok] ** 2 + got[2 * rows:][ok] ** 2
+    assert np.abs(n2 - 1).max() < 1e-5
+    # integrateWarpedRGB
+    kf = util.rand_invdepth(r, rows, cols, 0.1); ws = (kf + r.normal(0, 0.004, kf.shape)).astype(np.float32); ws[r.random(kf.shape) < 0.1] = np.nan
+    ws[np.isnan(kf) & (r.random(kf.shape) < 0.5)] = 0.7
+    cr, cg, cb = [util.rand_intensity(r, rows, cols, nan_frac=0.02) for _ in range(3)]
+    qs = r.uniform(0.5, 2.0, kf.shape).astype(np.float32); q = r.uniform(0.5, 4.0, kf.shape).astype(np.float32)
+    col = r.integers(0, 256, (rows, cols, 3)).astype(np.uint8)
+    kfd, qd, cd = dev(kf.copy()), dev(q.copy()), dev(col.copy())
+    ctx.integrateWarpedRGB(dev(ws), dev(cr), dev(cg), dev(cb), dev(qs), kfd, cd, qd)
+    rk, rc, rq = O.integrate_warped_rgb(ws, cr, cg, cb, qs, kf, col, q)
+    assert_bits(kfd.cpu().numpy(), rk, 0, "fused iD"); assert_bits(qd.cpu().numpy(), rq, 0, "fused weight")
+    assert np.array_equal(cd.cpu().numpy(), rc)
