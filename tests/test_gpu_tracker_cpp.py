@@ -147,3 +147,48 @@ def test_cli_eval_harness_on_tum_layout(tmp_path):
     misc = (tmp_path / "synth_desk_misc.txt").read_text().split("\n")
     assert misc[0].startswith("Mean time per frame: ") and misc[2].startswith("Max time per frame: ") and len(misc) >= 3 + n
     assert (tmp_path / "synth_desk_kf_times.txt").read_text().startswith("ObtainKeyframe ProcessKeyframeTotal Segmentation DescriptionBoW LoopDetection PoseGraphOptim\n")
+
+
+def test_two_host_threads_share_the_library():
+    """SURVEY 8(b) threading: the tracker thread and the KeyframeAlign thread of the reference call the bridge concurrently with no
+    locking (per-thread streams).  Here: a VisodoTracker on one OS thread and KeyframeAlign calls on another, at the same time (ctypes
+    drops the GIL inside the calls); both must give exactly what they give when run alone."""
+    import threading
+    n = 6
+    seq = synth.make_sequence(n, K=SMALL_K, rows=120, cols=160, device="cuda", **SLOW)
+    d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+    big = synth.make_sequence(4, device="cuda", trans_step=(0.01, 0.02), rot_step_deg=(0.5, 1.0))
+    bd = big["depth"].cpu().numpy().astype(np.uint16); bc = big["rgb"].cpu().numpy()
+    iD = [O.depth2invdepth(bd[k]) for k in (0, 3)]
+    grey = [np.clip(np.rint(O.intensity(bc[k])), 0, 255).astype(np.uint8) for k in (0, 3)]
+    kw = dict(rows=120, cols=160, fx=SMALL_K[0], fy=SMALL_K[1], cx=SMALL_K[2], cy=SMALL_K[3])
+
+    def track_all():
+        trk = host.Tracker(host.default_config(**kw))
+        for k in range(n):
+            trk.track(d[k], c[k])
+        return trk.poses()
+
+    def align_some(reps):
+        return [host.keyframe_align(iD[0], grey[0], iD[1], grey[1], synth.TUM_K) for _ in range(reps)]
+
+    ref_R, ref_t = track_all()
+    ref_ka = align_some(1)[0]
+    out = {}
+    errs = []
+
+    def run(name, fn, *a):
+        try:
+            out[name] = fn(*a)
+        except Exception as e:  # pragma: no cover
+            errs.append((name, e))
+
+    th = [threading.Thread(target=run, args=("trk", track_all)), threading.Thread(target=run, args=("ka", align_some, 3))]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    assert not errs, errs
+    assert np.array_equal(out["trk"][0], ref_R) and np.array_equal(out["trk"][1], ref_t)
+    for R, t, cov in out["ka"]:
+        assert np.array_equal(R, ref_ka[0]) and np.array_equal(t, ref_ka[1]) and np.array_equal(cov, ref_ka[2])
