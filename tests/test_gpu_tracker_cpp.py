@@ -147,6 +147,11 @@ def test_cli_eval_harness_on_tum_layout(tmp_path):
     misc = (tmp_path / "synth_desk_misc.txt").read_text().split("\n")
     assert misc[0].startswith("Mean time per frame: ") and misc[2].startswith("Max time per frame: ") and len(misc) >= 3 + n
     assert (tmp_path / "synth_desk_kf_times.txt").read_text().startswith("ObtainKeyframe ProcessKeyframeTotal Segmentation DescriptionBoW LoopDetection PoseGraphOptim\n")
+    # the reference's two-thread playback (tracker thread woken through new_frame_cond_) writes the same trajectory
+    os.makedirs(tmp_path / "thr")
+    out = subprocess.run([exe, "-eval", str(root) + "/", "-out", str(tmp_path / "thr"), "-threaded"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert (tmp_path / "thr" / "synth_desk_poses.txt").read_text() == (tmp_path / "synth_desk_poses.txt").read_text()
 
 
 def test_two_host_threads_share_the_library():
