@@ -215,3 +215,41 @@ def test_engine_reset_and_streamed_inputs_are_bit_identical():
     c = eng.records(0, T).copy()
     assert a.tobytes() == c.tobytes()
     eng.close(); ctx.close()
+
+
+def test_engine_lost_and_recovery(ctx):
+    """A lane whose sensor drops out for one frame (no valid depth): the normal equations are empty, the on-device solve yields NaN,
+    the lane flags itself lost, re-keys and recovers exactly like the oracle tracker -- while its neighbour lanes are unaffected."""
+    K = (synth.TUM_K[0] / 4, synth.TUM_K[1] / 4, (synth.TUM_K[2] + 0.5) / 4 - 0.5, (synth.TUM_K[3] + 0.5) / 4 - 0.5)
+    n, B = 8, 3
+    seqs, depth, rgb = make_lanes(B, n, 120, 160, K, trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8))
+    depth[3, 1] = 0                                     # lane 1, frame 3
+    eng = E.Engine(ctx, E.default_config(rows=120, cols=160, lanes=B, K=K, use_graph=0, record_capacity=n))
+    for k in range(n):
+        eng.step(depth[k], rgb[k])
+    rec = eng.records()
+    for l in range(B):
+        trk = O.Tracker(O.default_config(rows=120, cols=160, fx=K[0], fy=K[1], cx=K[2], cy=K[3]))
+        d = depth[:, l].cpu().numpy().view(np.uint16); c = rgb[:, l].cpu().numpy()
+        pose_idx = []
+        for k in range(n):
+            before = len(trk.poses()[0])
+            ret = trk.track(d[k], c[k])
+            pose_idx.append(len(trk.poses()[0]) - 1 if len(trk.poses()[0]) > before or k == 0 else None)
+            st = int(rec[k, l]["status"])
+            if k:
+                assert bool(st & E.ST_TRACKED) == ret, (l, k, st, ret)
+                assert bool(st & E.ST_LOST) == bool(trk.last_info().lost), (l, k, st)
+        Rs, ts = trk.poses()
+        if l == 1:
+            assert pose_idx[3] is not None and pose_idx[4] is None and pose_idx[5] is not None      # the frame tracked while lost adds no pose
+        else:
+            assert None not in pose_idx
+        for k in range(1, n):
+            if pose_idx[k] is None:
+                continue
+            i = pose_idx[k]
+            er, et = rot_angle(Rs[i], rec[k, l]["R"]), float(np.linalg.norm(ts[i] - rec[k, l]["t"]))
+            assert er < 1e-4 and et < 1e-4, (l, k, er, et)
+        trk.close()
+    eng.close()

@@ -197,3 +197,38 @@ def test_two_host_threads_share_the_library():
     assert np.array_equal(out["trk"][0], ref_R) and np.array_equal(out["trk"][1], ref_t)
     for R, t, cov in out["ka"]:
         assert np.array_equal(R, ref_ka[0]) and np.array_equal(t, ref_ka[1]) and np.array_equal(cov, ref_ka[2])
+
+
+def _blackout_sequence(n, black):
+    seq = synth.make_sequence(n, K=SMALL_K, rows=120, cols=160, device="cuda", **SLOW)
+    d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+    for k in black:
+        d[k][:] = 0                      # sensor drop-out: no valid depth -> empty normal equations -> NaN solve -> "I am LOST"
+    return d, c
+
+
+def test_cpp_tracker_lost_and_recovery():
+    """visodo.cpp:2056-2113: a frame without valid depth makes the solve fail; the tracker declares itself lost, re-keys on the
+    incoming frames (pushing no pose while it stays lost) and resumes odometry once a frame aligns again."""
+    n = 8
+    d, c = _blackout_sequence(n, black=(3,))
+    kw = dict(rows=120, cols=160, fx=SMALL_K[0], fy=SMALL_K[1], cx=SMALL_K[2], cy=SMALL_K[3])
+    trk = host.Tracker(host.default_config(**kw))
+    orc = O.Tracker(O.default_config(**kw))
+    rets = []
+    for k in range(n):
+        a, b = trk.track(d[k], c[k]), orc.track(d[k], c[k])
+        assert a == b, k
+        rets.append(b)
+        if k:
+            assert bool(trk.last_info().lost) == bool(orc.last_info().lost), k
+    assert rets[3] is False and rets[4] is False and all(rets[5:])      # lost at 3, frame 4 cannot align to the empty keyframe, then recovers
+    Ra, ta = trk.poses(); Rb, tb = orc.poses()
+    assert len(Ra) == len(Rb) == n - 1                                   # the frame tracked while lost pushes no pose
+    for k in range(len(Rb)):
+        assert rot_angle(Ra[k], Rb[k]) < 1e-4 and np.linalg.norm(ta[k] - tb[k]) < 1e-4, k
+    oa, ota, ca = trk.odometry(); ob, otb, cb = orc.odometry()
+    assert len(oa) == len(ob)
+    for k in range(len(ob)):
+        assert rot_angle(oa[k], ob[k]) < 1e-4 and np.linalg.norm(ota[k] - otb[k]) < 1e-4
+        assert np.allclose(ca[k], cb[k], rtol=1e-2, atol=1e-12 + 1e-2 * np.abs(cb[k]).max())
