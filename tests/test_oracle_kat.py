@@ -202,3 +202,63 @@ def test_calibration_front_end_kats():
     ok = np.isfinite(reg)
     assert ok.mean() > 0.5
     np.testing.assert_allclose(reg[ok], 0.5 / (1 - 0.5 * tz), rtol=1e-6)
+
+
+def test_jacobian_rows_vs_finite_differences():
+    """Jacobian KAT: with least-squares weights the right-hand side b of the normal equations is minus the gradient of
+    the cost  C(x) = 1/2 sum nfac (W0 - W1)^2 / s_d^2 + 1/2 sum (I0 - I1)^2 / s_i^2  with respect to the update x = (trans, rot)
+    applied the way the tracker applies it (visodo.cpp:1252-1263).  Checked per channel by central differences of the warps
+    themselves; Sobel gradients + bilinear resampling limit the agreement to a few percent."""
+    from rgbid import synth
+    K = (131.25, 131.25, 79.875, 59.875)
+    rows, cols = 120, 160
+    seq = synth.make_sequence(2, K=K, rows=rows, cols=cols, noise=False, dropout=0.0, trans_step=(0.004, 0.006), rot_step_deg=(0.2, 0.3))
+    d = seq["depth"].numpy().astype(np.uint16); c = seq["rgb"].numpy()
+    W0, Wc = O.depth2invdepth(d[0]), O.depth2invdepth(d[1])
+    I0, Ic = O.intensity(c[0]), O.intensity(c[1])
+    gwx, gwy = O.gradient(W0); gix, giy = O.gradient(I0)
+    sd, si = 0.0025, 5.0
+    v, u = np.mgrid[0:rows, 0:cols].astype(np.float64)
+    px_, py_ = (u - K[2]) / K[0], (v - K[3]) / K[1]
+    gx, gy = gwx * K[0], gwy * K[1]
+    gz = -(gx * px_ + gy * py_)
+    n = np.stack([gx / W0, gy / W0, gz / W0 + 1.0]); p = np.stack([px_, py_, np.ones_like(px_)])
+    nfac = np.abs((n * p).sum(0)) / np.sqrt((n * n).sum(0) * (p * p).sum(0))          # estimate_VO.cu:225-231
+
+    def warps(R, t):
+        Ri = R.T; ti = -Ri @ t
+        Rp, tp = util.project(K, Ri, ti)
+        W1 = O.warp_invdepth(Wc, W0, Rp, tp)
+        return W1, O.warp_intensity(Ic, W1, Rp, tp, O.INTERP_EXACT)
+
+    def update(R, t, x):                                                               # visodo.cpp:1252-1263
+        Rinc = np.linalg.inv(O.expmap_rot(x[3:]))
+        return Rinc @ R, Rinc @ t - Rinc @ x[:3]
+
+    R0, t0 = np.eye(3), np.zeros(3)
+    W1, I1 = warps(R0, t0)
+    inner = np.zeros((rows, cols), bool); inner[6:-6, 6:-6] = True                     # keep away from the frame border
+    # the iD warp is POINT sampled (piecewise constant in the pose): its differences must span more than a pixel (f t / z = 1.3 px)
+    for weighting, eps_t, eps_r, cos_min in ((O.PHOT_ONLY, 2e-3, 1.5e-3, 0.995), (O.GEOM_ONLY, 2e-2, 1e-2, 0.98)):
+        m = inner & np.isfinite(W1) & np.isfinite(W0) & np.isfinite(gwx) & np.isfinite(gwy) & np.isfinite(I1)
+        # restrict both the system and the cost to the same pixel set: everything outside becomes invalid (NaN keyframe iD)
+        W0m = np.where(m, W0, np.nan).astype(np.float32)
+        A, b = O.build_system(W0m, I0, gwx, gwy, gix, giy, W1, I1, K, student_nu=False, mestimator=O.LSQ, weighting=weighting,
+                              sigma_depthinv=sd, sigma_int=si)
+
+        def cost(R, t):
+            w1, i1 = warps(R, t)
+            ok = m & np.isfinite(w1) & np.isfinite(i1)
+            assert ok.sum() > 0.9 * m.sum()
+            if weighting == O.PHOT_ONLY:
+                return 0.5 * np.sum(((I0[ok].astype(np.float64) - i1[ok]) / si) ** 2) * m.sum() / ok.sum()
+            return 0.5 * np.sum(nfac[ok] * ((W0[ok].astype(np.float64) - w1[ok]) / sd) ** 2) * m.sum() / ok.sum()
+
+        g = np.zeros(6)
+        for i in range(6):
+            e = np.zeros(6); e[i] = eps_t if i < 3 else eps_r
+            g[i] = (cost(*update(R0, t0, e)) - cost(*update(R0, t0, -e))) / (2 * e[i])
+        cosang = float(np.dot(-g, b) / (np.linalg.norm(g) * np.linalg.norm(b)))
+        assert cosang > cos_min, (weighting, cosang, -g, b)
+        assert 0.85 < np.linalg.norm(g) / np.linalg.norm(b) < 1.15, (weighting, np.linalg.norm(g) / np.linalg.norm(b))
+        assert np.all(np.sign(-g[np.abs(b) > 0.05 * np.abs(b).max()]) == np.sign(b[np.abs(b) > 0.05 * np.abs(b).max()]))
