@@ -83,6 +83,10 @@ int rgbid_ctx_set_stream(rgbid_ctx* ctx, void* stream);
 int rgbid_ctx_set_async(rgbid_ctx* ctx, int async_on);       /* default 0: synchronous on return */
 int rgbid_ctx_set_interp_mode(rgbid_ctx* ctx, int mode);     /* default RGBID_INTERP_TEX8 */
 int rgbid_ctx_sync(rgbid_ctx* ctx);                          /* internal.h:456-457 sync() */
+/* orders the context's stream after a hipEvent_t recorded on another stream (interop with the caller's framework streams) */
+int rgbid_ctx_wait_event(rgbid_ctx* ctx, void* hip_event);
+/* the context's hipStream_t */
+int rgbid_ctx_get_stream(rgbid_ctx* ctx, void** hip_stream);
 /* showGPUMemoryUsage(), src/cuda/misc.cu:526-540 */
 int rgbid_mem_info(size_t* free_bytes, size_t* total_bytes);
 

@@ -328,12 +328,15 @@ class Tracker:
         self._h = C.c_void_p(lib().orc_tracker_create(C.byref(self.cfg)))
 
     def close(self):
-        if self._h:
-            lib().orc_tracker_destroy(self._h)
+        if self._h and _lib is not None:
+            _lib.orc_tracker_destroy(self._h)
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:   # interpreter shutdown
+            pass
 
     def track(self, depth_u16, rgb_u8):
         d = np.ascontiguousarray(depth_u16, np.uint16)

@@ -117,6 +117,12 @@ int rgbid_ctx_set_interp_mode(rgbid_ctx* c, int mode) {
   return RGBID_OK;
 }
 int rgbid_ctx_sync(rgbid_ctx* c) { if (!c) return RGBID_E_INVALID; RGBID_HIP(hipStreamSynchronize(c->stream)); return RGBID_OK; }
+int rgbid_ctx_wait_event(rgbid_ctx* c, void* ev) {
+  if (!c || !ev) return RGBID_E_INVALID;
+  RGBID_HIP(hipStreamWaitEvent(c->stream, (hipEvent_t)ev, 0));
+  return RGBID_OK;
+}
+int rgbid_ctx_get_stream(rgbid_ctx* c, void** s) { if (!c || !s) return RGBID_E_INVALID; *s = (void*)c->stream; return RGBID_OK; }
 int rgbid_mem_info(size_t* f, size_t* t) { if (!f || !t) return RGBID_E_INVALID; RGBID_HIP(hipMemGetInfo(f, t)); return RGBID_OK; }
 
 // ---- memory -----------------------------------------------------------------------------------------

@@ -88,6 +88,20 @@ class Context:
     def sync(self):
         check(self.L.rgbid_ctx_sync(self._h))
 
+    def stream_handle(self):
+        s = C.c_void_p()
+        check(self.L.rgbid_ctx_get_stream(self._h, C.byref(s)))
+        return s.value or 0
+
+    def wait_torch_stream(self, stream=None):
+        """order this context's stream after everything enqueued so far on a torch stream (default: torch's current stream)"""
+        stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        if (stream.cuda_stream or 0) == self.stream_handle():
+            return
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        check(self.L.rgbid_ctx_wait_event(self._h, C.c_void_p(ev.cuda_event)))
+
     # ---- frame preparation (src/cuda/misc.cu) ----
     def convertDepth2InvDepth(self, src, dst, factor_depth=1.0):
         check(self.L.rgbid_depth_to_invdepth(self._h, C.byref(img(src)), C.byref(img(dst)), C.c_float(factor_depth)))

@@ -61,6 +61,7 @@ class Engine:
         self.L = _lib.lib()
         self._h = C.c_void_p()
         check(self.L.rgbid_engine_create(C.byref(self._h), ctx._h, C.byref(self.cfg)))
+        self._inflight = []
         assert RECORD_DTYPE.itemsize == 4 * 8 + 8 * (9 + 3 + 9 + 3 + 36 + 9 + 3 + 36), RECORD_DTYPE.itemsize
 
     @property
@@ -87,6 +88,14 @@ class Engine:
         assert depth.is_cuda and rgb.is_cuda and depth.is_contiguous() and rgb.is_contiguous()
         assert depth.element_size() == 2 and tuple(depth.shape) == (c.lanes, c.rows, c.cols), depth.shape
         assert rgb.dtype == torch.uint8 and tuple(rgb.shape) == (c.lanes, c.rows, c.cols, 3), rgb.shape
+        # The engine consumes its inputs asynchronously on the context's stream: order that stream after the producer of the two
+        # tensors (torch's current stream) and keep them alive until the next host synchronisation (records() / Context.sync()),
+        # otherwise torch may recycle a temporary while the engine's staging copy is still pending.
+        self.ctx.wait_torch_stream()
+        self._inflight.append((depth, rgb))
+        if len(self._inflight) > 64:
+            self.ctx.sync()
+            self._inflight.clear()
         check(self.L.rgbid_engine_step(self._h, C.c_void_p(depth.data_ptr()), C.c_void_p(rgb.data_ptr())))
 
     def steps(self):
@@ -96,6 +105,7 @@ class Engine:
         n = self.steps() - first_step if n_steps is None else n_steps
         out = np.zeros((n, self.cfg.lanes), RECORD_DTYPE)
         check(self.L.rgbid_engine_read_records(self._h, int(first_step), int(n), out.ctypes.data_as(C.c_void_p)))
+        self._inflight.clear()   # read_records synchronises the stream
         return out
 
     def profile_begin(self, max_launches):

@@ -21,9 +21,14 @@ def track_chunked(ctx, depth, rgb, n_chunks, K, group=None, **cfg_kw):
     mine = D.rank_chunks(n_chunks, world, rank)
     L = max(b - a + 1 for a, b in ranges)
     eng = E.Engine(ctx, E.default_config(rows=rows, cols=cols, lanes=len(mine), K=K, record_capacity=L, **cfg_kw))
+    # Lane-major staging of the whole run, built once and kept alive until the records are read: the engine consumes its inputs
+    # asynchronously on its own HIP stream, so per-step temporaries (torch would recycle them on ITS stream) must not be used.
+    idx = torch.tensor([[min(ranges[c][0] + j, ranges[c][1]) for c in mine] for j in range(L)], device=depth.device)  # [L, lanes]
+    depth_l = depth[idx.reshape(-1)].reshape(L, len(mine), rows, cols).contiguous()   # shorter chunks repeat their last frame (unused)
+    rgb_l = rgb[idx.reshape(-1)].reshape(L, len(mine), rows, cols, 3).contiguous()
+    torch.cuda.synchronize(depth.device)
     for j in range(L):
-        idx = [min(ranges[c][0] + j, ranges[c][1]) for c in mine]   # shorter chunks repeat their last frame (result unused)
-        eng.step(depth[idx].contiguous(), rgb[idx].contiguous())
+        eng.step(depth_l[j], rgb_l[j])
     rec = eng.records()
     eng.close()
     local = np.full((len(mine), L, 12), np.nan)

@@ -253,3 +253,28 @@ def test_engine_lost_and_recovery(ctx):
             assert er < 1e-4 and et < 1e-4, (l, k, er, et)
         trk.close()
     eng.close()
+
+
+def test_engine_step_accepts_torch_temporaries_async():
+    """Engine.step orders the context's stream after torch's current stream and keeps its inputs alive until the next host sync, so
+    per-step temporaries produced on torch's stream (gathers, casts) are safe with an asynchronous context."""
+    from rgbid import device
+    K = (synth.TUM_K[0] / 4, synth.TUM_K[1] / 4, (synth.TUM_K[2] + 0.5) / 4 - 0.5, (synth.TUM_K[3] + 0.5) / 4 - 0.5)
+    T, B = 8, 4
+    seqs, depth, rgb = make_lanes(B, T, 120, 160, K)
+    ctx = device.Context(0)               # torch's current stream is the null stream here: the context owns a private stream
+    ctx.set_async(1)
+    eng = E.Engine(ctx, E.default_config(rows=120, cols=160, lanes=B, K=K, use_graph=0, record_capacity=T))
+    for k in range(T):
+        eng.step(depth[k], rgb[k])
+    a = eng.records(0, T).copy()
+    eng.reset()
+    perm = torch.arange(B, device="cuda")
+    for k in range(T):
+        # fresh temporaries every step, dropped immediately; extra allocations in between invite the caching allocator to recycle them
+        eng.step((depth[k].to(torch.int32) + 0)[perm].to(torch.int16).contiguous(), rgb[k][perm].clone())
+        junk = torch.full((B, 120, 160, 3), 7, dtype=torch.uint8, device="cuda"); del junk
+        junk = torch.full((B, 120, 160), 9, dtype=torch.int16, device="cuda"); del junk
+    b = eng.records(0, T).copy()
+    assert a.tobytes() == b.tobytes()
+    eng.close(); ctx.close()

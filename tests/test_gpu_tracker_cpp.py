@@ -232,3 +232,42 @@ def test_cpp_tracker_lost_and_recovery():
     for k in range(len(ob)):
         assert rot_angle(oa[k], ob[k]) < 1e-4 and np.linalg.norm(ota[k] - otb[k]) < 1e-4
         assert np.allclose(ca[k], cb[k], rtol=1e-2, atol=1e-12 + 1e-2 * np.abs(cb[k]).max())
+
+
+def test_track_dataset_tool_chunked(tmp_path):
+    """BASELINE config 4 end to end on one GPU: a TUM-layout dataset on disk -> product dataset reader -> chunk-sharded engine ->
+    TUM trajectory file.  With ONE chunk the file must equal the C++ tracker's trajectory (same frames, same algorithm); with several
+    chunks the poses differ only at chunk heads (fresh keyframe, no velocity prior) by less than the documented 2e-3 rad / 5e-3 m."""
+    import os
+    import subprocess
+    import sys
+    from scipy.spatial.transform import Rotation
+    from rgbid import tum
+    n = 9
+    seq = synth.make_sequence(n, device="cuda", trans_step=(0.004, 0.012), rot_step_deg=(0.2, 0.8))
+    d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+    root = tmp_path / "synth_office"
+    os.makedirs(root / "depth"); os.makedirs(root / "rgb")
+    lines = []
+    for k in range(n):
+        st = 1341847980.722988 + k / 30.0
+        tum.write_png(str(root / "depth" / f"{st:.6f}.png"), (d[k].astype(np.uint32) * 5).astype(np.uint16))
+        tum.write_png(str(root / "rgb" / f"{st:.6f}.png"), c[k])
+        lines.append(f"{st:.6f} depth/{st:.6f}.png {st:.6f} rgb/{st:.6f}.png")
+    (root / "assoc.txt").write_text("\n".join(lines) + "\n")
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "track_dataset.py")
+    traj = {}
+    for chunks in (1, 4):
+        out = tmp_path / f"traj{chunks}.txt"
+        r = subprocess.run([sys.executable, tool, str(root), "--match-file", "assoc.txt", "--chunks", str(chunks), "--out", str(out)],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        traj[chunks] = np.loadtxt(out)
+        assert traj[chunks].shape == (n, 8)
+    orc = O.Tracker(O.default_config())
+    for k in range(n):
+        orc.track(d[k], c[k])
+    Rb, tb = orc.poses()
+    for k in range(n):
+        assert np.linalg.norm(traj[1][k, 1:4] - tb[k]) < 1e-4 and rot_angle(Rotation.from_quat(traj[1][k, 4:]).as_matrix(), Rb[k]) < 1e-4
+        assert np.linalg.norm(traj[4][k, 1:4] - tb[k]) < 5e-3 and rot_angle(Rotation.from_quat(traj[4][k, 4:]).as_matrix(), Rb[k]) < 2e-3
