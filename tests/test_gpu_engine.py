@@ -278,3 +278,20 @@ def test_engine_step_accepts_torch_temporaries_async():
     b = eng.records(0, T).copy()
     assert a.tobytes() == b.tobytes()
     eng.close(); ctx.close()
+
+
+@pytest.mark.parametrize("name,rows,cols,cfg_kw", [
+    ("odd size (scalar kernel paths), 2 levels", 122, 166, dict(levels=2, iters=[6, 4])),
+    ("single level", 120, 160, dict(levels=1, iters=[8])),
+    ("finest level 1", 120, 160, dict(finest_level=1, iters=[0, 6, 4])),
+    ("Huber + sigma const + min weight", 120, 160, dict(mestimator=O.HUBER, sigma_estimator=O.SIGMA_CONS, weighting=O.MIN_WEIGHT)),
+    ("Tukey + filtered gradients + no motion model", 120, 160, dict(mestimator=O.TUKEY, image_filtering=O.FILTER_GRADS, motion_model=O.NO_MM)),
+    ("geometric only", 120, 160, dict(weighting=O.GEOM_ONLY)),
+    ("photometric only, exact bilinear", 120, 160, dict(weighting=O.PHOT_ONLY, interp_mode=O.INTERP_EXACT)),
+    ("keyframe counters", 120, 160, dict(max_odoKF_count=2, max_integrKF_count=3)),
+])
+def test_engine_configurations(ctx, name, rows, cols, cfg_kw):
+    """every run-time switch of the tracker through the batched engine, each held to the oracle (1e-4 rad / 1e-4 m, same keyframe decisions)"""
+    s = cols / 640.0
+    K = (525.0 * s, 525.0 * s, (319.5 + 0.5) * s - 0.5, (239.5 + 0.5) * rows / 480.0 - 0.5)
+    run_case(ctx, rows, cols, K, n_lanes=2, n_frames=5, cfg_kw=cfg_kw, seq_kw=dict(trans_step=(0.003, 0.01), rot_step_deg=(0.1, 0.6)), use_graph=0)
