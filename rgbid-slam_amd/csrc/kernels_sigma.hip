@@ -102,13 +102,14 @@ __device__ __forceinline__ void block_sum4(const float in[4], double out[4], dou
 }
 
 // Per-thread residual samples, produced by a getter get(i) (a plain array for the bridge calls; a lattice
-// sample of two maps for the batched engine).  REG: <= 24 samples per thread held in VGPRs (slots beyond n are
-// NaN and are skipped by the validity test); otherwise the getter is re-evaluated on every pass.
+// sample of two maps for the batched engine).  REG: <= 24 samples per thread held in VGPRs; otherwise the getter is
+// re-evaluated on every pass.  Each sample is kept SANITISED: e = residual or 0, m = 1 or 0 (finite or not; slots beyond n
+// are invalid), so the passes run branch-free -- an invalid sample contributes weight * 0 to every sum.
 template <bool REG, class Getter>
 struct Samples {
   // register path: <= 24 fp32 adds per thread; streaming path (up to a full frame per thread-stride): double
   using Acc = typename std::conditional<REG, float, double>::type;
-  float e[REG ? SIG_MAXPT : 1];
+  float e[REG ? SIG_MAXPT : 1], m[REG ? SIG_MAXPT : 1];
   Getter get;
   int n, tid, cnt;
   __device__ __forceinline__ Samples(const Getter& g, int n_, int tid_) : get(g), n(n_), tid(tid_) {
@@ -117,56 +118,60 @@ struct Samples {
 #pragma unroll
       for (int j = 0; j < SIG_MAXPT; ++j) {
         int i = tid + j * SIG_T;
-        e[j] = (i < n) ? get(i) : qnan();
+        float v = (i < n) ? get(i) : qnan();
+        bool ok = fabsf(v) < __builtin_inff();  // !isinf && !isnan
+        e[j] = ok ? v : 0.f;
+        m[j] = ok ? 1.f : 0.f;
       }
     }
   }
   template <class F>
-  __device__ __forceinline__ void for_each(F&& f) const {
+  __device__ __forceinline__ void for_each(F&& f) const {  // f(residual, valid)
     if constexpr (REG) {
 #pragma unroll
       for (int j = 0; j < SIG_MAXPT; ++j)
-        if (j < cnt) f(e[j]);  // wave-uniform
+        if (j < cnt) f(e[j], m[j]);  // wave-uniform
     } else {
-      for (int i = tid; i < n; i += SIG_T) f(get(i));
+      for (int i = tid; i < n; i += SIG_T) {
+        float v = get(i);
+        bool ok = fabsf(v) < __builtin_inff();
+        f(ok ? v : 0.f, ok ? 1.f : 0.f);
+      }
     }
   }
 };
 
-__device__ __forceinline__ bool finite_f(float x) { return fabsf(x) < __builtin_inff(); }  // !isinf && !isnan
-
 // one moments pass: partialBiasAndSigmaStudent (:258-332) when student_variant, else partialBiasAndSigma (:179-255).
 // Per-sample divisions are reciprocal multiplies (<= 1 ulp) and the per-thread partial sums are fp32: the pass
-// is VALU-bound on one CU, and the moments only feed a 10%-tolerance fixed point.
+// is VALU-bound, and the moments only feed a 10%-tolerance fixed point.
 template <class SM>
 __device__ __forceinline__ void pass_moments(const SM& S, float bias, float sigma, float nu, int mest, bool student_variant,
                                              double* sm, float& swsr, float& swr, float& sw, float& nel) {
   typename SM::Acc a[4] = {0, 0, 0, 0};
   const float inv_sigma = 1.f / sigma, nup1 = nu + 1.f;
-  S.for_each([&](float er) {
-    float is_valid = 0.f, wsr = 0.f, wr = 0.f, weight = 0.f;
-    if (finite_f(er)) {
-      if (student_variant) {
-        is_valid = 1.f;
-        if (mest == 0) weight = 1.f;
-        else {
-          float en = (er - bias) * inv_sigma;
-          weight = nup1 * __builtin_amdgcn_rcpf(nu + en * en);
-        }
-      } else {
-        weight = 1.f; is_valid = 1.f;
-        float en = (er - bias) * inv_sigma;
-        if ((mest == 1) && (fabsf(en) > TH_HUBER)) weight = TH_HUBER / fabsf(en);
-        else if (mest == 2) {
-          if (fabsf(en) < TH_TUKEY) { float aux1 = (en / TH_TUKEY) * (en / TH_TUKEY); weight = (1.f - aux1) * (1.f - aux1); }
-          else { weight = 0.f; is_valid = 0.f; }
-        } else if (mest == 3) weight = (STUDENT_DOF + 1.f) * __builtin_amdgcn_rcpf(STUDENT_DOF + en * en);
-      }
-      wr = er * weight;
-      wsr = wr * er;
-    }
-    a[0] += wsr; a[1] += wr; a[2] += weight; a[3] += is_valid;
-  });
+  auto acc = [&](float er, float weight, float valid) {  // weight is already 0 for an invalid sample
+    float wr = er * weight;
+    float wsr = wr * er;
+    a[0] += wsr; a[1] += wr; a[2] += weight; a[3] += valid;
+  };
+  if (student_variant) {
+    if (mest == 0) S.for_each([&](float er, float mv) { acc(er, mv, mv); });
+    else S.for_each([&](float er, float mv) {
+      float en = (er - bias) * inv_sigma;
+      acc(er, (nup1 * __builtin_amdgcn_rcpf(nu + en * en)) * mv, mv);
+    });
+  } else {
+    S.for_each([&](float er, float mv) {
+      float weight = 1.f, is_valid = 1.f;
+      float en = (er - bias) * inv_sigma;
+      if ((mest == 1) && (fabsf(en) > TH_HUBER)) weight = TH_HUBER / fabsf(en);
+      else if (mest == 2) {
+        if (fabsf(en) < TH_TUKEY) { float aux1 = (en / TH_TUKEY) * (en / TH_TUKEY); weight = (1.f - aux1) * (1.f - aux1); }
+        else { weight = 0.f; is_valid = 0.f; }
+      } else if (mest == 3) weight = (STUDENT_DOF + 1.f) * __builtin_amdgcn_rcpf(STUDENT_DOF + en * en);
+      acc(er, weight * mv, is_valid * mv);
+    });
+  }
   double t[4];
   float af[4] = {(float)a[0], (float)a[1], (float)a[2], (float)a[3]};
   block_sum4(af, t, sm);
@@ -185,12 +190,10 @@ template <class SM>
 __device__ __forceinline__ float func_weights_nu(const SM& S, float bias, float sigma, float nu, double* sm) {
   typename SM::Acc a[4] = {0, 0, 0, 0};
   const float inv_sigma = 1.f / sigma, nup1 = nu + 1.f;
-  S.for_each([&](float er) {
-    if (finite_f(er)) {
-      float en = (er - bias) * inv_sigma;
-      float weight = nup1 * __builtin_amdgcn_rcpf(nu + en * en);
-      a[0] += __logf(weight); a[1] += weight; a[2] += 1.f;
-    }
+  S.for_each([&](float er, float mv) {
+    float en = (er - bias) * inv_sigma;
+    float weight = nup1 * __builtin_amdgcn_rcpf(nu + en * en);  // finite and positive also for a sanitised (invalid) sample
+    a[0] += __logf(weight) * mv; a[1] += weight * mv; a[2] += mv;
   });
   double t[4];
   float af[4] = {(float)a[0], (float)a[1], (float)a[2], 0.f};
