@@ -85,6 +85,9 @@ int rgbid_ctx_set_interp_mode(rgbid_ctx* ctx, int mode);     /* default RGBID_IN
 int rgbid_ctx_sync(rgbid_ctx* ctx);                          /* internal.h:456-457 sync() */
 /* orders the context's stream after a hipEvent_t recorded on another stream (interop with the caller's framework streams) */
 int rgbid_ctx_wait_event(rgbid_ctx* ctx, void* hip_event);
+/* exhaustive device self-test of the kernels' exact reciprocal (csrc/common.h rcp_exact) against IEEE 1.0f/x over all 2^32 float
+ * bit patterns; *mismatches must come back 0 */
+int rgbid_selftest_rcp(rgbid_ctx* ctx, unsigned long long* mismatches);
 /* the context's hipStream_t */
 int rgbid_ctx_get_stream(rgbid_ctx* ctx, void** hip_stream);
 /* showGPUMemoryUsage(), src/cuda/misc.cu:526-540 */

@@ -117,6 +117,29 @@ int rgbid_ctx_set_interp_mode(rgbid_ctx* c, int mode) {
   return RGBID_OK;
 }
 int rgbid_ctx_sync(rgbid_ctx* c) { if (!c) return RGBID_E_INVALID; RGBID_HIP(hipStreamSynchronize(c->stream)); return RGBID_OK; }
+namespace {
+__global__ __launch_bounds__(256) void k_selftest_rcp(unsigned long long* mismatches) {
+  const uint32_t hi = blockIdx.x;  // 2^16 workgroups x 2^16 bit patterns
+  unsigned int bad = 0;
+  for (uint32_t lo = threadIdx.x; lo < 65536u; lo += blockDim.x) {
+    const float x = __uint_as_float((hi << 16) | lo);
+    const float a = rgbid::rcp_exact(x), b = 1.0f / x;
+    const bool same = (a != a && b != b) || (__float_as_uint(a) == __float_as_uint(b));
+    bad += same ? 0u : 1u;
+  }
+  if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+}  // namespace
+int rgbid_selftest_rcp(rgbid_ctx* c, unsigned long long* mismatches) {
+  if (!c || !mismatches) return RGBID_E_INVALID;
+  unsigned long long* d = static_cast<unsigned long long*>(c->small_dev);
+  RGBID_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(k_selftest_rcp, dim3(65536), dim3(256), 0, c->stream, d);
+  RGBID_HIP(hipGetLastError());
+  RGBID_HIP(hipMemcpyAsync(mismatches, d, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  RGBID_HIP(hipStreamSynchronize(c->stream));
+  return RGBID_OK;
+}
 int rgbid_ctx_wait_event(rgbid_ctx* c, void* ev) {
   if (!c || !ev) return RGBID_E_INVALID;
   RGBID_HIP(hipStreamWaitEvent(c->stream, (hipEvent_t)ev, 0));

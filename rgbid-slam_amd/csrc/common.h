@@ -62,19 +62,55 @@ struct WarpParams {  // K R^-1 K^-1 (row-major) and K t^-1, float (visodo.cpp:11
   float t[3];
 };
 
+// Correctly rounded reciprocal in 4 VALU instructions instead of the 11 of the generic IEEE division sequence hipcc emits for
+// 1.f / x: v_rcp_f32 (1 ulp) followed by ONE Newton step in FMA form returns exactly the IEEE quotient whenever the result is a
+// normal number (x itself not denormal) -- verified exhaustively over all 2^32 inputs (rgbid_selftest_rcp,
+// tests/test_gpu_kernels.py).  RcpFast evaluates that straight line and remembers whether any result left the verified range
+// (zero / denormal / inf / NaN result: v_cmp_class); the caller then recomputes that pixel with RcpIeee.  On real data no wave
+// ever takes the fallback; the warps are VALU-bound with four reciprocals per pixel, so this removes ~25 % of their instructions
+// without changing a single bit.
+struct RcpIeee {
+  __device__ __forceinline__ float operator()(float x) { return 1.f / x; }
+  __device__ __forceinline__ bool failed() const { return false; }
+};
+struct RcpFast {
+  bool bad = false;
+  __device__ __forceinline__ float operator()(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    bad |= !__builtin_amdgcn_classf(r, 0x108);  // 0x108 = negative normal | positive normal
+    return r;
+  }
+  __device__ __forceinline__ bool failed() const { return bad; }
+};
+__device__ __forceinline__ float rcp_exact(float x) {
+  RcpFast f;
+  float r = f(x);
+  if (__builtin_expect(f.failed(), 0)) r = 1.f / x;
+  return r;
+}
+
 // registerPixel (warping_registration.cu:129-146).  fp contraction is OFF here so the projected
 // coordinates -- and therefore every floor()/rint() pixel selection -- are bit-identical to the
-// scalar oracle; the divisions are IEEE (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
-__device__ __forceinline__ float register_pixel(float& xc, float& yc, int xd, int yd, float wd, const WarpParams& P) {
+// scalar oracle; the reciprocals are IEEE-exact (see above).
+template <class RCP>
+__device__ __forceinline__ float register_pixel_t(float& xc, float& yc, int xd, int yd, float wd, const WarpParams& P, RCP& rcp) {
 #pragma clang fp contract(off)
-  float zd = 1.f / wd;
+  float zd = rcp(wd);
   float X = (float)xd * zd, Y = (float)yd * zd;
   float X0 = (P.R[0] * X + P.R[1] * Y + P.R[2] * zd) + P.t[0];
   float X1 = (P.R[3] * X + P.R[4] * Y + P.R[5] * zd) + P.t[1];
   float X2 = (P.R[6] * X + P.R[7] * Y + P.R[8] * zd) + P.t[2];
-  float wc = 1.f / X2;
+  float wc = rcp(X2);
   xc = X0 * wc;
   yc = X1 * wc;
+  return wc;
+}
+__device__ __forceinline__ float register_pixel(float& xc, float& yc, int xd, int yd, float wd, const WarpParams& P) {
+  RcpFast f;
+  float wc = register_pixel_t(xc, yc, xd, yd, wd, P, f);
+  if (__builtin_expect(f.failed(), 0)) { RcpIeee s; wc = register_pixel_t(xc, yc, xd, yd, wd, P, s); }
   return wc;
 }
 

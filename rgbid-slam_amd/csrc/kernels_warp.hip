@@ -36,8 +36,15 @@ __global__ __launch_bounds__(256) void k_warp_invdepth(ImgB src, ImgB grid, ImgB
   float wv[RPB], out[RPB];
 #pragma unroll
   for (int i = 0; i < RPB; ++i) { int y = yb + i * TY; wv[i] = (y < dst.rows) ? px<float>(grid, lane, y, x) : qnan(); }
+  // one straight-line pass with the fast exact reciprocal for all RPB pixels; a single (never taken on real data) fallback
+  RcpFast fast;
 #pragma unroll
-  for (int i = 0; i < RPB; ++i) out[i] = warp_invdepth_px(S, x, yb + i * TY, wv[i], P);
+  for (int i = 0; i < RPB; ++i) out[i] = warp_invdepth_px_t(S, x, yb + i * TY, wv[i], P, fast);
+  if (__builtin_expect(fast.failed(), 0)) {
+    RcpIeee ieee;
+#pragma unroll
+    for (int i = 0; i < RPB; ++i) out[i] = warp_invdepth_px_t(S, x, yb + i * TY, wv[i], P, ieee);
+  }
 #pragma unroll
   for (int i = 0; i < RPB; ++i) { int y = yb + i * TY; if (y < dst.rows) px<float>(dst, lane, y, x) = out[i]; }
 }
@@ -60,8 +67,14 @@ __global__ __launch_bounds__(256) void k_warp_intensity(ImgB src, ImgB grid, Img
   float wv[RPB], out[RPB];
 #pragma unroll
   for (int i = 0; i < RPB; ++i) { int y = yb + i * TY; wv[i] = (y < dst.rows) ? px<float>(grid, lane, y, x) : qnan(); }
+  RcpFast fast;
 #pragma unroll
-  for (int i = 0; i < RPB; ++i) out[i] = warp_intensity_px(S, x, yb + i * TY, wv[i], P, interp_mode);
+  for (int i = 0; i < RPB; ++i) out[i] = warp_intensity_px_t(S, x, yb + i * TY, wv[i], P, interp_mode, fast);
+  if (__builtin_expect(fast.failed(), 0)) {
+    RcpIeee ieee;
+#pragma unroll
+    for (int i = 0; i < RPB; ++i) out[i] = warp_intensity_px_t(S, x, yb + i * TY, wv[i], P, interp_mode, ieee);
+  }
 #pragma unroll
   for (int i = 0; i < RPB; ++i) { int y = yb + i * TY; if (y < dst.rows) px<float>(dst, lane, y, x) = out[i]; }
 }
@@ -89,7 +102,7 @@ __global__ __launch_bounds__(256) void k_warp_invdepth_weighted(ImgB src, ImgB g
       if (in_bounds_rd(xs, ys, src.cols, src.rows)) {
         float w2 = px<float>(src, lane, f2i_rd(ys), f2i_rd(xs));
         float tz = P.t[2];
-        float v1_z = (1.f / w3 - tz) * w;
+        float v1_z = (rcp_exact(w3) - tz) * w;
         float w_factor = 1.f - w2 * tz;
         float w_factor2 = w_factor * w_factor;
         float weight_res = (w_factor2 * w_factor2) / (v1_z * v1_z);
@@ -262,7 +275,7 @@ __global__ __launch_bounds__(256) void k_vmap(ImgB depthinv, ImgB vmap, IntrP k,
   float fx_inv = 1.f / k.fx, fy_inv = 1.f / k.fy;
   RGBID_FOR_ROWS(v) {
     if (u >= depthinv.cols || v >= rows) continue;
-    float z = 1.f / px<float>(depthinv, lane, v, u);
+    float z = rcp_exact(px<float>(depthinv, lane, v, u));
     if (!isnan(z)) {
       px<float>(vmap, lane, v, u) = z * ((float)u - k.cx) * fx_inv;
       px<float>(vmap, lane, v + rows, u) = z * ((float)v - k.cy) * fy_inv;
@@ -289,7 +302,7 @@ __global__ __launch_bounds__(256) void k_vmap4(ImgB depthinv, ImgB vmap, IntrP k
     bool ok[4], all = true;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float z = 1.f / wi[i];
+      float z = rcp_exact(wi[i]);
       ok[i] = !isnan(z);
       all = all && ok[i];
       X[i] = ok[i] ? z * ((float)(u + i) - k.cx) * fx_inv : qnan();
@@ -331,7 +344,7 @@ __global__ __launch_bounds__(256) void k_nmap_cross(ImgB vmap, ImgB nmap, int ro
         float az = px<float>(vmap, lane, v + 2 * rows, u), bz = px<float>(vmap, lane, v + 2 * rows, u + 1), cz = px<float>(vmap, lane, v + 1 + 2 * rows, u);
         float d1x = bx - ax, d1y = by - ay, d1z = bz - az, d2x = cx - ax, d2y = cy - ay, d2z = cz - az;
         float rx = d1y * d2z - d1z * d2y, ry = d1z * d2x - d1x * d2z, rz = d1x * d2y - d1y * d2x;
-        float inv = 1.0f / sqrtf(rx * rx + ry * ry + rz * rz);
+        float inv = rcp_exact(sqrtf(rx * rx + ry * ry + rz * rz));
         n0 = rx * inv;
         px<float>(nmap, lane, v + rows, u) = ry * inv;
         px<float>(nmap, lane, v + 2 * rows, u) = rz * inv;
@@ -357,11 +370,11 @@ __global__ __launch_bounds__(256) void k_nmap_grad(ImgB depthinv, ImgB gx_, ImgB
     float n0 = qnan();
     if (!(isnan(w) || isnan(gx) || isnan(gy))) {
       float nx = gx * k.fx, ny = gy * k.fy, nz = gx * (k.cx - (float)u) + gy * (k.cy - (float)v) + w;
-      float rn = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz);
+      float rn = rcp_exact(sqrtf(nx * nx + ny * ny + nz * nz));
       nx *= rn; ny *= rn; nz *= rn;
-      float z = 1.f / w;
+      float z = rcp_exact(w);
       float vx = z * ((float)u - k.cx) * (1.f / k.fx), vy = z * ((float)v - k.cy) * (1.f / k.fy), vz = z;
-      float rv = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
+      float rv = rcp_exact(sqrtf(vx * vx + vy * vy + vz * vz));
       vx *= rv; vy *= rv; vz *= rv;
       float acos_vn = vx * nx + vy * ny + vz * nz;
       if ((double)acos_vn > 0.1) {
@@ -390,11 +403,11 @@ __global__ __launch_bounds__(256) void k_nmap_grad4(ImgB depthinv, ImgB gx_, Img
       float w = wi[i], gx = gxi[i], gy = gyi[i];
       float uu = (float)(u + i);
       float nx = gx * k.fx, ny = gy * k.fy, nz = gx * (k.cx - uu) + gy * (k.cy - (float)v) + w;
-      float rn = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz);
+      float rn = rcp_exact(sqrtf(nx * nx + ny * ny + nz * nz));
       nx *= rn; ny *= rn; nz *= rn;
-      float z = 1.f / w;
+      float z = rcp_exact(w);
       float vx = z * (uu - k.cx) * (1.f / k.fx), vy = z * ((float)v - k.cy) * (1.f / k.fy), vz = z;
-      float rv = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
+      float rv = rcp_exact(sqrtf(vx * vx + vy * vy + vz * vz));
       vx *= rv; vy *= rv; vz *= rv;
       float acos_vn = vx * nx + vy * ny + vz * nz;
       keep[i] = !(isnan(w) || isnan(gx) || isnan(gy)) && ((double)acos_vn > 0.1);
@@ -435,7 +448,7 @@ __global__ __launch_bounds__(256) void k_generate_image(ImgB vmap, ImgB nmap, Im
     float vy = px<float>(vmap, lane, y + rows, x), vz = px<float>(vmap, lane, y + 2 * rows, x);
     float ny = px<float>(nmap, lane, y + rows, x), nz = px<float>(nmap, lane, y + 2 * rows, x);
     float dx = L.x - vx, dy = L.y - vy, dz = L.z - vz;
-    float rd = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    float rd = rcp_exact(sqrtf(dx * dx + dy * dy + dz * dz));
     dx *= rd; dy *= rd; dz *= rd;
     float weight = 1.f;
     weight *= fabsf(dx * nx + dy * ny + dz * nz);

@@ -2,7 +2,7 @@
 // Gauss-Newton kernel (kernels_system.hip) and the lattice pre-pass of the sigma/nu kernel (kernels_sigma.hip).
 // All three therefore produce bit-identical W1 / I1 values.
 //
-// Numerics: fp contraction is off inside these functions and the divisions are IEEE, so every value and every
+// Numerics: fp contraction is off inside these functions and the divisions / reciprocals are IEEE-exact (common.h rcp_exact), so every value and every
 // floor()/rint() pixel selection is bit-identical to the scalar oracle.  Control flow: branch-free.  The CUDA
 // kernels nest three `if`s per pixel (valid iD, in bounds, res > 0); a wave64 would serialise all of them, so the
 // arithmetic runs unconditionally on sanitised inputs, every gather uses a clamped (always legal) address, and
@@ -50,34 +50,48 @@ __device__ __forceinline__ float tex2d_linear(const FMap& src, float xs, float y
 }
 
 // trafo3DKernelInvDepthGridStride, warping_registration.cu:505-546 (one pixel; w = keyframe inverse depth)
-__device__ __forceinline__ float warp_invdepth_px(const FMap& src, int x, int y, float w, const WarpParams& P) {
+template <class RCP>
+__device__ __forceinline__ float warp_invdepth_px_t(const FMap& src, int x, int y, float w, const WarpParams& P, RCP& rcp) {
 #pragma clang fp contract(off)
   const bool valid = !isnan(w);
   const float ws = valid ? w : 1.f;
   float xs, ys;
-  float w3 = register_pixel(xs, ys, x, y, ws, P);
+  float w3 = register_pixel_t(xs, ys, x, y, ws, P, rcp);
   xs += 0.5f; ys += 0.5f;
   int ix = cvt_rd(xs), iy = cvt_rd(ys);
   const bool inb = inside(ix, iy, src.cols, src.rows);
   float w2 = src.at(clampi(iy, src.rows - 1), clampi(ix, src.cols - 1));
   float tz = P.t[2];
-  float v1_z = (1.f / w3 - tz) * ws;
+  float v1_z = (rcp(w3) - tz) * ws;
   float res = (v1_z / (1.f - w2 * tz)) * w2;
   return (valid & inb & (res > 0.f)) ? res : qnan();
 }
+__device__ __forceinline__ float warp_invdepth_px(const FMap& src, int x, int y, float w, const WarpParams& P) {
+  RcpFast f;
+  float res = warp_invdepth_px_t(src, x, y, w, P, f);
+  if (__builtin_expect(f.failed(), 0)) { RcpIeee s; res = warp_invdepth_px_t(src, x, y, w, P, s); }
+  return res;
+}
 
 // trafo3DKernelIntensityWithInvDepthGridStride, warping_registration.cu:465-501 (one pixel; w = sampling-grid iD)
-__device__ __forceinline__ float warp_intensity_px(const FMap& src, int x, int y, float w, const WarpParams& P, int interp_mode) {
+template <class RCP>
+__device__ __forceinline__ float warp_intensity_px_t(const FMap& src, int x, int y, float w, const WarpParams& P, int interp_mode, RCP& rcp) {
 #pragma clang fp contract(off)
   const bool valid = !isnan(w);
   const float ws = valid ? w : 1.f;
   float xs, ys;
-  register_pixel(xs, ys, x, y, ws, P);
+  register_pixel_t(xs, ys, x, y, ws, P, rcp);
   xs += 0.5f; ys += 0.5f;
   const bool inb = inside(cvt_rd(xs), cvt_rd(ys), src.cols, src.rows);
   float res = tex2d_linear(src, xs, ys, interp_mode);
   res = fmaxf(0.f, fminf(res, 255.f));  // NaN -> 255, as CUDA's min/max
   return (valid & inb) ? res : qnan();
+}
+__device__ __forceinline__ float warp_intensity_px(const FMap& src, int x, int y, float w, const WarpParams& P, int interp_mode) {
+  RcpFast f;
+  float res = warp_intensity_px_t(src, x, y, w, P, interp_mode, f);
+  if (__builtin_expect(f.failed(), 0)) { RcpIeee s; res = warp_intensity_px_t(src, x, y, w, P, interp_mode, s); }
+  return res;
 }
 
 }  // namespace rgbid

@@ -88,6 +88,12 @@ class Context:
     def sync(self):
         check(self.L.rgbid_ctx_sync(self._h))
 
+    def selftest_rcp(self):
+        """mismatches of the kernels' exact reciprocal vs IEEE 1.0f/x over all 2^32 inputs (must be 0)"""
+        n = C.c_ulonglong(1)
+        check(self.L.rgbid_selftest_rcp(self._h, C.byref(n)))
+        return n.value
+
     def stream_handle(self):
         s = C.c_void_p()
         check(self.L.rgbid_ctx_get_stream(self._h, C.byref(s)))

@@ -387,3 +387,9 @@ def test_unused_bridge_functions(ctx, rows, cols):
     rk, rc, rq = O.integrate_warped_rgb(ws, cr, cg, cb, qs, kf, col, q)
     assert_bits(kfd.cpu().numpy(), rk, 0, "fused iD"); assert_bits(qd.cpu().numpy(), rq, 0, "fused weight")
     assert np.array_equal(cd.cpu().numpy(), rc)
+
+
+def test_exact_reciprocal_is_ieee_for_every_float(ctx):
+    """csrc/common.h rcp_exact (v_rcp_f32 + one FMA Newton step, full IEEE sequence outside [2^-126, 2^126)) == 1.0f / x for ALL 2^32
+    float bit patterns -- the proof that the shorter instruction sequence cannot change any projected coordinate."""
+    assert ctx.selftest_rcp() == 0
