@@ -271,3 +271,20 @@ def test_track_dataset_tool_chunked(tmp_path):
     for k in range(n):
         assert np.linalg.norm(traj[1][k, 1:4] - tb[k]) < 1e-4 and rot_angle(Rotation.from_quat(traj[1][k, 4:]).as_matrix(), Rb[k]) < 1e-4
         assert np.linalg.norm(traj[4][k, 1:4] - tb[k]) < 5e-3 and rot_angle(Rotation.from_quat(traj[4][k, 4:]).as_matrix(), Rb[k]) < 2e-3
+
+
+def test_cpp_bridge_and_containers(tmp_path):
+    """tests/cpp/test_bridge.cpp: the reference's container semantics and bridge prototypes from plain C++ (g++, no HIP header),
+    including the print-and-exit(0) error convention of pcl::gpu::error."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "rgbid-slam_amd", "lib")
+    exe = str(tmp_path / "test_bridge")
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "test_bridge.cpp"),
+                           "-L" + lib, "-lrgbid_host", "-lrgbid_hip", "-Wl,-rpath," + lib, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "all ok" in r.stdout, r.stdout + r.stderr
+    assert r.stdout.count("\nok ") + r.stdout.startswith("ok ") >= 14
+    r = subprocess.run([exe, "error"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "Error: " in r.stdout and "internal.h:" in r.stdout and "FAILED" not in r.stdout, r.stdout + r.stderr
