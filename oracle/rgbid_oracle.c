@@ -238,7 +238,8 @@ static inline float tex2d_linear(const float* src, int rows, int cols, float xs,
     a = rintf(a * 256.f) * 0.00390625f;
     b = rintf(b * 256.f) * 0.00390625f;
   }
-  int i0 = f2i_rd(fx0), j0 = f2i_rd(fy0);
+  /* saturated conversions can return INT_MAX: bring the index into [-2, size] first (no effect on the clamps, no signed overflow) */
+  int i0 = imin(imax(f2i_rd(fx0), -2), cols), j0 = imin(imax(f2i_rd(fy0), -2), rows);
   int i1 = imin(imax(i0 + 1, 0), cols - 1), j1 = imin(imax(j0 + 1, 0), rows - 1);
   i0 = imin(imax(i0, 0), cols - 1); j0 = imin(imax(j0, 0), rows - 1);
   float T00 = src[(size_t)j0 * cols + i0], T10 = src[(size_t)j0 * cols + i1];
@@ -565,8 +566,10 @@ void orc_register_depthinv(const float* src, int rows, int cols, int irows, int 
       if (wc > 0.01f) {
         float dilation = wc / wd;
         int32_t bits; memcpy(&bits, &wc, 4);
-        int xmin = f2i_rn(xc - 0.5f * dilation) + offset_x, xmax = f2i_rn(xc + 0.5f * dilation) + offset_x;
-        int ymin = f2i_rn(yc - 0.5f * dilation) + offset_y, ymax = f2i_rn(yc + 0.5f * dilation) + offset_y;
+        /* the conversions saturate (CUDA semantics); adding the offset / the +1 of the loop bound is done on indices first clamped
+         * to [-1, size] so nothing overflows: the clipped loop ranges are the same */
+        int xmin = imin(imax(f2i_rn(xc - 0.5f * dilation), -icols), icols) + offset_x, xmax = imin(imax(f2i_rn(xc + 0.5f * dilation), -icols), icols) + offset_x;
+        int ymin = imin(imax(f2i_rn(yc - 0.5f * dilation), -irows), irows) + offset_y, ymax = imin(imax(f2i_rn(yc + 0.5f * dilation), -irows), irows) + offset_y;
         for (int x = imax(0, xmin); x < imin(xmax + 1, icols); x++)
           for (int y = imax(0, ymin); y < imin(ymax + 1, irows); y++)
             if (zbuf[(size_t)y * icols + x] < bits) zbuf[(size_t)y * icols + x] = bits;   /* dst is all-NaN during this kernel */

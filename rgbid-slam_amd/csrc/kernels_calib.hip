@@ -108,8 +108,10 @@ __global__ __launch_bounds__(256) void k_reg_splat(ImgB src, ImgB inter_i, float
   if (wc > 0.01f) {
     float dilation = wc / wd;
     int bits = __float_as_int(wc);
-    int xmin = f2i_rn(xc - 0.5f * dilation) + offset_x, xmax = f2i_rn(xc + 0.5f * dilation) + offset_x;
-    int ymin = f2i_rn(yc - 0.5f * dilation) + offset_y, ymax = f2i_rn(yc + 0.5f * dilation) + offset_y;
+    // saturating conversions; indices are brought into [-size, size] before the offset / the loop's +1 so nothing can overflow
+    const int ic = inter_i.cols, ir = inter_i.rows;
+    int xmin = min(max(f2i_rn(xc - 0.5f * dilation), -ic), ic) + offset_x, xmax = min(max(f2i_rn(xc + 0.5f * dilation), -ic), ic) + offset_x;
+    int ymin = min(max(f2i_rn(yc - 0.5f * dilation), -ir), ir) + offset_y, ymax = min(max(f2i_rn(yc + 0.5f * dilation), -ir), ir) + offset_y;
     for (int y = max(0, ymin); y < min(ymax + 1, inter_i.rows); y++)
       for (int x = max(0, xmin); x < min(xmax + 1, inter_i.cols); x++) atomicMax(&px<int>(inter_i, lane, y, x), bits);
   }

@@ -39,7 +39,9 @@ __device__ __forceinline__ float tex2d_linear(const FMap& src, float xs, float y
     a = rintf(a * 256.f) * 0.00390625f;
     b = rintf(b * 256.f) * 0.00390625f;
   }
-  int i0 = __float2int_rd(fx0), j0 = __float2int_rd(fy0);
+  // saturated conversions (huge / infinite coordinates give INT_MAX): bring the texel index into [-2, size] first, which changes
+  // neither clamp below but keeps `+ 1` away from signed overflow (undefined behaviour the optimiser may exploit)
+  int i0 = min(max(__float2int_rd(fx0), -2), src.cols), j0 = min(max(__float2int_rd(fy0), -2), src.rows);
   int i1 = clampi(i0 + 1, src.cols - 1), j1 = clampi(j0 + 1, src.rows - 1);
   i0 = clampi(i0, src.cols - 1);
   j0 = clampi(j0, src.rows - 1);
