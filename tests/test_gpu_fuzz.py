@@ -99,3 +99,58 @@ def test_fuzz_stencils_and_fusion(ctx, seed):
     with np.errstate(all="ignore"):
         ok_, oq = O.integrate_warped(ws, qs, kf, q)
     assert_bits(kfd.cpu().numpy(), ok_, 0, "fused iD"); assert_bits(qd.cpu().numpy(), oq, 0, "fused weight")
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_engine_sizes_and_garbage(ctx, seed):
+    """The batched engine at random odd sizes / pyramid depths: (1) parity with the oracle tracker on a benign synthetic sequence,
+    (2) crash-safety on garbage frames (random depth incl. zeros and 65535, random colours, an all-zero frame): every launch must
+    stay in bounds whatever the poses become, and the lane must report a well-formed record."""
+    from rgbid import engine as E, synth
+    from tests.test_gpu_engine import run_case
+    r = util.rng(3000 + seed)
+    levels = int(r.integers(1, 4))
+    rows = int(r.integers(10 << (levels - 1), 140)); cols = int(r.integers(12 << (levels - 1), 180))
+    s = cols / 640.0
+    K = (525.0 * s, 525.0 * s * float(r.uniform(0.9, 1.1)), cols / 2.0 - 0.5 + float(r.uniform(-3, 3)), rows / 2.0 - 0.5 + float(r.uniform(-3, 3)))
+    iters = [int(r.integers(1, 7)) for _ in range(levels)]
+    run_case(ctx, rows, cols, K, n_lanes=2, n_frames=3, cfg_kw=dict(levels=levels, iters=iters), seq_kw=dict(trans_step=(0.002, 0.008), rot_step_deg=(0.1, 0.5)), use_graph=0)
+    B, T = 3, 5
+    depth = torch.from_numpy(r.integers(0, 65536, (T, B, rows, cols)).astype(np.uint16).view(np.int16)).cuda()
+    depth[2, 0] = 0; depth[3, 1] = -1                                      # an empty frame, a saturated (65535) frame
+    rgb = torch.from_numpy(r.integers(0, 256, (T, B, rows, cols, 3)).astype(np.uint8)).cuda()
+    eng = E.Engine(ctx, E.default_config(rows=rows, cols=cols, lanes=B, K=K, levels=levels, iters=iters, use_graph=0, record_capacity=T))
+    for k in range(T):
+        eng.step(depth[k], rgb[k])
+    rec = eng.records()
+    assert rec.shape == (T, B) and (rec["status"][0] & E.ST_FIRST).all()
+    assert np.isin(rec["status"][1:] & ~(E.ST_TRACKED | E.ST_LOST | E.ST_ODO_KF | E.ST_INTEGR_KF), 0).all()
+    eng.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_cpp_tracker_and_keyframe_align_garbage(seed, tmp_path):
+    """crash-safety of the host-driven paths on garbage input: VisodoTracker (incl. the custom-calibration front-end with a wild
+    calibration) and KeyframeAlign must return (tracked or not) without faulting"""
+    from rgbid import host
+    r = util.rng(4000 + seed)
+    rows, cols = 120, 160
+    cfg = host.default_config(rows=rows, cols=cols, fx=131.0, fy=131.0, cx=79.5, cy=59.5)
+    trk = host.Tracker(cfg)
+    if seed % 2:
+        (tmp_path / "wild.ini").write_text("[DEPTH_CALIBRATION]\ncustom_registration = 1\nfx = 90\nfy = 140\ncx = 20\ncy = 100\n"
+                                           "kd = 0.9 -2.0 0.05 -0.04 3.0\nc0 = 0.3\nc1 = -2.0\nq0 = 0.5 1 -1 2 0.1 0.2 0.3 0.4 0.5\nq1 = 1 2 3 -4 5 -6 7 -8 9\n"
+                                           "[STEREO_DEPTH2RGB]\ndRc = 0.6 -0.8 0 0.8 0.6 0 0 0 1\nt_dc = 0.4 -0.3 0.35\n")
+        trk.load_calibration(str(tmp_path / "wild.ini"))
+    for k in range(5):
+        d = r.integers(0, 65536, (rows, cols)).astype(np.uint16)
+        if k == 2:
+            d[:] = 0
+        c = r.integers(0, 256, (rows, cols, 3)).astype(np.uint8)
+        trk.track(d, c)
+    R, t = trk.poses()
+    assert len(R) >= 1
+    iD = [np.where(r.random((480, 640)) < 0.3, np.nan, r.uniform(-1, 5, (480, 640))).astype(np.float32) for _ in range(2)]
+    grey = [r.integers(0, 256, (480, 640)).astype(np.uint8) for _ in range(2)]
+    Rk, tk, cov = host.keyframe_align(iD[0], grey[0], iD[1], grey[1], (525.0, 525.0, 319.5, 239.5))
+    assert Rk.shape == (3, 3) and cov.shape == (6, 6)
