@@ -93,3 +93,29 @@ def test_settings_match_reference_parser():
         n = ref.ref_settings_get(INI.encode(), sec.encode(), key.encode(), buf, 4096)
         want = None if n < 0 else buf.value.decode()
         assert host.settings_get(INI, sec, key) == want, (sec, key, want)
+
+
+def test_settings_match_reference_parser_on_shipped_config_files():
+    """Every (section, key) of the nine configuration / calibration files the reference ships (config_data/*.ini), read by the
+    reference's own parser (oracle/_ref, built from /root/reference/src/settings.cpp) and by the product's parser.  Runs only where
+    /root/reference exists (the authoring container); nothing is copied."""
+    import glob
+    import re
+    so = os.path.join(ROOT, "oracle", "_ref", "libref_settings.so")
+    files = sorted(glob.glob("/root/reference/config_data/*.ini"))
+    if not os.path.exists(so) or not files:
+        pytest.skip("needs /root/reference and oracle/_ref")
+    ref = ctypes.CDLL(so)
+    n_keys = 0
+    for f in files:
+        text = open(f).read()
+        sections = set(m.strip() for m in re.findall(r"^\s*\[([^\]]*)\]", text, re.M)) | {"VISODO", "CALIBRATION"}
+        keys = set(m.strip() for m in re.findall(r"^\s*([A-Za-z_][A-Za-z0-9_]*)\s*=", text, re.M)) | {"fx", "kd", "dRc", "t_dc", "q0", "missing"}
+        for sec in sections:
+            for key in keys:
+                buf = ctypes.create_string_buffer(8192)
+                n = ref.ref_settings_get(f.encode(), sec.encode(), key.encode(), buf, 8192)
+                want = None if n < 0 else buf.value.decode()
+                assert host.settings_get(f, sec, key) == want, (f, sec, key, want)
+                n_keys += want is not None
+    assert n_keys > 60
