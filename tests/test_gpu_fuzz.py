@@ -40,7 +40,7 @@ def _case(seed):
     return rows, cols, grid, src, inten, Rp, tp
 
 
-@pytest.mark.parametrize("seed", range(36))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RGBID_FUZZ_N", "36"))))
 def test_fuzz_warps_visibility(ctx, seed):
     rows, cols, grid, src, inten, Rp, tp = _case(seed)
     new = lambda: torch.full((rows, cols), float("nan"), device="cuda")
@@ -69,7 +69,7 @@ def test_fuzz_warps_visibility(ctx, seed):
     assert np.array_equal(vm.cpu().numpy()[rows:2 * rows][ok], ov[rows:2 * rows][ok], equal_nan=True) and np.array_equal(vm.cpu().numpy()[2 * rows:][ok], ov[2 * rows:][ok], equal_nan=True)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RGBID_FUZZ_N", "12"))))
 def test_fuzz_stencils_and_fusion(ctx, seed):
     """Sobel, pyrDown and the fusion update on odd sizes with infinities / zeros / denormals / dense NaN in the maps."""
     r = util.rng(2000 + seed)

@@ -393,3 +393,35 @@ def test_exact_reciprocal_is_ieee_for_every_float(ctx):
     """csrc/common.h rcp_exact (v_rcp_f32 + one FMA Newton step, full IEEE sequence outside [2^-126, 2^126)) == 1.0f / x for ALL 2^32
     float bit patterns -- the proof that the shorter instruction sequence cannot change any projected coordinate."""
     assert ctx.selftest_rcp() == 0
+
+
+def test_c_abi_rejects_bad_arguments(ctx):
+    """error convention of the C-ABI: 0 = ok, negative = RGBID_E_* for bad arguments (never a crash, never a silent no-op)"""
+    import ctypes as C
+    from rgbid import device, _lib
+    L = _lib.lib()
+    a = torch.zeros((48, 64), device="cuda"); b = torch.zeros((48, 64), device="cuda"); small = torch.zeros((24, 32), device="cuda")
+    ia, ib, ism = device.img(a), device.img(b), device.img(small)
+    ms = C.c_float()
+    h = ctx._h
+    assert L.rgbid_compute_gradient(h, C.byref(ia), C.byref(ib), C.byref(ism), C.byref(ms)) < 0          # size mismatch
+    assert L.rgbid_compute_gradient(None, C.byref(ia), C.byref(ib), C.byref(ib), C.byref(ms)) < 0         # no context
+    assert L.rgbid_compute_gradient(h, None, C.byref(ib), C.byref(ib), C.byref(ms)) < 0                   # null image
+    bad = device.Img(0, 256, 48, 64)
+    assert L.rgbid_pyr_down(h, C.byref(bad), C.byref(ism), C.byref(ms)) < 0                               # null data pointer
+    assert L.rgbid_pyr_down(h, C.byref(ia), C.byref(ia), C.byref(ms)) < 0                                 # dst must be rows/2 x cols/2
+    R = (C.c_float * 9)(1, 0, 0, 0, 1, 0, 0, 0, 1); t = (C.c_float * 3)()
+    assert L.rgbid_warp_invdepth(h, C.byref(ia), C.byref(ib), C.byref(ism), R, t, C.byref(ms)) < 0
+    assert L.rgbid_warp_invdepth(h, C.byref(ia), C.byref(ib), C.byref(ia), None, t, C.byref(ms)) < 0
+    A = (C.c_double * 36)(); bb = (C.c_double * 6)()
+    k = device.Intr(50.0, 50.0, 31.5, 23.5)
+    args = [C.byref(ia)] * 8
+    assert L.rgbid_build_system_student_nu(h, *args, 3, 0, C.c_float(0.0025), C.c_float(5), C.c_float(0), C.c_float(0), C.c_float(5), C.c_float(5), k, None, bb, C.byref(ms)) < 0
+    args[7] = C.byref(ism)
+    assert L.rgbid_build_system_student_nu(h, *args, 3, 0, C.c_float(0.0025), C.c_float(5), C.c_float(0), C.c_float(0), C.c_float(5), C.c_float(5), k, A, bb, C.byref(ms)) < 0
+    assert L.rgbid_error_string(-1) and L.rgbid_error_string(12345)
+    e = C.c_void_p()
+    cfg = __import__("rgbid.engine", fromlist=["x"]).default_config(rows=2, cols=2, levels=3, lanes=1)
+    assert L.rgbid_engine_create(C.byref(e), h, C.byref(cfg)) < 0 and not e.value                         # pyramid too deep for the image
+    # and a good call still works afterwards
+    assert L.rgbid_compute_gradient(h, C.byref(ia), C.byref(ib), C.byref(ib), C.byref(ms)) == 0
