@@ -58,8 +58,10 @@ RGBID_HD void force_orthogonal(const double* M, double* R) {
   m3_mul(Mt, M, S);
   m3_id(V);
   for (int sweep = 0; sweep < 12; ++sweep) {
+    // converged once the off-diagonal mass is below the rounding level of the diagonal: a further rotation by an angle of that
+    // size cannot change a double (the input is a rotation up to rounding, so this is normally reached after one or two sweeps)
     double off = fabs(S[1]) + fabs(S[2]) + fabs(S[5]);
-    if (off < 1e-300) break;
+    if (off <= 1e-19 * (fabs(S[0]) + fabs(S[4]) + fabs(S[8]))) break;
     for (int p = 0; p < 2; ++p)
       for (int q = p + 1; q < 3; ++q) {
         double apq = S[p * 3 + q];
