@@ -290,11 +290,18 @@ static const PyrWeights& pyr_weights() {
 // A thread owns one output column and walks PD_ROWS output rows downwards, keeping the 5x5 source window in registers
 // (two new source rows = ten cached loads per output; out-of-image taps become NaN).  No LDS, no barriers.
 static constexpr int PD_ROWS = 8;
-__device__ __forceinline__ void pyr_load_row(const ImgB& src, int lane, int cy, const int cx[5], const bool cin[5], float r[5]) {
+// a source row of the window: value sanitised to 0 and validity as 0/1, so a tap is `sum1 += v * w; sum2 += m * w; count += m`
+// (adding +0 for an invalid tap leaves the sums bit-identical to skipping it: they start at +0 and can never become -0)
+__device__ __forceinline__ void pyr_load_row(const ImgB& src, int lane, int cy, const int cx[5], const bool cin[5], float r[5], float mk[5]) {
   const bool row_in = cy >= 0 && cy < src.rows;
   const float* rp = row_ptr<float>(src, lane, row_in ? cy : 0);
 #pragma unroll
-  for (int i = 0; i < 5; ++i) { float v = rp[cx[i]]; r[i] = (row_in && cin[i]) ? v : qnan(); }
+  for (int i = 0; i < 5; ++i) {
+    float v = rp[cx[i]];
+    bool ok = row_in && cin[i] && !isnan(v);
+    r[i] = ok ? v : 0.f;
+    mk[i] = ok ? 1.f : 0.f;
+  }
 }
 __global__ __launch_bounds__(256) void k_pyr_down_roll(ImgB src, ImgB dst, PyrWeights W, int strips, LaneMask m) {
   int lane = blockIdx.y;
@@ -306,30 +313,27 @@ __global__ __launch_bounds__(256) void k_pyr_down_roll(ImgB src, ImgB dst, PyrWe
   int cx[5]; bool cin[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) { int c = 2 * x - 2 + i; cin[i] = c >= 0 && c < src.cols; cx[i] = min(max(c, 0), src.cols - 1); }
-  float win[5][5];  // source rows 2y-2 .. 2y+2
+  float win[5][5], msk[5][5];  // source rows 2y-2 .. 2y+2
 #pragma unroll
-  for (int r = 0; r < 3; ++r) pyr_load_row(src, lane, 2 * y_begin - 2 + r, cx, cin, win[r + 2]);
+  for (int r = 0; r < 3; ++r) pyr_load_row(src, lane, 2 * y_begin - 2 + r, cx, cin, win[r + 2], msk[r + 2]);
   for (int y = y_begin; y < y_end; ++y) {
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int i = 0; i < 5; ++i) win[r][i] = win[r + 2][i];
-    pyr_load_row(src, lane, 2 * y + 1, cx, cin, win[3]);
-    pyr_load_row(src, lane, 2 * y + 2, cx, cin, win[4]);
-    float sum1 = 0.f, sum2 = 0.f;
-    int count = 0;
+      for (int i = 0; i < 5; ++i) { win[r][i] = win[r + 2][i]; msk[r][i] = msk[r + 2][i]; }
+    pyr_load_row(src, lane, 2 * y + 1, cx, cin, win[3], msk[3]);
+    pyr_load_row(src, lane, 2 * y + 2, cx, cin, win[4], msk[4]);
+    float sum1 = 0.f, sum2 = 0.f, count = 0.f;
 #pragma unroll
     for (int dy = 0; dy < 5; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 5; ++dx) {
-        const float val = win[dy][dx];
         const float weight = W.w[(dx - 2) * (dx - 2) + (dy - 2) * (dy - 2)];
-        const bool ok = !isnan(val);
-        sum1 = ok ? sum1 + val * weight : sum1;
-        sum2 = ok ? sum2 + weight : sum2;
-        count += ok ? 1 : 0;
+        sum1 = sum1 + win[dy][dx] * weight;
+        sum2 = sum2 + msk[dy][dx] * weight;
+        count += msk[dy][dx];
       }
-    px<float>(dst, lane, y, x) = count > 12 ? sum1 / sum2 : qnan();
+    px<float>(dst, lane, y, x) = count > 12.f ? sum1 / sum2 : qnan();
   }
 }
 void launch_pyr_down(hipStream_t s, int B, ImgB src, ImgB dst, LaneMask m) {
