@@ -39,28 +39,69 @@ def make_inputs(lanes, n_frames, rows, cols, K, device, n_unique=4):
     return seqs, depth, rgb
 
 
+def usable_cores():
+    """host cores this process may actually use: affinity mask, capped by the cgroup CPU quota (cpu.max / cfs_quota_us)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(seq, rows, cols, K, budget_s=12.0):
-    """The oracle's VisodoTracker restatement on the host cores (OpenMP over image rows), same frames, same config."""
+    """The oracle's VisodoTracker restatement on the host cores, same frames, same config.  Two ways of using the cores are timed
+    and the better one is reported: (a) one tracker with OpenMP over image rows (stops scaling at ~16 threads: 480 rows, a fork/join
+    per kernel), (b) one single-threaded tracker per core on independent copies of the sequence -- the CPU analogue of the GPU's
+    lanes."""
+    import subprocess
+    import tempfile
     from oracle import oracle as O
     d = seq["depth"].cpu().numpy().astype(np.uint16)
     c = seq["rgb"].cpu().numpy()
     cfg = O.default_config(rows=rows, cols=cols, fx=K[0], fy=K[1], cx=K[2], cy=K[3])
-    # OpenMP over image rows stops scaling well before a 128-thread host is full (480 rows, fork/join per kernel): cap at 16
-    O.set_num_threads(min(os.cpu_count() or 1, 16))
+    ncpu = usable_cores()
+    # (a) OpenMP over rows
+    O.set_num_threads(min(ncpu, 16))
     frames = 0
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
+    while time.perf_counter() - t0 < budget_s / 2:
         trk = O.Tracker(cfg)
         trk.track(d[0], c[0])  # first frame = keyframe creation (not an aligned frame)
-        t_start = time.perf_counter()
         for k in range(1, d.shape[0]):
             trk.track(d[k], c[k])
             frames += 1
         trk.close()
     el = time.perf_counter() - t0
-    return {"value": frames / el, "unit": "frames/s", "cores": int(O.num_threads()), "kind": "port",
-            "sample": f"{frames} aligned 640x480 frames of lane 0 (same synthetic frames, full per-frame pipeline) in {el:.1f} s, "
-                      f"oracle C restatement with OpenMP on {O.num_threads()} host threads"}
+    omp = {"value": frames / el, "cores": int(O.num_threads()), "frames": frames, "seconds": el}
+    # (b) one single-threaded tracker per core
+    best = dict(omp, how="one tracker, OpenMP over image rows")
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            npz = os.path.join(tmp, "frames.npz")
+            np.savez(npz, depth=d, rgb=c, K=np.array(K, np.float64))
+            worker = os.path.join(ROOT, "tools", "cpu_worker.py")
+            env = dict(os.environ, OMP_NUM_THREADS="1")
+            procs = [subprocess.Popen([sys.executable, worker, npz, str(budget_s)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
+                     for _ in range(ncpu)]
+            outs = [p.communicate(timeout=budget_s * 6 + 120)[0].split() for p in procs]
+        fr = sum(int(o[0]) for o in outs if len(o) == 2)
+        tm = max(float(o[1]) for o in outs if len(o) == 2)
+        multi = {"value": fr / tm, "cores": ncpu, "frames": fr, "seconds": tm}
+        if multi["value"] > best["value"]:
+            best = dict(multi, how="one single-threaded tracker per host core on independent copies of the sequence")
+    except Exception as e:  # the baseline is informative only: never fail the benchmark because of it
+        best["note"] = f"per-core instances not run ({type(e).__name__})"
+    return {"value": best["value"], "unit": "frames/s", "cores": int(best["cores"]), "kind": "port",
+            "sample": f"{best['frames']} aligned {cols}x{rows} frames (same synthetic frames, full per-frame pipeline) in {best['seconds']:.1f} s; "
+                      f"oracle C restatement, {best['how']}; OpenMP-over-rows figure: {omp['value']:.1f} frames/s on {omp['cores']} threads"}
 
 
 def pmc_traffic(lanes, rows, cols, fused):
