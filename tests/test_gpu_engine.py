@@ -295,3 +295,9 @@ def test_engine_configurations(ctx, name, rows, cols, cfg_kw):
     s = cols / 640.0
     K = (525.0 * s, 525.0 * s, (319.5 + 0.5) * s - 0.5, (239.5 + 0.5) * rows / 480.0 - 0.5)
     run_case(ctx, rows, cols, K, n_lanes=2, n_frames=5, cfg_kw=cfg_kw, seq_kw=dict(trans_step=(0.003, 0.01), rot_step_deg=(0.1, 0.6)), use_graph=0)
+
+
+def test_engine_negative_fy_icl_nuim_calibration(ctx):
+    """ICL-NUIM (Handa) sequences use fy < 0 (config_data/calibration_syntheticHanda.ini: 481.2, -480): the whole path must accept it."""
+    K = (481.2 / 4, -480.0 / 4, (319.5 + 0.5) / 4 - 0.5, (239.5 + 0.5) / 4 - 0.5)
+    run_case(ctx, 120, 160, K, n_lanes=2, n_frames=5, cfg_kw=dict(), seq_kw=dict(trans_step=(0.003, 0.01), rot_step_deg=(0.1, 0.6)), use_graph=0)
