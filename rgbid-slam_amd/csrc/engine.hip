@@ -588,18 +588,16 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
         if (c.warping == RGBID_WARP_FIRST) {
           // :1078-1105: warp the full-resolution frame, then reduce the WARPED maps down to the working level
           // (k_step_begin / k_solve_update project the pose with the level-0 intrinsics in this mode)
-          launch_warp_invdepth(s, B, e->iD_curr[0], e->iD_kf[0], e->wiD[0], nullptr, e->wp, M(f.gn));
-          launch_warp_intensity(s, B, e->I_curr[0], e->wiD[0], e->wI[0], nullptr, e->wp, c.interp_mode, M(f.gn));
-          e->launches += 2;
+          launch_warp_pair(s, B, e->iD_curr[0], e->I_curr[0], e->iD_kf[0], e->wiD[0], e->wI[0], e->wp, c.interp_mode, M(f.gn));
+          e->launches += 1;
           for (int i = 1; i <= level; ++i) {
             launch_pyr_down(s, B, e->wI[i - 1], e->wI[i], M(f.gn));
             launch_pyr_down(s, B, e->wiD[i - 1], e->wiD[i], M(f.gn));
             e->launches += 2;
           }
         } else {
-          launch_warp_invdepth(s, B, e->iD_curr[level], e->iD_kf[level], e->wiD[level], nullptr, e->wp, M(f.gn));
-          launch_warp_intensity(s, B, e->I_curr[level], e->wiD[level], e->wI[level], nullptr, e->wp, c.interp_mode, M(f.gn));
-          e->launches += 2;
+          launch_warp_pair(s, B, e->iD_curr[level], e->I_curr[level], e->iD_kf[level], e->wiD[level], e->wI[level], e->wp, c.interp_mode, M(f.gn));
+          e->launches += 1;
         }
         if (c.sigma_estimator == RGBID_SIGMA_PDF) {
           launch_sigma_pair(s, B, e->wiD[level], e->iD_kf[level], e->wI[level], e->I_kf[level], c.nsamples, e->sp, c.mestimator, M(f.gn));
@@ -626,12 +624,11 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
                              e->iD_curr[fl], e->I_curr[fl], e->wp, c.interp_mode, e->sp, e->partials, M(f.gn), fl < 2 ? fl : 2);
       e->launches += 2;
     } else {
-      launch_warp_invdepth(s, B, e->iD_curr[fl], e->iD_kf[fl], e->wiD[fl], nullptr, e->wp, M(f.gn));
-      launch_warp_intensity(s, B, e->I_curr[fl], e->wiD[fl], e->wI[fl], nullptr, e->wp, c.interp_mode, M(f.gn));
+      launch_warp_pair(s, B, e->iD_curr[fl], e->I_curr[fl], e->iD_kf[fl], e->wiD[fl], e->wI[fl], e->wp, c.interp_mode, M(f.gn));
       if (prof) { set_system_kernel_events(e->prof_ev[e->prof_used], e->prof_ev[e->prof_used + 1]); e->prof_used += 2; }
       nblk = launch_build_system(s, B, e->iD_kf[fl], e->I_kf[fl], e->gxD_c[fl], e->gyD_c[fl], e->gxI_c[fl], e->gyI_c[fl],
                                  e->wiD[fl], e->wI[fl], nullptr, e->sp, e->partials, M(f.gn), fl < 2 ? fl : 2);
-      e->launches += 4;
+      e->launches += 3;
     }
     if (c.chi_square_stats) {  // :1411-1415 (results unused by the reference)
       int n, lr, lc, st;

@@ -31,6 +31,8 @@ void launch_depth_to_invdepth(hipStream_t s, int B, ImgB src_u16, ImgB dst, floa
 void launch_intensity(hipStream_t s, int B, ImgB rgb, ImgB dst, LaneMask m);
 void launch_depth_to_float(hipStream_t s, int B, ImgB src_u16, ImgB dst, LaneMask m);
 void launch_float_to_rgb(hipStream_t s, int B, ImgB src, ImgB dst_rgb, LaneMask m);
+// engine: iD warp + intensity warp (sampled on the warped iD) of one GN iteration in one launch, bit-identical to the two kernels
+void launch_warp_pair(hipStream_t s, int B, ImgB src_iD, ImgB src_I, ImgB grid, ImgB dst_iD, ImgB dst_I, const WarpParams* lane_params, int interp_mode, LaneMask m);
 void launch_nmap_cross(hipStream_t s, int B, ImgB vmap, ImgB nmap, LaneMask m);
 void launch_integrate_warped_rgb(hipStream_t s, int B, ImgB warped, ImgB r, ImgB g, ImgB b, ImgB wweight, ImgB kf, ImgB colors, ImgB kfw, LaneMask m);
 void launch_decompose_rgb(hipStream_t s, int B, ImgB rgb, ImgB r, ImgB g, ImgB b, LaneMask m);

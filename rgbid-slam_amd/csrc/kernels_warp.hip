@@ -84,6 +84,45 @@ void launch_warp_intensity(hipStream_t s, int B, ImgB src, ImgB grid, ImgB dst, 
   else hipLaunchKernelGGL(k_warp_intensity<ByValue<WarpParams>>, g, b, 0, s, src, grid, dst, ByValue<WarpParams>{*hp}, interp_mode, m);
 }
 
+// ---- engine: both warps of a Gauss-Newton iteration in one pass ---------------------------------------------------------------
+// W1 = warp of the current inverse depth onto the keyframe grid, I1 = warp of the current intensity sampled with W1 (the tracker
+// passes the WARPED inverse depth as the sampling grid, visodo.cpp:1098-1100).  Same device functions as the two kernels above, so
+// the maps are bit-identical; W1 is consumed from registers (one load + one launch less per iteration).
+template <class PS>
+__global__ __launch_bounds__(256) void k_warp_pair(ImgB src_iD, ImgB src_I, ImgB grid, ImgB dst_iD, ImgB dst_I, PS ps, int interp_mode, LaneMask m) {
+  int lane = blockIdx.z;
+  if (!m.on(lane)) return;
+  int x = blockIdx.x * TX + threadIdx.x;
+  const WarpParams P = ps.get(lane);
+  const FMap SD(src_iD, lane), SI(src_I, lane);
+  if (x >= dst_iD.cols) return;
+  const int yb = blockIdx.y * (TY * RPB) + threadIdx.y;
+  float wv[RPB], w1[RPB], i1[RPB];
+#pragma unroll
+  for (int i = 0; i < RPB; ++i) { int y = yb + i * TY; wv[i] = (y < dst_iD.rows) ? px<float>(grid, lane, y, x) : qnan(); }
+  RcpFast fast;
+#pragma unroll
+  for (int i = 0; i < RPB; ++i) w1[i] = warp_invdepth_px_t(SD, x, yb + i * TY, wv[i], P, fast);
+#pragma unroll
+  for (int i = 0; i < RPB; ++i) i1[i] = warp_intensity_px_t(SI, x, yb + i * TY, w1[i], P, interp_mode, fast);
+  if (__builtin_expect(fast.failed(), 0)) {
+    RcpIeee ieee;
+#pragma unroll
+    for (int i = 0; i < RPB; ++i) w1[i] = warp_invdepth_px_t(SD, x, yb + i * TY, wv[i], P, ieee);
+#pragma unroll
+    for (int i = 0; i < RPB; ++i) i1[i] = warp_intensity_px_t(SI, x, yb + i * TY, w1[i], P, interp_mode, ieee);
+  }
+#pragma unroll
+  for (int i = 0; i < RPB; ++i) {
+    int y = yb + i * TY;
+    if (y < dst_iD.rows) { px<float>(dst_iD, lane, y, x) = w1[i]; px<float>(dst_I, lane, y, x) = i1[i]; }
+  }
+}
+void launch_warp_pair(hipStream_t s, int B, ImgB src_iD, ImgB src_I, ImgB grid, ImgB dst_iD, ImgB dst_I, const WarpParams* lp, int interp_mode, LaneMask m) {
+  dim3 g = grid2d(dst_iD.cols, dst_iD.rows, B), b(TX, TY);
+  hipLaunchKernelGGL(k_warp_pair<ByLane<WarpParams>>, g, b, 0, s, src_iD, src_I, grid, dst_iD, dst_I, ByLane<WarpParams>{lp}, interp_mode, m);
+}
+
 // ---- trafo3DKernelInvDepthWeightedGridStride (:549-594) -------------------------------------------
 template <class PS>
 __global__ __launch_bounds__(256) void k_warp_invdepth_weighted(ImgB src, ImgB grid, ImgB dst, ImgB weight, PS ps, LaneMask m) {
