@@ -238,10 +238,11 @@ static inline float tex2d_linear(const float* src, int rows, int cols, float xs,
     a = rintf(a * 256.f) * 0.00390625f;
     b = rintf(b * 256.f) * 0.00390625f;
   }
-  /* saturated conversions can return INT_MAX: bring the index into [-2, size] first (no effect on the clamps, no signed overflow) */
-  int i0 = imin(imax(f2i_rd(fx0), -2), cols), j0 = imin(imax(f2i_rd(fy0), -2), rows);
-  int i1 = imin(imax(i0 + 1, 0), cols - 1), j1 = imin(imax(j0 + 1, 0), rows - 1);
-  i0 = imin(imax(i0, 0), cols - 1); j0 = imin(imax(j0, 0), rows - 1);
+  /* clamp addressing: i0 -> clamp(i0, 0, n-1), i1 -> clamp(i0 + 1, 0, n-1); the conversions saturate (INT_MAX for huge
+   * coordinates), so clamp to [-1, n-1] BEFORE the + 1 (no signed overflow); same values */
+  int ic = imin(imax(f2i_rd(fx0), -1), cols - 1), jc = imin(imax(f2i_rd(fy0), -1), rows - 1);
+  int i1 = imin(ic + 1, cols - 1), j1 = imin(jc + 1, rows - 1);
+  int i0 = imax(ic, 0), j0 = imax(jc, 0);
   float T00 = src[(size_t)j0 * cols + i0], T10 = src[(size_t)j0 * cols + i1];
   float T01 = src[(size_t)j1 * cols + i0], T11 = src[(size_t)j1 * cols + i1];
   float oa = 1.f - a, ob = 1.f - b;

@@ -39,12 +39,12 @@ __device__ __forceinline__ float tex2d_linear(const FMap& src, float xs, float y
     a = rintf(a * 256.f) * 0.00390625f;
     b = rintf(b * 256.f) * 0.00390625f;
   }
-  // saturated conversions (huge / infinite coordinates give INT_MAX): bring the texel index into [-2, size] first, which changes
-  // neither clamp below but keeps `+ 1` away from signed overflow (undefined behaviour the optimiser may exploit)
-  int i0 = min(max(__float2int_rd(fx0), -2), src.cols), j0 = min(max(__float2int_rd(fy0), -2), src.rows);
-  int i1 = clampi(i0 + 1, src.cols - 1), j1 = clampi(j0 + 1, src.rows - 1);
-  i0 = clampi(i0, src.cols - 1);
-  j0 = clampi(j0, src.rows - 1);
+  // clamp addressing of both taps, i0 -> clamp(i0, 0, n-1), i1 -> clamp(i0 + 1, 0, n-1), evaluated so that the saturated
+  // conversions (huge / infinite coordinates give INT_MAX) can never overflow the `+ 1` (signed overflow is undefined behaviour the
+  // optimiser may exploit): c = clamp(i0, -1, n-1); i1 = min(c + 1, n-1); i0 = max(c, 0)  -- the same values in 5 instead of 6 ops
+  const int ic = min(max(__float2int_rd(fx0), -1), src.cols - 1), jc = min(max(__float2int_rd(fy0), -1), src.rows - 1);
+  const int i1 = min(ic + 1, src.cols - 1), j1 = min(jc + 1, src.rows - 1);
+  const int i0 = max(ic, 0), j0 = max(jc, 0);
   int r0 = j0 * src.pitch, r1 = j1 * src.pitch;
   float T00 = src.base[r0 + i0], T10 = src.base[r0 + i1], T01 = src.base[r1 + i0], T11 = src.base[r1 + i1];
   float oa = 1.f - a, ob = 1.f - b;
