@@ -125,6 +125,30 @@ struct Samples {
       }
     }
   }
+  // After the last moments pass the residuals themselves are no longer needed: the nu bisection only uses en^2 = ((e - bias)/sigma)^2,
+  // the same for every candidate nu, so the register copy is overwritten with it once (no extra VGPRs, 3 instructions less per
+  // sample and pass).  The streaming path recomputes it on the fly.
+  __device__ __forceinline__ void to_squared_normalised(float bias, float inv_sigma) {
+    if constexpr (REG) {
+#pragma unroll
+      for (int j = 0; j < SIG_MAXPT; ++j) { float en = (e[j] - bias) * inv_sigma; e[j] = en * en; }
+    }
+  }
+  template <class F>
+  __device__ __forceinline__ void for_each_en2(float bias, float inv_sigma, F&& f) const {  // f(en^2, valid)
+    if constexpr (REG) {
+#pragma unroll
+      for (int j = 0; j < SIG_MAXPT; ++j)
+        if (j < cnt) f(e[j], m[j]);
+    } else {
+      for (int i = tid; i < n; i += SIG_T) {
+        float v = get(i);
+        bool ok = fabsf(v) < __builtin_inff();
+        float en = ((ok ? v : 0.f) - bias) * inv_sigma;
+        f(en * en, ok ? 1.f : 0.f);
+      }
+    }
+  }
   template <class F>
   __device__ __forceinline__ void for_each(F&& f) const {  // f(residual, valid)
     if constexpr (REG) {
@@ -185,14 +209,13 @@ __device__ __forceinline__ void final_bias_sigma(float swsr, float swr, float sw
   sigma = sqrtf((swsr - 2.f * b * swr + b * b * sw) / nel);
 }
 
-// partialFuncWeightsNu :410-468 + finalReductionFuncWeightsNu :471-512
+// partialFuncWeightsNu :410-468 + finalReductionFuncWeightsNu :471-512 (S holds en^2 after to_squared_normalised)
 template <class SM>
-__device__ __forceinline__ float func_weights_nu(const SM& S, float bias, float sigma, float nu, double* sm) {
+__device__ __forceinline__ float func_weights_nu(const SM& S, float bias, float inv_sigma, float nu, double* sm) {
   typename SM::Acc a[4] = {0, 0, 0, 0};
-  const float inv_sigma = 1.f / sigma, nup1 = nu + 1.f;
-  S.for_each([&](float er, float mv) {
-    float en = (er - bias) * inv_sigma;
-    float weight = nup1 * __builtin_amdgcn_rcpf(nu + en * en);  // finite and positive also for a sanitised (invalid) sample
+  const float nup1 = nu + 1.f;
+  S.for_each_en2(bias, inv_sigma, [&](float en2, float mv) {
+    float weight = nup1 * __builtin_amdgcn_rcpf(nu + en2);  // finite and positive also for a sanitised (invalid) sample
     a[0] += __logf(weight) * mv; a[1] += weight * mv; a[2] += mv;
   });
   double t[4];
@@ -209,7 +232,9 @@ __device__ __forceinline__ float C_nu(const NuTable& T, float nu, float fw) {
 
 // bisection of C(nu) on [2,10]: sigmaFuncs.cu:934-1039 == :1100-1205
 template <class SM>
-__device__ __forceinline__ float estimate_nu(const SM& S, const NuTable& T, float bias, float sigma, double* sm) {
+__device__ __forceinline__ float estimate_nu(SM& S, const NuTable& T, float bias, float sigma_, double* sm) {
+  const float sigma = 1.f / sigma_;  // inv_sigma; S.e becomes en^2 (the residuals are not used after this point)
+  S.to_squared_normalised(bias, sigma);
   float nu_up = 10.f, nu_down = 2.f, nu_new = 0.f, nu;
   float C_down = C_nu(T, nu_down, func_weights_nu(S, bias, sigma, nu_down, sm));
   float C_up = C_nu(T, nu_up, func_weights_nu(S, bias, sigma, nu_up, sm));
@@ -230,7 +255,7 @@ __device__ __forceinline__ float estimate_nu(const SM& S, const NuTable& T, floa
 
 // the three host wrappers of the reference as one device routine over a sample set
 template <class SM>
-__device__ __forceinline__ void sigma_core(const SM& S, const NuTable& T, int mode, int mestimator, float& bias, float& sigma, float& nu, double* sm) {
+__device__ __forceinline__ void sigma_core(SM& S, const NuTable& T, int mode, int mestimator, float& bias, float& sigma, float& nu, double* sm) {
   float swsr, swr, sw, nel;
   if (mode == 0) {
     // computeSigmaAndNuStudent :858-1066
