@@ -301,3 +301,30 @@ def test_engine_negative_fy_icl_nuim_calibration(ctx):
     """ICL-NUIM (Handa) sequences use fy < 0 (config_data/calibration_syntheticHanda.ini: 481.2, -480): the whole path must accept it."""
     K = (481.2 / 4, -480.0 / 4, (319.5 + 0.5) / 4 - 0.5, (239.5 + 0.5) / 4 - 0.5)
     run_case(ctx, 120, 160, K, n_lanes=2, n_frames=5, cfg_kw=dict(), seq_kw=dict(trans_step=(0.003, 0.01), rot_step_deg=(0.1, 0.6)), use_graph=0)
+
+
+def test_engine_create_destroy_does_not_leak(ctx):
+    """40 create / step / destroy cycles (graph and eager) leave the device memory where it was"""
+    import ctypes as C
+    from rgbid import _lib
+    L = _lib.lib()
+    K = (131.25, 131.25, 79.5, 59.5)
+    seqs, depth, rgb = make_lanes(2, 2, 120, 160, K)
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert L.rgbid_mem_info(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    def cycle(g):
+        eng = E.Engine(ctx, E.default_config(rows=120, cols=160, lanes=2, K=K, use_graph=g, record_capacity=2))
+        eng.step(depth[0], rgb[0]); eng.step(depth[1], rgb[1]); eng.records()
+        eng.close()
+
+    cycle(0); cycle(1)
+    torch.cuda.synchronize()
+    before = free_bytes()
+    for i in range(40):
+        cycle(i % 2)
+    torch.cuda.synchronize()
+    assert abs(free_bytes() - before) < (8 << 20), (before, free_bytes())
