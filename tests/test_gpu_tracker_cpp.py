@@ -288,3 +288,32 @@ def test_cpp_bridge_and_containers(tmp_path):
     assert r.stdout.count("\nok ") + r.stdout.startswith("ok ") >= 14
     r = subprocess.run([exe, "error"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "Error: " in r.stdout and "internal.h:" in r.stdout and "FAILED" not in r.stdout, r.stdout + r.stderr
+
+
+def test_cpp_objects_do_not_leak_device_memory():
+    """VisodoTracker and KeyframeAlign allocate dozens of ref-counted device arrays: 15 construct / use / destroy cycles return every byte"""
+    import ctypes as C
+    from rgbid import _lib
+    L = _lib.lib()
+    seq = synth.make_sequence(2, K=SMALL_K, rows=120, cols=160, device="cuda", **SLOW)
+    d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+    iD = [O.depth2invdepth(np.zeros((480, 640), np.uint16) + 1500) for _ in range(2)]
+    grey = [np.full((480, 640), 100, np.uint8) for _ in range(2)]
+    kw = dict(rows=120, cols=160, fx=SMALL_K[0], fy=SMALL_K[1], cx=SMALL_K[2], cy=SMALL_K[3])
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert L.rgbid_mem_info(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    def cycle():
+        trk = host.Tracker(host.default_config(**kw))
+        trk.track(d[0], c[0]); trk.track(d[1], c[1])
+        trk.close()
+        host.keyframe_align(iD[0], grey[0], iD[1], grey[1], synth.TUM_K)
+
+    cycle()
+    torch_free = free_bytes()
+    for _ in range(15):
+        cycle()
+    assert abs(free_bytes() - torch_free) < (8 << 20), (torch_free, free_bytes())
