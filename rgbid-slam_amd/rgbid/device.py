@@ -7,6 +7,7 @@ A 2-D float32 tensor [rows, cols] is a DeviceArray2D<float>; its row stride is t
 padded views to exercise step != cols*4).  u16 depth is an int16/uint16 tensor, RGB a uint8 [rows, cols, 3].
 """
 import ctypes as C
+import weakref
 
 import torch
 
@@ -67,9 +68,12 @@ class Context:
         check(L.rgbid_ctx_create(C.byref(self._h), int(device), stream))
         self.device = device
         self.L = L
+        self._dependents = weakref.WeakSet()   # engines created on this context: they must go before the stream does
 
     def close(self):
         if self._h:
+            for d in list(self._dependents):
+                d.close()
             self.L.rgbid_ctx_destroy(self._h)
             self._h = None
 

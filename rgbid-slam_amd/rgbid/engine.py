@@ -62,6 +62,7 @@ class Engine:
         self._h = C.c_void_p()
         check(self.L.rgbid_engine_create(C.byref(self._h), ctx._h, C.byref(self.cfg)))
         self._inflight = []
+        ctx._dependents.add(self)
         assert RECORD_DTYPE.itemsize == 4 * 8 + 8 * (9 + 3 + 9 + 3 + 36 + 9 + 3 + 36), RECORD_DTYPE.itemsize
 
     @property
@@ -70,8 +71,10 @@ class Engine:
 
     def close(self):
         if self._h:
-            self.L.rgbid_engine_destroy(self._h)
+            if self.ctx._h:   # a context that is already gone took its stream with it; its close() destroys the engines first
+                self.L.rgbid_engine_destroy(self._h)
             self._h = None
+            self._inflight = []
 
     def __del__(self):
         try:
