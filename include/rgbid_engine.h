@@ -61,6 +61,7 @@ typedef struct rgbid_pose_record {
 
 void rgbid_engine_default_config(rgbid_engine_config* cfg);   /* ctor defaults + shipped ini + factory calibration */
 int rgbid_engine_create(rgbid_engine** e, rgbid_ctx* ctx, const rgbid_engine_config* cfg);
+/* an engine borrows its context's stream: destroy the engine BEFORE rgbid_ctx_destroy(ctx) */
 int rgbid_engine_destroy(rgbid_engine* e);
 /* VisodoTracker::reset() for every lane */
 int rgbid_engine_reset(rgbid_engine* e);
