@@ -154,3 +154,22 @@ def test_fuzz_cpp_tracker_and_keyframe_align_garbage(seed, tmp_path):
     grey = [r.integers(0, 256, (480, 640)).astype(np.uint8) for _ in range(2)]
     Rk, tk, cov = host.keyframe_align(iD[0], grey[0], iD[1], grey[1], (525.0, 525.0, 319.5, 239.5))
     assert Rk.shape == (3, 3) and cov.shape == (6, 6)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RGBID_FUZZ_CPP_N", "6"))))
+def test_fuzz_cpp_tracker_configurations(seed):
+    """random combinations of every VisodoTracker switch (warping, M-estimator, sigma estimator, weighting, gradient filtering,
+    motion model, finest level, termination, iteration schedule, visibility thresholds) through the C++ tracker vs the oracle"""
+    from tests.test_gpu_tracker_cpp import run, SMALL_K, SLOW
+    r = util.rng(5000 + seed)
+    warping = int(r.integers(0, 2))
+    kw = dict(warping=warping, mestimator=int(r.integers(0, 4)), sigma_estimator=int(r.choice([O.SIGMA_PDF, O.SIGMA_CONS])),
+              weighting=int(r.integers(0, 4)), image_filtering=int(r.integers(0, 2)), motion_model=int(r.integers(0, 2)),
+              finest_level=int(r.integers(0, 2)), iters=[int(r.integers(2, 8)), int(r.integers(1, 6)), int(r.integers(1, 4))],
+              visratio_odo=float(r.choice([0.9, 0.97])), visratio_integr=float(r.choice([0.7, 0.93])),
+              # CHI_SQUARED reads the level-0 warped maps, which are only refreshed at every level in warp-first mode
+              termination=int(r.choice([O.CHI_SQUARED, O.ALL_ITERS])) if warping == O.WARP_FIRST else O.ALL_ITERS)
+    # plain least squares has no outlier rejection: depth discontinuities make its normal equations sensitive to the last bits of the
+    # per-pixel arithmetic, so those combinations are held to 1e-3 instead of the 1e-4 of the robust (shipped) estimators
+    lsq = kw["mestimator"] == O.LSQ
+    run(120, 160, SMALL_K, 4, kw, SLOW, pose_tol=1e-3 if lsq else 1e-4, map_outliers=1.0 if lsq else 5e-3)
