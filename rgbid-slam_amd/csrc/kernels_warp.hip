@@ -130,27 +130,29 @@ __global__ __launch_bounds__(256) void k_warp_invdepth_weighted(ImgB src, ImgB g
   if (!m.on(lane)) return;
   int x = blockIdx.x * TX + threadIdx.x;
   const WarpParams P = ps.get(lane);
-  RGBID_FOR_ROWS(y) {
-    if (x >= dst.cols || y >= dst.rows) continue;
-    float out = qnan();
-    float w = px<float>(grid, lane, y, x);
-    if (!isnan(w)) {
-      float xs, ys;
-      float w3 = register_pixel(xs, ys, x, y, w, P);
-      xs += 0.5f; ys += 0.5f;
-      if (in_bounds_rd(xs, ys, src.cols, src.rows)) {
-        float w2 = px<float>(src, lane, f2i_rd(ys), f2i_rd(xs));
-        float tz = P.t[2];
-        float v1_z = (rcp_exact(w3) - tz) * w;
-        float w_factor = 1.f - w2 * tz;
-        float w_factor2 = w_factor * w_factor;
-        float weight_res = (w_factor2 * w_factor2) / (v1_z * v1_z);
-        float res = (v1_z / w_factor) * w2;
-        if (res > 0.f) out = res;
-        if (weight_res > 0.f) px<float>(weight, lane, y, x) = weight_res;  // untouched otherwise, as the reference
-      }
+  const FMap S(src, lane);
+  if (x >= dst.cols) return;
+  // same structure as k_warp_invdepth: RPB independent pixels, straight-line exact reciprocals, one IEEE fallback
+  const int yb = blockIdx.y * (TY * RPB) + threadIdx.y;
+  float wv[RPB], out[RPB], wt[RPB];
+  bool st[RPB];
+#pragma unroll
+  for (int i = 0; i < RPB; ++i) { int y = yb + i * TY; wv[i] = (y < dst.rows) ? px<float>(grid, lane, y, x) : qnan(); }
+  RcpFast fast;
+#pragma unroll
+  for (int i = 0; i < RPB; ++i) out[i] = warp_invdepth_weighted_px_t(S, x, yb + i * TY, wv[i], P, fast, wt[i], st[i]);
+  if (__builtin_expect(fast.failed(), 0)) {
+    RcpIeee ieee;
+#pragma unroll
+    for (int i = 0; i < RPB; ++i) out[i] = warp_invdepth_weighted_px_t(S, x, yb + i * TY, wv[i], P, ieee, wt[i], st[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < RPB; ++i) {
+    int y = yb + i * TY;
+    if (y < dst.rows) {
+      px<float>(dst, lane, y, x) = out[i];
+      if (st[i]) px<float>(weight, lane, y, x) = wt[i];  // untouched otherwise, as the reference
     }
-    px<float>(dst, lane, y, x) = out;
   }
 }
 void launch_warp_invdepth_weighted(hipStream_t s, int B, ImgB src, ImgB grid, ImgB dst, ImgB weight, const WarpParams* hp, const WarpParams* lp, LaneMask m) {

@@ -75,6 +75,30 @@ __device__ __forceinline__ float warp_invdepth_px(const FMap& src, int x, int y,
   return res;
 }
 
+// trafo3DKernelInvDepthWeightedGridStride, warping_registration.cu:549-594 (one pixel): the warped inverse depth plus the weight
+// (1 - w2 tz)^4 / v^2; `store_weight` tells the caller whether the reference would have written the weight (only when > 0)
+template <class RCP>
+__device__ __forceinline__ float warp_invdepth_weighted_px_t(const FMap& src, int x, int y, float w, const WarpParams& P, RCP& rcp,
+                                                              float& weight_res, bool& store_weight) {
+#pragma clang fp contract(off)
+  const bool valid = !isnan(w);
+  const float ws = valid ? w : 1.f;
+  float xs, ys;
+  float w3 = register_pixel_t(xs, ys, x, y, ws, P, rcp);
+  xs += 0.5f; ys += 0.5f;
+  int ix = cvt_rd(xs), iy = cvt_rd(ys);
+  const bool inb = inside(ix, iy, src.cols, src.rows);
+  float w2 = src.at(clampi(iy, src.rows - 1), clampi(ix, src.cols - 1));
+  float tz = P.t[2];
+  float v1_z = (rcp(w3) - tz) * ws;
+  float w_factor = 1.f - w2 * tz;
+  float w_factor2 = w_factor * w_factor;
+  weight_res = (w_factor2 * w_factor2) / (v1_z * v1_z);
+  float res = (v1_z / w_factor) * w2;
+  store_weight = valid & inb & (weight_res > 0.f);
+  return (valid & inb & (res > 0.f)) ? res : qnan();
+}
+
 // trafo3DKernelIntensityWithInvDepthGridStride, warping_registration.cu:465-501 (one pixel; w = sampling-grid iD)
 template <class RCP>
 __device__ __forceinline__ float warp_intensity_px_t(const FMap& src, int x, int y, float w, const WarpParams& P, int interp_mode, RCP& rcp) {
