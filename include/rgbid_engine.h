@@ -75,6 +75,8 @@ int rgbid_engine_read_records(rgbid_engine* e, int first_step, int n_steps, rgbi
 /* device pointer of the record ring (rgbid_pose_record[capacity][lanes]) for zero-copy gathers */
 int rgbid_engine_records_dev(rgbid_engine* e, void** ptr, int* capacity);
 /* debugging / parity access to a lane's fused keyframe maps (device pointers + geometry) */
+/* device views of a lane's Phong preview (cfg.preview = 1; getImage, visodo.cpp:559-580) and of the keyframe colours it shades */
+int rgbid_engine_preview(rgbid_engine* e, int lane, rgbid_img* preview_u8x3, rgbid_img* keyframe_colors_u8x3);
 int rgbid_engine_keyframe_maps(rgbid_engine* e, int lane, rgbid_img* depthinv, rgbid_img* weight, rgbid_img* vmap,
                                rgbid_img* nmap, rgbid_img* overlap_mask);
 /* Event timing of the dominant kernel: while profiling is on, every launch of the level-0 (full resolution)

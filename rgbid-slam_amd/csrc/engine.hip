@@ -405,6 +405,13 @@ __global__ void k_decide(LaneState* st, Flags f, const unsigned int* counts, War
   ++s.global_time;
 }
 
+// getImage (visodo.cpp:559-580): the Phong light sits at the integration keyframe's global position
+__global__ void k_set_light(const LaneState* st, LightP* light, int B) {
+  int lane = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lane >= B) return;
+  light[lane] = LightP{(float)st[lane].integrKF_t[0], (float)st[lane].integrKF_t[1], (float)st[lane].integrKF_t[2]};
+}
+
 __global__ void k_step_end(LaneState* st, rgbid_pose_record* rec, int B) {
   int lane = blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= B) return;
@@ -676,6 +683,8 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   launch_nmap_gradients(s, B, e->iD_integr, e->gxD_integr, e->gyD_integr, e->nmap, K0, M(f.maps));
   e->launches += 5;
   if (c.preview) {  // getImage :559-580
+    hipLaunchKernelGGL(k_set_light, dim3(gb), dim3(tb), 0, s, e->state, e->light, B);
+    e->launches++;
     launch_generate_image(s, B, e->vmap, e->nmap, e->colors_integr, e->preview, nullptr, e->light, ALL);
     e->launches++;
   }
@@ -860,6 +869,13 @@ int rgbid_engine_keyframe_maps(rgbid_engine* e, int lane, rgbid_img* depthinv, r
   if (vmap) *vmap = lane_img(e->vmap, lane);
   if (nmap) *nmap = lane_img(e->nmap, lane);
   if (overlap_mask) *overlap_mask = lane_img(e->overlap_mask, lane);
+  return RGBID_OK;
+}
+
+int rgbid_engine_preview(rgbid_engine* e, int lane, rgbid_img* preview, rgbid_img* colors) {
+  if (!e || lane < 0 || lane >= e->B || !e->cfg.preview) return RGBID_E_INVALID;
+  if (preview) *preview = lane_img(e->preview, lane);
+  if (colors) *colors = lane_img(e->colors_integr, lane);
   return RGBID_OK;
 }
 

@@ -128,6 +128,19 @@ class Engine:
     def launches_per_step(self):
         return self.L.rgbid_engine_launches_per_step(self._h)
 
+    def preview(self, lane):
+        """Host copies of a lane's preview image and keyframe colours (u8 [rows, cols, 3]); needs cfg.preview = 1."""
+        imgs = [Img(), Img()]
+        check(self.L.rgbid_engine_preview(self._h, int(lane), C.byref(imgs[0]), C.byref(imgs[1])))
+        self.ctx.sync()
+        outs = []
+        for im in imgs:
+            host = np.empty((im.rows, im.cols, 3), np.uint8)
+            check(self.L.rgbid_memcpy2d_d2h(self.ctx._h, host.ctypes.data_as(C.c_void_p), C.c_size_t(im.cols * 3), C.c_void_p(im.data), C.c_size_t(im.step),
+                                            C.c_size_t(im.cols * 3), C.c_size_t(im.rows)))
+            outs.append(host)
+        return outs
+
     def keyframe_maps(self, lane):
         """Host copies of a lane's fused keyframe maps: depthinv, weight, vmap, nmap, overlap mask."""
         imgs = [Img() for _ in range(5)]

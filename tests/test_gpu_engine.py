@@ -343,3 +343,31 @@ def test_engine_create_destroy_does_not_leak(ctx):
         cycle(i % 2)
     torch.cuda.synchronize()
     assert abs(free_bytes() - before) < (8 << 20), (before, free_bytes())
+
+
+def test_engine_preview_and_chi_square_options(ctx):
+    """cfg.preview renders getImage (visodo.cpp:559-580: Phong shading of the keyframe vertex / normal maps with the keyframe colours,
+    light at the integration keyframe's global position) and cfg.chi_square_stats runs the reference's unused full-resolution
+    chi-square; neither may change a single pose record."""
+    K = (synth.TUM_K[0] / 4, synth.TUM_K[1] / 4, (synth.TUM_K[2] + 0.5) / 4 - 0.5, (synth.TUM_K[3] + 0.5) / 4 - 0.5)
+    T, B = 6, 2
+    seqs, depth, rgb = make_lanes(B, T, 120, 160, K, trans_step=(0.01, 0.02), rot_step_deg=(0.5, 1.0))
+    recs = []
+    for extra in (dict(), dict(preview=1, chi_square_stats=1)):
+        eng = E.Engine(ctx, E.default_config(rows=120, cols=160, lanes=B, K=K, use_graph=0, record_capacity=T, visratio_integr=0.97, **extra))
+        for k in range(T):
+            eng.step(depth[k], rgb[k])
+        recs.append(eng.records().copy())
+        if extra:
+            assert (recs[-1]["status"][1:] & E.ST_INTEGR_KF).any()           # the light source has moved away from the origin at least once
+            for l in range(B):
+                img, colors = eng.preview(l)
+                kd, kw, vm, nm, km = eng.keyframe_maps(l)
+                # global position of the lane's current integration keyframe = pose of the last frame that re-keyed it
+                kf = max(k for k in range(T) if recs[-1]["status"][k, l] & (E.ST_INTEGR_KF | E.ST_FIRST))
+                light = recs[-1]["t"][kf, l].astype(np.float32)
+                ref = O.generate_image_rgb(vm, nm, colors, light)
+                diff = np.abs(img.astype(np.int32) - ref.astype(np.int32))
+                assert diff.max() <= 1 and np.count_nonzero(diff) <= 1e-3 * diff.size, (l, diff.max(), np.count_nonzero(diff))
+        eng.close()
+    assert recs[0].tobytes() == recs[1].tobytes()
