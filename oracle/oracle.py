@@ -480,3 +480,9 @@ def float2rgb(src):
     s_ = _f(src); out = np.empty(s_.shape + (3,), np.uint8)
     lib().orc_float2rgb(_p(s_), _p(out), s_.shape[0], s_.shape[1])
     return out
+
+
+def init_weight(src_depth):
+    s = _f(src_depth); out = np.empty_like(s)
+    lib().orc_init_weight(_p(s), _p(out), s.shape[0], s.shape[1])
+    return out

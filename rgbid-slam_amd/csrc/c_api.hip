@@ -13,10 +13,12 @@
 
 using namespace rgbid;
 
-#define RGBID_HIP(expr)                         \
-  do {                                          \
-    hipError_t e_ = (expr);                     \
-    if (e_ != hipSuccess) return (int)e_;       \
+// a failing HIP call is reported through the return value; the runtime's sticky "last error" is cleared so that the caller's
+// other HIP users (e.g. a framework sharing the process) do not trip over it later
+#define RGBID_HIP(expr)                                             \
+  do {                                                              \
+    hipError_t e_ = (expr);                                         \
+    if (e_ != hipSuccess) { (void)hipGetLastError(); return (int)e_; } \
   } while (0)
 
 extern "C" {
@@ -58,8 +60,11 @@ int rgbid_get_device_prop(int device, rgbid_device_prop* prop) {
 }
 
 int rgbid_set_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { (void)hipGetLastError(); return RGBID_E_NODEV; }  // no sticky error left behind
   hipError_t e = hipSetDevice(device);
-  return e == hipSuccess ? RGBID_OK : RGBID_E_NODEV;
+  if (e != hipSuccess) { (void)hipGetLastError(); return RGBID_E_NODEV; }
+  return RGBID_OK;
 }
 
 int rgbid_ctx_create(rgbid_ctx** out, int device, void* stream) {

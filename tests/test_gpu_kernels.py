@@ -425,3 +425,57 @@ def test_c_abi_rejects_bad_arguments(ctx):
     assert L.rgbid_engine_create(C.byref(e), h, C.byref(cfg)) < 0 and not e.value                         # pyramid too deep for the image
     # and a good call still works afterwards
     assert L.rgbid_compute_gradient(h, C.byref(ia), C.byref(ib), C.byref(ib), C.byref(ms)) == 0
+
+
+def test_remaining_abi_entry_points(ctx):
+    """the small entry points the tracker tests only reach indirectly: copies, fills, keyframe weight, raw memory functions, stream
+    adoption, device queries, device-side record ring"""
+    import ctypes as C
+    from rgbid import device, _lib, engine as E
+    L = _lib.lib()
+    r = util.rng(61)
+    rows, cols = 37, 53
+    a = util.rand_invdepth(r, rows, cols); b = util.rand_intensity(r, rows, cols)
+    da, db = new(rows, cols), new(rows, cols)
+    ctx.copyImages(dev(a), dev(b), da, db)
+    assert_bits(da.cpu().numpy(), a, 0, "copyImages depth"); assert_bits(db.cpu().numpy(), b, 0, "copyImages intensity")
+    dc = new(rows, cols); ctx.copyImage(dev(a), dc); assert_bits(dc.cpu().numpy(), a, 0, "copyImage")
+    rgb = r.integers(0, 256, (rows, cols, 3)).astype(np.uint8)
+    drgb = torch.zeros((rows, cols, 3), dtype=torch.uint8, device="cuda"); ctx.copyImageRGB(dev(rgb), drgb)
+    assert np.array_equal(drgb.cpu().numpy(), rgb)
+    w = new(rows, cols); ctx.initialiseWeightKeyframe(dev(a), w)                      # misc.cu:272-287: weight 1 everywhere
+    assert np.array_equal(w.cpu().numpy(), O.init_weight(a)) and (w.cpu().numpy() == 1).all()
+    for t, bits, want in ((torch.empty((rows, cols), device="cuda"), 0x40490fdb, np.float32(np.pi)),
+                          (torch.empty((rows, cols), dtype=torch.int32, device="cuda"), 0xfffffffe, -2),
+                          (torch.empty((rows, cols), dtype=torch.uint8, device="cuda"), 7, 7)):
+        ctx.initialiseDeviceMemory2D(t, bits)                                          # initialiseDeviceMemory2D<T>
+        assert (t.cpu().numpy() == want).all()
+    # raw memory functions (what pcl::gpu::DeviceMemory2D sits on)
+    n = C.c_int(); assert L.rgbid_device_count(C.byref(n)) == 0 and n.value >= 1
+    assert L.rgbid_set_device(0) == 0 and L.rgbid_set_device(n.value + 7) != 0
+    p, step = C.c_void_p(), C.c_size_t()
+    assert L.rgbid_malloc_pitch(C.byref(p), C.byref(step), C.c_size_t(cols * 4), C.c_size_t(rows)) == 0 and step.value % 256 == 0 and step.value >= cols * 4
+    host_in = np.ascontiguousarray(b); host_out = np.zeros_like(host_in)
+    assert L.rgbid_memcpy2d_h2d(ctx._h, p, step, host_in.ctypes.data_as(C.c_void_p), C.c_size_t(cols * 4), C.c_size_t(cols * 4), C.c_size_t(rows)) == 0
+    q = C.c_void_p(); assert L.rgbid_malloc(C.byref(q), C.c_size_t(step.value * rows)) == 0
+    assert L.rgbid_memcpy2d_d2d(ctx._h, q, step, p, step, C.c_size_t(cols * 4), C.c_size_t(rows)) == 0
+    assert L.rgbid_memcpy2d_d2h(ctx._h, host_out.ctypes.data_as(C.c_void_p), C.c_size_t(cols * 4), q, step, C.c_size_t(cols * 4), C.c_size_t(rows)) == 0
+    assert np.array_equal(host_out, host_in)
+    flat_in = np.arange(100, dtype=np.float32); flat_out = np.zeros_like(flat_in)
+    assert L.rgbid_memcpy_h2d(ctx._h, p, flat_in.ctypes.data_as(C.c_void_p), C.c_size_t(400)) == 0
+    assert L.rgbid_memcpy_d2d(ctx._h, q, p, C.c_size_t(400)) == 0
+    assert L.rgbid_memcpy_d2h(ctx._h, flat_out.ctypes.data_as(C.c_void_p), q, C.c_size_t(400)) == 0 and np.array_equal(flat_in, flat_out)
+    assert L.rgbid_free(p) == 0 and L.rgbid_free(q) == 0
+    # a context can be moved onto the caller's stream
+    s = torch.cuda.Stream()
+    c2 = device.Context(0)
+    assert L.rgbid_ctx_set_stream(c2._h, C.c_void_p(s.cuda_stream)) == 0 and c2.stream_handle() == s.cuda_stream
+    g1, g2 = new(rows, cols), new(rows, cols); c2.computeGradient(dev(a), g1, g2); c2.sync()
+    ogx, _ = O.gradient(a); assert_bits(g1.cpu().numpy(), ogx, 0, "gradient on an adopted stream")
+    c2.close()
+    # device-side record ring of the engine
+    K = (131.25, 131.25, 79.5, 59.5)
+    eng = E.Engine(ctx, E.default_config(rows=120, cols=160, lanes=2, K=K, use_graph=0, record_capacity=3))
+    ptr, cap = C.c_void_p(), C.c_int()
+    assert L.rgbid_engine_records_dev(eng._h, C.byref(ptr), C.byref(cap)) == 0 and ptr.value and cap.value == 3 and eng.steps() == 0
+    eng.close()

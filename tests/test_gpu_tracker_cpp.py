@@ -333,3 +333,29 @@ def test_cpp_objects_do_not_leak_device_memory():
     for _ in range(15):
         cycle()
     assert abs(free_bytes() - torch_free) < (8 << 20), (torch_free, free_bytes())
+
+
+def test_cpp_tracker_load_settings_and_calibration_files(tmp_path):
+    """VisodoTracker::loadSettings ([VISODO] keys of config_data/visodoRGBDconfig.ini) and loadCalibration ([CALIBRATION]) switch the
+    tracker exactly like the equivalent constructor arguments: trajectory = oracle with that configuration."""
+    (tmp_path / "visodo.ini").write_text("[VISODO]\nM_ESTIMATOR = Huber\nMOTION_MODEL = none\nWARP_ORDER = warpFirst\nIMAGE_FILTERING = gradients\n"
+                                         "SIGMA_ESTIMATOR = sigmaConst\nINTEGRATION_VISRATIO_THRESHOLD = 0.93\nODOMETRY_VISRATIO_THRESHOLD = 0.97\nFINEST_PYR_LEVEL = 1\n")
+    K = (SMALL_K[0] * 1.02, SMALL_K[1] * 0.98, SMALL_K[2] + 0.7, SMALL_K[3] - 0.4)
+    (tmp_path / "calib.ini").write_text(f"[CALIBRATION]\nfx = {K[0]}\nfy = {K[1]}\ncx = {K[2]}\ncy = {K[3]}\nkd = 0 0 0 0 0\nfactor_depth = 0.96\n")
+    n = 5
+    seq = synth.make_sequence(n, K=K, rows=120, cols=160, device="cuda", **SLOW)
+    d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+    trk = host.Tracker(host.default_config(rows=120, cols=160))         # defaults, everything else comes from the two files
+    trk.load_settings(str(tmp_path / "visodo.ini"))
+    trk.load_calibration(str(tmp_path / "calib.ini"))
+    orc = O.Tracker(O.default_config(rows=120, cols=160, fx=K[0], fy=K[1], cx=K[2], cy=K[3], factor_depth=0.96, mestimator=O.HUBER, motion_model=O.NO_MM,
+                                     warping=O.WARP_FIRST, image_filtering=O.FILTER_GRADS, sigma_estimator=O.SIGMA_CONS, visratio_integr=0.93,
+                                     visratio_odo=0.97, finest_level=1))
+    for k in range(n):
+        assert trk.track(d[k], c[k]) == orc.track(d[k], c[k])
+        if k:
+            ia, ib = trk.last_info(), orc.last_info()
+            assert bool(ia.odo_kf_switched) == bool(ib.odo_kf_switched) and bool(ia.integr_kf_switched) == bool(ib.integr_kf_switched)
+    Ra, ta = trk.poses(); Rb, tb = orc.poses()
+    for k in range(n):
+        assert rot_angle(Ra[k], Rb[k]) < 1e-4 and np.linalg.norm(ta[k] - tb[k]) < 1e-4, k
