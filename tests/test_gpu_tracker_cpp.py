@@ -287,6 +287,12 @@ def test_track_dataset_tool_chunked(tmp_path):
     for k in range(n):
         assert np.linalg.norm(traj[1][k, 1:4] - tb[k]) < 1e-4 and rot_angle(Rotation.from_quat(traj[1][k, 4:]).as_matrix(), Rb[k]) < 1e-4
         assert np.linalg.norm(traj[4][k, 1:4] - tb[k]) < 5e-3 and rot_angle(Rotation.from_quat(traj[4][k, 4:]).as_matrix(), Rb[k]) < 2e-3
+    # the same run with torch.distributed initialised on RCCL (one rank): the pose gather goes through all_gather_into_tensor on the GPU
+    out = tmp_path / "traj4_dist.txt"
+    r = subprocess.run([sys.executable, tool, str(root), "--match-file", "assoc.txt", "--chunks", "4", "--out", str(out), "--force-dist"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert out.read_text() == (tmp_path / "traj4.txt").read_text()
 
 
 def test_cpp_bridge_and_containers(tmp_path):

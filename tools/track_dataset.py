@@ -30,14 +30,18 @@ def main():
     ap.add_argument("--max-frames", type=int, default=-1)
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with a single rank")
     ap.add_argument("--K", type=float, nargs=4, default=[525.0, 525.0, 319.5, 239.5], help="fx fy cx cy (tools/evaluation.cpp:64-67)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "needs a HIP device (there is no CPU path)"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from rgbid import device, sequence, tum
@@ -63,7 +67,7 @@ def main():
         tum.write_trajectory(args.out, stamps, R, t)
         print(f"{len(frames)} frames in {args.chunks} chunks on {world} GPU(s): {el:.3f} s ({len(frames) / el:.1f} frames/s incl. engine set-up) -> {args.out}")
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
