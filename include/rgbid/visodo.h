@@ -80,6 +80,8 @@ struct KeyframeRecord {
 // stands in for KeyframeManager (keyframe_manager.h:77-104): poses_, constraints_, buffer_keyframes_.try_push
 struct TrackerSink {
   virtual ~TrackerSink() {}
+  // poses_.back() as the back-end currently holds it (a pose-graph optimisation may have moved it); false = "unchanged since pushed"
+  virtual bool backPose(Pose&) { return false; }
   virtual void pushPose(const Pose&) {}
   virtual void pushConstraint(const PoseConstraint&) {}
   virtual bool tryPushKeyframe(std::shared_ptr<KeyframeRecord>) { return true; }
@@ -153,6 +155,7 @@ class VisodoTracker {
   std::condition_variable created_cond_;
   bool compute_deltat_flag_, real_time_flag_, exit_;
   TrackerSink* keyframe_manager_ptr_;
+  Pose sink_back_pose_;   // shadow of keyframe_manager_ptr_->poses_.back() (refreshed through TrackerSink::backPose)
   std::vector<float> kf_times_;
   std::mutex mutex_shared_camera_pose_;
   Affine3d shared_camera_pose_;

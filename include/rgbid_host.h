@@ -62,6 +62,28 @@ int rgbid_tracker_keyframe_maps(rgbid_tracker* t, float* depthinv_host, float* w
 /* level-0 inverse depth / intensity of the last prepared frame (after undistortion + registration when custom_registration=1), to host */
 int rgbid_tracker_current_maps(const rgbid_tracker* t, float* depthinv, float* intensity);
 
+/* ---- what trackNewFrame hands to the back-end.  The reference writes into its KeyframeManager
+ * (include/keyframe_manager.h:77-104): poses_ (src/visodo.cpp:2033-2038, 2073-2079, 2157-2164), constraints_ (:1646-1650, 2071-2076,
+ * 2155-2160) and the bounded buffer_keyframes_ (try_push, :1632-1644; capacity 100, src/keyframe_manager.cpp:45).  rgbid_tracker_collect
+ * attaches a sink with the same three containers to the tracker; a maintainer's own back-end derives RGBID_SLAM::TrackerSink instead. ---- */
+enum { RGBID_SEQ_ODO = 0, RGBID_SEQ_KF = 1 };   /* PoseConstraint::SEQ_ODO / SEQ_KF (include/pose_graph_manager.h) */
+typedef struct rgbid_keyframe_info {
+  int id, rows, cols;
+  float K[9], kd[5];                  /* calibration of the exported images (Keyframe ctor, include/keyframe.h:45-70) */
+  double R[9], t[3];                  /* global pose of the keyframe */
+  double R_rel[9], t_rel[3];          /* to the next keyframe */
+} rgbid_keyframe_info;
+int rgbid_tracker_collect(rgbid_tracker* t, int keyframe_capacity);   /* call before the first frame; capacity <= 0 -> 100 */
+int rgbid_tracker_num_sink_poses(const rgbid_tracker* t);
+int rgbid_tracker_get_sink_pose(const rgbid_tracker* t, int i, int* id, double R[9], double tv[3]);
+int rgbid_tracker_set_sink_pose(rgbid_tracker* t, int i, const double R[9], const double tv[3]);  /* the back-end's optimiser moving a pose */
+int rgbid_tracker_num_constraints(const rgbid_tracker* t);
+int rgbid_tracker_get_constraint(const rgbid_tracker* t, int i, int* ini_id, int* end_id, int* type, double R[9], double tv[3], double cov[36]);
+int rgbid_tracker_num_keyframes(const rgbid_tracker* t);   /* keyframes waiting in the bounded buffer */
+int rgbid_tracker_peek_keyframe(const rgbid_tracker* t, int i, rgbid_keyframe_info* info, unsigned char* overlap_mask /* rows*cols */,
+                                unsigned char* colors /* rows*cols*3 */, float* depthinv /* rows*cols */, float* normals /* 3*rows*cols planar */);
+int rgbid_tracker_pop_keyframe(rgbid_tracker* t);          /* buffer_keyframes_.try_pop: drops the oldest; RGBID_E_INVALID when empty */
+
 /* KeyframeAlign::alignKeyframes (src/keyframe_align.cpp:115-357): host inputs, R/t in-out (initial guess -> result) */
 int rgbid_keyframe_align(int device, int rows, int cols, const float* depthinv_ini, const unsigned char* grey_ini,
                          const float* depthinv_end, const unsigned char* grey_end, float fx, float fy, float cx, float cy,

@@ -18,6 +18,7 @@ NO_MM, CONSTANT_VELOCITY = range(2)
 SIGMA_MAD, SIGMA_PDF, SIGMA_CONS = range(3)
 INDEPENDENT, MIN_WEIGHT, GEOM_ONLY, PHOT_ONLY = range(4)
 WARP_FIRST, PYR_FIRST = range(2)
+SEQ_ODO, SEQ_KF = 0, 1   # PoseConstraint types of the streams to the back-end
 CHI_SQUARED, ALL_ITERS = range(2)
 NO_FILTERS, FILTER_GRADS = range(2)
 INTERP_EXACT, INTERP_TEX8 = range(2)
@@ -373,6 +374,39 @@ class Tracker:
         cc = CustomCalib(IntrK(*[float(v) for v in rgb_k]), IntrK(*[float(v) for v in depth_k]), dist,
                          (C.c_float * 9)(*[float(v) for v in np.asarray(dRc).reshape(9)]), (C.c_float * 3)(*[float(v) for v in t_dc]))
         lib().orc_tracker_set_custom_calibration(self._h, C.byref(cc))
+
+    # ---- streams to the back-end (f-3) ----
+    def sink_poses(self):
+        n = lib().orc_tracker_num_sink_poses(self._h)
+        ids = np.empty(n, np.int32); Rs = np.empty((n, 9)); ts = np.empty((n, 3))
+        for i in range(n):
+            v = C.c_int()
+            lib().orc_tracker_get_sink_pose(self._h, i, C.byref(v), _p(Rs[i]), _p(ts[i]))
+            ids[i] = v.value
+        return ids, Rs.reshape(n, 3, 3), ts
+
+    def constraints(self):
+        out = []
+        for i in range(lib().orc_tracker_num_constraints(self._h)):
+            a, b, ty = C.c_int(), C.c_int(), C.c_int()
+            R = np.empty(9); t = np.empty(3); cov = np.empty(36)
+            lib().orc_tracker_get_constraint(self._h, i, C.byref(a), C.byref(b), C.byref(ty), _p(R), _p(t), _p(cov))
+            out.append(dict(ini=a.value, end=b.value, type=ty.value, R=R.reshape(3, 3), t=t, cov=cov.reshape(6, 6)))
+        return out
+
+    def num_keyframes(self):
+        return lib().orc_tracker_num_keyframes(self._h)
+
+    def keyframe(self, i):
+        rows, cols = self.cfg.rows, self.cfg.cols
+        v = C.c_int(); R = np.empty(9); t = np.empty(3); Rr = np.empty(9); tr = np.empty(3)
+        pm, pc, pd, pn = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        lib().orc_tracker_get_keyframe(self._h, int(i), C.byref(v), _p(R), _p(t), _p(Rr), _p(tr), C.byref(pm), C.byref(pc), C.byref(pd), C.byref(pn))
+        n = rows * cols
+        grab = lambda ptr, ct, cnt, shape, dt: np.frombuffer((ct * cnt).from_address(ptr.value), dt).reshape(shape).copy()
+        return dict(id=v.value, R=R.reshape(3, 3), t=t, R_rel=Rr.reshape(3, 3), t_rel=tr,
+                    overlap_mask=grab(pm, C.c_uint8, n, (rows, cols), np.uint8), colors=grab(pc, C.c_uint8, 3 * n, (rows, cols, 3), np.uint8),
+                    depthinv=grab(pd, C.c_float, n, (rows, cols), np.float32), normals=grab(pn, C.c_float, 3 * n, (3, rows, cols), np.float32))
 
     def cur_depthinv(self):
         lib().orc_tracker_cur_depthinv.restype = C.c_void_p

@@ -158,6 +158,18 @@ void orc_tracker_get_pose(const orc_tracker* t, int i, double R[9], double tv[3]
 /* sequential odometry i (odo_rmats_/odo_tvecs_/odo_covmats_) */
 int  orc_tracker_num_odo(const orc_tracker* t);
 void orc_tracker_get_odo(const orc_tracker* t, int i, double R[9], double tv[3], double cov[36]);
+/* ---- what trackNewFrame hands to the back-end: Pose / PoseConstraint streams (visodo.cpp:2073-2083, 2154-2165) and the
+ * keyframe export record of resetIntegrationKeyframe (:1612-1652; include/keyframe.h:45-70, pose_graph_manager.h:54-108) ---- */
+enum { ORC_SEQ_ODO = 0, ORC_SEQ_KF = 1 };
+int  orc_tracker_num_sink_poses(const orc_tracker* t);
+void orc_tracker_get_sink_pose(const orc_tracker* t, int i, int* id, double R[9], double tv[3]);
+int  orc_tracker_num_constraints(const orc_tracker* t);
+void orc_tracker_get_constraint(const orc_tracker* t, int i, int* ini_id, int* end_id, int* type, double R[9], double tv[3], double cov[36]);
+int  orc_tracker_num_keyframes(const orc_tracker* t);
+/* arrays: overlap mask u8[N], colours u8[3N], inverse depth f32[N], normals f32[3N] (planar) as downloaded at the keyframe switch */
+void orc_tracker_get_keyframe(const orc_tracker* t, int i, int* id, double R[9], double tv[3], double R_rel[9], double t_rel[3],
+                              const uint8_t** overlap_mask, const uint8_t** colors, const float** depthinv, const float** normals);
+
 /* prepareImagesCustomCalibration (visodo.cpp:775-824) instead of prepareImages: rgb intrinsics with distortion, depth intrinsics,
  * depth distortion model, depth->rgb extrinsics (loadCalibration :183-318) */
 typedef struct {

@@ -199,8 +199,16 @@ static void m6_ABAt_add(const double J[36], const double C[36], double out[36]) 
 /* ------------------------------------------------------------------ tracker state */
 #define ORC_MAX_LEVELS 8
 
+typedef struct { int id; double R[9], t[3]; } sink_pose;
+typedef struct { int ini, end, type; double R[9], t[3], cov[36]; } sink_constraint;
+typedef struct { int id; double R[9], t[3], Rrel[9], trel[3]; uint8_t* mask; uint8_t* colors; float* iD; float* normals; } sink_keyframe;
+
 struct orc_tracker {
   orc_tracker_config c;
+  /* streams to the back-end (f-3) */
+  sink_pose* sp; int n_sp, cap_sp;
+  sink_constraint* sc; int n_sc, cap_sc;
+  sink_keyframe* sk; int n_sk, cap_sk;
   int custom_registration; orc_custom_calib cc;   /* prepareImagesCustomCalibration instead of prepareImages */
   int global_time, lost;
   int odoKF_count, integrKF_count, last_odoKF_index, last_integrKF_index;
@@ -289,6 +297,8 @@ void orc_tracker_destroy(orc_tracker* t) {
   free(t->iD_integr); free(t->iD_integr_raw); free(t->w_integr); free(t->warped_iD_integr); free(t->warped_w);
   free(t->vmap); free(t->nmap); free(t->gxD_integr); free(t->gyD_integr); free(t->colors_integr); free(t->overlap_mask);
   free(t->rmats); free(t->tvecs); free(t->odo_rmats); free(t->odo_tvecs); free(t->odo_cov);
+  for (int i = 0; i < t->n_sk; ++i) { free(t->sk[i].mask); free(t->sk[i].colors); free(t->sk[i].iD); free(t->sk[i].normals); }
+  free(t->sp); free(t->sc); free(t->sk);
   free(t);
 }
 
@@ -477,8 +487,20 @@ static void reset_odometry_keyframe(orc_tracker* t) {
   m3_id(t->delta_R); memset(t->delta_t_, 0, sizeof(t->delta_t_)); m6_zero(t->delta_cov);
 }
 
+static void sink_push_pose(orc_tracker* t, int id, const double R[9], const double tv[3]) {
+  if (t->n_sp == t->cap_sp) { t->cap_sp = t->cap_sp ? 2 * t->cap_sp : 64; t->sp = (sink_pose*)realloc(t->sp, sizeof(sink_pose) * t->cap_sp); }
+  sink_pose* p = &t->sp[t->n_sp++];
+  p->id = id; memcpy(p->R, R, sizeof(p->R)); memcpy(p->t, tv, sizeof(p->t));
+}
+static void sink_push_constraint(orc_tracker* t, int ini, int end, int type, const double R[9], const double tv[3], const double cov[36]) {
+  if (t->n_sc == t->cap_sc) { t->cap_sc = t->cap_sc ? 2 * t->cap_sc : 64; t->sc = (sink_constraint*)realloc(t->sc, sizeof(sink_constraint) * t->cap_sc); }
+  sink_constraint* q = &t->sc[t->n_sc++];
+  q->ini = ini; q->end = end; q->type = type;
+  memcpy(q->R, R, sizeof(q->R)); memcpy(q->t, tv, sizeof(q->t)); memcpy(q->cov, cov, sizeof(q->cov));
+}
+
 static void reset_integration_keyframe(orc_tracker* t) {
-  /* resetIntegrationKeyframe visodo.cpp:1577-1672 (the Keyframe / PoseConstraint pushes to the back-end are out of scope) */
+  /* resetIntegrationKeyframe visodo.cpp:1577-1672 */
   t->integrKF_count = 0;
   double J[36], tn[3], S[9];
   m6_zero(J);
@@ -490,6 +512,31 @@ static void reset_integration_keyframe(orc_tracker* t) {
   m6_ABAt_add(J, t->delta_cov, t->o2i_next_cov);
   for (int i = 0; i < 3; ++i) t->o2i_next_t[i] = tn[i] + t->o2i_next_t[i];
   m3_mul(t->o2i_next_R, t->delta_R, t->o2i_next_R);
+  {
+    /* :1612-1652  T{k-1,k} = inv(T{odo,k-1}) T{odo,k}, its covariance, the Keyframe record (4 downloads) and the SEQ_KF constraint */
+    double lastT[9], Rkf[9], d[3], tkf[3], Jn[36], Jl[36], Sk[9], SR[9], ckf[36];
+    m3_T(t->o2i_last_R, lastT);
+    m3_mul(lastT, t->o2i_next_R, Rkf);
+    for (int i = 0; i < 3; ++i) d[i] = t->o2i_next_t[i] - t->o2i_last_t[i];
+    m3_mulv(lastT, d, tkf);
+    m6_zero(Jn); m6_set_block(Jn, 0, 0, lastT, 1.0); m6_set_block(Jn, 3, 3, lastT, 1.0);
+    m6_zero(Jl); m6_set_block(Jl, 0, 0, lastT, -1.0); m6_set_block(Jl, 3, 3, lastT, -1.0);
+    skew3(tkf, Sk); m3_mul(Sk, lastT, SR); m6_set_block(Jl, 0, 3, SR, 1.0);
+    m6_zero(ckf);
+    m6_ABAt_add(Jl, t->o2i_last_cov, ckf);
+    m6_ABAt_add(Jn, t->o2i_next_cov, ckf);
+    if (t->n_sk == t->cap_sk) { t->cap_sk = t->cap_sk ? 2 * t->cap_sk : 16; t->sk = (sink_keyframe*)realloc(t->sk, sizeof(sink_keyframe) * t->cap_sk); }
+    sink_keyframe* k = &t->sk[t->n_sk++];
+    size_t n0 = (size_t)t->c.rows * t->c.cols;
+    k->id = t->last_integrKF_index;
+    memcpy(k->R, t->integrKF_R, sizeof(k->R)); memcpy(k->t, t->integrKF_t, sizeof(k->t));
+    memcpy(k->Rrel, Rkf, sizeof(k->Rrel)); memcpy(k->trel, tkf, sizeof(k->trel));
+    k->mask = (uint8_t*)malloc(n0); memcpy(k->mask, t->overlap_mask, n0);
+    k->colors = (uint8_t*)malloc(3 * n0); memcpy(k->colors, t->colors_integr, 3 * n0);
+    k->iD = (float*)malloc(n0 * sizeof(float)); memcpy(k->iD, t->iD_integr, n0 * sizeof(float));
+    k->normals = (float*)malloc(3 * n0 * sizeof(float)); memcpy(k->normals, t->nmap, 3 * n0 * sizeof(float));
+    sink_push_constraint(t, t->last_integrKF_index, t->global_time, ORC_SEQ_KF, Rkf, tkf, ckf);
+  }
   t->last_integrKF_index = t->global_time;
   memcpy(t->integrKF_R, t->last_est_R, sizeof(t->integrKF_R));
   memcpy(t->integrKF_t, t->last_est_t, sizeof(t->integrKF_t));
@@ -676,6 +723,7 @@ int orc_tracker_track(orc_tracker* t, const uint16_t* depth, const uint8_t* rgb)
     save_odo_keyframe(t);
     save_integr_keyframe(t, rgb);
     memset(t->overlap_mask, 0, (size_t)c->rows * c->cols);
+    { double I3[9], z3[3] = { 0, 0, 0 }; m3_id(I3); sink_push_pose(t, 0, I3, z3); }  /* :2034-2041 */
     return 0;
   }
   double dR_prev[9], dt_prev[3], dcov_prev[36];
@@ -691,6 +739,14 @@ int orc_tracker_track(orc_tracker* t, const uint16_t* depth, const uint8_t* rgb)
     push_pose(t, t->last_est_R, t->last_est_t);
     if (!ok) { /* :2066-2097 */
       t->lost = 1;
+      {
+        /* dummy odometry constraint (zero motion, covariance 100 I) + a pose that repeats the last one in the back-end's list */
+        double I3[9], z3[3] = { 0, 0, 0 }, c100[36];
+        m3_id(I3); m6_zero(c100);
+        for (int i = 0; i < 6; ++i) c100[i * 7] = 100.0;
+        sink_push_constraint(t, t->global_time - 1, t->global_time, ORC_SEQ_ODO, I3, z3, c100);
+        sink_push_pose(t, t->global_time, t->sp[t->n_sp - 1].R, t->sp[t->n_sp - 1].t);
+      }
       reset_odometry_keyframe(t);
       reset_integration_keyframe(t);
       save_odo_keyframe(t);
@@ -729,6 +785,16 @@ int orc_tracker_track(orc_tracker* t, const uint16_t* depth, const uint8_t* rgb)
     m6_ABAt_add(Jl, dcov_prev, cseq);
     m6_ABAt_add(Jn, t->delta_cov, cseq);
     push_odo(t, Rseq, tseq, cseq);
+    sink_push_constraint(t, t->global_time - 1, t->global_time, ORC_SEQ_ODO, Rseq, tseq, cseq);   /* :2154-2165 */
+    {
+      /* the new pose continues the BACK-END's last pose (which a pose-graph optimisation may have moved), not last_estimated_* (:2161-2162) */
+      const sink_pose* b = &t->sp[t->n_sp - 1];
+      double Rn[9], tn2[3];
+      m3_mul(b->R, Rseq, Rn);
+      m3_mulv(b->R, tseq, tn2);
+      for (int i = 0; i < 3; ++i) tn2[i] += b->t[i];
+      sink_push_pose(t, t->global_time, Rn, tn2);
+    }
   }
   memcpy(t->info.delta_R, t->delta_R, sizeof(t->delta_R)); memcpy(t->info.delta_t, t->delta_t_, sizeof(t->delta_t_));
   memcpy(t->info.delta_cov, t->delta_cov, sizeof(t->delta_cov));
@@ -774,6 +840,22 @@ void orc_tracker_get_odo(const orc_tracker* t, int i, double R[9], double tv[3],
   memcpy(cov, t->odo_cov + 36 * i, 36 * sizeof(double));
 }
 void orc_tracker_last_info(const orc_tracker* t, orc_frame_info* info) { *info = t->info; }
+int orc_tracker_num_sink_poses(const orc_tracker* t) { return t->n_sp; }
+void orc_tracker_get_sink_pose(const orc_tracker* t, int i, int* id, double R[9], double tv[3]) {
+  *id = t->sp[i].id; memcpy(R, t->sp[i].R, 72); memcpy(tv, t->sp[i].t, 24);
+}
+int orc_tracker_num_constraints(const orc_tracker* t) { return t->n_sc; }
+void orc_tracker_get_constraint(const orc_tracker* t, int i, int* ini, int* end, int* type, double R[9], double tv[3], double cov[36]) {
+  *ini = t->sc[i].ini; *end = t->sc[i].end; *type = t->sc[i].type;
+  memcpy(R, t->sc[i].R, 72); memcpy(tv, t->sc[i].t, 24); memcpy(cov, t->sc[i].cov, 288);
+}
+int orc_tracker_num_keyframes(const orc_tracker* t) { return t->n_sk; }
+void orc_tracker_get_keyframe(const orc_tracker* t, int i, int* id, double R[9], double tv[3], double R_rel[9], double t_rel[3],
+                              const uint8_t** mask, const uint8_t** colors, const float** iD, const float** normals) {
+  const sink_keyframe* k = &t->sk[i];
+  *id = k->id; memcpy(R, k->R, 72); memcpy(tv, k->t, 24); memcpy(R_rel, k->Rrel, 72); memcpy(t_rel, k->trel, 24);
+  *mask = k->mask; *colors = k->colors; *iD = k->iD; *normals = k->normals;
+}
 void orc_tracker_set_custom_calibration(orc_tracker* t, const orc_custom_calib* cc) { t->custom_registration = cc != NULL; if (cc) t->cc = *cc; }
 const float* orc_tracker_cur_depthinv(const orc_tracker* t) { return t->iD_curr[0]; }
 const float* orc_tracker_cur_intensity(const orc_tracker* t) { return t->I_curr[0]; }

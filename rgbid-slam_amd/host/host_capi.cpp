@@ -4,6 +4,10 @@
 
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <vector>
 #include <fstream>
 #include <new>
 
@@ -17,7 +21,25 @@ namespace RGBID_SLAM { namespace device { DeviceProp dev_prop; int dev_id = 0; }
 using namespace RGBID_SLAM;
 namespace se3 = rgbid::se3;
 
-struct rgbid_tracker { VisodoTracker* t; };
+// KeyframeManager's three containers (include/keyframe_manager.h:77-104) behind TrackerSink
+struct CollectSink : TrackerSink {
+  std::mutex m;
+  std::vector<Pose> poses;
+  std::vector<PoseConstraint> constraints;
+  std::deque<std::shared_ptr<KeyframeRecord>> keyframes;
+  size_t capacity = 100;
+  bool backPose(Pose& p) override { std::lock_guard<std::mutex> l(m); if (poses.empty()) return false; p = poses.back(); return true; }
+  void pushPose(const Pose& p) override { std::lock_guard<std::mutex> l(m); poses.push_back(p); }
+  void pushConstraint(const PoseConstraint& c) override { std::lock_guard<std::mutex> l(m); constraints.push_back(c); }
+  bool tryPushKeyframe(std::shared_ptr<KeyframeRecord> k) override {
+    std::lock_guard<std::mutex> l(m);
+    if (keyframes.size() >= capacity) return false;
+    keyframes.push_back(k);
+    return true;
+  }
+};
+
+struct rgbid_tracker { VisodoTracker* t; CollectSink* sink = nullptr; };
 
 extern "C" {
 
@@ -73,7 +95,7 @@ int rgbid_tracker_create(rgbid_tracker** out, const rgbid_tracker_config* c, int
   return RGBID_OK;
 }
 
-int rgbid_tracker_destroy(rgbid_tracker* h) { if (h) { delete h->t; delete h; } return RGBID_OK; }
+int rgbid_tracker_destroy(rgbid_tracker* h) { if (h) { delete h->t; delete h->sink; delete h; } return RGBID_OK; }
 int rgbid_tracker_load_settings(rgbid_tracker* h, const char* ini_path) {
   if (!h || !ini_path) return RGBID_E_INVALID;
   std::ifstream f(ini_path);
@@ -134,6 +156,86 @@ int rgbid_tracker_current_maps(const rgbid_tracker* h, float* depthinv, float* i
   int cols = const_cast<VisodoTracker&>(t).cols();
   if (depthinv) t.currentDepthinv(0).download(depthinv, (size_t)cols * 4);
   if (intensity) t.currentIntensity(0).download(intensity, (size_t)cols * 4);
+  return RGBID_OK;
+}
+
+int rgbid_tracker_collect(rgbid_tracker* h, int keyframe_capacity) {
+  if (!h) return RGBID_E_INVALID;
+  if (!h->sink) h->sink = new CollectSink();
+  h->sink->capacity = keyframe_capacity > 0 ? (size_t)keyframe_capacity : 100;
+  h->t->keyframe_manager_ptr_ = h->sink;
+  return RGBID_OK;
+}
+int rgbid_tracker_num_sink_poses(const rgbid_tracker* h) {
+  if (!h || !h->sink) return 0;
+  std::lock_guard<std::mutex> l(h->sink->m);
+  return (int)h->sink->poses.size();
+}
+int rgbid_tracker_get_sink_pose(const rgbid_tracker* h, int i, int* id, double R[9], double tv[3]) {
+  if (!h || !h->sink) return RGBID_E_INVALID;
+  std::lock_guard<std::mutex> l(h->sink->m);
+  if (i < 0 || i >= (int)h->sink->poses.size()) return RGBID_E_INVALID;
+  const Pose& p = h->sink->poses[i];
+  if (id) *id = p.id_;
+  if (R) for (int k = 0; k < 9; ++k) R[k] = p.rotation_.m[k];
+  if (tv) for (int k = 0; k < 3; ++k) tv[k] = p.translation_[k];
+  return RGBID_OK;
+}
+int rgbid_tracker_set_sink_pose(rgbid_tracker* h, int i, const double R[9], const double tv[3]) {
+  if (!h || !h->sink || !R || !tv) return RGBID_E_INVALID;
+  std::lock_guard<std::mutex> l(h->sink->m);
+  if (i < 0 || i >= (int)h->sink->poses.size()) return RGBID_E_INVALID;
+  Pose& p = h->sink->poses[i];
+  for (int k = 0; k < 9; ++k) p.rotation_.m[k] = R[k];
+  for (int k = 0; k < 3; ++k) p.translation_[k] = tv[k];
+  return RGBID_OK;
+}
+int rgbid_tracker_num_constraints(const rgbid_tracker* h) {
+  if (!h || !h->sink) return 0;
+  std::lock_guard<std::mutex> l(h->sink->m);
+  return (int)h->sink->constraints.size();
+}
+int rgbid_tracker_get_constraint(const rgbid_tracker* h, int i, int* ini_id, int* end_id, int* type, double R[9], double tv[3], double cov[36]) {
+  if (!h || !h->sink) return RGBID_E_INVALID;
+  std::lock_guard<std::mutex> l(h->sink->m);
+  if (i < 0 || i >= (int)h->sink->constraints.size()) return RGBID_E_INVALID;
+  const PoseConstraint& c = h->sink->constraints[i];
+  if (ini_id) *ini_id = c.ini_id_;
+  if (end_id) *end_id = c.end_id_;
+  if (type) *type = c.type_;
+  if (R) for (int k = 0; k < 9; ++k) R[k] = c.rotation_.m[k];
+  if (tv) for (int k = 0; k < 3; ++k) tv[k] = c.translation_[k];
+  if (cov) for (int k = 0; k < 36; ++k) cov[k] = c.covariance_[k];
+  return RGBID_OK;
+}
+int rgbid_tracker_num_keyframes(const rgbid_tracker* h) {
+  if (!h || !h->sink) return 0;
+  std::lock_guard<std::mutex> l(h->sink->m);
+  return (int)h->sink->keyframes.size();
+}
+int rgbid_tracker_peek_keyframe(const rgbid_tracker* h, int i, rgbid_keyframe_info* info, unsigned char* overlap_mask, unsigned char* colors,
+                                float* depthinv, float* normals) {
+  if (!h || !h->sink) return RGBID_E_INVALID;
+  std::lock_guard<std::mutex> l(h->sink->m);
+  if (i < 0 || i >= (int)h->sink->keyframes.size()) return RGBID_E_INVALID;
+  const KeyframeRecord& k = *h->sink->keyframes[i];
+  if (info) {
+    info->id = k.id; info->rows = k.rows; info->cols = k.cols;
+    for (int j = 0; j < 9; ++j) { info->K[j] = k.K.m[j]; info->R[j] = k.rotation.m[j]; info->R_rel[j] = k.rotation_rel.m[j]; }
+    for (int j = 0; j < 5; ++j) info->kd[j] = k.kd[j];
+    for (int j = 0; j < 3; ++j) { info->t[j] = k.translation[j]; info->t_rel[j] = k.translation_rel[j]; }
+  }
+  if (overlap_mask) std::memcpy(overlap_mask, k.overlap_mask_.data(), k.overlap_mask_.size());
+  if (colors) std::memcpy(colors, k.colors_.data(), k.colors_.size() * sizeof(PixelRGB));
+  if (depthinv) std::memcpy(depthinv, k.depthinv_.data(), k.depthinv_.size() * sizeof(float));
+  if (normals) std::memcpy(normals, k.normals_.data(), k.normals_.size() * sizeof(float));
+  return RGBID_OK;
+}
+int rgbid_tracker_pop_keyframe(rgbid_tracker* h) {
+  if (!h || !h->sink) return RGBID_E_INVALID;
+  std::lock_guard<std::mutex> l(h->sink->m);
+  if (h->sink->keyframes.empty()) return RGBID_E_INVALID;
+  h->sink->keyframes.pop_front();
   return RGBID_OK;
 }
 

@@ -702,6 +702,7 @@ bool VisodoTracker::trackNewFrame() {
     kf_time_accum_ = 0.f;
     Pose pose_new; pose_new.id_ = 0; pose_new.rotation_ = Matrix3ft::Identity(); pose_new.translation_ = Vector3ft::Zero(); pose_new.scale_ = 1.f;
     sink->pushPose(pose_new);
+    sink_back_pose_ = pose_new;
     setSharedCameraPose(pose_new.getAffine());
     last_info_.odo_kf_switched = last_info_.integr_kf_switched = true;
     return false;
@@ -723,8 +724,10 @@ bool VisodoTracker::trackNewFrame() {
       dummy.rotation_ = Matrix3ft::Identity(); dummy.translation_ = Vector3ft::Zero(); dummy.scale_ = 1.f; dummy.covariance_ = zero6();
       for (int i = 0; i < 6; ++i) dummy.covariance_[i * 7] = 100.0;
       sink->pushConstraint(dummy);
-      Pose p; p.id_ = global_time_; p.rotation_ = last_estimated_rotation_; p.translation_ = last_estimated_translation_; p.scale_ = 1.f;
+      sink->backPose(sink_back_pose_);
+      Pose p = sink_back_pose_; p.id_ = global_time_; p.scale_ = 1.f;   // repeats the back-end's last pose (:2077-2078)
       sink->pushPose(p);
+      sink_back_pose_ = p;
       resetOdometryKeyframe();
       resetIntegrationKeyframe();
       saveCurrentImagesAsOdoKeyframes();
@@ -762,8 +765,15 @@ bool VisodoTracker::trackNewFrame() {
     PoseConstraint c; c.ini_id_ = global_time_ - 1; c.end_id_ = global_time_; c.type_ = PoseConstraint::SEQ_ODO;
     c.rotation_ = Rseq; c.translation_ = tseq; c.scale_ = 1.f; c.covariance_ = cseq;
     sink->pushConstraint(c);
-    Pose p; p.id_ = global_time_; p.rotation_ = last_estimated_rotation_; p.translation_ = last_estimated_translation_; p.scale_ = 1.f;
+    // the new pose continues the back-end's last pose, not last_estimated_* (:2161-2162)
+    sink->backPose(sink_back_pose_);
+    Pose p; p.id_ = global_time_; p.scale_ = 1.f;
+    se3::m3_mul(sink_back_pose_.rotation_.m, Rseq.m, p.rotation_.m);
+    double tb[3];
+    se3::m3_mulv(sink_back_pose_.rotation_.m, tseq.v, tb);
+    for (int i = 0; i < 3; ++i) p.translation_[i] = sink_back_pose_.translation_[i] + tb[i];
     sink->pushPose(p);
+    sink_back_pose_ = p;
     setSharedCameraPose(p.getAffine());
   }
   // odometry keyframe :2172-2180

@@ -26,6 +26,13 @@ class TrackerInfo(C.Structure):
                 ("visratio_integr", C.c_float), ("sigma_int", C.c_float), ("sigma_depthinv", C.c_float), ("nu_int", C.c_float), ("nu_depthinv", C.c_float)]
 
 
+class KeyframeInfo(C.Structure):
+    _fields_ = [("id", C.c_int), ("rows", C.c_int), ("cols", C.c_int), ("K", C.c_float * 9), ("kd", C.c_float * 5),
+                ("R", C.c_double * 9), ("t", C.c_double * 3), ("R_rel", C.c_double * 9), ("t_rel", C.c_double * 3)]
+
+
+SEQ_ODO, SEQ_KF = 0, 1
+
 _h = None
 
 
@@ -137,6 +144,49 @@ class Tracker:
         d = np.empty((self.cfg.rows, self.cfg.cols), np.float32); i = np.empty_like(d)
         check(lib().rgbid_tracker_current_maps(self._h, _p(d), _p(i)))
         return d, i
+
+    # ---- the streams handed to the back-end (poses_, constraints_, buffer_keyframes_ of the reference's KeyframeManager) ----
+    def collect(self, keyframe_capacity=100):
+        check(lib().rgbid_tracker_collect(self._h, int(keyframe_capacity)))
+
+    def sink_poses(self):
+        n = lib().rgbid_tracker_num_sink_poses(self._h)
+        ids = np.empty(n, np.int32); Rs = np.empty((n, 9)); ts = np.empty((n, 3))
+        for i in range(n):
+            v = C.c_int()
+            check(lib().rgbid_tracker_get_sink_pose(self._h, i, C.byref(v), _p(Rs[i]), _p(ts[i])))
+            ids[i] = v.value
+        return ids, Rs.reshape(n, 3, 3), ts
+
+    def set_sink_pose(self, i, R, t):
+        R, t = _d(R, 9), _d(t, 3)
+        check(lib().rgbid_tracker_set_sink_pose(self._h, int(i), _p(R), _p(t)))
+
+    def constraints(self):
+        """list of dicts {ini, end, type, R, t, cov}"""
+        out = []
+        for i in range(lib().rgbid_tracker_num_constraints(self._h)):
+            a, b, ty = C.c_int(), C.c_int(), C.c_int()
+            R = np.empty(9); t = np.empty(3); cov = np.empty(36)
+            check(lib().rgbid_tracker_get_constraint(self._h, i, C.byref(a), C.byref(b), C.byref(ty), _p(R), _p(t), _p(cov)))
+            out.append(dict(ini=a.value, end=b.value, type=ty.value, R=R.reshape(3, 3), t=t, cov=cov.reshape(6, 6)))
+        return out
+
+    def num_keyframes(self):
+        return lib().rgbid_tracker_num_keyframes(self._h)
+
+    def peek_keyframe(self, i):
+        rows, cols = self.cfg.rows, self.cfg.cols
+        info = KeyframeInfo()
+        mask = np.empty((rows, cols), np.uint8); colors = np.empty((rows, cols, 3), np.uint8)
+        iD = np.empty((rows, cols), np.float32); nrm = np.empty((3, rows, cols), np.float32)
+        check(lib().rgbid_tracker_peek_keyframe(self._h, int(i), C.byref(info), _p(mask), _p(colors), _p(iD), _p(nrm)))
+        assert (info.rows, info.cols) == (rows, cols)
+        return dict(id=info.id, K=np.array(info.K).reshape(3, 3), kd=np.array(info.kd), R=np.array(info.R).reshape(3, 3), t=np.array(info.t),
+                    R_rel=np.array(info.R_rel).reshape(3, 3), t_rel=np.array(info.t_rel), overlap_mask=mask, colors=colors, depthinv=iD, normals=nrm)
+
+    def pop_keyframe(self):
+        return lib().rgbid_tracker_pop_keyframe(self._h) == 0
 
     def track(self, depth_u16, rgb_u8):
         d = np.ascontiguousarray(depth_u16, np.uint16); r = np.ascontiguousarray(rgb_u8, np.uint8)

@@ -365,3 +365,121 @@ def test_cpp_tracker_load_settings_and_calibration_files(tmp_path):
     Ra, ta = trk.poses(); Rb, tb = orc.poses()
     for k in range(n):
         assert rot_angle(Ra[k], Rb[k]) < 1e-4 and np.linalg.norm(ta[k] - tb[k]) < 1e-4, k
+
+
+def _cmp_backend_streams(trk, orc, rows, cols, K=None, pose_tol=1e-4):
+    K = K or SMALL_K
+    """Pose / PoseConstraint / keyframe streams of the product (collecting TrackerSink through the C-ABI) against the oracle's."""
+    ia, Ra, ta = trk.sink_poses(); ib, Rb, tb = orc.sink_poses()
+    assert np.array_equal(ia, ib)
+    for k in range(len(ib)):
+        assert rot_angle(Ra[k], Rb[k]) < pose_tol and np.linalg.norm(ta[k] - tb[k]) < pose_tol, k
+    ca, cb = trk.constraints(), orc.constraints()
+    assert [(c["ini"], c["end"], c["type"]) for c in ca] == [(c["ini"], c["end"], c["type"]) for c in cb]
+    for a, b in zip(ca, cb):
+        assert rot_angle(a["R"], b["R"]) < pose_tol and np.linalg.norm(a["t"] - b["t"]) < pose_tol, (b["ini"], b["end"], b["type"])
+        sc = np.sqrt(np.outer(np.diag(b["cov"]), np.diag(b["cov"]))) + 1e-30
+        assert (np.abs(a["cov"] - b["cov"]) / sc).max() < 1e-2, (b["ini"], b["end"], b["type"])
+    assert trk.num_keyframes() == orc.num_keyframes()
+    for i in range(orc.num_keyframes()):
+        a, b = trk.peek_keyframe(i), orc.keyframe(i)
+        assert a["id"] == b["id"]
+        assert rot_angle(a["R"], b["R"]) < pose_tol and np.linalg.norm(a["t"] - b["t"]) < pose_tol
+        assert rot_angle(a["R_rel"], b["R_rel"]) < pose_tol and np.linalg.norm(a["t_rel"] - b["t_rel"]) < pose_tol
+        assert np.array_equal(a["colors"], b["colors"])                                   # bytes: exact
+        assert np.count_nonzero(a["overlap_mask"] != b["overlap_mask"]) <= 2e-3 * rows * cols   # pixels at the 0.020 covisibility gate may flip
+        da, db = a["depthinv"], b["depthinv"]
+        assert np.count_nonzero(np.isnan(da) != np.isnan(db)) <= 2e-3 * db.size
+        m = ~np.isnan(da) & ~np.isnan(db)
+        rel = np.abs(da[m] - db[m]) / db[m]
+        assert np.count_nonzero(rel > 1e-4) <= max(16, 5e-3 * rel.size) and np.median(rel) < 1e-5
+        # normals (planes 1,2 are only written where plane 0 is valid, maps.cu:171-176).  They amplify differences of the fused map by
+        # f/w (~260x here), so (1) they must be EXACTLY the normal map of the exported inverse depth (oracle function on the product's map,
+        # a few ulp), and (2) agree with the oracle tracker's normals in angle on all but a few percent of the pixels.
+        na, nb = a["normals"], b["normals"]
+        va, vb = ~np.isnan(na[0]), ~np.isnan(nb[0])
+        assert np.count_nonzero(va != vb) <= 6e-3 * vb.size
+        gx, gy = O.gradient(da)
+        own = O.nmap_gradients(da, gx, gy, K).reshape(3, rows, cols)
+        vo = ~np.isnan(own[0])
+        assert np.count_nonzero(vo != va) <= 4                                             # the 0.1 viewing-angle gate
+        assert np.abs(own[:, vo & va] - na[:, vo & va]).max() < 2e-6
+        both = va & vb
+        ang = np.arccos(np.clip((na[:, both] * nb[:, both]).sum(0), -1, 1))
+        assert np.count_nonzero(ang > 0.05) <= 0.03 * both.sum() and np.median(ang) < 5e-3, (np.median(ang), np.mean(ang > 0.05))
+    return len(cb), orc.num_keyframes()
+
+
+def test_backend_streams_keyframe_switches():
+    """what trackNewFrame hands to the back-end (visodo.cpp:1612-1652, 2033-2038, 2155-2164) -- one Pose per frame, one
+    SEQ_ODO PoseConstraint per tracked frame, and at each integration-keyframe switch the exported keyframe (global + relative pose,
+    overlap mask, colours, fused inverse depth, normals) plus its SEQ_KF constraint -- equals the oracle's on a sequence that switches."""
+    rows, cols, n = 120, 160, 9
+    seq = synth.make_sequence(n, K=SMALL_K, rows=rows, cols=cols, device="cuda", trans_step=(0.01, 0.02), rot_step_deg=(0.5, 1.0))
+    d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+    kw = dict(rows=rows, cols=cols, fx=SMALL_K[0], fy=SMALL_K[1], cx=SMALL_K[2], cy=SMALL_K[3], visratio_odo=0.985, visratio_integr=0.97)
+    trk = host.Tracker(host.default_config(**kw)); trk.collect()
+    orc = O.Tracker(O.default_config(**kw))
+    for k in range(n):
+        assert trk.track(d[k], c[k]) == orc.track(d[k], c[k])
+        if k:
+            ia, ib = trk.last_info(), orc.last_info()
+            assert bool(ia.integr_kf_switched) == bool(ib.integr_kf_switched) and bool(ia.odo_kf_switched) == bool(ib.odo_kf_switched), k
+    n_c, n_kf = _cmp_backend_streams(trk, orc, rows, cols)
+    assert n_kf >= 2 and n_c == (n - 1) + n_kf                 # every switch exported a keyframe and its SEQ_KF constraint
+    info = trk.peek_keyframe(0)
+    assert np.allclose(info["K"], [[SMALL_K[0], 0, SMALL_K[2]], [0, SMALL_K[1], SMALL_K[3]], [0, 0, 1]]) and not info["kd"].any()
+    assert info["id"] == 0 and np.allclose(info["R"], np.eye(3)) and not info["t"].any()
+    # the consumer side of the bounded buffer
+    assert trk.pop_keyframe() and trk.num_keyframes() == n_kf - 1 and trk.peek_keyframe(0)["id"] == orc.keyframe(1)["id"]
+    trk.close(); orc.close()
+
+
+def test_backend_streams_lost_frame_and_full_buffer():
+    """visodo.cpp:2066-2085: the frame that loses tracking pushes a dummy SEQ_ODO constraint (identity, covariance 100 I), a pose that repeats
+    the back-end's last one, and -- through resetIntegrationKeyframe -- the keyframe before the failure with its SEQ_KF constraint.
+    With a full keyframe buffer (try_push fails, :1644) the keyframe AND its constraint are dropped."""
+    n = 8
+    d, c = _blackout_sequence(n, black=(3,))
+    kw = dict(rows=120, cols=160, fx=SMALL_K[0], fy=SMALL_K[1], cx=SMALL_K[2], cy=SMALL_K[3])
+    trk = host.Tracker(host.default_config(**kw)); trk.collect()
+    full = host.Tracker(host.default_config(**kw)); full.collect(keyframe_capacity=1)
+    orc = O.Tracker(O.default_config(**kw))
+    for k in range(n):
+        r = orc.track(d[k], c[k])
+        assert trk.track(d[k], c[k]) == r and full.track(d[k], c[k]) == r
+    _cmp_backend_streams(trk, orc, 120, 160)
+    cons = orc.constraints()
+    dummy = [q for q in cons if q["type"] == O.SEQ_ODO and q["end"] == 3][0]
+    assert np.array_equal(dummy["R"], np.eye(3)) and not dummy["t"].any() and np.array_equal(dummy["cov"], 100 * np.eye(6))
+    ids, Rs, ts = trk.sink_poses()
+    assert np.array_equal(Rs[3], Rs[2]) and np.array_equal(ts[3], ts[2])
+    # bounded buffer: only the first keyframe fits; later switches push neither keyframe nor SEQ_KF constraint
+    assert full.num_keyframes() == 1
+    kf_full = [q for q in full.constraints() if q["type"] == host.SEQ_KF]
+    kf_all = [q for q in trk.constraints() if q["type"] == host.SEQ_KF]
+    assert len(kf_full) == 1 and len(kf_all) == trk.num_keyframes() >= 1
+    assert len([q for q in full.constraints() if q["type"] == host.SEQ_ODO]) == len([q for q in cons if q["type"] == O.SEQ_ODO])
+    trk.close(); full.close(); orc.close()
+
+
+def test_backend_pose_moved_by_optimiser_is_continued():
+    """visodo.cpp:2161-2162: the pose pushed for frame k continues poses_.back() AS THE BACK-END HOLDS IT (a pose-graph optimisation may
+    have moved it), composed with the sequential odometry -- not the tracker's own global estimate."""
+    n = 5
+    seq = synth.make_sequence(n, K=SMALL_K, rows=120, cols=160, device="cuda", **SLOW)
+    d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+    kw = dict(rows=120, cols=160, fx=SMALL_K[0], fy=SMALL_K[1], cx=SMALL_K[2], cy=SMALL_K[3])
+    trk = host.Tracker(host.default_config(**kw)); trk.collect()
+    for k in range(3):
+        trk.track(d[k], c[k])
+    Rm = host.expmap_rot([0.02, -0.01, 0.03]); tm = np.array([0.5, -0.25, 1.0])
+    trk.set_sink_pose(2, Rm, tm)
+    trk.track(d[3], c[3])
+    ids, Rs, ts = trk.sink_poses()
+    q = trk.constraints()[-1]
+    assert (q["ini"], q["end"], q["type"]) == (2, 3, host.SEQ_ODO)
+    assert np.allclose(Rs[3], Rm @ q["R"], atol=1e-12) and np.allclose(ts[3], tm + Rm @ q["t"], atol=1e-12)
+    Rg, tg = trk.poses()                                   # the tracker's own trajectory is untouched
+    assert rot_angle(Rg[3], Rs[3]) > 1e-2
+    trk.close()

@@ -262,3 +262,47 @@ def test_jacobian_rows_vs_finite_differences():
         assert cosang > cos_min, (weighting, cosang, -g, b)
         assert 0.85 < np.linalg.norm(g) / np.linalg.norm(b) < 1.15, (weighting, np.linalg.norm(g) / np.linalg.norm(b))
         assert np.all(np.sign(-g[np.abs(b) > 0.05 * np.abs(b).max()]) == np.sign(b[np.abs(b) > 0.05 * np.abs(b).max()]))
+
+
+def test_backend_streams_are_self_consistent():
+    """f-3 (visodo.cpp:1610-1611, 2128-2129, 2161-2162): known-answer properties of the Pose / PoseConstraint / keyframe streams.
+    Chaining the SEQ_ODO constraints from the identity reproduces the pushed poses; every SEQ_KF constraint equals the chain of the
+    SEQ_ODO constraints between its two ids; the exported keyframe's relative pose is that constraint, its global pose the pose pushed
+    at its id; the keyframe ids chain (end of one = id of the next)."""
+    from rgbid import synth
+    K = (131.25, 131.25, 79.5, 59.5)
+    rows, cols, n = 120, 160, 7
+    seq = synth.make_sequence(n, K=K, rows=rows, cols=cols, trans_step=(0.01, 0.02), rot_step_deg=(0.5, 1.0))
+    d = seq["depth"].numpy().astype(np.uint16); c = seq["rgb"].numpy()
+    trk = O.Tracker(O.default_config(rows=rows, cols=cols, fx=K[0], fy=K[1], cx=K[2], cy=K[3], visratio_odo=0.985, visratio_integr=0.97))
+    for k in range(n):
+        trk.track(d[k], c[k])
+    ids, Rs, ts = trk.sink_poses()
+    assert list(ids) == list(range(n))
+    cons = trk.constraints()
+    odo = {q["end"]: q for q in cons if q["type"] == O.SEQ_ODO}
+    assert sorted(odo) == list(range(1, n)) and all(q["ini"] == q["end"] - 1 for q in odo.values())
+    R, t = np.eye(3), np.zeros(3)
+    for k in range(1, n):
+        t = t + R @ odo[k]["t"]; R = R @ odo[k]["R"]
+        assert np.allclose(Rs[k], R, atol=1e-12) and np.allclose(ts[k], t, atol=1e-12)
+    Rg, tg = trk.poses()                                    # ... and they agree with the tracker's own global trajectory
+    assert np.allclose(Rs, Rg, atol=1e-9) and np.allclose(ts, tg, atol=1e-9)
+    kfc = [q for q in cons if q["type"] == O.SEQ_KF]
+    assert len(kfc) == trk.num_keyframes() >= 2
+    prev_end = 0
+    for i, q in enumerate(kfc):
+        assert q["ini"] == prev_end
+        prev_end = q["end"]
+        R, t = np.eye(3), np.zeros(3)
+        for k in range(q["ini"] + 1, q["end"] + 1):
+            t = t + R @ odo[k]["t"]; R = R @ odo[k]["R"]
+        assert np.allclose(q["R"], R, atol=1e-9) and np.allclose(q["t"], t, atol=1e-9)
+        kf = trk.keyframe(i)
+        assert kf["id"] == q["ini"] and np.array_equal(kf["R_rel"], q["R"]) and np.array_equal(kf["t_rel"], q["t"])
+        assert np.allclose(kf["R"], Rs[kf["id"]], atol=1e-9) and np.allclose(kf["t"], ts[kf["id"]], atol=1e-9)
+        assert np.array_equal(kf["colors"], c[kf["id"]])                   # the keyframe's colours are its frame's
+        ev = np.linalg.eigvalsh(0.5 * (q["cov"] + q["cov"].T))
+        assert ev.min() > 0                                                # a proper covariance
+        assert np.isfinite(kf["depthinv"]).mean() > 0.5 and (i == 0 or kf["overlap_mask"].any())
+    trk.close()
