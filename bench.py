@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--levels", type=int, default=3)
     ap.add_argument("--graph", type=int, default=0, help="replay each step as one hipGraph (roofline events then need a 2nd pass)")
     ap.add_argument("--fused", type=int, default=0)
+    ap.add_argument("--keyframes", type=int, default=2, help="per-lane capacity of the keyframe export ring: the outgoing keyframe is handed to the back-end at every switch, as trackNewFrame does (0 = no export)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--h2d", type=int, default=0, help="also time the same steps with the frames streamed from pinned host memory (PCIe-inclusive rate; never `value`)")
     args = ap.parse_args()
@@ -179,7 +180,7 @@ def main():
     ctx.set_async(1)
     iters = [10, 5, 3] + [3] * (args.levels - 3) if args.levels >= 3 else [10, 5, 3][:args.levels]
     eng = E.Engine(ctx, E.default_config(rows=rows, cols=cols, levels=args.levels, lanes=B, K=K, iters=iters, use_graph=args.graph,
-                                         fused_gn=args.fused, record_capacity=T))
+                                         fused_gn=args.fused, record_capacity=T, keyframe_capacity=args.keyframes))
     eng.step(depth[0], rgb[0])                # frame 0: keyframe creation
     for k in range(1, 1 + W):                 # untimed warm-up steps
         eng.step(depth[k], rgb[k])
@@ -273,10 +274,12 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic TUM-like {cols}x{rows} RGB-D streams (stand-in for TUM fr1/desk: dataset not in image), "
                                    f"{B} lanes/GPU, {args.levels}-level pyramid, GN iterations {iters}, Student-t + sigmaML, pyrFirst, "
-                                   f"keyframe iD fusion on, preview off, full trackNewFrame per lane per step",
+                                   f"keyframe iD fusion + keyframe export on, preview off, full trackNewFrame per lane per step",
                        "lanes_per_gpu": B, "graph": bool(args.graph), "fused_gn": bool(args.fused),
                        "launches_per_step": eng.launches_per_step(), "engine_hbm_bytes": eng.bytes(),
-                       "tracked_frames_rank0": tracked, "expected_rank0": B * Kst},
+                       "tracked_frames_rank0": tracked, "expected_rank0": B * Kst,
+                       "keyframe_export_capacity": args.keyframes,
+                       "keyframes_exported_in_timed_steps_rank0": int(np.count_nonzero(rec["status"] & E.ST_KF_EXPORTED))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(B, rows, cols, args.fused),
                          "kernel": "rgbid::k_build_system<ByLane<SysParams>, true, 0> (level-0 residual + 27-term normal equations)",

@@ -40,6 +40,7 @@ typedef struct rgbid_engine_config {
   int preview;               /* also render the Phong preview (getImage, visodo.cpp:559-580) each step */
   int record_capacity;       /* steps of pose records kept on the device (ring) */
   int warping;               /* RGBID_PYR_FIRST (default) or RGBID_WARP_FIRST: warp at level 0 and pyrDown the warped maps (visodo.cpp:1078-1105) */
+  int keyframe_capacity;     /* keyframes exported to the back-end kept per lane on the device (ring); 0 = no export (see below) */
 } rgbid_engine_config;
 
 #define RGBID_ST_TRACKED    1   /* trackNewFrame returned true */
@@ -47,6 +48,7 @@ typedef struct rgbid_engine_config {
 #define RGBID_ST_ODO_KF     4   /* odometry keyframe was (re)created from this frame */
 #define RGBID_ST_INTEGR_KF  8   /* integration keyframe was (re)created from this frame */
 #define RGBID_ST_FIRST     16   /* first frame of the lane */
+#define RGBID_ST_KF_EXPORTED 32 /* the outgoing integration keyframe went to the export ring this step (cfg.keyframe_capacity > 0) */
 
 typedef struct rgbid_pose_record {
   int frame, status;
@@ -79,6 +81,27 @@ int rgbid_engine_records_dev(rgbid_engine* e, void** ptr, int* capacity);
 int rgbid_engine_preview(rgbid_engine* e, int lane, rgbid_img* preview_u8x3, rgbid_img* keyframe_colors_u8x3);
 int rgbid_engine_keyframe_maps(rgbid_engine* e, int lane, rgbid_img* depthinv, rgbid_img* weight, rgbid_img* vmap,
                                rgbid_img* nmap, rgbid_img* overlap_mask);
+/* ---- keyframe export (resetIntegrationKeyframe, src/visodo.cpp:1610-1652; include/keyframe.h:45-70).  With cfg.keyframe_capacity > 0 every
+ * integration-keyframe switch of a lane (resetIntegrationKeyframe: status bit RGBID_ST_KF_EXPORTED) copies, on the device and
+ * inside the step, what the reference downloads for its back-end into the lane's ring slot (seq % capacity): the header below and one
+ * packed block  overlap mask u8[N] | colours u8[3N] | inverse depth f32[N] | normals f32[3N planar]  (N = rows*cols, the layouts of
+ * Keyframe::overlap_mask_/colors_/depthinv_/normals_).  The frame-to-frame SEQ_ODO constraints and the poses are the pose records. ---- */
+typedef struct rgbid_keyframe_header {
+  int id, end_id;                 /* last_integrKF_index_ and global_time_: the ids of the SEQ_KF constraint (:1646) */
+  int lane, seq;                  /* exporting lane and the running number of its exports */
+  double R[9], t[3];              /* global pose of the exported keyframe */
+  double R_rel[9], t_rel[3];      /* to the next keyframe = the SEQ_KF constraint ... */
+  double cov_rel[36];             /* ... and its covariance (:1617-1629) */
+} rgbid_keyframe_header;
+/* exports so far per lane: counts[lanes] (host).  Synchronises. */
+int rgbid_engine_keyframe_counts(rgbid_engine* e, int* counts);
+/* export `seq` of `lane` to host memory through one pinned staging buffer (a single asynchronous D2H of header + packed block, then a
+ * stream wait).  Any output may be NULL.  RGBID_E_INVALID when seq is not (or no longer) in the lane's ring. */
+int rgbid_engine_read_keyframe(rgbid_engine* e, int lane, int seq, rgbid_keyframe_header* header, unsigned char* overlap_mask,
+                               unsigned char* colors, float* depthinv, float* normals);
+/* device views for zero-copy consumers: header ring [lanes][capacity] and packed blocks [lanes][capacity][20 N bytes] */
+int rgbid_engine_keyframes_dev(rgbid_engine* e, void** headers, void** blocks, size_t* block_bytes);
+
 /* Event timing of the dominant kernel: while profiling is on, every launch of the level-0 (full resolution)
  * residual + normal-equation kernel is bracketed by a hipEvent pair on the context's stream (steps run eagerly,
  * not as a graph).  profile_end synchronises and returns the summed kernel time, the number of launches and the

@@ -38,6 +38,7 @@ struct LaneState {
   double velocity[3], omega[3];
   int global_time, lost, odoKF_count, integrKF_count, last_odoKF_index, last_integrKF_index;
   int gn_failed;
+  int kf_exported;  // keyframes this lane has handed to the export ring
   int status;       // RGBID_ST_* bits of the current step
   float vis_odo, vis_int;
   float rec_sigma_i, rec_sigma_d, rec_nu_i, rec_nu_d;  // scale estimates of the last GN iteration (diagnostics)
@@ -45,6 +46,7 @@ struct LaneState {
 
 struct Flags {  // int[B] each; consumed through LaneMask
   int *track, *first, *gn, *vis, *sw_odo, *sw_int, *overlap, *fuse, *maps;
+  int* kf_slot;  // ring slot the lane exports its outgoing integration keyframe into this step, or -1 (not a LaneMask flag)
 };
 
 struct StepCfg {  // by-value kernel argument with what the scalar kernels need
@@ -53,6 +55,8 @@ struct StepCfg {  // by-value kernel argument with what the scalar kernels need
   float visratio_odo, visratio_integr, delta_t;
   int mestimator, weighting;
   int start_warp_level;  // pyramid level whose intrinsics project the first warp of a frame
+  rgbid_keyframe_header* kf_hdr;  // export ring headers [B][kf_cap] (nullptr: no export)
+  int kf_cap;
 };
 
 __device__ void set_warp_from_pose(const StepCfg& c, int level, const double* R, const double* t, WarpParams& wp) {
@@ -86,8 +90,8 @@ __device__ void reset_odometry_keyframe(LaneState& s) {
   se3::m6_zero(s.delta_cov);
 }
 
-__device__ void reset_integration_keyframe(LaneState& s) {
-  // resetIntegrationKeyframe visodo.cpp:1577-1672 (the Keyframe / PoseConstraint pushes feed the CPU back-end: out of scope)
+__device__ void reset_integration_keyframe(LaneState& s, const StepCfg& c, const Flags& f, int lane) {
+  // resetIntegrationKeyframe visodo.cpp:1577-1672
   s.integrKF_count = 0;
   double J[36], tn[3], S[9];
   se3::m6_zero(J);
@@ -99,6 +103,27 @@ __device__ void reset_integration_keyframe(LaneState& s) {
   se3::m6_JCJt_add(J, s.delta_cov, s.o2i_next_cov);
   for (int i = 0; i < 3; ++i) s.o2i_next_t[i] = tn[i] + s.o2i_next_t[i];
   se3::m3_mul(s.o2i_next_R, s.delta_R, s.o2i_next_R);
+  if (c.kf_hdr) {
+    // the Keyframe record + SEQ_KF constraint for the back-end (:1610-1652): header here, the four images by k_export_keyframe
+    int slot = s.kf_exported % c.kf_cap;
+    rgbid_keyframe_header& h = c.kf_hdr[(size_t)lane * c.kf_cap + slot];
+    double lastT[9], d[3], Jn[36], Jl[36], S2[9], SR[9];
+    se3::m3_T(s.o2i_last_R, lastT);
+    se3::m3_mul(lastT, s.o2i_next_R, h.R_rel);
+    for (int i = 0; i < 3; ++i) d[i] = s.o2i_next_t[i] - s.o2i_last_t[i];
+    se3::m3_mulv(lastT, d, h.t_rel);
+    se3::m6_zero(Jn); se3::m6_set_block(Jn, 0, 0, lastT, 1.0); se3::m6_set_block(Jn, 3, 3, lastT, 1.0);
+    se3::m6_zero(Jl); se3::m6_set_block(Jl, 0, 0, lastT, -1.0); se3::m6_set_block(Jl, 3, 3, lastT, -1.0);
+    se3::skew(h.t_rel, S2); se3::m3_mul(S2, lastT, SR); se3::m6_set_block(Jl, 0, 3, SR, 1.0);
+    se3::m6_zero(h.cov_rel);
+    se3::m6_JCJt_add(Jl, s.o2i_last_cov, h.cov_rel);
+    se3::m6_JCJt_add(Jn, s.o2i_next_cov, h.cov_rel);
+    h.id = s.last_integrKF_index; h.end_id = s.global_time; h.lane = lane; h.seq = s.kf_exported;
+    se3::m3_copy(s.integrKF_R, h.R);
+    for (int i = 0; i < 3; ++i) h.t[i] = s.integrKF_t[i];
+    f.kf_slot[lane] = slot;
+    s.kf_exported++;
+  }
   s.last_integrKF_index = s.global_time;
   se3::m3_copy(s.last_est_R, s.integrKF_R);
   for (int i = 0; i < 3; ++i) s.integrKF_t[i] = s.last_est_t[i];
@@ -116,7 +141,7 @@ __global__ void k_step_begin(LaneState* st, Flags f, WarpParams* wp, SysParams* 
   if (lane >= B) return;
   LaneState& s = st[lane];
   s.status = 0; s.gn_failed = 0; s.vis_odo = 0.f; s.vis_int = 0.f;
-  f.vis[lane] = 0; f.overlap[lane] = 0; f.fuse[lane] = 0;
+  f.vis[lane] = 0; f.overlap[lane] = 0; f.fuse[lane] = 0; f.kf_slot[lane] = -1;
   if (s.global_time == 0) {
     f.first[lane] = 1; f.track[lane] = 0; f.gn[lane] = 0; f.sw_odo[lane] = 1; f.sw_int[lane] = 1; f.maps[lane] = 1;
     s.global_time = 1;
@@ -286,7 +311,7 @@ __global__ __launch_bounds__(256) void k_frame_finish(const double* partials, in
     if (!ok) {
       s.lost = 1;
       reset_odometry_keyframe(s);
-      reset_integration_keyframe(s);
+      reset_integration_keyframe(s, c, f, lane);
       f.sw_odo[lane] = 1; f.sw_int[lane] = 1; f.maps[lane] = 1;
       s.status = RGBID_ST_LOST | RGBID_ST_ODO_KF | RGBID_ST_INTEGR_KF;
       ++s.global_time;
@@ -386,7 +411,7 @@ __global__ void k_decide(LaneState* st, Flags f, const unsigned int* counts, War
   // integration keyframe :2188-2211
   s.vis_int = fminf(ratio(3), ratio(2));
   if ((s.integrKF_count >= c.max_integrKF_count) || (s.vis_int < c.visratio_integr)) {
-    reset_integration_keyframe(s);
+    reset_integration_keyframe(s, c, f, lane);
     f.sw_int[lane] = 1; f.overlap[lane] = 1; f.maps[lane] = 1;
     s.status |= RGBID_ST_INTEGR_KF;
   } else {
@@ -405,6 +430,27 @@ __global__ void k_decide(LaneState* st, Flags f, const unsigned int* counts, War
   ++s.global_time;
 }
 
+// the four downloads of resetIntegrationKeyframe (:1638-1641) as one device-side packed copy into the lane's ring slot:
+// section 0 overlap mask, 1 colours, 2 inverse depth, 3 normals (3*rows rows).  blockIdx = (row chunk, section, lane).
+struct KfSrc { ImgB im[4]; int row_bytes[4]; size_t off[4]; };
+__global__ __launch_bounds__(256) void k_export_keyframe(KfSrc src, char* blocks, size_t block_bytes, int cap, const int* kf_slot) {
+  int lane = blockIdx.z, sec = blockIdx.y;
+  int slot = kf_slot[lane];
+  if (slot < 0) return;
+  const ImgB& im = src.im[sec];
+  const int rb = src.row_bytes[sec];
+  char* dst = blocks + ((size_t)lane * cap + slot) * block_bytes + src.off[sec];
+  for (int y = blockIdx.x; y < im.rows; y += gridDim.x) {
+    const char* sp = row_ptr<char>(im, lane, y);
+    char* dp = dst + (size_t)y * rb;
+    if (((rb & 15) == 0) && ((((uintptr_t)sp | (uintptr_t)dp) & 15) == 0)) {
+      for (int i = threadIdx.x; i < (rb >> 4); i += blockDim.x) reinterpret_cast<float4*>(dp)[i] = reinterpret_cast<const float4*>(sp)[i];
+    } else {
+      for (int i = threadIdx.x; i < rb; i += blockDim.x) dp[i] = sp[i];
+    }
+  }
+}
+
 // getImage (visodo.cpp:559-580): the Phong light sits at the integration keyframe's global position
 __global__ void k_set_light(const LaneState* st, LightP* light, int B) {
   int lane = blockIdx.x * blockDim.x + threadIdx.x;
@@ -412,11 +458,12 @@ __global__ void k_set_light(const LaneState* st, LightP* light, int B) {
   light[lane] = LightP{(float)st[lane].integrKF_t[0], (float)st[lane].integrKF_t[1], (float)st[lane].integrKF_t[2]};
 }
 
-__global__ void k_step_end(LaneState* st, rgbid_pose_record* rec, int B) {
+__global__ void k_step_end(LaneState* st, rgbid_pose_record* rec, const int* kf_slot, int B) {
   int lane = blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= B) return;
   LaneState& s = st[lane];
   rgbid_pose_record& R = rec[lane];
+  if (kf_slot[lane] >= 0) s.status |= RGBID_ST_KF_EXPORTED;
   R.status = s.status;
   R.vis_odo = s.vis_odo; R.vis_integr = s.vis_int;
   if (s.status & RGBID_ST_FIRST) {
@@ -456,6 +503,12 @@ struct rgbid_engine {
   unsigned int* counts = nullptr;
   rgbid_pose_record* records = nullptr;  // [capacity][B]
   rgbid_pose_record* rec_cur = nullptr;  // [B] staging written by the step, copied into the ring
+  // keyframe export ring (cfg.keyframe_capacity > 0)
+  rgbid_keyframe_header* kf_hdr = nullptr;  // [B][cap]
+  char* kf_blocks = nullptr;                // [B][cap][kf_block_bytes]
+  size_t kf_block_bytes = 0;
+  char* kf_staging = nullptr;               // pinned host: header + block
+  int* kf_counts_host = nullptr;            // pinned host [B]
   int steps = 0;
   int launches = 0;
   hipGraphExec_t graph_first = nullptr, graph_next = nullptr;
@@ -546,7 +599,9 @@ void enqueue_save_odo_kf(rgbid_engine* e, hipStream_t s) {
 int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   const rgbid_engine_config& c = e->cfg;
   const int B = e->B, L = e->L;
-  const StepCfg sc = step_cfg(c);
+  StepCfg sc_ = step_cfg(c);
+  sc_.kf_hdr = e->kf_hdr; sc_.kf_cap = c.keyframe_capacity;
+  const StepCfg sc = sc_;
   const IntrP K0{c.fx, c.fy, c.cx, c.cy};
   const int tb = 64, gb = div_up(B, tb);
   e->launches = 0;
@@ -662,6 +717,18 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   }
   // ---- odometry keyframe switch
   enqueue_save_odo_kf(e, s);
+  if (!first && e->kf_hdr) {
+    // the outgoing keyframe leaves for the back-end (:1631-1652) BEFORE computeOverlapping rewrites the mask and the incoming frame
+    // overwrites the maps (:2197-2202): the exported mask is the keyframe's overlap with its predecessor
+    const size_t N = (size_t)c.rows * c.cols;
+    KfSrc ks;
+    ks.im[0] = e->overlap_mask; ks.im[1] = e->colors_integr; ks.im[2] = e->iD_integr; ks.im[3] = e->nmap;
+    ks.row_bytes[0] = c.cols; ks.row_bytes[1] = 3 * c.cols; ks.row_bytes[2] = 4 * c.cols; ks.row_bytes[3] = 4 * c.cols;
+    ks.off[0] = 0; ks.off[1] = N; ks.off[2] = 4 * N; ks.off[3] = 8 * N;
+    hipLaunchKernelGGL(k_export_keyframe, dim3(min(c.rows, 60), 4, B), dim3(256), 0, s, ks, e->kf_blocks, e->kf_block_bytes, c.keyframe_capacity,
+                       f.kf_slot);
+    e->launches++;
+  }
   // ---- integration keyframe: computeOverlapping (:1517-1539) + saveCurrentImagesAsIntegrationKeyframes (:880-893) ...
   if (!first) {
     hipMemsetAsync(e->counts, 0, sizeof(unsigned int) * 2 * B, s);
@@ -688,7 +755,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
     launch_generate_image(s, B, e->vmap, e->nmap, e->colors_integr, e->preview, nullptr, e->light, ALL);
     e->launches++;
   }
-  hipLaunchKernelGGL(k_step_end, dim3(gb), dim3(tb), 0, s, e->state, e->rec_cur, B);
+  hipLaunchKernelGGL(k_step_end, dim3(gb), dim3(tb), 0, s, e->state, e->rec_cur, f.kf_slot, B);
   e->launches++;
   hipError_t err = hipGetLastError();
   return err == hipSuccess ? RGBID_OK : (int)err;
@@ -713,6 +780,7 @@ void rgbid_engine_default_config(rgbid_engine_config* c) {
   c->use_graph = 1; c->fused_gn = 0; c->chi_square_stats = 0; c->preview = 0;
   c->record_capacity = 64;
   c->warping = RGBID_PYR_FIRST;
+  c->keyframe_capacity = 0;
 }
 
 int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_config* cfg) {
@@ -762,6 +830,14 @@ int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_c
   if (!r) r = alloc_dev(e, (void**)&e->counts, sizeof(unsigned int) * 8 * B);
   if (!r) r = alloc_dev(e, (void**)&e->records, sizeof(rgbid_pose_record) * (size_t)cfg->record_capacity * B);
   if (!r) r = alloc_dev(e, (void**)&e->rec_cur, sizeof(rgbid_pose_record) * B);
+  if (!r) r = alloc_dev(e, (void**)&e->flags.kf_slot, sizeof(int) * B);
+  if (!r && cfg->keyframe_capacity > 0) {
+    e->kf_block_bytes = 20 * (size_t)rows * cols;   // u8 mask + 3 u8 colours + f32 inverse depth + 3 f32 normals per pixel
+    r = alloc_dev(e, (void**)&e->kf_hdr, sizeof(rgbid_keyframe_header) * (size_t)cfg->keyframe_capacity * B);
+    if (!r) r = alloc_dev(e, (void**)&e->kf_blocks, e->kf_block_bytes * cfg->keyframe_capacity * B, /*zero=*/false);
+    if (!r && hipHostMalloc((void**)&e->kf_staging, sizeof(rgbid_keyframe_header) + e->kf_block_bytes, hipHostMallocDefault) != hipSuccess) r = RGBID_E_NOMEM;
+    if (!r && hipHostMalloc((void**)&e->kf_counts_host, sizeof(int) * B, hipHostMallocDefault) != hipSuccess) r = RGBID_E_NOMEM;
+  }
   if (!r) { hipError_t he = hipStreamSynchronize(ctx->stream); if (he != hipSuccess) r = (int)he; }
   if (r) { rgbid_engine_destroy(e); return r; }
   *out = e;
@@ -775,6 +851,8 @@ int rgbid_engine_destroy(rgbid_engine* e) {
   if (e->graph_first) hipGraphExecDestroy(e->graph_first);
   if (e->graph_next) hipGraphExecDestroy(e->graph_next);
   for (void* p : e->allocs) hipFree(p);
+  if (e->kf_staging) hipHostFree(e->kf_staging);
+  if (e->kf_counts_host) hipHostFree(e->kf_counts_host);
   for (hipEvent_t ev : e->prof_ev) hipEventDestroy(ev);
   delete e;
   return RGBID_OK;
@@ -853,6 +931,58 @@ int rgbid_engine_records_dev(rgbid_engine* e, void** ptr, int* capacity) {
   if (!e || !ptr) return RGBID_E_INVALID;
   *ptr = e->records;
   if (capacity) *capacity = e->cfg.record_capacity;
+  return RGBID_OK;
+}
+
+int rgbid_engine_keyframe_counts(rgbid_engine* e, int* counts) {
+  if (!e || !counts) return RGBID_E_INVALID;
+  if (!e->kf_hdr) { for (int i = 0; i < e->B; ++i) counts[i] = 0; return RGBID_OK; }
+  hipSetDevice(e->ctx->device);
+  hipError_t he = hipMemcpy2DAsync(e->kf_counts_host, sizeof(int), &e->state[0].kf_exported, sizeof(LaneState), sizeof(int), e->B,
+                                   hipMemcpyDeviceToHost, e->ctx->stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(e->ctx->stream);
+  if (he != hipSuccess) return (int)he;
+  memcpy(counts, e->kf_counts_host, sizeof(int) * e->B);
+  return RGBID_OK;
+}
+
+int rgbid_engine_read_keyframe(rgbid_engine* e, int lane, int seq, rgbid_keyframe_header* header, unsigned char* overlap_mask,
+                               unsigned char* colors, float* depthinv, float* normals) {
+  if (!e || !e->kf_hdr || lane < 0 || lane >= e->B || seq < 0) return RGBID_E_INVALID;
+  hipSetDevice(e->ctx->device);
+  const int cap = e->cfg.keyframe_capacity, slot = seq % cap;
+  hipStream_t s = e->ctx->stream;
+  rgbid_keyframe_header* h = reinterpret_cast<rgbid_keyframe_header*>(e->kf_staging);
+  const bool images = overlap_mask || colors || depthinv || normals;
+  hipError_t he = hipMemcpyAsync(h, e->kf_hdr + (size_t)lane * cap + slot, sizeof(*h), hipMemcpyDeviceToHost, s);
+  if (he == hipSuccess && images)
+    he = hipMemcpyAsync(e->kf_staging + sizeof(*h), e->kf_blocks + ((size_t)lane * cap + slot) * e->kf_block_bytes, e->kf_block_bytes,
+                        hipMemcpyDeviceToHost, s);
+  if (he == hipSuccess) he = hipStreamSynchronize(s);
+  if (he != hipSuccess) return (int)he;
+  int count = 0;
+  {
+    he = hipMemcpyAsync(e->kf_counts_host, &e->state[lane].kf_exported, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (he == hipSuccess) he = hipStreamSynchronize(s);
+    if (he != hipSuccess) return (int)he;
+    count = e->kf_counts_host[0];
+  }
+  if (seq >= count || seq < count - cap || h->seq != seq) return RGBID_E_INVALID;  // not exported yet / already overwritten
+  if (header) *header = *h;
+  const size_t N = (size_t)e->cfg.rows * e->cfg.cols;
+  const char* blk = e->kf_staging + sizeof(*h);
+  if (overlap_mask) memcpy(overlap_mask, blk, N);
+  if (colors) memcpy(colors, blk + N, 3 * N);
+  if (depthinv) memcpy(depthinv, blk + 4 * N, 4 * N);
+  if (normals) memcpy(normals, blk + 8 * N, 12 * N);
+  return RGBID_OK;
+}
+
+int rgbid_engine_keyframes_dev(rgbid_engine* e, void** headers, void** blocks, size_t* block_bytes) {
+  if (!e || !e->kf_hdr) return RGBID_E_INVALID;
+  if (headers) *headers = e->kf_hdr;
+  if (blocks) *blocks = e->kf_blocks;
+  if (block_bytes) *block_bytes = e->kf_block_bytes;
   return RGBID_OK;
 }
 

@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import Img, check
 from .device import Context
 
-ST_TRACKED, ST_LOST, ST_ODO_KF, ST_INTEGR_KF, ST_FIRST = 1, 2, 4, 8, 16
+ST_TRACKED, ST_LOST, ST_ODO_KF, ST_INTEGR_KF, ST_FIRST, ST_KF_EXPORTED = 1, 2, 4, 8, 16, 32
 
 
 class EngineConfig(C.Structure):
@@ -27,8 +27,13 @@ class EngineConfig(C.Structure):
         ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("factor_depth", C.c_float),
         ("interp_mode", C.c_int), ("delta_t", C.c_float),
         ("use_graph", C.c_int), ("fused_gn", C.c_int), ("chi_square_stats", C.c_int), ("preview", C.c_int),
-        ("record_capacity", C.c_int), ("warping", C.c_int),
+        ("record_capacity", C.c_int), ("warping", C.c_int), ("keyframe_capacity", C.c_int),
     ]
+
+
+class KeyframeHeader(C.Structure):
+    _fields_ = [("id", C.c_int), ("end_id", C.c_int), ("lane", C.c_int), ("seq", C.c_int), ("R", C.c_double * 9), ("t", C.c_double * 3),
+                ("R_rel", C.c_double * 9), ("t_rel", C.c_double * 3), ("cov_rel", C.c_double * 36)]
 
 
 RECORD_DTYPE = np.dtype([
@@ -109,6 +114,46 @@ class Engine:
         out = np.zeros((n, self.cfg.lanes), RECORD_DTYPE)
         check(self.L.rgbid_engine_read_records(self._h, int(first_step), int(n), out.ctypes.data_as(C.c_void_p)))
         self._inflight.clear()   # read_records synchronises the stream
+        return out
+
+    def keyframe_counts(self):
+        """keyframes each lane has exported for the back-end so far (cfg.keyframe_capacity > 0)"""
+        out = np.zeros(self.cfg.lanes, np.int32)
+        check(self.L.rgbid_engine_keyframe_counts(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def read_keyframe(self, lane, seq, images=True):
+        """export `seq` of `lane`: header fields + (overlap_mask, colors, depthinv, normals) host arrays"""
+        rows, cols = self.cfg.rows, self.cfg.cols
+        h = KeyframeHeader()
+        mask = np.empty((rows, cols), np.uint8); colors = np.empty((rows, cols, 3), np.uint8)
+        iD = np.empty((rows, cols), np.float32); nrm = np.empty((3, rows, cols), np.float32)
+        ptr = (lambda a: a.ctypes.data_as(C.c_void_p)) if images else (lambda a: None)
+        check(self.L.rgbid_engine_read_keyframe(self._h, int(lane), int(seq), C.byref(h), ptr(mask), ptr(colors), ptr(iD), ptr(nrm)))
+        out = dict(id=h.id, end_id=h.end_id, lane=h.lane, seq=h.seq, R=np.array(h.R).reshape(3, 3), t=np.array(h.t),
+                   R_rel=np.array(h.R_rel).reshape(3, 3), t_rel=np.array(h.t_rel), cov_rel=np.array(h.cov_rel).reshape(6, 6))
+        if images:
+            out.update(overlap_mask=mask, colors=colors, depthinv=iD, normals=nrm)
+        return out
+
+    def keyframe_counts(self):
+        """keyframes each lane has exported for the back-end so far (cfg.keyframe_capacity > 0)"""
+        out = np.zeros(self.cfg.lanes, np.int32)
+        check(self.L.rgbid_engine_keyframe_counts(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def read_keyframe(self, lane, seq, images=True):
+        """export `seq` of `lane`: header fields + (overlap_mask, colors, depthinv, normals) host arrays"""
+        rows, cols = self.cfg.rows, self.cfg.cols
+        h = KeyframeHeader()
+        mask = np.empty((rows, cols), np.uint8); colors = np.empty((rows, cols, 3), np.uint8)
+        iD = np.empty((rows, cols), np.float32); nrm = np.empty((3, rows, cols), np.float32)
+        ptr = (lambda a: a.ctypes.data_as(C.c_void_p)) if images else (lambda a: None)
+        check(self.L.rgbid_engine_read_keyframe(self._h, int(lane), int(seq), C.byref(h), ptr(mask), ptr(colors), ptr(iD), ptr(nrm)))
+        out = dict(id=h.id, end_id=h.end_id, lane=h.lane, seq=h.seq, R=np.array(h.R).reshape(3, 3), t=np.array(h.t),
+                   R_rel=np.array(h.R_rel).reshape(3, 3), t_rel=np.array(h.t_rel), cov_rel=np.array(h.cov_rel).reshape(6, 6))
+        if images:
+            out.update(overlap_mask=mask, colors=colors, depthinv=iD, normals=nrm)
         return out
 
     def profile_begin(self, max_launches):

@@ -371,3 +371,100 @@ def test_engine_preview_and_chi_square_options(ctx):
                 assert diff.max() <= 1 and np.count_nonzero(diff) <= 1e-3 * diff.size, (l, diff.max(), np.count_nonzero(diff))
         eng.close()
     assert recs[0].tobytes() == recs[1].tobytes()
+
+
+def _cmp_keyframe(a, b, K, rows, cols, q=None):
+    """an exported keyframe of the engine (a) against the oracle tracker's (b) [+ the oracle's SEQ_KF constraint q]"""
+    assert a["id"] == b["id"]
+    assert rot_angle(a["R"], b["R"]) < 1e-4 and np.linalg.norm(a["t"] - b["t"]) < 1e-4
+    assert rot_angle(a["R_rel"], b["R_rel"]) < 1e-4 and np.linalg.norm(a["t_rel"] - b["t_rel"]) < 1e-4
+    if q is not None:
+        assert (a["id"], a["end_id"]) == (q["ini"], q["end"])
+        sc = np.sqrt(np.outer(np.diag(q["cov"]), np.diag(q["cov"]))) + 1e-30
+        assert (np.abs(a["cov_rel"] - q["cov"]) / sc).max() < 1e-2
+    assert np.array_equal(a["colors"], b["colors"])
+    assert np.count_nonzero(a["overlap_mask"] != b["overlap_mask"]) <= 2e-3 * rows * cols
+    da, db = a["depthinv"], b["depthinv"]
+    assert np.count_nonzero(np.isnan(da) != np.isnan(db)) <= 2e-3 * db.size
+    m = ~np.isnan(da) & ~np.isnan(db)
+    rel = np.abs(da[m] - db[m]) / db[m]
+    assert np.count_nonzero(rel > 1e-4) <= max(16, 5e-3 * rel.size) and np.median(rel) < 1e-5
+    # normals amplify map differences by f/w: exact against the oracle's normal-map function of the EXPORTED inverse depth (cf. test_gpu_tracker_cpp)
+    na = a["normals"]
+    gx, gy = O.gradient(da)
+    own = O.nmap_gradients(da, gx, gy, K).reshape(3, rows, cols)
+    va, vo = ~np.isnan(na[0]), ~np.isnan(own[0])
+    assert np.count_nonzero(vo != va) <= 4 and np.abs(own[:, vo & va] - na[:, vo & va]).max() < 2e-6
+    vb = ~np.isnan(b["normals"][0])
+    assert np.count_nonzero(va != vb) <= 6e-3 * vb.size
+
+
+@pytest.mark.parametrize("use_graph", [0, 1])
+def test_engine_keyframe_export(ctx, use_graph):
+    """SURVEY 8 f-3 in the batched engine: at every integration-keyframe switch (visodo.cpp:1610-1652) the lane's outgoing keyframe --
+    header (ids, global pose, pose to the next keyframe, SEQ_KF covariance) and the packed overlap mask / colours / fused inverse depth /
+    normals -- lands in the lane's export ring on the device; read back through the pinned staging buffer it equals the oracle's export.
+    One lane loses a frame (the failure path exports too, :2084-2085); lanes switch at different frames."""
+    K = (synth.TUM_K[0] / 4, synth.TUM_K[1] / 4, (synth.TUM_K[2] + 0.5) / 4 - 0.5, (synth.TUM_K[3] + 0.5) / 4 - 0.5)
+    rows, cols, n, B = 120, 160, 9, 3
+    seqs, depth, rgb = make_lanes(B, n, rows, cols, K, trans_step=(0.01, 0.02), rot_step_deg=(0.5, 1.0))
+    depth[4, 2] = 0                                                        # lane 2 loses frame 4
+    cfg_kw = dict(visratio_odo=0.985, visratio_integr=0.97)
+    eng = E.Engine(ctx, E.default_config(rows=rows, cols=cols, lanes=B, K=K, use_graph=use_graph, record_capacity=n, keyframe_capacity=8, **cfg_kw))
+    for k in range(n):
+        eng.step(depth[k], rgb[k])
+    rec = eng.records()
+    counts = eng.keyframe_counts()
+    total = 0
+    for l in range(B):
+        trk = O.Tracker(O.default_config(rows=rows, cols=cols, fx=K[0], fy=K[1], cx=K[2], cy=K[3], **cfg_kw))
+        d = depth[:, l].cpu().numpy().view(np.uint16); c = rgb[:, l].cpu().numpy()
+        exported = 0
+        for k in range(n):
+            trk.track(d[k], c[k])
+            before = exported
+            exported = trk.num_keyframes()
+            assert bool(int(rec[k, l]["status"]) & E.ST_KF_EXPORTED) == (exported > before), (l, k)   # same frames export
+        assert counts[l] == trk.num_keyframes() >= 1
+        kfc = [q for q in trk.constraints() if q["type"] == O.SEQ_KF]
+        for i in range(counts[l]):
+            a = eng.read_keyframe(l, i)
+            assert (a["lane"], a["seq"]) == (l, i)
+            _cmp_keyframe(a, trk.keyframe(i), K, rows, cols, kfc[i])
+            hdr = eng.read_keyframe(l, i, images=False)
+            assert hdr["id"] == a["id"] and np.array_equal(hdr["cov_rel"], a["cov_rel"])
+        total += counts[l]
+        with pytest.raises(Exception):
+            eng.read_keyframe(l, counts[l])                                  # not exported yet
+        trk.close()
+    assert total >= B + 1
+    eng.close()
+
+
+def test_engine_keyframe_ring_wraps_and_off_by_default(ctx):
+    """The export ring keeps the last `keyframe_capacity` keyframes of a lane: older ones are refused, not returned stale; an engine
+    created without a ring exports nothing and says so."""
+    K = (synth.TUM_K[0] / 4, synth.TUM_K[1] / 4, (synth.TUM_K[2] + 0.5) / 4 - 0.5, (synth.TUM_K[3] + 0.5) / 4 - 0.5)
+    rows, cols, n = 120, 160, 7
+    seqs, depth, rgb = make_lanes(1, n, rows, cols, K, trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8))
+    eng = E.Engine(ctx, E.default_config(rows=rows, cols=cols, lanes=1, K=K, record_capacity=n, keyframe_capacity=2, max_integrKF_count=1))
+    trk = O.Tracker(O.default_config(rows=rows, cols=cols, fx=K[0], fy=K[1], cx=K[2], cy=K[3], max_integrKF_count=1))
+    d = depth[:, 0].cpu().numpy().view(np.uint16); c = rgb[:, 0].cpu().numpy()
+    for k in range(n):
+        eng.step(depth[k], rgb[k]); trk.track(d[k], c[k])
+    cnt = int(eng.keyframe_counts()[0])
+    assert cnt == trk.num_keyframes() == n - 1                                # max_integrKF_count = 1: a switch on every tracked frame
+    for i in (cnt - 1, cnt - 2):
+        _cmp_keyframe(eng.read_keyframe(0, i), trk.keyframe(i), K, rows, cols)
+    with pytest.raises(Exception):
+        eng.read_keyframe(0, cnt - 3)                                         # overwritten
+    eng.reset()
+    assert int(eng.keyframe_counts()[0]) == 0
+    eng.close(); trk.close()
+    off = E.Engine(ctx, E.default_config(rows=rows, cols=cols, lanes=1, K=K, record_capacity=n))
+    for k in range(3):
+        off.step(depth[k], rgb[k])
+    assert int(off.keyframe_counts()[0]) == 0
+    with pytest.raises(Exception):
+        off.read_keyframe(0, 0)
+    off.close()
