@@ -18,9 +18,16 @@ struct ImgB {
   int rows, cols;
 };
 
+// The row offset is a 24-bit multiply (rows and the pitch in bytes are < 2^24, a lane's image < 4 GB): the 64-bit y * pitch it replaces
+// compiles to quarter-rate v_mad_u64_u32 / v_mul_lo_u32 pairs, several per pixel in kernels that are VALU-bound.  The lane term is
+// wave-uniform in every kernel (the lane is a block index) and stays on the scalar unit.
 template <typename T>
 __device__ __forceinline__ T* row_ptr(const ImgB& im, int lane, int y) {
+#ifdef RGBID_ROW_PTR_MUL64
   return reinterpret_cast<T*>(static_cast<char*>(im.base) + (size_t)lane * im.lane_stride + (size_t)y * im.pitch);
+#else
+  return reinterpret_cast<T*>(static_cast<char*>(im.base) + (size_t)lane * im.lane_stride + (size_t)__umul24((unsigned)y, (unsigned)im.pitch));
+#endif
 }
 template <typename T>
 __device__ __forceinline__ T& px(const ImgB& im, int lane, int y, int x) { return row_ptr<T>(im, lane, y)[x]; }
@@ -112,6 +119,24 @@ __device__ __forceinline__ float register_pixel(float& xc, float& yc, int xd, in
   float wc = register_pixel_t(xc, yc, xd, yd, wd, P, f);
   if (__builtin_expect(f.failed(), 0)) { RcpIeee s; wc = register_pixel_t(xc, yc, xd, yd, wd, P, s); }
   return wc;
+}
+
+// XCD-aware tile order for the gather kernels.  The hardware places consecutive workgroups (x fastest, then y, then z) on consecutive
+// XCDs, each with its own L2, so spatially adjacent tiles -- whose bilinear / point-sample footprints share cache lines (a 64-px row
+// segment shifted by the warp touches 3 lines instead of 2, plus a halo row) -- would be fetched from HBM once PER XCD.  The tiles are
+// renumbered so that XCD k walks a contiguous slab of (lane, tile row, tile column) space: neighbours then meet in the same L2.
+struct TileId { int bx, by, lane; };
+__device__ __forceinline__ TileId xcd_slab_tile() {
+  const unsigned nx = gridDim.x, ny = gridDim.y, n = nx * ny * gridDim.z;
+  const unsigned L = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+  const unsigned per = n >> 3;
+  const unsigned V = (L < (per << 3)) ? (L & 7u) * per + (L >> 3) : L;   // tail tiles keep their id
+  const unsigned r = V / nx;
+  TileId t;
+  t.bx = (int)(V - r * nx);
+  t.lane = (int)(r / ny);
+  t.by = (int)(r - (unsigned)t.lane * ny);
+  return t;
 }
 
 __device__ __forceinline__ bool in_bounds_rd(float xs, float ys, int cols, int rows) {

@@ -94,12 +94,13 @@ __global__ __launch_bounds__(256) void k_warp_pair(ImgB src_iD, ImgB src_I, ImgB
   if (!m.on(lane)) return;
   int x = blockIdx.x * TX + threadIdx.x;
   const WarpParams P = ps.get(lane);
-  const FMap SD(src_iD, lane), SI(src_I, lane);
+  const FMap SD(src_iD, lane), SI(src_I, lane), G(grid, lane);
+  const FMapW DW(dst_iD, lane), DI(dst_I, lane);
   if (x >= dst_iD.cols) return;
   const int yb = blockIdx.y * (TY * RPB) + threadIdx.y;
   float wv[RPB], w1[RPB], i1[RPB];
 #pragma unroll
-  for (int i = 0; i < RPB; ++i) { int y = yb + i * TY; wv[i] = (y < dst_iD.rows) ? px<float>(grid, lane, y, x) : qnan(); }
+  for (int i = 0; i < RPB; ++i) { int y = yb + i * TY; wv[i] = (y < dst_iD.rows) ? G.at(y, x) : qnan(); }
   RcpFast fast;
 #pragma unroll
   for (int i = 0; i < RPB; ++i) w1[i] = warp_invdepth_px_t(SD, x, yb + i * TY, wv[i], P, fast);
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void k_warp_pair(ImgB src_iD, ImgB src_I, ImgB
 #pragma unroll
   for (int i = 0; i < RPB; ++i) {
     int y = yb + i * TY;
-    if (y < dst_iD.rows) { px<float>(dst_iD, lane, y, x) = w1[i]; px<float>(dst_I, lane, y, x) = i1[i]; }
+    if (y < dst_iD.rows) { DW.at(y, x) = w1[i]; DI.at(y, x) = i1[i]; }
   }
 }
 void launch_warp_pair(hipStream_t s, int B, ImgB src_iD, ImgB src_I, ImgB grid, ImgB dst_iD, ImgB dst_I, const WarpParams* lp, int interp_mode, LaneMask m) {

@@ -17,15 +17,32 @@ __device__ __forceinline__ int cvt_rd(float x) { return __float2int_rd(x); }  //
 __device__ __forceinline__ bool inside(int ix, int iy, int cols, int rows) {
   return ((unsigned)ix < (unsigned)cols) & ((unsigned)iy < (unsigned)rows);  // == !(ix<0 || iy<0 || ix>=cols || iy>=rows)
 }
-__device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi); }
+// clamp(v, lo, hi) as ONE v_med3_i32 (lo <= hi always holds here: hi = rows - 1 or cols - 1 of a non-empty image); the compiler keeps
+// min(max()) as two instructions because it cannot prove the ordering, and the gather kernels are VALU-bound
+__device__ __forceinline__ int clampi(int v, int hi) { int r; asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "v"(hi)); return r; }
+__device__ __forceinline__ int clamp_from_m1(int v, int hi) { int r; asm("v_med3_i32 %0, %1, -1, %2" : "=v"(r) : "v"(v), "v"(hi)); return r; }
 
-// lane-local element view of a float map: base pointer + pitch in elements (32-bit offsets)
+// lane-local element view of a float map: base pointer (wave-uniform: the lane is a block index) + pitch in elements.  Gather addresses
+// are UNSIGNED 32-bit element offsets formed with 24-bit multiplies: v_mul_lo_u32 issues at quarter rate and a signed 64-bit address costs
+// two more VALU instructions per gather, which matters in the VALU-bound warps (rows, pitch < 2^24 elements: asserted by the launchers'
+// image sizes; coordinates are clamped to the image before they get here, so the offsets are non-negative).
 struct FMap {
   const float* base;
   int pitch, rows, cols;
   __device__ __forceinline__ FMap(const ImgB& im, int lane)
       : base(row_ptr<float>(im, lane, 0)), pitch((int)(im.pitch >> 2)), rows(im.rows), cols(im.cols) {}
-  __device__ __forceinline__ float at(int y, int x) const { return base[y * pitch + x]; }
+  __device__ __forceinline__ unsigned row(int y) const { return __umul24((unsigned)y, (unsigned)pitch); }
+  __device__ __forceinline__ float at_off(unsigned off) const { return base[off]; }
+  __device__ __forceinline__ float at(int y, int x) const { return base[row(y) + (unsigned)x]; }
+};
+
+// writable counterpart (kernel outputs): the generic px<T>(im, lane, y, x) forms lane * lane_stride + y * pitch in 64 bits -- two quarter-rate
+// v_mad_u64_u32 per access -- while here the lane base is wave-uniform (scalar unit) and the element offset a 24-bit multiply-add
+struct FMapW {
+  float* base;
+  int pitch;
+  __device__ __forceinline__ FMapW(const ImgB& im, int lane) : base(row_ptr<float>(im, lane, 0)), pitch((int)(im.pitch >> 2)) {}
+  __device__ __forceinline__ float& at(int y, int x) const { return base[__umul24((unsigned)y, (unsigned)pitch) + (unsigned)x]; }
 };
 
 // CUDA linear filtering at unnormalised coordinates with clamp addressing (what tex2D<float> computes for the
@@ -42,11 +59,11 @@ __device__ __forceinline__ float tex2d_linear(const FMap& src, float xs, float y
   // clamp addressing of both taps, i0 -> clamp(i0, 0, n-1), i1 -> clamp(i0 + 1, 0, n-1), evaluated so that the saturated
   // conversions (huge / infinite coordinates give INT_MAX) can never overflow the `+ 1` (signed overflow is undefined behaviour the
   // optimiser may exploit): c = clamp(i0, -1, n-1); i1 = min(c + 1, n-1); i0 = max(c, 0)  -- the same values in 5 instead of 6 ops
-  const int ic = min(max(__float2int_rd(fx0), -1), src.cols - 1), jc = min(max(__float2int_rd(fy0), -1), src.rows - 1);
+  const int ic = clamp_from_m1(__float2int_rd(fx0), src.cols - 1), jc = clamp_from_m1(__float2int_rd(fy0), src.rows - 1);
   const int i1 = min(ic + 1, src.cols - 1), j1 = min(jc + 1, src.rows - 1);
   const int i0 = max(ic, 0), j0 = max(jc, 0);
-  int r0 = j0 * src.pitch, r1 = j1 * src.pitch;
-  float T00 = src.base[r0 + i0], T10 = src.base[r0 + i1], T01 = src.base[r1 + i0], T11 = src.base[r1 + i1];
+  const unsigned r0 = src.row(j0), r1 = src.row(j1);
+  float T00 = src.at_off(r0 + (unsigned)i0), T10 = src.at_off(r0 + (unsigned)i1), T01 = src.at_off(r1 + (unsigned)i0), T11 = src.at_off(r1 + (unsigned)i1);
   float oa = 1.f - a, ob = 1.f - b;
   return (oa * ob) * T00 + (a * ob) * T10 + (oa * b) * T01 + (a * b) * T11;
 }
