@@ -24,6 +24,9 @@ static constexpr float TH_HUBER = 1.345f, TH_TUKEY = 4.685f, STUDENT_DOF = 5.f;
 
 struct SysConst {  // per-thread derived constants
   float inv_fx, inv_fy, cx_f, cy_f, inv_sd, inv_si, be_d, be_i, wmul_d, wmul_i, nud1, nui1;
+  float rho2;            // (sigma_d / sigma_i)^2: the intensity channel's weight relative to the common factor 1 / sigma_d^2
+  float nud1_m, nui1_s;  // (nu_d + 1) * wmul_d  and  (nu_i + 1) * wmul_i * rho2: Student-t numerators with the channel switches folded in
+  float wmul_i_s;        // wmul_i * rho2
 };
 
 __device__ __forceinline__ float m_weight(float e, int mest) {  // computeWeight estimate_VO.cu:141-167
@@ -37,9 +40,15 @@ __device__ __forceinline__ float m_weight(float e, int mest) {  // computeWeight
 }
 
 // One pixel: invDepthConstraint (:214-262) + intensityConstraint (:176-212) + the 27-term update (:408-418).
-// Written as explicit FMAs with shared sub-expressions (about 150 VALU operations per pixel; the naive
-// `acc += a*J + d*J'` costs three operations per term without fast-math reassociation).  Invalid constraints
-// are neutralised by sanitising their INPUTS (so every row entry stays finite) and zeroing their weight: they
+// The kernel is VALU-bound (SQ counters: 95 % VALU-busy while streaming 80 % of the HBM peak), so the row algebra is arranged for the
+// fewest instructions, not for the reference's order of operations (the sums agree with the oracle to ~1e-6 relative; tolerance 2e-5):
+//  * both rows are accumulated WITHOUT their 1/sigma factors: A = (1/sigma_d^2) sum[ w_d nfac Jd Jd' + (w_i rho2) Ji Ji' ] with
+//    rho2 = (sigma_d/sigma_i)^2 folded into the intensity weight's numerator; the common factor multiplies the 27 workgroup sums once
+//    (in double, block_reduce_store) -- 8 multiplies per pixel less;
+//  * nfac = |n^ . p^| with n = g/w0 + e_z: n . p == 1 identically (g_z = -(g_x p_x + g_y p_y)), so nfac = |w0| rsqrt(|m|^2 |p|^2) with
+//    m = n w0 = (g_x, g_y, g_z + w0): no reciprocal of w0, no normal -- 6 operations less (and without the reference's cancellation noise);
+//  * explicit FMAs with shared sub-expressions (the naive `acc += a*J + d*J'` costs three operations per term without reassociation).
+// Invalid constraints are neutralised by sanitising their INPUTS (so every row entry stays finite) and zeroing their weight: they
 // contribute exactly 0, as in the reference (weight 0 times a stale finite row).
 __device__ __forceinline__ void accumulate_pixel(float acc[SYS_TERMS], float px_, float py_, float pp_y, float w0, float i0, float gwx, float gwy,
                                                  float gix, float giy, float w1, float i1, const SysParams& P, const SysConst& C) {
@@ -48,43 +57,46 @@ __device__ __forceinline__ void accumulate_pixel(float acc[SYS_TERMS], float px_
   const bool vi = v0 && !(isnan(i0) || isnan(i1) || isnan(gix) || isnan(giy));
   w0 = v0 ? w0 : 1.f;
   w1 = vd ? w1 : w0; gwx = vd ? gwx : 0.f; gwy = vd ? gwy : 0.f;
-  i1 = vi ? i1 : 0.f; i0 = vi ? i0 : 0.f; gix = vi ? gix : 0.f; giy = vi ? giy : 0.f;
-  // ---- inverse-depth row
+  gix = vi ? gix : 0.f; giy = vi ? giy : 0.f;
+  // ---- inverse-depth row (times sigma_d)
   float gx = gwx * P.fx, gy = gwy * P.fy;
   float gz = -fmaf(gx, px_, gy * py_);
-  float iw0 = __builtin_amdgcn_rcpf(w0);
-  float nx = gx * iw0, ny = gy * iw0, nz = fmaf(gz, iw0, 1.f);
-  float ndp = fmaf(nx, px_, fmaf(ny, py_, nz));                        // n . p   (p.z = 1)
-  float nn = fmaf(nx, nx, fmaf(ny, ny, nz * nz)), pp = fmaf(px_, px_, pp_y);
-  float nfac = fabsf(ndp) * __builtin_amdgcn_rsqf(nn * pp);            // |n^ . p^|
-  float sd0 = w0 * C.inv_sd, gz1 = gz + w1;
+  float gz0 = gz + w0, gz1 = gz + w1;
+  float mm = fmaf(gx, gx, fmaf(gy, gy, gz0 * gz0)), pp = fmaf(px_, px_, pp_y);
+  float nfac = fabsf(w0) * __builtin_amdgcn_rsqf(mm * pp);             // |n^ . p^|
   float Jd[6];
-  Jd[0] = gx * sd0;
-  Jd[1] = gy * sd0;
-  Jd[2] = gz1 * sd0;                                                   // (gz*w0 + w0*w1)/sigma
-  Jd[3] = fmaf(gz1, py_, -gy) * C.inv_sd;                              // -(g' x p)
-  Jd[4] = fmaf(-gz1, px_, gx) * C.inv_sd;
-  Jd[5] = fmaf(gy, px_, -(gx * py_)) * C.inv_sd;
-  float ed = (w0 - w1) * C.inv_sd;
-  float eu = ed - C.be_d;
-  float wd = P.student_nu ? C.nud1 * __builtin_amdgcn_rcpf(fmaf(eu, eu, P.nu_d)) : m_weight(eu, P.mestimator);
-  wd = vd ? wd * C.wmul_d : 0.f;
-  // ---- intensity row
+  Jd[0] = gx * w0;
+  Jd[1] = gy * w0;
+  Jd[2] = gz1 * w0;                                                    // gz*w0 + w0*w1
+  Jd[3] = fmaf(gz1, py_, -gy);                                         // -(g' x p)
+  Jd[4] = fmaf(-gz1, px_, gx);
+  Jd[5] = fmaf(gy, px_, -(gx * py_));
+  float ed = w0 - w1;
+  float eu = fmaf(ed, C.inv_sd, -C.be_d);
+  float wd = P.student_nu ? C.nud1_m * __builtin_amdgcn_rcpf(fmaf(eu, eu, P.nu_d)) : m_weight(eu, P.mestimator) * C.wmul_d;
+  wd = vd ? wd : 0.f;
+  // ---- intensity row (times sigma_i; its weight carries rho2)
   float hx = gix * P.fx, hy = giy * P.fy;
   float hz = -fmaf(hx, px_, hy * py_);
-  float si0 = w0 * C.inv_si;
   float Ji[6];
-  Ji[0] = hx * si0;
-  Ji[1] = hy * si0;
-  Ji[2] = hz * si0;
-  Ji[3] = fmaf(hz, py_, -hy) * C.inv_si;
-  Ji[4] = fmaf(-hz, px_, hx) * C.inv_si;
-  Ji[5] = fmaf(hy, px_, -(hx * py_)) * C.inv_si;
-  float ei = (i0 - i1) * C.inv_si;
-  float eiu = ei - C.be_i;
-  float wi = P.student_nu ? C.nui1 * __builtin_amdgcn_rcpf(fmaf(eiu, eiu, P.nu_i)) : m_weight(eiu, P.mestimator);
-  wi = vi ? wi * C.wmul_i : 0.f;
-  if (P.weighting == 1) wi = fminf(wd, wi);  // MIN_WEIGHT (:403-406)
+  Ji[0] = hx * w0;
+  Ji[1] = hy * w0;
+  Ji[2] = hz * w0;
+  Ji[3] = fmaf(hz, py_, -hy);
+  Ji[4] = fmaf(-hz, px_, hx);
+  Ji[5] = fmaf(hy, px_, -(hx * py_));
+  float ei = i0 - i1;
+  ei = vi ? ei : 0.f;
+  float eiu = fmaf(ei, C.inv_si, -C.be_i);
+  float wi;
+  if (P.weighting == 1) {  // MIN_WEIGHT (:403-406): the minimum is taken on the true weights
+    wi = P.student_nu ? C.nui1 * __builtin_amdgcn_rcpf(fmaf(eiu, eiu, P.nu_i)) : m_weight(eiu, P.mestimator);
+    wi = vi ? wi * C.wmul_i : 0.f;
+    wi = fminf(wd, wi) * C.rho2;
+  } else {
+    wi = P.student_nu ? C.nui1_s * __builtin_amdgcn_rcpf(fmaf(eiu, eiu, P.nu_i)) : m_weight(eiu, P.mestimator) * C.wmul_i_s;
+    wi = vi ? wi : 0.f;
+  }
   float sd = nfac * wd;
   int s = 0;
 #pragma unroll
@@ -105,11 +117,14 @@ __device__ __forceinline__ SysConst make_const(const SysParams& P) {
   C.wmul_d = (float)(1 - (P.weighting == 3));  // PHOT_ONLY
   C.wmul_i = (float)(1 - (P.weighting == 2));  // GEOM_ONLY
   C.nud1 = P.nu_d + 1.f; C.nui1 = P.nu_i + 1.f;
+  const float rho = P.sigma_d / P.sigma_i;
+  C.rho2 = rho * rho;
+  C.nud1_m = C.nud1 * C.wmul_d; C.nui1_s = C.nui1 * C.wmul_i * C.rho2; C.wmul_i_s = C.wmul_i * C.rho2;
   return C;
 }
 
-// workgroup reduction of 27 per-thread fp32 sums -> one row of doubles in `out`
-__device__ __forceinline__ void block_reduce_store(float acc[SYS_TERMS], double* out) {
+// workgroup reduction of 27 per-thread fp32 sums -> one row of doubles in `out`, times the common factor 1 / sigma_d^2
+__device__ __forceinline__ void block_reduce_store(float acc[SYS_TERMS], double* out, double scale) {
   __shared__ float sm[SYS_T / 64][SYS_TERMS + 1];
   int wid = threadIdx.x >> 6, lid = threadIdx.x & 63;
 #pragma unroll
@@ -122,7 +137,7 @@ __device__ __forceinline__ void block_reduce_store(float acc[SYS_TERMS], double*
     double t = 0.0;
 #pragma unroll
     for (int w = 0; w < SYS_T / 64; ++w) t += (double)sm[w][threadIdx.x];
-    out[threadIdx.x] = t;
+    out[threadIdx.x] = t * scale;
   }
 }
 
@@ -178,11 +193,15 @@ __global__ __launch_bounds__(SYS_T) void k_build_system(ImgB W0, ImgB I0, ImgB g
     const int upr = cols >> 2;  // float4 units per row
     const int units = rows * upr;
     int u0 = blk * (SYS_T * upt) + threadIdx.x;
+    // (row, unit-in-row) of the thread's units advance by SYS_T units per step: one division up front, then add-and-wrap
+    const int step_y = SYS_T / upr, step_x = SYS_T - step_y * upr;   // wave-uniform
+    int y = u0 / upr, xu = u0 - y * upr;
 #pragma unroll 1
-    for (int j = 0; j < upt; ++j) {
+    for (int j = 0; j < upt; ++j, y += step_y, xu += step_x) {
+      if (xu >= upr) { xu -= upr; ++y; }
       int u = u0 + j * SYS_T;
       if (u < units) {
-        int y = u / upr, x = (u - y * upr) << 2;
+        const int x = xu << 2;
         float4 w0 = ld_stream4(row_ptr<float>(W0, lane, y) + x);
         float4 i0 = ld_stream4(row_ptr<float>(I0, lane, y) + x);
         float4 a = ld_stream4(row_ptr<float>(gWx, lane, y) + x);
@@ -224,7 +243,7 @@ __global__ __launch_bounds__(SYS_T) void k_build_system(ImgB W0, ImgB I0, ImgB g
       }
     }
   }
-  block_reduce_store(acc, out);
+  block_reduce_store(acc, out, (double)C.inv_sd * (double)C.inv_sd);
 }
 
 static inline bool vec_ok(const ImgB& a) { return ((a.pitch & 15) == 0) && ((a.lane_stride & 15) == 0) && ((((uintptr_t)a.base) & 15) == 0); }
