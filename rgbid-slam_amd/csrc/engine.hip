@@ -745,10 +745,14 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
     launch_warp_invdepth_weighted(s, B, e->iD_curr[0], e->iD_integr, e->warped_iD_integr, e->warped_w, nullptr, e->fuse_wp, M(f.fuse));
     launch_integrate_warped(s, B, e->warped_iD_integr, e->warped_w, e->iD_integr, e->w_integr, M(f.fuse));
   }
-  launch_vmap(s, B, e->iD_integr, e->vmap, K0, M(f.maps));
-  launch_gradient(s, B, e->iD_integr, e->gxD_integr, e->gyD_integr, M(f.maps));
-  launch_nmap_gradients(s, B, e->iD_integr, e->gxD_integr, e->gyD_integr, e->nmap, K0, M(f.maps));
-  e->launches += 5;
+  if (launch_kf_maps(s, B, e->iD_integr, e->vmap, e->nmap, K0, M(f.maps))) {
+    e->launches += 3;
+  } else {
+    launch_vmap(s, B, e->iD_integr, e->vmap, K0, M(f.maps));
+    launch_gradient(s, B, e->iD_integr, e->gxD_integr, e->gyD_integr, M(f.maps));
+    launch_nmap_gradients(s, B, e->iD_integr, e->gxD_integr, e->gyD_integr, e->nmap, K0, M(f.maps));
+    e->launches += 5;
+  }
   if (c.preview) {  // getImage :559-580
     hipLaunchKernelGGL(k_set_light, dim3(gb), dim3(tb), 0, s, e->state, e->light, B);
     e->launches++;

@@ -239,6 +239,78 @@ void launch_gradient(hipStream_t s, int B, ImgB src, ImgB gx, ImgB gy, LaneMask 
   hipLaunchKernelGGL(k_gradient, grid2d(src.cols, src.rows, B), dim3(TX, TY), 0, s, src, gx, gy, m);
 }
 
+// ---- engine: vertex map + Sobel + normal map of the fused keyframe in ONE pass --------------------------------------------------
+// createVMap (maps.cu:63-90), computeGradientDepth (misc.cu:176-220) and createNMapGradients (maps.cu:134-179) run back to back on the
+// same inverse-depth map after every fusion step (visodo.cpp:1758-1762, 886-892).  As three kernels they move 4+12, 4+8 and 12+12 B/px
+// plus the read-modify-write blends of the two 4-px kernels; fused, the map is read once through k_gradient4's rolling 3-row window, the
+// gradients stay in registers, and the six output planes are written with full 16-byte stores (24 B/px).  Per-pixel arithmetic is that
+// of the three kernels, so every value the reference defines is bit-identical.  One deliberate difference: planes 1 and 2 of an INVALID
+// pixel (plane 0 = NaN), which the reference leaves untouched -- i.e. stale or uninitialised -- are written as NaN here.
+__global__ __launch_bounds__(256) void k_kf_maps4(ImgB src, ImgB vmap, ImgB nmap, IntrP k, int cols4, int strips, LaneMask m) {
+  int lane = blockIdx.y;
+  if (!m.on(lane)) return;
+  int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= cols4 * strips) return;
+  const int rows = src.rows;
+  int strip = u / cols4, x = (u - strip * cols4) * 4;
+  int y_begin = strip * GR_ROWS, y_end = min(y_begin + GR_ROWS, rows);
+  int xl = max(x - 1, 0), xr = min(x + 4, src.cols - 1);
+  const float fx_inv = 1.f / k.fx, fy_inv = 1.f / k.fy;
+  float a[6], b[6], c[6];  // rows y-1, y, y+1 (replicated at the border)
+  sobel_load_row(src, lane, max(y_begin - 1, 0), x, xl, xr, a);
+  sobel_load_row(src, lane, y_begin, x, xl, xr, b);
+  for (int y = y_begin; y < y_end; ++y) {
+    sobel_load_row(src, lane, min(y + 1, rows - 1), x, xl, xr, c);
+    float X[4], Y[4], Z[4], N0[4], N1[4], N2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // Sobel / 8 (k_gradient4)
+      float res_hor = 0.f, res_vert = 0.f;
+#pragma unroll
+      for (int dx = -1; dx < 2; dx++)
+#pragma unroll
+        for (int dy = -1; dy < 2; dy++) {
+          float t = dy < 0 ? a[i + 1 + dx] : (dy == 0 ? b[i + 1 + dx] : c[i + 1 + dx]);
+          res_hor += t * (float)(dx * (2 - dy * dy));
+          res_vert += t * (float)(dy * (2 - dx * dx));
+        }
+      const float gx = res_hor / 8.f, gy = res_vert / 8.f;
+      const float w = b[i + 1];
+      const float uu = (float)(x + i), vv = (float)y;
+      // vertex (k_vmap4)
+      const float z = rcp_exact(w);
+      const bool okv = !isnan(z);
+      X[i] = okv ? z * (uu - k.cx) * fx_inv : qnan();
+      Y[i] = z * (vv - k.cy) * fy_inv;     // NaN when invalid
+      Z[i] = z;
+      // normal (k_nmap_grad4)
+      float nx = gx * k.fx, ny = gy * k.fy, nz = gx * (k.cx - uu) + gy * (k.cy - vv) + w;
+      float rn = rcp_exact(sqrtf(nx * nx + ny * ny + nz * nz));
+      nx *= rn; ny *= rn; nz *= rn;
+      float vx = z * (uu - k.cx) * (1.f / k.fx), vy = z * (vv - k.cy) * (1.f / k.fy), vz = z;
+      float rv = rcp_exact(sqrtf(vx * vx + vy * vy + vz * vz));
+      vx *= rv; vy *= rv; vz *= rv;
+      float acos_vn = vx * nx + vy * ny + vz * nz;
+      const bool keep = !(isnan(w) || isnan(gx) || isnan(gy)) && ((double)acos_vn > 0.1);
+      N0[i] = keep ? nx : qnan(); N1[i] = keep ? ny : qnan(); N2[i] = keep ? nz : qnan();
+    }
+    *reinterpret_cast<float4*>(row_ptr<float>(vmap, lane, y) + x) = make_float4(X[0], X[1], X[2], X[3]);
+    *reinterpret_cast<float4*>(row_ptr<float>(vmap, lane, y + rows) + x) = make_float4(Y[0], Y[1], Y[2], Y[3]);
+    *reinterpret_cast<float4*>(row_ptr<float>(vmap, lane, y + 2 * rows) + x) = make_float4(Z[0], Z[1], Z[2], Z[3]);
+    *reinterpret_cast<float4*>(row_ptr<float>(nmap, lane, y) + x) = make_float4(N0[0], N0[1], N0[2], N0[3]);
+    *reinterpret_cast<float4*>(row_ptr<float>(nmap, lane, y + rows) + x) = make_float4(N1[0], N1[1], N1[2], N1[3]);
+    *reinterpret_cast<float4*>(row_ptr<float>(nmap, lane, y + 2 * rows) + x) = make_float4(N2[0], N2[1], N2[2], N2[3]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { a[i] = b[i]; b[i] = c[i]; }
+  }
+}
+bool launch_kf_maps(hipStream_t s, int B, ImgB depthinv, ImgB vmap, ImgB nmap, IntrP k, LaneMask m) {
+  if (!((depthinv.cols % 4 == 0) && vec4_ok(depthinv, 4) && vec4_ok(vmap, 4) && vec4_ok(nmap, 4))) return false;  // caller falls back to the three kernels
+  int cols4 = depthinv.cols / 4, strips = div_up(depthinv.rows, GR_ROWS);
+  hipLaunchKernelGGL(k_kf_maps4, dim3(div_up(cols4 * strips, 256), B), dim3(256), 0, s, depthinv, vmap, nmap, k, cols4, strips, m);
+  return true;
+}
+
 // ---- copies / fills (misc.cu:225-287,327-341) --------------------------------------------------
 // row-wise byte copy: 16 B per thread where the row allows it
 __global__ __launch_bounds__(256) void k_copy_rows(ImgB src, ImgB dst, int row_bytes, LaneMask m) {
