@@ -742,8 +742,12 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   e->launches += 7;
   // ... or integrateImagesIntoKeyframes (:1674-1764)
   if (!first) {
-    launch_warp_invdepth_weighted(s, B, e->iD_curr[0], e->iD_integr, e->warped_iD_integr, e->warped_w, nullptr, e->fuse_wp, M(f.fuse));
-    launch_integrate_warped(s, B, e->warped_iD_integr, e->warped_w, e->iD_integr, e->w_integr, M(f.fuse));
+    if (launch_fuse_frame(s, B, e->iD_curr[0], e->iD_integr, e->w_integr, e->warped_w, e->fuse_wp, M(f.fuse))) {
+      e->launches -= 1;
+    } else {
+      launch_warp_invdepth_weighted(s, B, e->iD_curr[0], e->iD_integr, e->warped_iD_integr, e->warped_w, nullptr, e->fuse_wp, M(f.fuse));
+      launch_integrate_warped(s, B, e->warped_iD_integr, e->warped_w, e->iD_integr, e->w_integr, M(f.fuse));
+    }
   }
   if (launch_kf_maps(s, B, e->iD_integr, e->vmap, e->nmap, K0, M(f.maps))) {
     e->launches += 3;

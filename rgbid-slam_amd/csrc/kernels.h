@@ -54,6 +54,8 @@ void launch_integrate_warped(hipStream_t s, int B, ImgB warped, ImgB wweight, Im
 void launch_visibility(hipStream_t s, int B, ImgB src, ImgB dst, ImgB mask, const WarpParams* host_p, const WarpParams* lane_p, unsigned int* counts, LaneMask m);
 void launch_vmap(hipStream_t s, int B, ImgB depthinv, ImgB vmap, IntrP k, LaneMask m);
 void launch_nmap_gradients(hipStream_t s, int B, ImgB depthinv, ImgB gx, ImgB gy, ImgB nmap, IntrP k, LaneMask m);
+// engine: warpInvDepthWithTrafo3DWeighted + integrateWarpedFrame in one pass (false: layout not 16-byte friendly, nothing launched)
+bool launch_fuse_frame(hipStream_t s, int B, ImgB src, ImgB kf, ImgB kfw, ImgB wweight, const WarpParams* lane_params, LaneMask m);
 // engine: createVMap + computeGradientDepth + createNMapGradients of one map in one pass (false: layout not 16-byte friendly, nothing launched)
 bool launch_kf_maps(hipStream_t s, int B, ImgB depthinv, ImgB vmap, ImgB nmap, IntrP k, LaneMask m);
 void launch_generate_image(hipStream_t s, int B, ImgB vmap, ImgB nmap, ImgB rgb, ImgB dst, const LightP* host_l, const LightP* lane_l, LaneMask m);

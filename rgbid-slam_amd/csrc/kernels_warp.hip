@@ -222,6 +222,57 @@ void launch_integrate_warped(hipStream_t s, int B, ImgB warped, ImgB wweight, Im
   hipLaunchKernelGGL(k_integrate, grid2d(kf.cols, kf.rows, B), dim3(TX, TY), 0, s, warped, wweight, kf, kfw, m);
 }
 
+// ---- engine: integrateImagesIntoKeyframes (visodo.cpp:1674-1764) as ONE kernel -----------------------------------------------------
+// warpInvDepthWithTrafo3DWeighted writes the warped inverse depth + its weight (8 B/px) which integrateWarpedFrame reads straight back
+// together with the keyframe map and weight it updates in place.  Fused, a thread owns 4 consecutive keyframe pixels: the keyframe inverse
+// depth is both the warp's sampling grid and the fusion's w_KF (one 16-byte load), the warped value and weight stay in registers, and the
+// keyframe map / weight are written back once (40 -> ~25 B/px).  The reference's warped-weight buffer is kept EXACTLY as the two kernels
+// leave it -- written only where the weight is positive, stale elsewhere -- because the fusion reads it wherever the warped value is
+// valid, which can (only with infinite intermediates) include pixels whose weight was not stored: full groups store 16 bytes, mixed groups
+// store their pixels one by one, and the stale value is fetched only in that exotic case.  Same device functions, bit-identical maps.
+template <class PS>
+__global__ __launch_bounds__(256) void k_fuse_frame4(ImgB src, ImgB kf, ImgB kfw, ImgB wweight, PS ps, int cols4, int units, LaneMask m) {
+  int lane = blockIdx.y;
+  if (!m.on(lane)) return;
+  const WarpParams P = ps.get(lane);
+  const FMap S(src, lane);
+  for (int u = blockIdx.x * 256 + threadIdx.x; u < units; u += gridDim.x * 256) {
+    int y = u / cols4, x = (u - y * cols4) * 4;
+    float4* kp = reinterpret_cast<float4*>(row_ptr<float>(kf, lane, y) + x);
+    float4* qp = reinterpret_cast<float4*>(row_ptr<float>(kfw, lane, y) + x);
+    float* wp = row_ptr<float>(wweight, lane, y) + x;
+    float4 k4 = *kp, q4 = *qp;
+    float k[4] = {k4.x, k4.y, k4.z, k4.w}, q[4] = {q4.x, q4.y, q4.z, q4.w}, ws[4], wt[4];
+    bool st[4];
+    RcpFast fast;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ws[i] = warp_invdepth_weighted_px_t(S, x + i, y, k[i], P, fast, wt[i], st[i]);
+    if (__builtin_expect(fast.failed(), 0)) {
+      RcpIeee ieee;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ws[i] = warp_invdepth_weighted_px_t(S, x + i, y, k[i], P, ieee, wt[i], st[i]);
+    }
+    const bool all_st = st[0] & st[1] & st[2] & st[3];
+    if (all_st) *reinterpret_cast<float4*>(wp) = make_float4(wt[0], wt[1], wt[2], wt[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float qs = wt[i];
+      if (!st[i]) {
+        if (!isnan(ws[i])) qs = wp[i];   // valid warped value whose weight was not stored: the reference fuses with the stale weight
+      } else if (!all_st) wp[i] = wt[i];
+      integrate_px(ws[i], qs, k[i], q[i]);
+    }
+    *kp = make_float4(k[0], k[1], k[2], k[3]);
+    *qp = make_float4(q[0], q[1], q[2], q[3]);
+  }
+}
+bool launch_fuse_frame(hipStream_t s, int B, ImgB src, ImgB kf, ImgB kfw, ImgB wweight, const WarpParams* lp, LaneMask m) {
+  if (!(vec4_ok(kf) && vec4_ok(kfw) && vec4_ok(wweight))) return false;   // caller falls back to the two kernels
+  int cols4 = kf.cols / 4, units = cols4 * kf.rows;
+  hipLaunchKernelGGL(k_fuse_frame4<ByLane<WarpParams>>, dim3(div_up(units, 256 * 2), B), dim3(256), 0, s, src, kf, kfw, wweight, ByLane<WarpParams>{lp}, cols4, units, m);
+  return true;
+}
+
 // ---- integrateWarpedRGBKernel (:673-708): colour + inverse-depth fusion (bridge function; the reference's only caller,
 // visodo.cpp:1826, sits in a routine trackNewFrame no longer invokes) ---------------------------------------------
 __global__ __launch_bounds__(256) void k_integrate_rgb(ImgB warped, ImgB r_w, ImgB g_w, ImgB b_w, ImgB wweight, ImgB kf, ImgB colors, ImgB kfw, LaneMask m) {
