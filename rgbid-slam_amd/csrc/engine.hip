@@ -705,15 +705,12 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
     e->launches++;
   }
   // ---- covisibility with both keyframes (visodo.cpp:2172-2188), 4 ratio evaluations
-  ImgB none{nullptr, 0, 0, 0, 0};
   if (!first) {
     hipMemsetAsync(e->counts, 0, sizeof(unsigned int) * 8 * B, s);
-    launch_visibility(s, B, e->iD_curr[0], e->iD_kf[0], none, nullptr, e->vis_ab, e->counts + 0 * 2 * B, M(f.vis));
-    launch_visibility(s, B, e->iD_kf[0], e->iD_curr[0], none, nullptr, e->vis_ba, e->counts + 1 * 2 * B, M(f.vis));
-    launch_visibility(s, B, e->iD_curr[0], e->iD_integr_raw, none, nullptr, e->ivis_ab, e->counts + 2 * 2 * B, M(f.vis));
-    launch_visibility(s, B, e->iD_integr_raw, e->iD_curr[0], none, nullptr, e->ivis_ba, e->counts + 3 * 2 * B, M(f.vis));
+    launch_visibility_pair(s, B, e->iD_curr[0], e->iD_kf[0], e->vis_ab, e->vis_ba, e->counts + 0 * 2 * B, e->counts + 1 * 2 * B, M(f.vis));
+    launch_visibility_pair(s, B, e->iD_curr[0], e->iD_integr_raw, e->ivis_ab, e->ivis_ba, e->counts + 2 * 2 * B, e->counts + 3 * 2 * B, M(f.vis));
     hipLaunchKernelGGL(k_decide, dim3(gb), dim3(tb), 0, s, e->state, f, e->counts, e->fuse_wp, sc, B);
-    e->launches += 6;
+    e->launches += 4;
   }
   // ---- odometry keyframe switch
   enqueue_save_odo_kf(e, s);

@@ -52,6 +52,9 @@ void launch_warp_invdepth_weighted(hipStream_t s, int B, ImgB src, ImgB grid, Im
 void launch_integrate_warped(hipStream_t s, int B, ImgB warped, ImgB wweight, ImgB kf, ImgB kfweight, LaneMask m);
 // counts[lane*2+0] = visible, [lane*2+1] = valid (float, must be zeroed by the caller); mask.base nullable
 void launch_visibility(hipStream_t s, int B, ImgB src, ImgB dst, ImgB mask, const WarpParams* host_p, const WarpParams* lane_p, unsigned int* counts, LaneMask m);
+// engine: both directions of computeCovisibility between two maps in one pass (counts_ab: a projected into b; counts_ba: b into a)
+void launch_visibility_pair(hipStream_t s, int B, ImgB a, ImgB b, const WarpParams* p_ab, const WarpParams* p_ba, unsigned int* counts_ab,
+                            unsigned int* counts_ba, LaneMask m);
 void launch_vmap(hipStream_t s, int B, ImgB depthinv, ImgB vmap, IntrP k, LaneMask m);
 void launch_nmap_gradients(hipStream_t s, int B, ImgB depthinv, ImgB gx, ImgB gy, ImgB nmap, IntrP k, LaneMask m);
 // engine: warpInvDepthWithTrafo3DWeighted + integrateWarpedFrame in one pass (false: layout not 16-byte friendly, nothing launched)

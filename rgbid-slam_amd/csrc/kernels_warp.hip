@@ -353,6 +353,63 @@ __global__ __launch_bounds__(256) void k_visibility(ImgB src, ImgB dst, ImgB mas
     if (b) atomicAdd(&counts[2 * lane + 1], b);
   }
 }
+// engine: computeCovisibility (visodo.cpp:1481-1514) evaluates the ratio in BOTH directions between the same two maps.  One kernel does
+// the pair: each thread loads its pixel of A and of B (coalesced) and runs the two projection -> gather -> gate chains side by side --
+// the single-direction kernel is latency-bound (SQ counters: waves parked 75 % of their cycles), so the second independent chain is
+// nearly free, and two of the four launches per frame disappear.  Counters: counts_ab / counts_ba as in k_visibility.
+__device__ __forceinline__ bool visible_px(const FMap& D, int cols, int rows, int x, int y, float w, bool valid, const WarpParams& P) {
+  float xd, yd;
+  float w_dst = register_pixel(xd, yd, x, y, valid ? w : 1.f, P);
+  bool inside_img = (xd > 0) && (xd < (float)(cols - 1)) && (yd > 0) && (yd < (float)(rows - 1));
+  int xi = clampi(__float2int_rn(xd), cols - 1), yi = clampi(__float2int_rn(yd), rows - 1);
+  return valid && inside_img && (fabsf(w_dst - D.at(yi, xi)) < 0.020f);
+}
+__global__ __launch_bounds__(256) void k_visibility_pair(ImgB A, ImgB Bm, const WarpParams* p_ab, const WarpParams* p_ba, unsigned int* counts_ab,
+                                                         unsigned int* counts_ba, LaneMask m) {
+  int lane = blockIdx.z;
+  if (!m.on(lane)) return;
+  __shared__ unsigned int sm[4][4];
+  const WarpParams Pab = p_ab[lane], Pba = p_ba[lane];
+  const FMap FA(A, lane), FB(Bm, lane);
+  const int cols = A.cols, rows = A.rows;
+  const int x = blockIdx.x * TX + threadIdx.x;
+  const bool xin = x < cols;
+  unsigned int n[4] = {0, 0, 0, 0};  // visible a->b, valid a, visible b->a, valid b
+  for (int g = 0; g < VIS_ROWS / (TY * 2); ++g) {
+    const int yb = blockIdx.y * VIS_ROWS + g * (TY * 2) + threadIdx.y;
+    float wa[2], wb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int y = yb + i * TY;
+      bool in = xin && y < rows;
+      wa[i] = in ? FA.at(y, x) : qnan();
+      wb[i] = in ? FB.at(y, x) : qnan();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int y = yb + i * TY;
+      const bool va = !isnan(wa[i]), vb = !isnan(wb[i]);
+      const bool sa = visible_px(FB, cols, rows, x, y, wa[i], va, Pab);
+      const bool sb = visible_px(FA, cols, rows, x, y, wb[i], vb, Pba);
+      n[0] += (unsigned int)__popcll(__ballot(sa)); n[1] += (unsigned int)__popcll(__ballot(va));
+      n[2] += (unsigned int)__popcll(__ballot(sb)); n[3] += (unsigned int)__popcll(__ballot(vb));
+    }
+  }
+  if (threadIdx.x == 0) { for (int k = 0; k < 4; ++k) sm[k][threadIdx.y] = n[k]; }  // one wave per threadIdx.y (TX == 64)
+  __syncthreads();
+  if (threadIdx.x < 4 && threadIdx.y == 0) {
+    const int k = threadIdx.x;
+    unsigned int t = sm[k][0] + sm[k][1] + sm[k][2] + sm[k][3];
+    unsigned int* c = (k < 2 ? counts_ab : counts_ba) + 2 * lane + (k & 1);
+    if (t) atomicAdd(c, t);
+  }
+}
+void launch_visibility_pair(hipStream_t s, int B, ImgB a, ImgB b, const WarpParams* p_ab, const WarpParams* p_ba, unsigned int* counts_ab,
+                            unsigned int* counts_ba, LaneMask m) {
+  dim3 g(div_up(a.cols, TX), div_up(a.rows, VIS_ROWS), B), blk(TX, TY);
+  hipLaunchKernelGGL(k_visibility_pair, g, blk, 0, s, a, b, p_ab, p_ba, counts_ab, counts_ba, m);
+}
+
 void launch_visibility(hipStream_t s, int B, ImgB src, ImgB dst, ImgB mask, const WarpParams* hp, const WarpParams* lp, unsigned int* counts, LaneMask m) {
   dim3 g(div_up(src.cols, TX), div_up(src.rows, VIS_ROWS), B), b(TX, TY);
   if (lp) hipLaunchKernelGGL(k_visibility<ByLane<WarpParams>>, g, b, 0, s, src, dst, mask, ByLane<WarpParams>{lp}, counts, m);
