@@ -485,7 +485,8 @@ struct rgbid_engine {
   std::vector<void*> allocs;
   size_t bytes = 0;
   // images
-  ImgB in_depth, in_rgb;
+  ImgB in_depth, in_rgb;      // pitched staging copies of the inputs (graph replay needs fixed addresses)
+  ImgB cur_depth, cur_rgb;    // what this step reads: the staging copies, or dense views of the caller's buffers (eager mode)
   ImgB iD_curr[MAXL], I_curr[MAXL], iD_kf[MAXL], I_kf[MAXL], iD_kf_f[MAXL], I_kf_f[MAXL];
   ImgB gxI[MAXL], gyI[MAXL], gxD[MAXL], gyD[MAXL], gxI_c[MAXL], gyI_c[MAXL], gxD_c[MAXL], gyD_c[MAXL];
   ImgB wiD[MAXL], wI[MAXL];
@@ -607,7 +608,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   e->launches = 0;
   Flags& f = e->flags;
   // ---- prepareImages (visodo.cpp:760-773)
-  launch_prep_frame(s, B, e->in_depth, e->in_rgb, e->iD_curr[0], e->I_curr[0], e->r_curr, e->g_curr, e->b_curr, c.factor_depth, ALL);
+  launch_prep_frame(s, B, e->cur_depth, e->cur_rgb, e->iD_curr[0], e->I_curr[0], e->r_curr, e->g_curr, e->b_curr, c.factor_depth, ALL);
   e->launches += 1;
   for (int i = 1; i < L; ++i) {
     launch_pyr_down(s, B, e->I_curr[i - 1], e->I_curr[i], ALL);
@@ -733,7 +734,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   }
   launch_copy_bytes(s, B, e->iD_curr[0], e->iD_integr, 4, M(f.sw_int));
   launch_copy_bytes(s, B, e->iD_curr[0], e->iD_integr_raw, 4, M(f.sw_int));
-  launch_copy_bytes(s, B, e->in_rgb, e->colors_integr, 3, M(f.sw_int));
+  launch_copy_bytes(s, B, e->cur_rgb, e->colors_integr, 3, M(f.sw_int));
   launch_fill(s, B, e->w_integr, 4, 0x3f800000u, M(f.sw_int));
   launch_fill(s, B, e->overlap_mask, 1, 0u, M(f.first));  // initialiseDeviceMemory2D(overlap_mask, 0) :2021
   e->launches += 7;
@@ -879,12 +880,20 @@ int rgbid_engine_step(rgbid_engine* e, const void* depth_dev, const void* rgb_de
   hipStream_t s = e->ctx->stream;
   const rgbid_engine_config& c = e->cfg;
   hipSetDevice(e->ctx->device);
-  // stage the inputs into the engine's pitched buffers (dense [lanes][rows][cols] -> pitched lanes)
-  hipError_t he = hipMemcpy2DAsync(e->in_depth.base, e->in_depth.pitch, depth_dev, (size_t)c.cols * 2, (size_t)c.cols * 2, (size_t)c.rows * e->B,
-                                   hipMemcpyDeviceToDevice, s);
-  if (he != hipSuccess) return (int)he;
-  he = hipMemcpy2DAsync(e->in_rgb.base, e->in_rgb.pitch, rgb_dev, (size_t)c.cols * 3, (size_t)c.cols * 3, (size_t)c.rows * e->B, hipMemcpyDeviceToDevice, s);
-  if (he != hipSuccess) return (int)he;
+  // A captured graph bakes its kernel arguments in, so graph replay reads fixed staging buffers (dense [lanes][rows][cols] -> pitched
+  // lanes); eager steps read the caller's dense buffers in place (they must stay valid until the step has run, as documented).
+  hipError_t he = hipSuccess;
+  if (c.use_graph && !e->prof_on) {
+    he = hipMemcpy2DAsync(e->in_depth.base, e->in_depth.pitch, depth_dev, (size_t)c.cols * 2, (size_t)c.cols * 2, (size_t)c.rows * e->B,
+                          hipMemcpyDeviceToDevice, s);
+    if (he != hipSuccess) return (int)he;
+    he = hipMemcpy2DAsync(e->in_rgb.base, e->in_rgb.pitch, rgb_dev, (size_t)c.cols * 3, (size_t)c.cols * 3, (size_t)c.rows * e->B, hipMemcpyDeviceToDevice, s);
+    if (he != hipSuccess) return (int)he;
+    e->cur_depth = e->in_depth; e->cur_rgb = e->in_rgb;
+  } else {
+    e->cur_depth = ImgB{const_cast<void*>(depth_dev), (size_t)c.cols * 2, (size_t)c.rows * c.cols * 2, c.rows, c.cols};
+    e->cur_rgb = ImgB{const_cast<void*>(rgb_dev), (size_t)c.cols * 3, (size_t)c.rows * c.cols * 3, c.rows, c.cols};
+  }
   int r = RGBID_OK;
   const bool first = (e->steps == 0);
   if (c.use_graph && !e->prof_on) {
