@@ -88,6 +88,10 @@ int rgbid_ctx_wait_event(rgbid_ctx* ctx, void* hip_event);
 /* exhaustive device self-test of the kernels' exact reciprocal (csrc/common.h rcp_exact) against IEEE 1.0f/x over all 2^32 float
  * bit patterns; *mismatches must come back 0 */
 int rgbid_selftest_rcp(rgbid_ctx* ctx, unsigned long long* mismatches);
+/* Same kind of proof for the bilateral filter's per-tap division by its range sigma: the 3-instruction sequence (multiply by the rounded
+ * reciprocal + two FMA corrections) is compared with IEEE x / divisor for all 2^32 x; *mismatches counts the x whose short result is
+ * flagged usable and differs (0 for the tracker's two sigmas, 2*0.0025 and 3 -- the only ones the filter uses it for: *used_by_filter). */
+int rgbid_selftest_div_const(rgbid_ctx* ctx, float divisor, unsigned long long* mismatches, int* used_by_filter);
 /* the context's hipStream_t */
 int rgbid_ctx_get_stream(rgbid_ctx* ctx, void** hip_stream);
 /* showGPUMemoryUsage(), src/cuda/misc.cu:526-540 */

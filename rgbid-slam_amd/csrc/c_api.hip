@@ -145,6 +145,17 @@ int rgbid_selftest_rcp(rgbid_ctx* c, unsigned long long* mismatches) {
   RGBID_HIP(hipStreamSynchronize(c->stream));
   return RGBID_OK;
 }
+int rgbid_selftest_div_const(rgbid_ctx* c, float divisor, unsigned long long* mismatches, int* used_by_filter) {
+  if (!c || !mismatches || !(divisor == divisor) || divisor == 0.f) return RGBID_E_INVALID;
+  unsigned long long* d = static_cast<unsigned long long*>(c->small_dev);
+  RGBID_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), c->stream));
+  rgbid::launch_selftest_div_const(c->stream, divisor, d);
+  RGBID_HIP(hipGetLastError());
+  RGBID_HIP(hipMemcpyAsync(mismatches, d, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  RGBID_HIP(hipStreamSynchronize(c->stream));
+  if (used_by_filter) *used_by_filter = rgbid::div_const_verified(divisor) ? 1 : 0;
+  return RGBID_OK;
+}
 int rgbid_ctx_wait_event(rgbid_ctx* c, void* ev) {
   if (!c || !ev) return RGBID_E_INVALID;
   RGBID_HIP(hipStreamWaitEvent(c->stream, (hipEvent_t)ev, 0));

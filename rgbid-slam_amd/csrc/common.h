@@ -98,6 +98,21 @@ __device__ __forceinline__ float rcp_exact(float x) {
   return r;
 }
 
+// x / c for a wave-uniform constant c, with rc = RN(1 / c) computed once on the host: q = RN(x rc), r = x - q c (exact in one FMA),
+// q' = RN(q + r rc) is the correctly rounded quotient (Markstein) -- 3 VALU instructions instead of the 11 of the IEEE division sequence --
+// whenever the result is a normal number and |x| >= 2^-100 (below that the remainder itself underflows).  `ok` reports that (or x == 0, whose quotient is a zero; its SIGN may differ from IEEE's for
+// x = -0, which no caller can observe: the bilateral filter squares it).  rgbid_selftest_div_const verifies the claim for a given c over
+// all 2^32 x on the device; callers use it only for constants that test has passed and recompute with `/` when !ok.
+struct DivConst { float c, rc; };
+__device__ __forceinline__ float div_const_fast(float x, const DivConst& d, bool& ok) {
+  float q = x * d.rc;
+  const float r = __builtin_fmaf(-d.c, q, x);
+  q = __builtin_fmaf(r, d.rc, q);
+  // the remainder x - q c carries bits down to 2^(exponent(x) - 46): it is exact only while that stays above the denormal floor 2^-149
+  ok = (__builtin_amdgcn_classf(q, 0x108) & (fabsf(x) >= 0x1p-100f)) | (x == 0.f);  // 0x108 = negative normal | positive normal
+  return q;
+}
+
 // registerPixel (warping_registration.cu:129-146).  fp contraction is OFF here so the projected
 // coordinates -- and therefore every floor()/rint() pixel selection -- are bit-identical to the
 // scalar oracle; the reciprocals are IEEE-exact (see above).

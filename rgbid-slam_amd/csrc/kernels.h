@@ -43,6 +43,8 @@ void launch_copy_bytes(hipStream_t s, int B, ImgB src, ImgB dst, int elem_size, 
 void launch_fill(hipStream_t s, int B, ImgB dst, int elem_size, uint32_t bits, LaneMask m);
 void launch_pyr_down(hipStream_t s, int B, ImgB src, ImgB dst, LaneMask m);
 void launch_bilateral(hipStream_t s, int B, ImgB src, ImgB dst, float sigma_floatmap, LaneMask m);
+bool div_const_verified(float c);   // constants for which the bilateral filter uses the short exact division
+void launch_selftest_div_const(hipStream_t s, float c, unsigned long long* mismatches_dev);
 
 // ---- warps / fusion / maps (kernels_warp.hip) ---------------------------------------------------
 // params: host pointer (by value) when lane_params == nullptr, else device array [B]

@@ -415,7 +415,35 @@ void launch_pyr_down(hipStream_t s, int B, ImgB src, ImgB dst, LaneMask m) {
 
 // ---- bilateralKernel (filters.cu:86-135), clipped 5x5 window -------------------------------------
 static constexpr int BR = 2;
-__global__ __launch_bounds__(256) void k_bilateral(ImgB src, ImgB dst, float sigma_floatmap, LaneMask m) {
+// the 24 off-centre taps of one pixel.  FAST: the per-tap division by sigma (a constant of the launch) as the 3-instruction exact sequence of
+// common.h div_const_fast; the caller recomputes the pixel with the IEEE division if any tap left its verified range.  The centre tap is the
+// pixel itself: its weight is expf(-0) = 1 exactly, so it enters the sums as (value, 1) without arithmetic -- at its place in the tap order.
+template <bool FAST>
+__device__ __forceinline__ float bilateral_px(const float (*tile)[TX + 2 * BR + 1], int ty, int tx, float value, float sigma_floatmap, DivConst dc, float s2ih,
+                                              bool& all_ok) {
+  float sum1 = 0.f, sum2 = 0.f;
+  // clipped window == full window over the NaN-padded tile (NaN taps are skipped either way); tap order cy outer, cx inner
+#pragma unroll
+  for (int dy = -BR; dy <= BR; ++dy)
+#pragma unroll
+    for (int dx = -BR; dx <= BR; ++dx) {
+      if (dx == 0 && dy == 0) { sum1 = sum1 + value; sum2 = sum2 + 1.f; continue; }   // value * 1.f, weight 1.f
+      const float tmp = tile[ty + dy][tx + dx];
+      const float space2 = (float)(dx * dx + dy * dy);
+      float fn;
+      if (FAST) { bool ok_; fn = div_const_fast(value - tmp, dc, ok_); all_ok = all_ok && (ok_ || isnan(tmp)); }
+      else fn = (value - tmp) / sigma_floatmap;
+      // the source mixes float and double here (`0.5*fn*fn`): keep the double evaluation
+      const double arg = (double)(s2ih * space2) + (0.5 * (double)fn) * (double)fn;
+      const float weight = expf((float)(-arg));
+      const bool ok = !isnan(tmp);
+      sum1 = ok ? sum1 + tmp * weight : sum1;
+      sum2 = ok ? sum2 + weight : sum2;
+    }
+  return sum1 / sum2;
+}
+template <bool FAST>
+__global__ __launch_bounds__(256) void k_bilateral(ImgB src, ImgB dst, float sigma_floatmap, DivConst dc, LaneMask m) {
   int lane = blockIdx.z;
   if (!m.on(lane)) return;
   __shared__ float tile[TY + 2 * BR][TX + 2 * BR + 1];
@@ -439,27 +467,42 @@ __global__ __launch_bounds__(256) void k_bilateral(ImgB src, ImgB dst, float sig
     if (x >= src.cols || y >= src.rows) continue;
     const float value = tile[threadIdx.y + BR][threadIdx.x + BR];
     if (isnan(value)) { px<float>(dst, lane, y, x) = qnan(); continue; }
-    float sum1 = 0.f, sum2 = 0.f;
-    // clipped window == full window over the NaN-padded tile (NaN taps are skipped either way); tap order cy outer, cx inner
-#pragma unroll
-    for (int dy = -BR; dy <= BR; ++dy)
-#pragma unroll
-      for (int dx = -BR; dx <= BR; ++dx) {
-        const float tmp = tile[threadIdx.y + BR + dy][threadIdx.x + BR + dx];
-        const float space2 = (float)(dx * dx + dy * dy);
-        const float fn = (value - tmp) / sigma_floatmap;
-        // the source mixes float and double here (`0.5*fn*fn`): keep the double evaluation
-        const double arg = (double)(s2ih * space2) + (0.5 * (double)fn) * (double)fn;
-        const float weight = expf((float)(-arg));
-        const bool ok = !isnan(tmp);
-        sum1 = ok ? sum1 + tmp * weight : sum1;
-        sum2 = ok ? sum2 + weight : sum2;
-      }
-    px<float>(dst, lane, y, x) = sum1 / sum2;
+    float res;
+    if (FAST) {
+      bool all_ok = true;
+      res = bilateral_px<true>(tile, threadIdx.y + BR, threadIdx.x + BR, value, sigma_floatmap, dc, s2ih, all_ok);
+      if (__builtin_expect(!all_ok, 0)) res = bilateral_px<false>(tile, threadIdx.y + BR, threadIdx.x + BR, value, sigma_floatmap, dc, s2ih, all_ok);
+    } else {
+      bool unused = true;
+      res = bilateral_px<false>(tile, threadIdx.y + BR, threadIdx.x + BR, value, sigma_floatmap, dc, s2ih, unused);
+    }
+    px<float>(dst, lane, y, x) = res;
   }
 }
+// constants whose 3-instruction division has been verified exhaustively (rgbid_selftest_div_const in the GPU tests): the tracker's two
+// range sigmas, 2 * 0.0025 (inverse depth) and 3 (intensity), visodo.cpp:843-844
+bool div_const_verified(float c) { return c == 2.f * 0.0025f || c == 3.f; }
 void launch_bilateral(hipStream_t s, int B, ImgB src, ImgB dst, float sigma_floatmap, LaneMask m) {
-  hipLaunchKernelGGL(k_bilateral, grid2d(src.cols, src.rows, B), dim3(TX, TY), 0, s, src, dst, sigma_floatmap, m);
+  const DivConst dc{sigma_floatmap, 1.0f / sigma_floatmap};
+  if (div_const_verified(sigma_floatmap)) hipLaunchKernelGGL(k_bilateral<true>, grid2d(src.cols, src.rows, B), dim3(TX, TY), 0, s, src, dst, sigma_floatmap, dc, m);
+  else hipLaunchKernelGGL(k_bilateral<false>, grid2d(src.cols, src.rows, B), dim3(TX, TY), 0, s, src, dst, sigma_floatmap, dc, m);
+}
+// exhaustive check of div_const_fast for one constant: every x whose fast result is flagged ok must equal x / c bit for bit (a zero result
+// only up to its sign); returns the number of violations over all 2^32 bit patterns of x
+__global__ __launch_bounds__(256) void k_selftest_div_const(DivConst d, unsigned long long* mismatches) {
+  const uint32_t hi = blockIdx.x;
+  unsigned int bad = 0;
+  for (uint32_t lo = threadIdx.x; lo < 65536u; lo += blockDim.x) {
+    const float x = __uint_as_float((hi << 16) | lo);
+    bool ok;
+    const float a = div_const_fast(x, d, ok), b = x / d.c;
+    const bool same = (__float_as_uint(a) == __float_as_uint(b)) || (a == 0.f && b == 0.f);
+    bad += (ok && !same) ? 1u : 0u;
+  }
+  if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+void launch_selftest_div_const(hipStream_t s, float c, unsigned long long* mismatches_dev) {
+  hipLaunchKernelGGL(k_selftest_div_const, dim3(65536), dim3(256), 0, s, DivConst{c, 1.0f / c}, mismatches_dev);
 }
 
 }  // namespace rgbid

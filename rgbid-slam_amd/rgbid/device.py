@@ -98,6 +98,12 @@ class Context:
         check(self.L.rgbid_selftest_rcp(self._h, C.byref(n)))
         return n.value
 
+    def selftest_div_const(self, divisor):
+        """(mismatches of the bilateral filter's short division by `divisor` vs IEEE over all 2^32 dividends, whether the filter uses it)"""
+        n, used = C.c_ulonglong(1), C.c_int(0)
+        check(self.L.rgbid_selftest_div_const(self._h, C.c_float(divisor), C.byref(n), C.byref(used)))
+        return n.value, bool(used.value)
+
     def stream_handle(self):
         s = C.c_void_p()
         check(self.L.rgbid_ctx_get_stream(self._h, C.byref(s)))

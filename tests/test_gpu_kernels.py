@@ -395,6 +395,18 @@ def test_exact_reciprocal_is_ieee_for_every_float(ctx):
     assert ctx.selftest_rcp() == 0
 
 
+def test_bilateral_short_division_is_ieee_for_every_dividend(ctx):
+    """csrc/common.h div_const_fast (multiply by the rounded reciprocal + two FMA corrections) == x / sigma for ALL 2^32 dividends x, for the two
+    range sigmas the tracker filters with (visodo.cpp:843-844) -- the only divisors the bilateral kernel uses it for; any other divisor takes the
+    IEEE division (and the filter is bit-exact against the oracle either way, test_bilateral / the fuzz suite)."""
+    for sigma in (np.float32(2.0) * np.float32(0.0025), np.float32(3.0)):
+        bad, used = ctx.selftest_div_const(float(sigma))
+        assert used and bad == 0, (sigma, bad)
+    for other in (0.7, 1e-3, 123.456):
+        bad, used = ctx.selftest_div_const(other)
+        assert not used
+
+
 def test_c_abi_rejects_bad_arguments(ctx):
     """error convention of the C-ABI: 0 = ok, negative = RGBID_E_* for bad arguments (never a crash, never a silent no-op)"""
     import ctypes as C
