@@ -723,7 +723,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
     ks.im[0] = e->overlap_mask; ks.im[1] = e->colors_integr; ks.im[2] = e->iD_integr; ks.im[3] = e->nmap;
     ks.row_bytes[0] = c.cols; ks.row_bytes[1] = 3 * c.cols; ks.row_bytes[2] = 4 * c.cols; ks.row_bytes[3] = 4 * c.cols;
     ks.off[0] = 0; ks.off[1] = N; ks.off[2] = 4 * N; ks.off[3] = 8 * N;
-    hipLaunchKernelGGL(k_export_keyframe, dim3(min(c.rows, 60), 4, B), dim3(256), 0, s, ks, e->kf_blocks, e->kf_block_bytes, c.keyframe_capacity,
+    hipLaunchKernelGGL(k_export_keyframe, dim3(min(c.rows, 8), 4, B), dim3(256), 0, s, ks, e->kf_blocks, e->kf_block_bytes, c.keyframe_capacity,
                        f.kf_slot);
     e->launches++;
   }

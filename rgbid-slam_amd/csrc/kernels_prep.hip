@@ -13,7 +13,7 @@ namespace rgbid {
 static constexpr int TX = 64, TY = 4;  // one wave per tile row
 // every workgroup sweeps RPB vertically stacked 64x4 tiles: 4x fewer workgroups to dispatch (a 64-lane 640x480
 // launch is 19 200 instead of 76 800 WGs), which matters most for launches whose lanes are predicated off
-static constexpr int RPB = 4;
+static constexpr int RPB = 16;   // an all-lanes-off 640x480 x 512-lane launch: 54 us of pure workgroup dispatch at 4, 14 us at 16
 
 static inline dim3 grid2d(int cols, int rows, int B) { return dim3(div_up(cols, TX), div_up(rows, TY * RPB), B); }
 #define RGBID_FOR_TILES(y0v) for (int it_ = 0, y0v = blockIdx.y * (TY * RPB); it_ < RPB; ++it_, y0v += TY)
@@ -316,22 +316,23 @@ bool launch_kf_maps(hipStream_t s, int B, ImgB depthinv, ImgB vmap, ImgB nmap, I
 __global__ __launch_bounds__(256) void k_copy_rows(ImgB src, ImgB dst, int row_bytes, LaneMask m) {
   int lane = blockIdx.z;
   if (!m.on(lane)) return;
-  int y = blockIdx.y;
-  const char* sp = row_ptr<char>(src, lane, y);
-  char* dp = row_ptr<char>(dst, lane, y);
-  bool vec = ((row_bytes & 15) == 0) && ((((uintptr_t)sp | (uintptr_t)dp) & 15) == 0);
-  if (vec) {
-    int n16 = row_bytes >> 4;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x)
-      reinterpret_cast<float4*>(dp)[i] = reinterpret_cast<const float4*>(sp)[i];
-  } else {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < row_bytes; i += gridDim.x * blockDim.x) dp[i] = sp[i];
+  for (int y = blockIdx.y; y < src.rows; y += gridDim.y) {   // a workgroup walks rows: few workgroups to dispatch when the lane is off
+    const char* sp = row_ptr<char>(src, lane, y);
+    char* dp = row_ptr<char>(dst, lane, y);
+    bool vec = ((row_bytes & 15) == 0) && ((((uintptr_t)sp | (uintptr_t)dp) & 15) == 0);
+    if (vec) {
+      int n16 = row_bytes >> 4;
+      for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x)
+        reinterpret_cast<float4*>(dp)[i] = reinterpret_cast<const float4*>(sp)[i];
+    } else {
+      for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < row_bytes; i += gridDim.x * blockDim.x) dp[i] = sp[i];
+    }
   }
 }
 void launch_copy_bytes(hipStream_t s, int B, ImgB src, ImgB dst, int elem_size, LaneMask m) {
   int row_bytes = src.cols * elem_size;
   int gx = max(1, min(8, div_up(row_bytes / 16, 256)));
-  hipLaunchKernelGGL(k_copy_rows, dim3(gx, src.rows, B), dim3(256), 0, s, src, dst, row_bytes, m);
+  hipLaunchKernelGGL(k_copy_rows, dim3(gx, min(src.rows, 32), B), dim3(256), 0, s, src, dst, row_bytes, m);
 }
 
 __global__ __launch_bounds__(256) void k_fill(ImgB dst, int elem_size, uint32_t bits, LaneMask m) {
@@ -414,7 +415,7 @@ void launch_pyr_down(hipStream_t s, int B, ImgB src, ImgB dst, LaneMask m) {
 }
 
 // ---- bilateralKernel (filters.cu:86-135), clipped 5x5 window -------------------------------------
-static constexpr int BR = 2;
+static constexpr int BR = 2, BIL_TILES = 4;
 // the 24 off-centre taps of one pixel.  FAST: the per-tap division by sigma (a constant of the launch) as the 3-instruction exact sequence of
 // common.h div_const_fast; the caller recomputes the pixel with the IEEE division if any tap left its verified range.  The centre tap is the
 // pixel itself: its weight is expf(-0) = 1 exactly, so it enters the sums as (value, 1) without arithmetic -- at its place in the tap order.
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256) void k_bilateral(ImgB src, ImgB dst, float sig
   const int x0 = blockIdx.x * TX;
   const float sigma_space = 5.f;
   const float s2ih = (float)(0.5 / (double)(sigma_space * sigma_space));
-  RGBID_FOR_TILES(y0) {
+  for (int it_ = 0, y0 = blockIdx.y * (TY * BIL_TILES); it_ < BIL_TILES; ++it_, y0 += TY) {   // 4 tiles per workgroup: more workgroups balance this heavy kernel better
     if (y0 >= src.rows) break;
     __syncthreads();
     for (int ty = threadIdx.y; ty < TY + 2 * BR; ty += TY) {
@@ -484,8 +485,8 @@ __global__ __launch_bounds__(256) void k_bilateral(ImgB src, ImgB dst, float sig
 bool div_const_verified(float c) { return c == 2.f * 0.0025f || c == 3.f; }
 void launch_bilateral(hipStream_t s, int B, ImgB src, ImgB dst, float sigma_floatmap, LaneMask m) {
   const DivConst dc{sigma_floatmap, 1.0f / sigma_floatmap};
-  if (div_const_verified(sigma_floatmap)) hipLaunchKernelGGL(k_bilateral<true>, grid2d(src.cols, src.rows, B), dim3(TX, TY), 0, s, src, dst, sigma_floatmap, dc, m);
-  else hipLaunchKernelGGL(k_bilateral<false>, grid2d(src.cols, src.rows, B), dim3(TX, TY), 0, s, src, dst, sigma_floatmap, dc, m);
+  if (div_const_verified(sigma_floatmap)) hipLaunchKernelGGL(k_bilateral<true>, dim3(div_up(src.cols, TX), div_up(src.rows, TY * BIL_TILES), B), dim3(TX, TY), 0, s, src, dst, sigma_floatmap, dc, m);
+  else hipLaunchKernelGGL(k_bilateral<false>, dim3(div_up(src.cols, TX), div_up(src.rows, TY * BIL_TILES), B), dim3(TX, TY), 0, s, src, dst, sigma_floatmap, dc, m);
 }
 // exhaustive check of div_const_fast for one constant: every x whose fast result is flagged ok must equal x / c bit for bit (a zero result
 // only up to its sign); returns the number of violations over all 2^32 bit patterns of x

@@ -311,7 +311,7 @@ void launch_integrate_warped_rgb(hipStream_t s, int B, ImgB warped, ImgB r, ImgB
 // Here a workgroup sweeps a 64 x 32 pixel strip; every wave ballots its predicates, popcounts into scalar
 // registers, the four waves meet in LDS and the workgroup issues ONE integer atomic per counter
 // (150 atomics per counter for a 640x480 lane: no contention, exact integer counts).
-static constexpr int VIS_ROWS = 32;
+static constexpr int VIS_ROWS = 96;   // rows per workgroup: the single-direction kernel mostly runs with few lanes on (overlap masks), so few workgroups
 template <class PS>
 __global__ __launch_bounds__(256) void k_visibility(ImgB src, ImgB dst, ImgB mask, PS ps, unsigned int* counts, LaneMask m) {
   int lane = blockIdx.z;
