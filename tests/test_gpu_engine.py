@@ -438,6 +438,11 @@ def test_engine_keyframe_export(ctx, use_graph):
             eng.read_keyframe(l, counts[l])                                  # not exported yet
         trk.close()
     assert total >= B + 1
+    # zero-copy view for device-side consumers
+    import ctypes as C
+    hdr, blk, nbytes = C.c_void_p(), C.c_void_p(), C.c_size_t()
+    assert eng.L.rgbid_engine_keyframes_dev(eng._h, C.byref(hdr), C.byref(blk), C.byref(nbytes)) == 0
+    assert hdr.value and blk.value and nbytes.value == 20 * rows * cols
     eng.close()
 
 
