@@ -207,7 +207,11 @@ int rgbid_memcpy2d_d2d(rgbid_ctx* c, void* d, size_t dp, const void* s, size_t s
 // ---- helpers ------------------------------------------------------------------------------------------
 namespace {
 
-inline bool ok_img(const rgbid_img* i) { return i && i->data && i->rows > 0 && i->cols > 0 && i->step > 0; }
+// rows and the row pitch enter the kernels' 24-bit row-offset multiply (common.h row_ptr): both must stay below 2^24 and the image below 4 GB
+inline bool ok_img(const rgbid_img* i) {
+  return i && i->data && i->rows > 0 && i->cols > 0 && i->step > 0 && i->rows < (1 << 24) && i->step < ((size_t)1 << 24) &&
+         (unsigned long long)i->rows * i->step < (1ull << 32);
+}
 inline bool same_size(const rgbid_img* a, const rgbid_img* b) { return a->rows == b->rows && a->cols == b->cols; }
 inline ImgB B1(const rgbid_img* i) { return ImgB{i->data, i->step, 0, i->rows, i->cols}; }
 inline ImgB Bnull() { return ImgB{nullptr, 0, 0, 0, 0}; }

@@ -795,7 +795,9 @@ int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_c
   if (cfg->rows <= 0 || cfg->cols <= 0 || cfg->levels < 1 || cfg->levels > MAXL || cfg->lanes < 1 || cfg->finest_level < 0 ||
       cfg->finest_level >= cfg->levels || (cfg->rows >> (cfg->levels - 1)) < 4 || (cfg->cols >> (cfg->levels - 1)) < 4 ||
       cfg->record_capacity < 1 || (cfg->warping != RGBID_PYR_FIRST && cfg->warping != RGBID_WARP_FIRST) ||
-      (cfg->warping == RGBID_WARP_FIRST && cfg->fused_gn)) return RGBID_E_INVALID;
+      (cfg->warping == RGBID_WARP_FIRST && cfg->fused_gn) || cfg->keyframe_capacity < 0 ||
+      cfg->cols > (1 << 20) || (unsigned long long)cfg->rows * 3ull * (((unsigned long long)cfg->cols * 4 + 255) & ~255ull) >= (1ull << 32))  // 24-bit row-offset arithmetic (common.h row_ptr)
+    return RGBID_E_INVALID;
   rgbid_engine* e = new (std::nothrow) rgbid_engine();
   if (!e) return RGBID_E_NOMEM;
   e->ctx = ctx; e->cfg = *cfg; e->B = cfg->lanes; e->L = cfg->levels;
