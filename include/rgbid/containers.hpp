@@ -48,6 +48,25 @@ inline rgbid_ctx* default_ctx() {
   return h.c;
 }
 
+// The reference's bridge contract is synchronous: every device function returns the elapsed milliseconds of its kernel (cudaTimer,
+// device.hpp:83-106) after a stream synchronise.  That is the default here too.  A caller that ignores those return values -- the tracker's
+// own frame loop does -- can open a ScopedAsyncBridge on its thread: until it closes, the bridge functions are enqueued without timing
+// events or synchronisation (they return 0.f); uploads / downloads and every function that hands results to host memory (normal equations,
+// sigma / nu, visibility ratios) still complete before returning, on the same per-thread stream, so program order is preserved.
+inline bool& bridge_untimed() { static thread_local bool u = false; return u; }
+struct ScopedAsyncBridge {
+  bool engaged;
+  explicit ScopedAsyncBridge(bool on = true) : engaged(on && !bridge_untimed()) {
+    if (engaged) { bridge_untimed() = true; rgbidSafeCall(rgbid_ctx_set_async(default_ctx(), 1)); }
+  }
+  ~ScopedAsyncBridge() {
+    if (engaged) { rgbid_ctx_sync(default_ctx()); rgbid_ctx_set_async(default_ctx(), 0); bridge_untimed() = false; }
+  }
+  ScopedAsyncBridge(const ScopedAsyncBridge&) = delete;
+  ScopedAsyncBridge& operator=(const ScopedAsyncBridge&) = delete;
+};
+inline float* ms_arg(float& ms) { ms = 0.f; return bridge_untimed() ? nullptr : &ms; }
+
 // kernel_containers.h:54-106
 template <typename T> struct DevPtr {
   typedef T elem_type;

@@ -131,7 +131,7 @@ inline float pyrDownDepth(DepthMapf& src, DepthMapf& dst, int numSMs = -1) {
   (void)numSMs;
   dst.create(src.rows() / 2, src.cols() / 2);  // pyrdown.cu:224
   float ms; rgbid_img a = c_img(src), b = c_img(dst);
-  rgbidSafeCall(rgbid_pyr_down(default_ctx(), &a, &b, &ms));
+  rgbidSafeCall(rgbid_pyr_down(default_ctx(), &a, &b, pcl::gpu::ms_arg(ms)));
   return ms;
 }
 inline float pyrDownIntensity(IntensityMapf& src, IntensityMapf& dst, int numSMs = -1) { return pyrDownDepth(src, dst, numSMs); }
@@ -152,7 +152,7 @@ inline void decomposeRGBInChannels(const PtrStepSz<uchar3>& src, IntensityMapf& 
 inline float computeGradientIntensity(const IntensityMapf& src, GradientMap& dst_hor, GradientMap& dst_vert, int numSMs = -1) {
   (void)numSMs;
   float ms; rgbid_img a = c_img(src), h = c_img(dst_hor), v = c_img(dst_vert);
-  rgbidSafeCall(rgbid_compute_gradient(default_ctx(), &a, &h, &v, &ms));
+  rgbidSafeCall(rgbid_compute_gradient(default_ctx(), &a, &h, &v, pcl::gpu::ms_arg(ms)));
   return ms;
 }
 inline float computeGradientDepth(const DepthMapf& src, GradientMap& dst_hor, GradientMap& dst_vert, int numSMs = -1) {
@@ -191,7 +191,7 @@ inline float computeErrorGridStride(const DeviceArray2D<float>& im1, const Devic
   rgbidSafeCall(rgbid_error_lattice_size(im0.rows(), im0.cols(), Nsamples, &n, 0, 0, 0));
   error.create(n);  // sigmaFuncs.cu:738
   float ms; rgbid_img a = c_img(im1), b = c_img(im0);
-  rgbidSafeCall(rgbid_compute_error(default_ctx(), &a, &b, error.ptr(), Nsamples, &n, &ms));
+  rgbidSafeCall(rgbid_compute_error(default_ctx(), &a, &b, error.ptr(), Nsamples, &n, pcl::gpu::ms_arg(ms)));
   return ms;
 }
 inline float computeChiSquare(DeviceArray<float>& error_int, DeviceArray<float>& error_depth, float sigma_int, float sigma_depth,
@@ -199,25 +199,25 @@ inline float computeChiSquare(DeviceArray<float>& error_int, DeviceArray<float>&
   (void)numSMs;
   float ms;
   rgbidSafeCall(rgbid_chi_square(default_ctx(), error_int.ptr(), error_depth.ptr(), (int)error_depth.size(), sigma_int, sigma_depth, Mestimator,
-                                 &chi_square, &chi_test, &Ndof, &ms));
+                                 &chi_square, &chi_test, &Ndof, pcl::gpu::ms_arg(ms)));
   return ms;
 }
 inline float computeSigmaPdf(DeviceArray<float>& error, float& bias, float& sigma, int Mestimator, int numSMs = -1) {
   (void)numSMs;
   float ms;
-  rgbidSafeCall(rgbid_sigma_pdf(default_ctx(), error.ptr(), (int)error.size(), &bias, &sigma, Mestimator, &ms));
+  rgbidSafeCall(rgbid_sigma_pdf(default_ctx(), error.ptr(), (int)error.size(), &bias, &sigma, Mestimator, pcl::gpu::ms_arg(ms)));
   return ms;
 }
 inline float computeSigmaAndNuStudent(DeviceArray<float>& error, float& bias, float& sigma, float& nu, int Mestimator, int numSMs = -1) {
   (void)numSMs;
   float ms;
-  rgbidSafeCall(rgbid_sigma_nu_student(default_ctx(), error.ptr(), (int)error.size(), &bias, &sigma, &nu, Mestimator, &ms));
+  rgbidSafeCall(rgbid_sigma_nu_student(default_ctx(), error.ptr(), (int)error.size(), &bias, &sigma, &nu, Mestimator, pcl::gpu::ms_arg(ms)));
   return ms;
 }
 inline float computeNuStudent(DeviceArray<float>& error, float& bias, float& sigma, float& nu, int numSMs = -1) {
   (void)numSMs;
   float ms;
-  rgbidSafeCall(rgbid_nu_student(default_ctx(), error.ptr(), (int)error.size(), bias, sigma, &nu, &ms));
+  rgbidSafeCall(rgbid_nu_student(default_ctx(), error.ptr(), (int)error.size(), bias, sigma, &nu, pcl::gpu::ms_arg(ms)));
   return ms;
 }
 
@@ -233,7 +233,7 @@ inline float buildSystemGridStride(const float3 delta_trans, const float3 delta_
   float ms;
   rgbid_img m[8] = {c_img(W0), c_img(I0), c_img(gradW0_x), c_img(gradW0_y), c_img(gradI0_x), c_img(gradI0_y), c_img(W1), c_img(I1)};
   rgbidSafeCall(rgbid_build_system(default_ctx(), &m[0], &m[1], &m[2], &m[3], &m[4], &m[5], &m[6], &m[7], Mestimator, weighting, sigma_depth,
-                                   sigma_int, bias_depth, bias_int, c_intr(intr), matrixA_host, vectorB_host, &ms));
+                                   sigma_int, bias_depth, bias_int, c_intr(intr), matrixA_host, vectorB_host, pcl::gpu::ms_arg(ms)));
   return ms;
 }
 inline float buildSystemStudentNuGridStride(const float3 delta_trans, const float3 delta_rot, const DepthMapf& W0, const IntensityMapf& I0,
@@ -248,7 +248,7 @@ inline float buildSystemStudentNuGridStride(const float3 delta_trans, const floa
   rgbid_img m[8] = {c_img(W0), c_img(I0), c_img(gradW0_x), c_img(gradW0_y), c_img(gradI0_x), c_img(gradI0_y), c_img(W1), c_img(I1)};
   rgbidSafeCall(rgbid_build_system_student_nu(default_ctx(), &m[0], &m[1], &m[2], &m[3], &m[4], &m[5], &m[6], &m[7], Mestimator, weighting,
                                               sigma_depth, sigma_int, bias_depth, bias_int, nu_depth, nu_int, c_intr(intr), matrixA_host,
-                                              vectorB_host, &ms));
+                                              vectorB_host, pcl::gpu::ms_arg(ms)));
   return ms;
 }
 
@@ -257,48 +257,48 @@ inline float warpIntensityWithTrafo3DInvDepth(IntensityMapf& src, IntensityMapf&
                                               float3 inv_translation, const Intr& intr, int numSMs = -1) {
   (void)intr; (void)numSMs;
   float ms; rgbid_img a = c_img(src), b = c_img(dst), c = c_img(depthinv_prev);
-  rgbidSafeCall(rgbid_warp_intensity(default_ctx(), &a, &b, &c, &inv_rotation.data[0].x, &inv_translation.x, &ms));
+  rgbidSafeCall(rgbid_warp_intensity(default_ctx(), &a, &b, &c, &inv_rotation.data[0].x, &inv_translation.x, pcl::gpu::ms_arg(ms)));
   return ms;
 }
 // ---- custom-calibration front-end (src/internal.h:354-356,437-440)
 inline float undistortIntensity(IntensityMapf& src, IntensityMapf& dst, const Intr& intr_int, int numSMs = -1) {
   (void)numSMs;
   float ms; rgbid_img a = c_img(src), b = c_img(dst); rgbid_intr_k k = c_intr_k(intr_int);
-  rgbidSafeCall(rgbid_undistort_intensity(default_ctx(), &a, &b, &k, &ms));
+  rgbidSafeCall(rgbid_undistort_intensity(default_ctx(), &a, &b, &k, pcl::gpu::ms_arg(ms)));
   return ms;
 }
 inline float undistortDepthInv(const DepthMapf& src, DepthMapf& src_corr, DepthMapf& dst, const Intr& intr_depth, const DepthDist& dp, int numSMs = -1) {
   (void)numSMs;
   float ms; rgbid_img a = c_img(src), b = c_img(src_corr), c = c_img(dst); rgbid_intr_k k = c_intr_k(intr_depth); rgbid_depth_dist d = c_depth_dist(dp);
-  rgbidSafeCall(rgbid_undistort_depthinv(default_ctx(), &a, &b, &c, &k, &d, &ms));
+  rgbidSafeCall(rgbid_undistort_depthinv(default_ctx(), &a, &b, &c, &k, &d, pcl::gpu::ms_arg(ms)));
   return ms;
 }
 inline float registerDepthinv(const DepthMapf& src, DepthMapf& intermediate, DeviceArray2D<int>& intermediate_as_int, DepthMapf& dst, const Mat33 dRc_proj,
                               float3 t_dc_proj, const Mat33 cRd_proj, int numSMs = -1) {
   (void)numSMs;
   float ms; rgbid_img a = c_img(src), b = c_img(intermediate), c = c_img(intermediate_as_int), d = c_img(dst);
-  rgbidSafeCall(rgbid_register_depthinv(default_ctx(), &a, &b, &c, &d, &dRc_proj.data[0].x, &t_dc_proj.x, &cRd_proj.data[0].x, &ms));
+  rgbidSafeCall(rgbid_register_depthinv(default_ctx(), &a, &b, &c, &d, &dRc_proj.data[0].x, &t_dc_proj.x, &cRd_proj.data[0].x, pcl::gpu::ms_arg(ms)));
   return ms;
 }
 inline float warpInvDepthWithTrafo3D(DepthMapf& src, DepthMapf& dst, const DepthMapf& depth_prev, Mat33 inv_rotation, float3 inv_translation,
                                      const Intr& intr, int numSMs = -1) {
   (void)intr; (void)numSMs;
   float ms; rgbid_img a = c_img(src), b = c_img(dst), c = c_img(depth_prev);
-  rgbidSafeCall(rgbid_warp_invdepth(default_ctx(), &a, &b, &c, &inv_rotation.data[0].x, &inv_translation.x, &ms));
+  rgbidSafeCall(rgbid_warp_invdepth(default_ctx(), &a, &b, &c, &inv_rotation.data[0].x, &inv_translation.x, pcl::gpu::ms_arg(ms)));
   return ms;
 }
 inline float warpInvDepthWithTrafo3DWeighted(DepthMapf& src, DepthMapf& dst, const DepthMapf& depth_prev, DeviceArray2D<float>& weight_warped,
                                              Mat33 inv_rotation_proj, float3 inv_translation_proj, const Intr& intr, int numSMs = -1) {
   (void)intr; (void)numSMs;
   float ms; rgbid_img a = c_img(src), b = c_img(dst), c = c_img(depth_prev), w = c_img(weight_warped);
-  rgbidSafeCall(rgbid_warp_invdepth_weighted(default_ctx(), &a, &b, &c, &w, &inv_rotation_proj.data[0].x, &inv_translation_proj.x, &ms));
+  rgbidSafeCall(rgbid_warp_invdepth_weighted(default_ctx(), &a, &b, &c, &w, &inv_rotation_proj.data[0].x, &inv_translation_proj.x, pcl::gpu::ms_arg(ms)));
   return ms;
 }
 inline float integrateWarpedFrame(const DepthMapf& warped_depth_src, const DeviceArray2D<float>& warped_weight_src, DepthMapf& depth_dst,
                                   DeviceArray2D<float>& weight_dst, int numSMs = -1) {
   (void)numSMs;
   float ms; rgbid_img a = c_img(warped_depth_src), b = c_img(warped_weight_src), c = c_img(depth_dst), d = c_img(weight_dst);
-  rgbidSafeCall(rgbid_integrate_warped_frame(default_ctx(), &a, &b, &c, &d, &ms));
+  rgbidSafeCall(rgbid_integrate_warped_frame(default_ctx(), &a, &b, &c, &d, pcl::gpu::ms_arg(ms)));
   return ms;
 }
 inline float getVisibilityRatioWithOverlapMask(const DepthMapf& depth_src, const DepthMapf& depth_dst, Mat33 rotation, float3 translation,
@@ -306,14 +306,14 @@ inline float getVisibilityRatioWithOverlapMask(const DepthMapf& depth_src, const
                                                int numSMs = -1) {
   (void)intr; (void)geom_tol; (void)numSMs;
   float ms; rgbid_img a = c_img(depth_src), b = c_img(depth_dst), m = c_img(overlap_mask);
-  rgbidSafeCall(rgbid_visibility_ratio(default_ctx(), &a, &b, &rotation.data[0].x, &translation.x, &m, &visibility_ratio, &ms));
+  rgbidSafeCall(rgbid_visibility_ratio(default_ctx(), &a, &b, &rotation.data[0].x, &translation.x, &m, &visibility_ratio, pcl::gpu::ms_arg(ms)));
   return ms;
 }
 inline float getVisibilityRatio(const DepthMapf& depth_src, const DepthMapf& depth_dst, Mat33 rotation, float3 translation, const Intr& intr,
                                 float& visibility_ratio, float geom_tol, int numSMs = -1) {
   (void)intr; (void)geom_tol; (void)numSMs;
   float ms; rgbid_img a = c_img(depth_src), b = c_img(depth_dst);
-  rgbidSafeCall(rgbid_visibility_ratio(default_ctx(), &a, &b, &rotation.data[0].x, &translation.x, 0, &visibility_ratio, &ms));
+  rgbidSafeCall(rgbid_visibility_ratio(default_ctx(), &a, &b, &rotation.data[0].x, &translation.x, 0, &visibility_ratio, pcl::gpu::ms_arg(ms)));
   return ms;
 }
 
@@ -345,7 +345,7 @@ inline float integrateWarpedRGB(const DepthMapf& depth_warped_src, const Intensi
   (void)numSMs;
   float ms; rgbid_img a = c_img(depth_warped_src), r = c_img(r_warped_src), g = c_img(g_warped_src), b = c_img(b_warped_src), w = c_img(weight_warped_src),
                       d = c_img(depth_dst), c = c_img(colors_dst), q = c_img(weight_dst);
-  rgbidSafeCall(rgbid_integrate_warped_rgb(default_ctx(), &a, &r, &g, &b, &w, &d, &c, &q, &ms));
+  rgbidSafeCall(rgbid_integrate_warped_rgb(default_ctx(), &a, &r, &g, &b, &w, &d, &c, &q, pcl::gpu::ms_arg(ms)));
   return ms;
 }
 // device_cast (src/internal.h:459-463): bit-copy between layout-compatible host and device PODs (e.g. a row-major float[9] -> Mat33)
@@ -371,7 +371,7 @@ inline void generateImageRGB(const MapArr& vmap, const MapArr& nmap, const PtrSt
 inline float bilateralFilter(const DeviceArray2D<float>& src, DeviceArray2D<float>& dst, const float sigma_floatmap, int numSMs = -1) {
   (void)numSMs;
   float ms; rgbid_img a = c_img(src), b = c_img(dst);
-  rgbidSafeCall(rgbid_bilateral_filter(default_ctx(), &a, &b, sigma_floatmap, &ms));
+  rgbidSafeCall(rgbid_bilateral_filter(default_ctx(), &a, &b, sigma_floatmap, pcl::gpu::ms_arg(ms)));
   return ms;
 }
 

@@ -134,6 +134,9 @@ class VisodoTracker {
   void setInterpMode(int mode);                           // RGBID_INTERP_EXACT / RGBID_INTERP_TEX8
   void setPreview(bool on) { preview_ = on; }             // getImage + 3 D2H per frame (visodo.cpp:2237-2241)
   void setVerbose(bool on) { verbose_ = on; }
+  // trackNewFrame ignores the milliseconds its device calls return, so by default it runs them through a ScopedAsyncBridge
+  // (include/rgbid/containers.hpp): no per-call timing events / synchronisation, results identical.  Off = the reference's fully synchronous calls.
+  void setAsyncBridge(bool on) { async_bridge_ = on; }
   const std::vector<Matrix3ft>& odoRotations() const { return odo_rmats_; }
   const std::vector<Vector3ft>& odoTranslations() const { return odo_tvecs_; }
   const std::vector<Matrix6d>& odoCovariances() const { return odo_covmats_; }
@@ -229,6 +232,7 @@ class VisodoTracker {
   Matrix3ft delta_rotation_odo2integr_next_; Vector3ft delta_translation_odo2integr_next_; Matrix6d delta_covariance_odo2integr_next_;
   float kf_time_accum_;
   bool preview_, verbose_;
+  bool async_bridge_ = true;
   LastFrameInfo last_info_;
   TrackerSink null_sink_;
 };

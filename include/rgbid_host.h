@@ -48,6 +48,9 @@ typedef struct rgbid_tracker_info {
 void rgbid_tracker_default_config(rgbid_tracker_config* c);  /* ctor defaults + shipped ini + factory calibration */
 int rgbid_tracker_create(rgbid_tracker** t, const rgbid_tracker_config* c, int device);
 int rgbid_tracker_destroy(rgbid_tracker* t);
+/* 1 (default): trackNewFrame enqueues its device calls without per-call timing events / synchronisation (it ignores the returned milliseconds);
+ * 0: every bridge call synchronous and timed, as in the reference.  Results are identical. */
+int rgbid_tracker_set_async_bridge(rgbid_tracker* t, int on);
 int rgbid_tracker_load_settings(rgbid_tracker* t, const char* ini_path);      /* VisodoTracker::loadSettings */
 int rgbid_tracker_load_calibration(rgbid_tracker* t, const char* ini_path);   /* VisodoTracker::loadCalibration */
 /* uploads depth (u16 mm, rows x cols) and rgb (u8 r,g,b) from HOST memory and runs trackNewFrame */

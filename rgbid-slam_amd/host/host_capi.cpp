@@ -96,6 +96,7 @@ int rgbid_tracker_create(rgbid_tracker** out, const rgbid_tracker_config* c, int
 }
 
 int rgbid_tracker_destroy(rgbid_tracker* h) { if (h) { delete h->t; delete h->sink; delete h; } return RGBID_OK; }
+int rgbid_tracker_set_async_bridge(rgbid_tracker* h, int on) { if (!h) return RGBID_E_INVALID; h->t->setAsyncBridge(on != 0); return RGBID_OK; }
 int rgbid_tracker_load_settings(rgbid_tracker* h, const char* ini_path) {
   if (!h || !ini_path) return RGBID_E_INVALID;
   std::ifstream f(ini_path);

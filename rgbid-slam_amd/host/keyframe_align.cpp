@@ -35,6 +35,7 @@ bool KeyframeAlign::alignKeyframes(const KeyframeImages& a, const KeyframeImages
 
 bool KeyframeAlign::alignKeyframes(const KeyframeImages& kf_ini, const KeyframeImages& kf_end, Matrix3ft& rotation_ini2end,
                                    Vector3ft& translation_ini2end, Matrix6d& covariance_ini2end) {
+  pcl::gpu::ScopedAsyncBridge bridge_scope;   // the returned kernel times are not used here either (see include/rgbid/containers.hpp)
   Intr cam_intrinsics(kf_ini.fx, kf_ini.fy, kf_ini.cx, kf_ini.cy, 0.075f);
   // uploads (:120-129); grey_image_.convertTo(CV_32F)
   depthinvs_ini_[0].upload(kf_ini.depthinv, (size_t)cols_ * 4, rows_, cols_);

@@ -677,6 +677,7 @@ float VisodoTracker::computeInterframeTime() {
 
 bool VisodoTracker::trackNewFrame() {
   // src/visodo.cpp:1967-2247
+  pcl::gpu::ScopedAsyncBridge bridge_scope(async_bridge_);
   delta_t_ = computeInterframeTime();
   kf_time_accum_ += delta_t_;
   double t1 = now_ms();

@@ -136,6 +136,9 @@ class Tracker:
     def load_settings(self, path):
         check(lib().rgbid_tracker_load_settings(self._h, path.encode()))
 
+    def set_async_bridge(self, on):
+        check(lib().rgbid_tracker_set_async_bridge(self._h, int(bool(on))))
+
     def load_calibration(self, path):
         check(lib().rgbid_tracker_load_calibration(self._h, path.encode()))
 

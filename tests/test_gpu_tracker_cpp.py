@@ -483,3 +483,25 @@ def test_backend_pose_moved_by_optimiser_is_continued():
     Rg, tg = trk.poses()                                   # the tracker's own trajectory is untouched
     assert rot_angle(Rg[3], Rs[3]) > 1e-2
     trk.close()
+
+
+def test_async_bridge_changes_nothing_but_the_time():
+    """include/rgbid/containers.hpp ScopedAsyncBridge: trackNewFrame runs its device calls without the per-call timing events and stream
+    synchronisations of the reference's bridge contract (it ignores the returned milliseconds).  Program order on the per-thread stream is
+    unchanged, so every pose, covariance and fused map must be BIT-identical to the fully synchronous run."""
+    n = 7
+    seq = synth.make_sequence(n, K=SMALL_K, rows=120, cols=160, device="cuda", trans_step=(0.01, 0.02), rot_step_deg=(0.5, 1.0))
+    d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+    kw = dict(rows=120, cols=160, fx=SMALL_K[0], fy=SMALL_K[1], cx=SMALL_K[2], cy=SMALL_K[3], visratio_odo=0.985, visratio_integr=0.97)
+    out = []
+    for on in (0, 1):
+        trk = host.Tracker(host.default_config(**kw)); trk.set_async_bridge(on); trk.collect()
+        for k in range(n):
+            trk.track(d[k], c[k])
+        R, t = trk.poses(); oR, ot, ocov = trk.odometry(); kd, kw_ = trk.keyframe_maps()
+        nrm = trk.peek_keyframe(0)["normals"]
+        nrm[:, np.isnan(nrm[0])] = np.nan          # planes 1, 2 of an invalid normal are untouched (uninitialised) memory, as in the reference
+        out.append((R, t, ocov, kd, kw_, trk.num_keyframes(), nrm))
+        trk.close()
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
