@@ -103,16 +103,20 @@ __device__ __forceinline__ void block_sum4(const float in[4], double out[4], dou
 
 // Per-thread residual samples, produced by a getter get(i) (a plain array for the bridge calls; a lattice
 // sample of two maps for the batched engine).  REG: <= 24 samples per thread held in VGPRs; otherwise the getter is
-// re-evaluated on every pass.  Each sample is kept SANITISED: e = residual or 0, m = 1 or 0 (finite or not; slots beyond n
-// are invalid), so the passes run branch-free -- an invalid sample contributes weight * 0 to every sum.
+// re-evaluated on every pass.  Samples are kept SANITISED (an invalid residual -- NaN, infinite or a slot beyond n -- is stored as 0) so
+// the passes run branch-free.  Every sum a pass forms is LINEAR in the validity flag: sum_valid f(e_i) = sum_all f(e_i) - n_invalid f(0).
+// The register path therefore keeps no per-sample flag at all: it sums f over all its slots with flag 1 and then calls f once more on the
+// value an invalid slot holds with flag -n_invalid (24 VGPRs and one multiply per sample, sum and pass less).
 template <bool REG, class Getter>
 struct Samples {
   // register path: <= 24 fp32 adds per thread; streaming path (up to a full frame per thread-stride): double
   using Acc = typename std::conditional<REG, float, double>::type;
-  float e[REG ? SIG_MAXPT : 1], m[REG ? SIG_MAXPT : 1];
+  float e[REG ? SIG_MAXPT : 1];
+  float zero_slot;   // what an invalid slot currently holds (0, or its image under to_squared_normalised)
+  float neg_ninv;    // -(number of invalid slots among this thread's cnt slots)
   Getter get;
   int n, tid, cnt;
-  __device__ __forceinline__ Samples(const Getter& g, int n_, int tid_) : get(g), n(n_), tid(tid_) {
+  __device__ __forceinline__ Samples(const Getter& g, int n_, int tid_) : zero_slot(0.f), neg_ninv(0.f), get(g), n(n_), tid(tid_) {
     cnt = (n + SIG_T - 1) / SIG_T;
     if constexpr (REG) {
 #pragma unroll
@@ -121,7 +125,7 @@ struct Samples {
         float v = (i < n) ? get(i) : qnan();
         bool ok = fabsf(v) < __builtin_inff();  // !isinf && !isnan
         e[j] = ok ? v : 0.f;
-        m[j] = ok ? 1.f : 0.f;
+        if (j < cnt) neg_ninv -= ok ? 0.f : 1.f;
       }
     }
   }
@@ -132,14 +136,17 @@ struct Samples {
     if constexpr (REG) {
 #pragma unroll
       for (int j = 0; j < SIG_MAXPT; ++j) { float en = (e[j] - bias) * inv_sigma; e[j] = en * en; }
+      float en = (zero_slot - bias) * inv_sigma;
+      zero_slot = en * en;
     }
   }
   template <class F>
-  __device__ __forceinline__ void for_each_en2(float bias, float inv_sigma, F&& f) const {  // f(en^2, valid)
+  __device__ __forceinline__ void for_each_en2(float bias, float inv_sigma, F&& f) const {  // f(en^2, validity flag); f linear in the flag
     if constexpr (REG) {
 #pragma unroll
       for (int j = 0; j < SIG_MAXPT; ++j)
-        if (j < cnt) f(e[j], m[j]);
+        if (j < cnt) f(e[j], 1.f);
+      f(zero_slot, neg_ninv);
     } else {
       for (int i = tid; i < n; i += SIG_T) {
         float v = get(i);
@@ -150,11 +157,12 @@ struct Samples {
     }
   }
   template <class F>
-  __device__ __forceinline__ void for_each(F&& f) const {  // f(residual, valid)
+  __device__ __forceinline__ void for_each(F&& f) const {  // f(residual, validity flag); f linear in the flag
     if constexpr (REG) {
 #pragma unroll
       for (int j = 0; j < SIG_MAXPT; ++j)
-        if (j < cnt) f(e[j], m[j]);  // wave-uniform
+        if (j < cnt) f(e[j], 1.f);  // wave-uniform
+      f(zero_slot, neg_ninv);
     } else {
       for (int i = tid; i < n; i += SIG_T) {
         float v = get(i);
@@ -164,6 +172,10 @@ struct Samples {
     }
   }
 };
+
+// x * y + a in the accumulator's precision (fp32 for the register path, double for the streaming path)
+__device__ __forceinline__ float mad_acc(float x, float y, float a) { return fmaf(x, y, a); }
+__device__ __forceinline__ double mad_acc(float x, float y, double a) { return fma((double)x, (double)y, a); }
 
 // one moments pass: partialBiasAndSigmaStudent (:258-332) when student_variant, else partialBiasAndSigma (:179-255).
 // Per-sample divisions are reciprocal multiplies (<= 1 ulp) and the per-thread partial sums are fp32: the pass
@@ -180,10 +192,18 @@ __device__ __forceinline__ void pass_moments(const SM& S, float bias, float sigm
   };
   if (student_variant) {
     if (mest == 0) S.for_each([&](float er, float mv) { acc(er, mv, mv); });
-    else S.for_each([&](float er, float mv) {
-      float en = (er - bias) * inv_sigma;
-      acc(er, (nup1 * __builtin_amdgcn_rcpf(nu + en * en)) * mv, mv);
-    });
+    else {
+      // w = (nu + 1) / (nu + en^2): the constant numerator is applied to the three weighted sums once, after the loop, and the
+      // normalisation is one FMA -- 7 VALU + 1 reciprocal per sample (the pass is instruction-bound; the sums only feed a 10 % fixed point)
+      const float nb = -bias * inv_sigma;
+      S.for_each([&](float er, float mv) {
+        const float en = fmaf(er, inv_sigma, nb);
+        const float r = __builtin_amdgcn_rcpf(fmaf(en, en, nu)) * mv;
+        const float wr = er * r;
+        a[0] = mad_acc(wr, er, a[0]); a[1] += wr; a[2] += r; a[3] += mv;
+      });
+      a[0] *= nup1; a[1] *= nup1; a[2] *= nup1;
+    }
   } else {
     S.for_each([&](float er, float mv) {
       float weight = 1.f, is_valid = 1.f;
@@ -214,10 +234,14 @@ template <class SM>
 __device__ __forceinline__ float func_weights_nu(const SM& S, float bias, float inv_sigma, float nu, double* sm) {
   typename SM::Acc a[4] = {0, 0, 0, 0};
   const float nup1 = nu + 1.f;
+  // sum ln w = N ln(nu+1) + ln 2 * sum log2 r  and  sum w = (nu+1) sum r  with r = 1 / (nu + en^2) (finite and positive also for a
+  // sanitised sample): 3 VALU + reciprocal + log2 per sample, the constants once per thread
   S.for_each_en2(bias, inv_sigma, [&](float en2, float mv) {
-    float weight = nup1 * __builtin_amdgcn_rcpf(nu + en2);  // finite and positive also for a sanitised (invalid) sample
-    a[0] += __logf(weight) * mv; a[1] += weight * mv; a[2] += mv;
+    const float r = __builtin_amdgcn_rcpf(nu + en2);
+    a[0] = mad_acc(__builtin_amdgcn_logf(r), mv, a[0]); a[1] = mad_acc(r, mv, a[1]); a[2] += mv;
   });
+  a[0] = (typename SM::Acc)0.69314718055994531 * a[0] + (typename SM::Acc)__logf(nup1) * a[2];
+  a[1] *= nup1;
   double t[4];
   float af[4] = {(float)a[0], (float)a[1], (float)a[2], 0.f};
   block_sum4(af, t, sm);
