@@ -119,10 +119,15 @@ struct Samples {
   __device__ __forceinline__ Samples(const Getter& g, int n_, int tid_) : zero_slot(0.f), neg_ninv(0.f), get(g), n(n_), tid(tid_) {
     cnt = (n + SIG_T - 1) / SIG_T;
     if constexpr (REG) {
+      // the thread's samples tid, tid + SIG_T, ... are visited through the getter's cursor (seek once, then fixed strides): a lattice
+      // getter turns that into one integer division per thread instead of one per sample
+      Getter cur = get;
+      cur.seek(tid);
 #pragma unroll
       for (int j = 0; j < SIG_MAXPT; ++j) {
         int i = tid + j * SIG_T;
-        float v = (i < n) ? get(i) : qnan();
+        float v = (i < n) ? cur.load() : qnan();
+        cur.step();
         bool ok = fabsf(v) < __builtin_inff();  // !isinf && !isnan
         e[j] = ok ? v : 0.f;
         if (j < cnt) neg_ninv -= ok ? 0.f : 1.f;
@@ -309,9 +314,14 @@ __device__ __forceinline__ void sigma_core(SM& S, const NuTable& T, int mode, in
   }
 }
 
+// getters: operator()(i) = sample i (streaming path); seek / load / step = cursor over samples i, i + SIG_T, ... (register path)
 struct ArrayGetter {
   const float* p;
+  int pos;
   __device__ __forceinline__ float operator()(int i) const { return p[i]; }
+  __device__ __forceinline__ void seek(int i) { pos = i; }
+  __device__ __forceinline__ float load() const { return p[pos]; }
+  __device__ __forceinline__ void step() { pos += SIG_T; }
 };
 
 template <bool REG>
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(SIG_T) void k_sigma(NuTable T, int mode, const floa
   int lane = blockIdx.x;
   if (!m.on(lane)) return;
   __shared__ double sm[SIG_W * 4 + 4];
-  Samples<REG, ArrayGetter> S(ArrayGetter{err + (size_t)lane * err_lane_stride}, n, threadIdx.x);
+  Samples<REG, ArrayGetter> S(ArrayGetter{err + (size_t)lane * err_lane_stride, 0}, n, threadIdx.x);
   SigmaIO v = io[lane];
   float bias = v.bias, sigma = v.sigma, nu = v.nu;
   sigma_core(S, T, mode, mestimator, bias, sigma, nu, sm);
@@ -340,10 +350,14 @@ void launch_sigma(hipStream_t s, int B, int mode, const float* err, size_t err_l
 struct LatticeGetter {
   ImgB a, b;  // a - b
   int lane, lcols, stride;
-  __device__ __forceinline__ float operator()(int i) const {
-    int y = i / lcols, x = i - y * lcols;
-    return px<float>(a, lane, stride * y, stride * x) - px<float>(b, lane, stride * y, stride * x);
+  int y, x, sy, sx;  // cursor: lattice row / column of the current sample and the (row, column) advance of SIG_T samples
+  __device__ __forceinline__ float at(int ly, int lx) const {
+    return px<float>(a, lane, stride * ly, stride * lx) - px<float>(b, lane, stride * ly, stride * lx);
   }
+  __device__ __forceinline__ float operator()(int i) const { int ly = i / lcols; return at(ly, i - ly * lcols); }
+  __device__ __forceinline__ void seek(int i) { y = i / lcols; x = i - y * lcols; sy = SIG_T / lcols; sx = SIG_T - sy * lcols; }
+  __device__ __forceinline__ float load() const { return at(y, x); }
+  __device__ __forceinline__ void step() { y += sy; x += sx; if (x >= lcols) { x -= lcols; ++y; } }
 };
 
 template <bool REG>
@@ -352,7 +366,7 @@ __global__ __launch_bounds__(SIG_T) void k_sigma_pair(NuTable T, ImgB W1, ImgB W
   int lane = blockIdx.x, ch = blockIdx.y;
   if (!m.on(lane)) return;
   __shared__ double sm[SIG_W * 4 + 4];
-  LatticeGetter g{ch == 0 ? W1 : I1, ch == 0 ? W0 : I0, lane, lcols, stride};
+  LatticeGetter g{ch == 0 ? W1 : I1, ch == 0 ? W0 : I0, lane, lcols, stride, 0, 0, 0, 0};
   Samples<REG, LatticeGetter> S(g, lrows * lcols, threadIdx.x);
   float bias = 0.f, sigma = ch == 0 ? 0.0025f : 5.f, nu = 5.f;
   sigma_core(S, T, 0, mestimator, bias, sigma, nu, sm);
@@ -375,13 +389,18 @@ struct FusedLatticeGetter {
   ImgB cur_iD, cur_I, W0, I0;
   WarpParams P;
   int lane, lcols, stride, ch, interp_mode;
-  __device__ __forceinline__ float operator()(int i) const {
-    int y = (i / lcols) * stride, x = (i - (i / lcols) * lcols) * stride;
+  int cy, cx, sy, sx;  // cursor (lattice row / column) and the advance of SIG_T samples
+  __device__ __forceinline__ float at(int ly, int lx) const {
+    int y = ly * stride, x = lx * stride;
     float w0 = px<float>(W0, lane, y, x);
     float w1 = warp_invdepth_px(FMap(cur_iD, lane), x, y, w0, P);
     if (ch == 0) return w1 - w0;
     return warp_intensity_px(FMap(cur_I, lane), x, y, w1, P, interp_mode) - px<float>(I0, lane, y, x);
   }
+  __device__ __forceinline__ float operator()(int i) const { int ly = i / lcols; return at(ly, i - ly * lcols); }
+  __device__ __forceinline__ void seek(int i) { cy = i / lcols; cx = i - cy * lcols; sy = SIG_T / lcols; sx = SIG_T - sy * lcols; }
+  __device__ __forceinline__ float load() const { return at(cy, cx); }
+  __device__ __forceinline__ void step() { cy += sy; cx += sx; if (cx >= lcols) { cx -= lcols; ++cy; } }
 };
 
 template <bool REG>
@@ -390,7 +409,7 @@ __global__ __launch_bounds__(SIG_T) void k_sigma_pair_fused(NuTable T, ImgB Wcur
   int lane = blockIdx.x, ch = blockIdx.y;
   if (!m.on(lane)) return;
   __shared__ double sm[SIG_W * 4 + 4];
-  FusedLatticeGetter g{Wcur, Icur, W0, I0, wp[lane], lane, lcols, stride, ch, interp_mode};
+  FusedLatticeGetter g{Wcur, Icur, W0, I0, wp[lane], lane, lcols, stride, ch, interp_mode, 0, 0, 0, 0};
   Samples<REG, FusedLatticeGetter> S(g, lrows * lcols, threadIdx.x);
   float bias = 0.f, sigma = ch == 0 ? 0.0025f : 5.f, nu = 5.f;
   sigma_core(S, T, 0, mestimator, bias, sigma, nu, sm);
