@@ -79,13 +79,21 @@ static constexpr int SIG_T = 1024, SIG_MAXPT = 24, SIG_W = SIG_T / 64;
 static constexpr float TH_HUBER = 1.345f, TH_TUKEY = 4.685f, STUDENT_DOF = 5.f;
 
 // block-wide sum of 4 per-thread fp32 partials: DPP wave reduction in fp32, then the 16 wave totals are
-// added in double in a fixed order and broadcast.  sm: SIG_W*4 + 4 doubles of LDS.
-__device__ __forceinline__ void block_sum4(const float in[4], double out[4], double* sm) {
+// added in double in a fixed order and broadcast.  Two alternating LDS buffers (the passes are strictly sequential) make the
+// write-after-read barrier of a single buffer unnecessary: 2 barriers per pass.  sm: 2 * (SIG_W*4 + 4) doubles of LDS.
+static constexpr int SIG_SM = 2 * (SIG_W * 4 + 4);
+struct BlockSum {
+  double* sm;
+  int phase;
+  __device__ __forceinline__ explicit BlockSum(double* p) : sm(p), phase(0) {}
+};
+__device__ __forceinline__ void block_sum4(const float in[4], double out[4], BlockSum& bs) {
   float w[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) w[k] = wave_sum_l63(in[k]);
   int wid = threadIdx.x >> 6, lid = threadIdx.x & 63;
-  __syncthreads();
+  double* sm = bs.sm + (bs.phase & 1) * (SIG_W * 4 + 4);
+  bs.phase++;
   if (lid == 63) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) sm[wid * 4 + k] = (double)w[k];
@@ -187,7 +195,7 @@ __device__ __forceinline__ double mad_acc(float x, float y, double a) { return f
 // is VALU-bound, and the moments only feed a 10%-tolerance fixed point.
 template <class SM>
 __device__ __forceinline__ void pass_moments(const SM& S, float bias, float sigma, float nu, int mest, bool student_variant,
-                                             double* sm, float& swsr, float& swr, float& sw, float& nel) {
+                                             BlockSum& sm, float& swsr, float& swr, float& sw, float& nel) {
   typename SM::Acc a[4] = {0, 0, 0, 0};
   const float inv_sigma = 1.f / sigma, nup1 = nu + 1.f;
   auto acc = [&](float er, float weight, float valid) {  // weight is already 0 for an invalid sample
@@ -236,7 +244,7 @@ __device__ __forceinline__ void final_bias_sigma(float swsr, float swr, float sw
 
 // partialFuncWeightsNu :410-468 + finalReductionFuncWeightsNu :471-512 (S holds en^2 after to_squared_normalised)
 template <class SM>
-__device__ __forceinline__ float func_weights_nu(const SM& S, float bias, float inv_sigma, float nu, double* sm) {
+__device__ __forceinline__ float func_weights_nu(const SM& S, float bias, float inv_sigma, float nu, BlockSum& sm) {
   typename SM::Acc a[4] = {0, 0, 0, 0};
   const float nup1 = nu + 1.f;
   // sum ln w = N ln(nu+1) + ln 2 * sum log2 r  and  sum w = (nu+1) sum r  with r = 1 / (nu + en^2) (finite and positive also for a
@@ -261,7 +269,7 @@ __device__ __forceinline__ float C_nu(const NuTable& T, float nu, float fw) {
 
 // bisection of C(nu) on [2,10]: sigmaFuncs.cu:934-1039 == :1100-1205
 template <class SM>
-__device__ __forceinline__ float estimate_nu(SM& S, const NuTable& T, float bias, float sigma_, double* sm) {
+__device__ __forceinline__ float estimate_nu(SM& S, const NuTable& T, float bias, float sigma_, BlockSum& sm) {
   const float sigma = 1.f / sigma_;  // inv_sigma; S.e becomes en^2 (the residuals are not used after this point)
   S.to_squared_normalised(bias, sigma);
   float nu_up = 10.f, nu_down = 2.f, nu_new = 0.f, nu;
@@ -284,7 +292,7 @@ __device__ __forceinline__ float estimate_nu(SM& S, const NuTable& T, float bias
 
 // the three host wrappers of the reference as one device routine over a sample set
 template <class SM>
-__device__ __forceinline__ void sigma_core(SM& S, const NuTable& T, int mode, int mestimator, float& bias, float& sigma, float& nu, double* sm) {
+__device__ __forceinline__ void sigma_core(SM& S, const NuTable& T, int mode, int mestimator, float& bias, float& sigma, float& nu, BlockSum& sm) {
   float swsr, swr, sw, nel;
   if (mode == 0) {
     // computeSigmaAndNuStudent :858-1066
@@ -328,7 +336,8 @@ template <bool REG>
 __global__ __launch_bounds__(SIG_T) void k_sigma(NuTable T, int mode, const float* err, size_t err_lane_stride, int n, SigmaIO* io, int mestimator, LaneMask m) {
   int lane = blockIdx.x;
   if (!m.on(lane)) return;
-  __shared__ double sm[SIG_W * 4 + 4];
+  __shared__ double sm_[SIG_SM];
+  BlockSum sm(sm_);
   Samples<REG, ArrayGetter> S(ArrayGetter{err + (size_t)lane * err_lane_stride, 0}, n, threadIdx.x);
   SigmaIO v = io[lane];
   float bias = v.bias, sigma = v.sigma, nu = v.nu;
@@ -365,7 +374,8 @@ __global__ __launch_bounds__(SIG_T) void k_sigma_pair(NuTable T, ImgB W1, ImgB W
                                                       SysParams* sp, int mestimator, LaneMask m) {
   int lane = blockIdx.x, ch = blockIdx.y;
   if (!m.on(lane)) return;
-  __shared__ double sm[SIG_W * 4 + 4];
+  __shared__ double sm_[SIG_SM];
+  BlockSum sm(sm_);
   LatticeGetter g{ch == 0 ? W1 : I1, ch == 0 ? W0 : I0, lane, lcols, stride, 0, 0, 0, 0};
   Samples<REG, LatticeGetter> S(g, lrows * lcols, threadIdx.x);
   float bias = 0.f, sigma = ch == 0 ? 0.0025f : 5.f, nu = 5.f;
@@ -408,7 +418,8 @@ __global__ __launch_bounds__(SIG_T) void k_sigma_pair_fused(NuTable T, ImgB Wcur
                                                             int lrows, int lcols, int stride, SysParams* sp, int mestimator, LaneMask m) {
   int lane = blockIdx.x, ch = blockIdx.y;
   if (!m.on(lane)) return;
-  __shared__ double sm[SIG_W * 4 + 4];
+  __shared__ double sm_[SIG_SM];
+  BlockSum sm(sm_);
   FusedLatticeGetter g{Wcur, Icur, W0, I0, wp[lane], lane, lcols, stride, ch, interp_mode, 0, 0, 0, 0};
   Samples<REG, FusedLatticeGetter> S(g, lrows * lcols, threadIdx.x);
   float bias = 0.f, sigma = ch == 0 ? 0.0025f : 5.f, nu = 5.f;
@@ -433,7 +444,8 @@ __global__ __launch_bounds__(SIG_T) void k_chi_square(const float* err_int, cons
                                                       float sigma_int, float sigma_depth, int mest, float* out, LaneMask m) {
   int lane = blockIdx.x;
   if (!m.on(lane)) return;
-  __shared__ double sm[SIG_W * 4 + 4];
+  __shared__ double sm_[SIG_SM];
+  BlockSum sm(sm_);
   float a[4] = {0.f, 0.f, 0.f, 0.f};
   for (int half = 0; half < 2; ++half) {
     const float* e = (half == 0 ? err_int : err_depth) + (size_t)lane * err_lane_stride;
