@@ -1,0 +1,33 @@
+import sys, time
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/rgbid-slam_amd")
+import numpy as np, torch
+from oracle import oracle as O
+from rgbid import synth, engine as E, device
+def rot_angle(Ra, Rb): return float(np.arccos(np.clip((np.trace(Ra.T @ Rb) - 1) / 2, -1, 1)))
+K = (synth.TUM_K[0] / 4, synth.TUM_K[1] / 4, (synth.TUM_K[2] + 0.5) / 4 - 0.5, (synth.TUM_K[3] + 0.5) / 4 - 0.5)
+n, B, rows, cols = 300, 4, 120, 160
+seqs = [synth.make_sequence(n, seed=synth.SEED + 31 * l, K=K, rows=rows, cols=cols, device="cuda", trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8)) for l in range(B)]
+depth = torch.stack([s["depth"] for s in seqs], 1).to(torch.int16).contiguous(); rgb = torch.stack([s["rgb"] for s in seqs], 1).contiguous()
+ctx = device.Context(0)
+eng = E.Engine(ctx, E.default_config(rows=rows, cols=cols, lanes=B, K=K, record_capacity=n, keyframe_capacity=4))
+for k in range(n): eng.step(depth[k], rgb[k])
+rec = eng.records()
+for l in range(B):
+    trk = O.Tracker(O.default_config(rows=rows, cols=cols, fx=K[0], fy=K[1], cx=K[2], cy=K[3]))
+    d = depth[:, l].cpu().numpy().view(np.uint16); c = rgb[:, l].cpu().numpy()
+    worst = (0, 0, -1); div = None
+    for k in range(n):
+        trk.track(d[k], c[k])
+        if k:
+            st = int(rec[k, l]["status"]); info = trk.last_info()
+            if bool(st & E.ST_ODO_KF) != bool(info.odo_kf_switched) or bool(st & E.ST_INTEGR_KF) != bool(info.integr_kf_switched):
+                div = (k, info.visratio_odo, info.visratio_integr); break
+    Rs, ts = trk.poses()
+    m = len(Rs) if div is None else div[0]
+    for k in range(1, m):
+        er, et = rot_angle(Rs[k], rec[k, l]["R"]), float(np.linalg.norm(ts[k] - rec[k, l]["t"]))
+        if max(er, et) > max(worst[0], worst[1]): worst = (er, et, k)
+    gt_R, gt_t = seqs[l]["R_wc"].numpy(), seqs[l]["t_wc"].numpy()
+    print("lane", l, "frames compared", m, "worst |dR| %.2e rad |dt| %.2e m at frame %d" % worst, "decision divergence:", div,
+          "| drift vs ground truth at end: %.2e rad %.2e m" % (rot_angle(gt_R[m - 1], rec[m - 1, l]["R"]), np.linalg.norm(gt_t[m - 1] - rec[m - 1, l]["t"])),
+          "| keyframes exported", int(eng.keyframe_counts()[l]), "oracle", trk.num_keyframes())
