@@ -68,7 +68,9 @@ int rgbid_engine_destroy(rgbid_engine* e);
 /* VisodoTracker::reset() for every lane */
 int rgbid_engine_reset(rgbid_engine* e);
 /* one trackNewFrame for every lane; depth/rgb are device pointers laid out as described above.
- * Asynchronous on the context's stream (sync with rgbid_ctx_sync or a record read). */
+ * Asynchronous on the context's stream (sync with rgbid_ctx_sync or a record read).  With use_graph = 0 the step's kernels read the two
+ * buffers IN PLACE (no staging copy): keep them valid and unmodified until the step has executed; with use_graph = 1 they are copied into
+ * the engine's own staging buffers first (a captured graph needs fixed addresses) and may be reused once that copy has run. */
 int rgbid_engine_step(rgbid_engine* e, const void* depth_dev, const void* rgb_dev);
 /* number of steps taken since reset */
 int rgbid_engine_steps(const rgbid_engine* e);
