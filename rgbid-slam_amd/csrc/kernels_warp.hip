@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_warp_pair(ImgB src_iD, ImgB src_I, ImgB
 #pragma unroll
   for (int i = 0; i < RPB; ++i) {
     int y = yb + i * TY;
-    if (y < dst_iD.rows) { DW.at(y, x) = w1[i]; DI.at(y, x) = i1[i]; }
+    if (y < dst_iD.rows) { DW.store(y, x, w1[i]); DI.store(y, x, i1[i]); }
   }
 }
 void launch_warp_pair(hipStream_t s, int B, ImgB src_iD, ImgB src_I, ImgB grid, ImgB dst_iD, ImgB dst_I, const WarpParams* lp, int interp_mode, LaneMask m) {

@@ -22,27 +22,36 @@ __device__ __forceinline__ bool inside(int ix, int iy, int cols, int rows) {
 __device__ __forceinline__ int clampi(int v, int hi) { int r; asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "v"(hi)); return r; }
 __device__ __forceinline__ int clamp_from_m1(int v, int hi) { int r; asm("v_med3_i32 %0, %1, -1, %2" : "=v"(r) : "v"(v), "v"(hi)); return r; }
 
-// lane-local element view of a float map: base pointer (wave-uniform: the lane is a block index) + pitch in elements.  Gather addresses
-// are UNSIGNED 32-bit element offsets formed with 24-bit multiplies: v_mul_lo_u32 issues at quarter rate and a signed 64-bit address costs
-// two more VALU instructions per gather, which matters in the VALU-bound warps (rows, pitch < 2^24 elements: asserted by the launchers'
-// image sizes; coordinates are clamped to the image before they get here, so the offsets are non-negative).
+// lane-local view of a float map for gathers: a raw buffer descriptor over the lane's image (wave-uniform: the lane is a block index) and
+// 32-bit BYTE offsets formed with 24-bit multiplies.  v_mul_lo_u32 issues at quarter rate and a 64-bit flat address costs two more VALU
+// instructions per access, which matters in the VALU-bound warps (rows, pitch < 2^24 and the image < 4 GB: checked at the C-ABI; coordinates
+// are clamped to the image before they get here, so every offset is inside the descriptor's range).
 struct FMap {
   const float* base;
   int pitch, rows, cols;
+  __amdgpu_buffer_rsrc_t rsrc;   // raw buffer descriptor over the lane's image: loads take a 32-bit BYTE offset, no 64-bit address arithmetic
+  unsigned pitch_b;
   __device__ __forceinline__ FMap(const ImgB& im, int lane)
-      : base(row_ptr<float>(im, lane, 0)), pitch((int)(im.pitch >> 2)), rows(im.rows), cols(im.cols) {}
-  __device__ __forceinline__ unsigned row(int y) const { return __umul24((unsigned)y, (unsigned)pitch); }
-  __device__ __forceinline__ float at_off(unsigned off) const { return base[off]; }
-  __device__ __forceinline__ float at(int y, int x) const { return base[row(y) + (unsigned)x]; }
+      : base(row_ptr<float>(im, lane, 0)), pitch((int)(im.pitch >> 2)), rows(im.rows), cols(im.cols),
+        rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row_ptr<float>(im, lane, 0)), 0, (int)((unsigned)im.rows * (unsigned)im.pitch), 0x00020000)),
+        pitch_b((unsigned)im.pitch) {}
+  __device__ __forceinline__ unsigned row(int y) const { return __umul24((unsigned)y, pitch_b); }              // byte offset of a row
+  __device__ __forceinline__ float at_off(unsigned row_b, int x) const {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, row_b + ((unsigned)x << 2), 0, 0));
+  }
+  __device__ __forceinline__ float at(int y, int x) const { return at_off(row(y), x); }
 };
 
-// writable counterpart (kernel outputs): the generic px<T>(im, lane, y, x) forms lane * lane_stride + y * pitch in 64 bits -- two quarter-rate
-// v_mad_u64_u32 per access -- while here the lane base is wave-uniform (scalar unit) and the element offset a 24-bit multiply-add
+// writable counterpart (kernel outputs): raw buffer stores with a 32-bit byte offset (a 24-bit multiply-add) on a wave-uniform descriptor
 struct FMapW {
-  float* base;
-  int pitch;
-  __device__ __forceinline__ FMapW(const ImgB& im, int lane) : base(row_ptr<float>(im, lane, 0)), pitch((int)(im.pitch >> 2)) {}
-  __device__ __forceinline__ float& at(int y, int x) const { return base[__umul24((unsigned)y, (unsigned)pitch) + (unsigned)x]; }
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned pitch_b;
+  __device__ __forceinline__ FMapW(const ImgB& im, int lane)
+      : rsrc(__builtin_amdgcn_make_buffer_rsrc(row_ptr<float>(im, lane, 0), 0, (int)((unsigned)im.rows * (unsigned)im.pitch), 0x00020000)),
+        pitch_b((unsigned)im.pitch) {}
+  __device__ __forceinline__ void store(int y, int x, float v) const {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsrc, __umul24((unsigned)y, pitch_b) + ((unsigned)x << 2), 0, 0);
+  }
 };
 
 // CUDA linear filtering at unnormalised coordinates with clamp addressing (what tex2D<float> computes for the
@@ -63,7 +72,7 @@ __device__ __forceinline__ float tex2d_linear(const FMap& src, float xs, float y
   const int i1 = min(ic + 1, src.cols - 1), j1 = min(jc + 1, src.rows - 1);
   const int i0 = max(ic, 0), j0 = max(jc, 0);
   const unsigned r0 = src.row(j0), r1 = src.row(j1);
-  float T00 = src.at_off(r0 + (unsigned)i0), T10 = src.at_off(r0 + (unsigned)i1), T01 = src.at_off(r1 + (unsigned)i0), T11 = src.at_off(r1 + (unsigned)i1);
+  float T00 = src.at_off(r0, i0), T10 = src.at_off(r0, i1), T01 = src.at_off(r1, i0), T11 = src.at_off(r1, i1);
   float oa = 1.f - a, ob = 1.f - b;
   return (oa * ob) * T00 + (a * ob) * T10 + (oa * b) * T01 + (a * b) * T11;
 }
