@@ -1,0 +1,313 @@
+"""A second, independent restatement of a handful of the reference's kernels in vectorised numpy (float64 arithmetic on float32 data),
+written from the reference sources -- not from oracle/ -- so that tests/test_oracle_vs_numpy_mirror.py can cross-check the C oracle
+against it (to rounding, not bit for bit: the two evaluate in different precision and order).  TEST INFRASTRUCTURE ONLY.
+
+Each function cites the reference lines it follows."""
+import numpy as np
+
+
+def _shift(a, dy, dx, fill=np.nan):
+    """a[y+dy, x+dx] with `fill` outside the image"""
+    out = np.full(a.shape, fill, a.dtype)
+    h, w = a.shape
+    ys, yd = (slice(dy, h), slice(0, h - dy)) if dy >= 0 else (slice(0, h + dy), slice(-dy, h))
+    xs, xd = (slice(dx, w), slice(0, w - dx)) if dx >= 0 else (slice(0, w + dx), slice(-dx, w))
+    out[yd, xd] = a[ys, xs]
+    return out
+
+
+def pyr_down(src):
+    """pyrDownKernelGridStridef, src/cuda/pyrdown.cu:84-132 (radius 2, sigma 1 :76-80): Gaussian-weighted mean of the valid samples of the
+    5x5 window around (2x, 2y) clipped to the image; NaN unless more than 12 samples are valid."""
+    src = src.astype(np.float64)
+    rows, cols = src.shape[0] // 2, src.shape[1] // 2
+    s1 = np.zeros((rows, cols)); s2 = np.zeros((rows, cols)); cnt = np.zeros((rows, cols), int)
+    big = np.pad(src, 2, constant_values=np.nan)                       # out-of-image taps: never valid
+    for dy in range(-2, 3):
+        for dx in range(-2, 3):
+            tap = big[2 + dy:2 + dy + 2 * rows:2, 2 + dx:2 + dx + 2 * cols:2]
+            ok = ~np.isnan(tap)
+            w = np.exp(-(dx * dx + dy * dy) * 0.5)
+            s1 += np.where(ok, tap, 0.0) * w; s2 += ok * w; cnt += ok
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return np.where(cnt > 12, s1 / s2, np.nan)
+
+
+def sobel(src):
+    """gradientKernel, src/cuda/misc.cu:176-220: 3x3 Sobel with replicated borders, divided by 8; NaN taps propagate."""
+    p = np.pad(src.astype(np.float64), 1, mode="edge")
+    h, w = src.shape
+    gx = np.zeros((h, w)); gy = np.zeros((h, w))
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            t = p[1 + dy:1 + dy + h, 1 + dx:1 + dx + w]
+            gx = gx + t * (dx * (2 - dy * dy)); gy = gy + t * (dy * (2 - dx * dx))
+    return gx / 8.0, gy / 8.0
+
+
+def bilateral(src, sigma_value, sigma_space=5.0):
+    """bilateralKernel, src/cuda/filters.cu:86-135 (RADIUS 2, sigma_space 5 :60-70) with the window clipped to the image (the reference's
+    unsigned index arithmetic is documented as a deviation in DESIGN.md): NaN centre -> NaN, NaN taps skipped."""
+    a = src.astype(np.float64)
+    s1 = np.zeros(a.shape); s2 = np.zeros(a.shape)
+    for dy in range(-2, 3):
+        for dx in range(-2, 3):
+            tap = _shift(a, dy, dx)
+            ok = ~np.isnan(tap)
+            fn = (a - tap) / sigma_value
+            w = np.exp(-((dx * dx + dy * dy) * (0.5 / (sigma_space * sigma_space)) + 0.5 * fn * fn))
+            s1 += np.where(ok, tap * w, 0.0); s2 += np.where(ok, w, 0.0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return np.where(np.isnan(a), np.nan, s1 / s2)
+
+
+def depth_to_invdepth(depth_u16, factor_depth=1.0):
+    """depth2invDepthKernel, src/cuda/misc.cu:104-124: (1 / factor_depth) * 1000 / min(value, 10000) for value > 0 (millimetres), else NaN."""
+    v = np.minimum(depth_u16.astype(np.float64), 10000.0)
+    with np.errstate(divide="ignore"):
+        return np.where(depth_u16 > 0, (1.0 / factor_depth) * 1000.0 / v, np.nan)
+
+
+def intensity(rgb_u8):
+    """intensityKernel, src/cuda/misc.cu:128-148: Rec. 709 luma 0.2126 R + 0.7152 G + 0.0722 B clamped to [0, 255]."""
+    r, g, b = [rgb_u8[..., k].astype(np.float64) for k in range(3)]
+    return np.clip(0.2126 * r + 0.7152 * g + 0.0722 * b, 0.0, 255.0)
+
+
+def register_pixel(x, y, w, Rp, tp):
+    """registerPixel, src/cuda/warping_registration.cu:129-146: X = R_proj (x, y, 1) / w + t_proj; returns (X.x/X.z, X.y/X.z, 1/X.z)."""
+    z = 1.0 / w
+    X = Rp[:, 0, None, None] * (x * z) + Rp[:, 1, None, None] * (y * z) + Rp[:, 2, None, None] * z + tp[:, None, None]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return X[0] / X[2], X[1] / X[2], 1.0 / X[2]
+
+
+def warp_invdepth(src, grid, Rp, tp):
+    """trafo3DKernelInvDepthGridStride, src/cuda/warping_registration.cu:505-546: project every valid keyframe pixel (inverse depth `grid`)
+    into `src`, point-sample at floor(coordinate + 0.5), rescale the sampled inverse depth into the keyframe's frame; NaN unless > 0."""
+    h, w_ = grid.shape
+    y, x = np.mgrid[0:h, 0:w_].astype(np.float64)
+    g = grid.astype(np.float64)
+    Rp = np.asarray(Rp, np.float64).reshape(3, 3); tp = np.asarray(tp, np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        xs, ys, w3 = register_pixel(x, y, g, Rp, tp)
+        ix = np.floor(xs + 0.5); iy = np.floor(ys + 0.5)
+        inb = (ix >= 0) & (iy >= 0) & (ix < w_) & (iy < h) & ~np.isnan(g)
+        w2 = src.astype(np.float64)[np.clip(iy, 0, h - 1).astype(int) * inb, np.clip(ix, 0, w_ - 1).astype(int) * inb]
+        v = (1.0 / w3 - tp[2]) * g
+        res = v / (1.0 - w2 * tp[2]) * w2
+        return np.where(inb & (res > 0), res, np.nan)
+
+
+def bilinear(src, xs, ys, tex8):
+    """tex2D<float> with cudaFilterModeLinear / clamp addressing at unnormalised coordinates (CUDA programming guide, texture fetching):
+    xB = x - 0.5, weights from frac(xB) -- stored in 1.8 fixed point by the hardware when tex8 -- taps clamped to the image."""
+    h, w_ = src.shape
+    xb, yb = xs - 0.5, ys - 0.5
+    x0, y0 = np.floor(xb), np.floor(yb)
+    a, b = xb - x0, yb - y0
+    if tex8:
+        a, b = np.rint(a * 256.0) / 256.0, np.rint(b * 256.0) / 256.0
+    cl = lambda v, n: np.clip(np.nan_to_num(v, nan=0.0, posinf=1e9, neginf=-1e9), 0, n - 1).astype(int)
+    s = src.astype(np.float64)
+    t00, t10 = s[cl(y0, h), cl(x0, w_)], s[cl(y0, h), cl(x0 + 1, w_)]
+    t01, t11 = s[cl(y0 + 1, h), cl(x0, w_)], s[cl(y0 + 1, h), cl(x0 + 1, w_)]
+    return (1 - a) * (1 - b) * t00 + a * (1 - b) * t10 + (1 - a) * b * t01 + a * b * t11
+
+
+def warp_intensity(src, grid, Rp, tp, tex8):
+    """trafo3DKernelIntensityWithInvDepthGridStride, src/cuda/warping_registration.cu:465-501: same projection, bilinear texture fetch at
+    coordinate + 0.5, clamped to [0, 255]; NaN where the grid is invalid or the point-sample position leaves the image."""
+    h, w_ = grid.shape
+    y, x = np.mgrid[0:h, 0:w_].astype(np.float64)
+    g = grid.astype(np.float64)
+    Rp = np.asarray(Rp, np.float64).reshape(3, 3); tp = np.asarray(tp, np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        xs, ys, _ = register_pixel(x, y, g, Rp, tp)
+        xs, ys = xs + 0.5, ys + 0.5
+        ix, iy = np.floor(xs), np.floor(ys)
+        inb = (ix >= 0) & (iy >= 0) & (ix < w_) & (iy < h) & ~np.isnan(g)
+        val = np.clip(bilinear(src, np.where(inb, xs, 0.5), np.where(inb, ys, 0.5), tex8), 0.0, 255.0)
+        return np.where(inb, val, np.nan)
+
+
+def visibility_ratio(src, dst, Rp, tp):
+    """partialVisibilityKernel + getVisibilityRatio, src/cuda/warping_registration.cu:297-461, 825-869: of the valid pixels of `src`, the
+    fraction that projects strictly inside `dst` and agrees with the inverse depth found there (round-to-nearest pixel) to 0.020."""
+    h, w_ = src.shape
+    y, x = np.mgrid[0:h, 0:w_].astype(np.float64)
+    s = src.astype(np.float64)
+    Rp = np.asarray(Rp, np.float64).reshape(3, 3); tp = np.asarray(tp, np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        xd, yd, wd = register_pixel(x, y, s, Rp, tp)
+        valid = ~np.isnan(s)
+        inside = valid & (xd > 0) & (xd < w_ - 1) & (yd > 0) & (yd < h - 1)
+        xi = np.where(inside, np.rint(xd), 0).astype(int); yi = np.where(inside, np.rint(yd), 0).astype(int)
+        vis = inside & (np.abs(wd - dst.astype(np.float64)[yi, xi]) < 0.020)
+    nval = int(valid.sum())
+    return (float(vis.sum()) / nval if nval >= 1 else 0.0), vis, valid
+
+
+def integrate(warped, wweight, kf, kfw):
+    """integrateWarpedFrameKernel, src/cuda/warping_registration.cu:637-669: weighted running mean of the keyframe inverse depth, gated at
+    3 * 0.0075; an empty keyframe pixel adopts the warped sample."""
+    kf = kf.astype(np.float64).copy(); kfw = kfw.astype(np.float64).copy()
+    ws, qs = warped.astype(np.float64), wweight.astype(np.float64)
+    have = ~np.isnan(ws)
+    adopt = have & np.isnan(kf)
+    with np.errstate(invalid="ignore"):
+        fuse = have & ~np.isnan(kf) & (np.abs(ws - kf) < 3 * 0.0075)
+    nw = kfw + qs
+    fused = (kf * kfw + ws * qs) / np.where(fuse, nw, 1.0)
+    out_kf = np.where(adopt, ws, np.where(fuse, fused, kf))
+    out_w = np.where(adopt, qs, np.where(fuse, nw, kfw))
+    return out_kf, out_w
+
+
+def build_system(W0, I0, gWx, gWy, gIx, gIy, W1, I1, K, sigma_d, sigma_i, bias_d=0.0, bias_i=0.0, nu_d=5.0, nu_i=5.0, student_nu=True,
+                 mestimator=3, weighting=0):
+    """constraintsHandler::{invDepthConstraint, intensityConstraint, computeWeight, computeWeightStudent, computeStudentNuSystemGridStride},
+    src/cuda/estimate_VO.cu:141-262, 354-418 and the host-side unpacking :774-786: the 6x6 normal equations A x = b of one Gauss-Newton
+    iteration over all pixels.  Rows are [translation | rotation]; weighting: 0 independent, 1 min-weight, 2 geometric only, 3 photometric only;
+    mestimator (fixed-nu path): 0 least squares, 1 Huber, 2 Tukey, 3 Student-t with 5 dof."""
+    fx, fy, cx, cy = [float(v) for v in K]
+    f = lambda a: np.asarray(a, np.float64)
+    W0, I0, gWx, gWy, gIx, gIy, W1, I1 = map(f, (W0, I0, gWx, gWy, gIx, gIy, W1, I1))
+    h, w_ = W0.shape
+    v, u = np.mgrid[0:h, 0:w_].astype(np.float64)
+    p = np.stack([(u - cx) / fx, (v - cy) / fy, np.ones_like(u)])
+
+    def weight(e, nu):
+        if student_nu:
+            return (nu + 1.0) / (nu + e * e)
+        if mestimator == 1:
+            return np.where(np.abs(e) > 1.345, 1.345 / np.abs(e), 1.0)
+        if mestimator == 2:
+            return np.where(np.abs(e) < 4.685, (1.0 - (e / 4.685) ** 2) ** 2, 0.0)
+        if mestimator == 3:
+            return 6.0 / (5.0 + e * e)
+        return np.ones_like(e)
+
+    with np.errstate(invalid="ignore", divide="ignore"):
+        # inverse-depth constraint
+        g = np.stack([gWx * fx, gWy * fy, np.zeros_like(gWx)]); g[2] = -(g[0] * p[0] + g[1] * p[1])
+        n = g / W0; n[2] = n[2] + 1.0
+        n = n / np.sqrt((n * n).sum(0)); pu = p / np.sqrt((p * p).sum(0))
+        nfac = np.abs((n * pu).sum(0))
+        row_t = g * W0; row_t[2] = row_t[2] + W0 * W1
+        g2 = g.copy(); g2[2] = g2[2] + W1
+        row_r = -np.cross(g2, p, axis=0)
+        Jd = np.concatenate([row_t, row_r]) / sigma_d
+        ed = -(W1 - W0) / sigma_d
+        vd = ~(np.isnan(W0) | np.isnan(W1) | np.isnan(gWx) | np.isnan(gWy))
+        wd = np.where(vd, weight(ed - bias_d / sigma_d, nu_d), 0.0) * (0.0 if weighting == 3 else 1.0)
+        # intensity constraint
+        hI = np.stack([gIx * fx, gIy * fy, np.zeros_like(gIx)]); hI[2] = -(hI[0] * p[0] + hI[1] * p[1])
+        Ji = np.concatenate([hI * W0, -np.cross(hI, p, axis=0)]) / sigma_i
+        ei = -(I1 - I0) / sigma_i
+        vi = ~(np.isnan(W0) | np.isnan(I0) | np.isnan(I1) | np.isnan(gIx) | np.isnan(gIy))
+        wi = np.where(vi, weight(ei - bias_i / sigma_i, nu_i), 0.0) * (0.0 if weighting == 2 else 1.0)
+        if weighting == 1:
+            wi = np.minimum(wd, wi)
+    z = lambda a, ok: np.where(ok, a, 0.0)
+    Jd, ed, nfac = z(Jd, vd), z(ed, vd), z(nfac, vd)
+    Ji, ei = z(Ji, vi), z(ei, vi)
+    A = np.einsum("ihw,jhw,hw->ij", Ji, Ji, wi) + np.einsum("ihw,jhw,hw->ij", Jd, Jd, nfac * wd)
+    b = np.einsum("ihw,hw,hw->i", Ji, ei, wi) + np.einsum("ihw,hw,hw->i", Jd, ed, nfac * wd)
+    return A, b
+
+
+def sigma_nu_student(err, bias, sigma, mestimator=3):
+    """computeSigmaAndNuStudent, src/cuda/sigmaFuncs.cu:858-1066 with partialBiasAndSigmaStudent :281-332, finalReductionBiasAndSigma :361-407,
+    partialFuncWeightsNu :410-468 and its final reduction :471-512.  Returns (bias, sigma, nu).
+    IRLS: first pass least squares, then Student weights with nu = 5, at most 10 passes, stop when sigma changes by < 10 %;
+    nu: bisection of C(nu) = -psi(nu/2) + ln(nu/2) + mean(ln w - w) + 1 + psi((nu+1)/2) - ln((nu+1)/2) on [2, 10], at most 5 steps,
+    stopping when the bracket is below 1; returns the last midpoint."""
+    from scipy.special import digamma
+    e = np.asarray(err, np.float64)
+    e = e[np.isfinite(e)]
+    sh_bias, sh_sigma, nu_irls, mest = float(bias), float(sigma), 5.0, 0
+    for i in range(10):
+        if mest == 0:
+            w = np.ones_like(e)
+        else:
+            en = (e - sh_bias) / sh_sigma
+            w = (nu_irls + 1.0) / (nu_irls + en * en)
+        swr, swsr, sw, n = (e * w).sum(), (e * e * w).sum(), w.sum(), e.size
+        b = swr / sw
+        s = np.sqrt((swsr - 2.0 * b * swr + b * b * sw) / n)
+        prev = sh_sigma
+        sh_bias, sh_sigma, mest = b, s, mestimator
+        if i > 0 and abs(s - prev) / prev < 0.1:
+            break
+
+    def C(nu):
+        en = (e - sh_bias) / sh_sigma
+        w = (nu + 1.0) / (nu + en * en)
+        fw = (np.log(w).sum() - w.sum()) / e.size
+        return -digamma(nu / 2) + np.log(nu / 2) + fw + 1.0 + digamma((nu + 1) / 2) - np.log((nu + 1) / 2)
+
+    up, down = 10.0, 2.0
+    c_down, c_up = C(down), C(up)
+    if c_up * c_down > 0:
+        nu = down if c_down <= 0 else up
+    else:
+        new = None
+        for _ in range(5):
+            new = (up + down) / 2
+            if up - down < 1.0:
+                break
+            c_new = C(new)
+            if c_new * c_up > 0:
+                c_up, up = c_new, new
+            else:
+                c_down, down = c_new, new
+        nu = new
+    return sh_bias, sh_sigma, nu
+
+
+def vmap(depthinv, K):
+    """computeVmapKernel, src/cuda/maps.cu:63-90: back-projection; planes (x, y, z) stacked vertically; only plane 0 is set to NaN when invalid."""
+    fx, fy, cx, cy = [float(v) for v in K]
+    w = depthinv.astype(np.float64)
+    h, w_ = w.shape
+    v, u = np.mgrid[0:h, 0:w_].astype(np.float64)
+    with np.errstate(divide="ignore"):
+        z = 1.0 / w
+    return np.stack([z * (u - cx) / fx, z * (v - cy) / fy, z])
+
+
+def nmap_gradients(depthinv, gx, gy, K):
+    """computeNmapGradientsKernel, src/cuda/maps.cu:134-179: normal from the inverse-depth gradients, kept when it faces the viewing ray
+    (cosine > 0.1)."""
+    fx, fy, cx, cy = [float(v) for v in K]
+    w, gx, gy = [a.astype(np.float64) for a in (depthinv, gx, gy)]
+    h, w_ = w.shape
+    v, u = np.mgrid[0:h, 0:w_].astype(np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        n = np.stack([gx * fx, gy * fy, gx * (cx - u) + gy * (cy - v) + w])
+        n = n / np.sqrt((n * n).sum(0))
+        z = 1.0 / w
+        vt = np.stack([z * (u - cx) / fx, z * (v - cy) / fy, z])
+        vt = vt / np.sqrt((vt * vt).sum(0))
+        keep = (vt * n).sum(0) > 0.1
+    return np.where(keep, n, np.nan)
+
+
+def warp_invdepth_weighted(src, grid, Rp, tp):
+    """trafo3DKernelInvDepthWeightedGridStride, src/cuda/warping_registration.cu:549-594: the inverse-depth warp plus the propagated weight
+    (1 - w2 tz)^4 / v^2; returns (warped, weight) with NaN where the kernel writes nothing."""
+    h, w_ = grid.shape
+    y, x = np.mgrid[0:h, 0:w_].astype(np.float64)
+    g = grid.astype(np.float64)
+    Rp = np.asarray(Rp, np.float64).reshape(3, 3); tp = np.asarray(tp, np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        xs, ys, w3 = register_pixel(x, y, g, Rp, tp)
+        ix = np.floor(xs + 0.5); iy = np.floor(ys + 0.5)
+        inb = (ix >= 0) & (iy >= 0) & (ix < w_) & (iy < h) & ~np.isnan(g)
+        w2 = src.astype(np.float64)[np.clip(iy, 0, h - 1).astype(int) * inb, np.clip(ix, 0, w_ - 1).astype(int) * inb]
+        v = (1.0 / w3 - tp[2]) * g
+        wf = 1.0 - w2 * tp[2]
+        wt = wf ** 4 / (v * v)
+        res = v / wf * w2
+        return np.where(inb & (res > 0), res, np.nan), np.where(inb & (wt > 0), wt, np.nan)

@@ -1,0 +1,129 @@
+"""Cross-check of the C oracle (oracle/) against tests/np_mirror.py, a second restatement of the same reference kernels written in
+vectorised numpy from the reference sources.  The two share no code and evaluate in different precision (fp32 in reference order vs
+float64), so they agree to rounding -- and, where a kernel selects pixels by floor / round, on all but the handful of samples that sit
+within rounding of a selection boundary.  A transcription error in either shows up as a gross mismatch."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import np_mirror as M
+from tests import util
+
+K = (131.25, 131.25, 79.5, 59.5)
+ROWS, COLS = 120, 160
+
+
+def maps(seed, nan_frac=0.05):
+    r = util.rng(seed)
+    w = util.rand_invdepth(r, ROWS, COLS, nan_frac=nan_frac)
+    i = (r.random((ROWS, COLS)) * 255).astype(np.float32)
+    return r, w, i
+
+
+def close(a, b, rtol, atol=0.0, max_bad=0):
+    """same NaN pattern and values within tolerance, except at most max_bad entries"""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    bad = np.isnan(a) != np.isnan(b)
+    both = ~np.isnan(a) & ~np.isnan(b)
+    bad |= both & (np.abs(np.where(both, a - b, 0.0)) > atol + rtol * np.abs(np.where(both, b, 0.0)))
+    assert bad.sum() <= max_bad, (int(bad.sum()), max_bad)
+
+
+def test_conversions():
+    r = util.rng(1)
+    d = r.integers(0, 12000, (ROWS, COLS)).astype(np.uint16); d[r.random((ROWS, COLS)) < 0.1] = 0
+    close(O.depth2invdepth(d), M.depth_to_invdepth(d), 1e-6)
+    close(O.depth2invdepth(d, 5.0), M.depth_to_invdepth(d, 5.0), 1e-6)
+    rgb = r.integers(0, 256, (ROWS, COLS, 3)).astype(np.uint8)
+    close(O.intensity(rgb), M.intensity(rgb), 1e-6, 1e-4)
+
+
+@pytest.mark.parametrize("nan_frac", [0.0, 0.05, 0.5])
+def test_pyrdown_sobel_bilateral(nan_frac):
+    r, w, i = maps(2, nan_frac)
+    close(O.pyr_down(w), M.pyr_down(w), 2e-6)
+    close(O.pyr_down(i), M.pyr_down(i), 2e-6, 1e-4)
+    gx, gy = O.gradient(w); mx, my = M.sobel(w)
+    close(gx, mx, 1e-5, 1e-7); close(gy, my, 1e-5, 1e-7)
+    close(O.bilateral(w, 2 * 0.0025), M.bilateral(w, 2 * 0.0025), 2e-5)
+    close(O.bilateral(i, 3.0), M.bilateral(i, 3.0), 2e-5, 1e-3)
+
+
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_warps_visibility_fusion(seed):
+    r, w0, i0 = maps(seed)
+    _, wc, _ = maps(seed + 100)
+    ic = util.rand_intensity(r, ROWS, COLS)      # smooth texture: fp32 coordinates are good to ~1e-5 px, i.e. ~1e-3 grey levels here
+    R, t = util.small_motion(r, K, 0.03, 1.5)
+    Rp, tp = util.project(K, R, t)
+    # point-sampled inverse-depth warp: a sample within rounding of a pixel boundary may pick the neighbour
+    ow = O.warp_invdepth(wc, w0, Rp, tp); mw = M.warp_invdepth(wc, w0, Rp, tp)
+    close(ow, mw, 2e-5, max_bad=8)
+    for mode, tex8 in ((O.INTERP_EXACT, False), (O.INTERP_TEX8, True)):
+        oi = O.warp_intensity(ic, ow, Rp, tp, mode); mi = M.warp_intensity(ic, ow, Rp, tp, tex8)
+        close(oi, mi, 1e-5, 5e-3 if not tex8 else 1.0, max_bad=8)        # a 1.8 fixed-point weight flips by 1/256 at its rounding boundary
+        assert np.nanmedian(np.abs(oi - mi)) < 1e-3
+    ratio, nvis, nval, mask = O.visibility_ratio(w0, wc, Rp, tp, with_mask=True)
+    mratio, vis, valid = M.visibility_ratio(w0, wc, Rp, tp)
+    assert abs(ratio - mratio) < 5e-4 and nval == valid.sum() and abs(nvis - vis.sum()) <= 4
+    assert np.count_nonzero(mask[valid].astype(bool) != vis[valid]) <= 4
+    # fusion update
+    warped = ow; ww = (r.random((ROWS, COLS)) + 0.5).astype(np.float32)
+    kf = util.rand_invdepth(r, ROWS, COLS, nan_frac=0.2); kfw = (r.random((ROWS, COLS)) * 3 + 1).astype(np.float32)
+    ok_, okw = O.integrate_warped(warped, ww, kf, kfw)
+    mk, mkw = M.integrate(warped, ww, kf, kfw)
+    close(ok_, mk, 1e-6, max_bad=2); close(okw, mkw, 1e-6, max_bad=2)
+
+
+@pytest.mark.parametrize("student_nu,mest,weighting", [(True, 3, 0), (True, 3, 1), (False, 0, 0), (False, 1, 2), (False, 2, 3), (False, 3, 0)])
+def test_normal_equations(student_nu, mest, weighting):
+    """the 27-term system of estimate_VO.cu against the numpy restatement, for the Student-nu path and every fixed-nu M-estimator / weighting"""
+    r, W0, _ = maps(11)
+    I0 = util.rand_intensity(r, ROWS, COLS); I0[r.random((ROWS, COLS)) < 0.02] = np.nan
+    gwx, gwy = O.gradient(W0); gix, giy = O.gradient(I0)
+    W1 = (W0 * (1 + 0.01 * r.standard_normal((ROWS, COLS)))).astype(np.float32); W1[r.random((ROWS, COLS)) < 0.05] = np.nan
+    I1 = (I0 + 4 * r.standard_normal((ROWS, COLS))).astype(np.float32)
+    kw = dict(sigma_depthinv=0.004, sigma_int=6.0, bias_depthinv=0.0003, bias_int=-0.4, nu_depthinv=3.5, nu_int=7.0)
+    A, b = O.build_system(W0, I0, gwx, gwy, gix, giy, W1, I1, K, student_nu=student_nu, mestimator=mest, weighting=weighting, **kw)
+    Am, bm = M.build_system(W0, I0, gwx, gwy, gix, giy, W1, I1, K, kw["sigma_depthinv"], kw["sigma_int"], kw["bias_depthinv"], kw["bias_int"],
+                            kw["nu_depthinv"], kw["nu_int"], student_nu=student_nu, mestimator=mest, weighting=weighting)
+    sc = np.sqrt(np.outer(np.diag(Am), np.diag(Am)))
+    assert np.abs(A - Am).max() / sc.max() < 1e-5 and (np.abs(A - Am) / sc).max() < 1e-4, (np.abs(A - Am) / sc).max()
+    assert np.abs(b - bm).max() < 2e-5 * np.abs(bm).max(), np.abs(b - bm).max() / np.abs(bm).max()
+    assert np.allclose(A, A.T) and np.linalg.eigvalsh(Am).min() > 0
+
+
+@pytest.mark.parametrize("dof,scale,bias", [(3.0, 0.004, 0.0005), (5.0, 4.0, -0.7), (8.0, 0.01, 0.0), (30.0, 2.0, 0.3), (2.2, 1.0, 0.0)])
+def test_sigma_nu_estimator(dof, scale, bias):
+    """IRLS scale / bias and the Student-t degrees of freedom by bisection (sigmaFuncs.cu:858-1066) against the numpy restatement, on
+    Student-t distributed residuals contaminated with NaN and infinities"""
+    r = util.rng(int(dof * 10))
+    e = (bias + scale * r.standard_t(dof, 19200)).astype(np.float32)
+    e[r.random(e.size) < 0.03] = np.nan
+    e[:5] = np.inf; e[5:9] = -np.inf
+    start_sigma = 0.0025 if scale < 0.1 else 5.0
+    ob, os_, onu = O.sigma_nu_student(e, 0.0, start_sigma)
+    mb, ms, mnu = M.sigma_nu_student(e, 0.0, start_sigma)
+    assert abs(os_ - ms) < 2e-4 * ms and abs(ob - mb) < 2e-4 * ms, (ob, mb, os_, ms)
+    assert onu == mnu, (onu, mnu)
+    assert abs(ms - scale * (np.sqrt(dof / (dof - 2)) if dof > 2.5 else 1.0)) / ms < 1.0      # sanity: the right order of magnitude
+
+
+def test_maps_and_weighted_warp():
+    r, w0, _ = maps(21)
+    _, wc, _ = maps(22)
+    ov = O.vmap(w0, K).reshape(3, ROWS, COLS); mv = M.vmap(w0, K)
+    valid = ~np.isnan(w0)
+    close(ov[0], mv[0], 2e-6, 1e-6)
+    close(ov[1][valid], mv[1][valid], 2e-6, 1e-6); close(ov[2][valid], mv[2][valid], 2e-6)      # planes 1, 2 are untouched where invalid
+    gx, gy = O.gradient(w0)
+    on = O.nmap_gradients(w0, gx, gy, K).reshape(3, ROWS, COLS); mn = M.nmap_gradients(w0, gx, gy, K)
+    keep = ~np.isnan(mn[0])
+    assert np.count_nonzero(np.isnan(on[0]) != np.isnan(mn[0])) <= 2                             # the 0.1 cosine gate
+    both = keep & ~np.isnan(on[0])
+    assert np.abs(on[:, both] - mn[:, both]).max() < 5e-6
+    R, t = util.small_motion(r, K, 0.03, 1.5)
+    Rp, tp = util.project(K, R, t)
+    ow, owt = O.warp_invdepth_weighted(wc, w0, Rp, tp, weight_init=np.full((ROWS, COLS), np.nan, np.float32))
+    mw, mwt = M.warp_invdepth_weighted(wc, w0, Rp, tp)
+    close(ow, mw, 2e-5, max_bad=8); close(owt, mwt, 1e-4, max_bad=8)
