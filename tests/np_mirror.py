@@ -311,3 +311,59 @@ def warp_invdepth_weighted(src, grid, Rp, tp):
         wt = wf ** 4 / (v * v)
         res = v / wf * w2
         return np.where(inb & (res > 0), res, np.nan), np.where(inb & (wt > 0), wt, np.nan)
+
+
+def lattice(im1, im0, min_nsamples=10000):
+    """computeErrorGridStride, src/cuda/sigmaFuncs.cu:109-131, 701-765: halve the sampling lattice while both sizes stay even and it keeps at
+    least min_nsamples points; residual im1 - im0 at (stride y, stride x)."""
+    rows, cols = im0.shape
+    r, c = rows, cols
+    if min_nsamples < rows * cols:
+        while True:
+            c2, r2 = c // 2, r // 2
+            if 2 * c2 != c or 2 * r2 != r or min_nsamples > c2 * r2:
+                break
+            c, r = c2, r2
+    stride = int(round(np.sqrt(rows * cols / (r * c))))
+    return (im1.astype(np.float64)[::stride, ::stride][:r, :c] - im0.astype(np.float64)[::stride, ::stride][:r, :c]).reshape(-1)
+
+
+def exp_map_rot(w):
+    """expMapRot, src/util_funcs.cpp:125-147 (Rodrigues; the forced re-orthogonalisation is a no-op to rounding)"""
+    w = np.asarray(w, np.float64)
+    th = np.linalg.norm(w)
+    Om = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-5:
+        return np.eye(3) + Om + 0.5 * Om @ Om
+    return np.eye(3) + np.sin(th) / th * Om + (1 - np.cos(th)) / th ** 2 * Om @ Om
+
+
+def align_pair(depth0, rgb0, depth1, rgb1, K, iters=(10, 5, 3), min_nsamples=10000):
+    """VisodoTracker::estimateVisualOdometry, src/visodo.cpp:1041-1263 for the shipped configuration (PYR_FIRST, Student-t, sigma from the
+    residual pdf, independent weights, no filtering, start at the identity): coarse-to-fine Gauss-Newton of the pose of the current frame
+    (1) relative to the keyframe (0).  Built only from the mirror's own kernels.  Returns (R, t)."""
+    levels = len(iters)
+    kf_w, kf_i = [depth_to_invdepth(depth0)], [intensity(rgb0)]
+    cu_w, cu_i = [depth_to_invdepth(depth1)], [intensity(rgb1)]
+    for l in range(1, levels):
+        kf_w.append(pyr_down(kf_w[-1])); kf_i.append(pyr_down(kf_i[-1]))
+        cu_w.append(pyr_down(cu_w[-1])); cu_i.append(pyr_down(cu_i[-1]))
+    R, t = np.eye(3), np.zeros(3)
+    for l in range(levels - 1, -1, -1):
+        Kl = tuple(v / (1 << l) for v in K)                                            # getCalibMatrix(level), :1886-1900
+        Km = np.array([[Kl[0], 0, Kl[2]], [0, Kl[1], Kl[3]], [0, 0, 1.0]])
+        gwx, gwy = sobel(kf_w[l]); gix, giy = sobel(kf_i[l])
+        for _ in range(iters[l]):
+            Ri = np.linalg.inv(R); ti = -Ri @ t
+            Rp, tp = Km @ Ri @ np.linalg.inv(Km), Km @ ti                              # :1108-1114
+            W1 = warp_invdepth(cu_w[l], kf_w[l], Rp, tp)
+            I1 = warp_intensity(cu_i[l], W1, Rp, tp, tex8=True)
+            bi, si, nui = sigma_nu_student(lattice(I1, kf_i[l], min_nsamples), 0.0, 5.0)        # :1168-1187
+            bd, sd, nud = sigma_nu_student(lattice(W1, kf_w[l], min_nsamples), 0.0, 0.0025)
+            nui = max(nui, nud)
+            A, b = build_system(kf_w[l], kf_i[l], gwx, gwy, gix, giy, W1, I1, Kl, sd, si, bd, bi, nud, nui)
+            x = np.linalg.solve(A, b)                                                   # :1249
+            Rinc = np.linalg.inv(exp_map_rot(x[3:]))                                    # :1252-1263
+            t = Rinc @ t - Rinc @ x[:3]
+            R = Rinc @ R
+    return R, t

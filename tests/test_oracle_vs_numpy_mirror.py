@@ -127,3 +127,22 @@ def test_maps_and_weighted_warp():
     ow, owt = O.warp_invdepth_weighted(wc, w0, Rp, tp, weight_init=np.full((ROWS, COLS), np.nan, np.float32))
     mw, mwt = M.warp_invdepth_weighted(wc, w0, Rp, tp)
     close(ow, mw, 2e-5, max_bad=8); close(owt, mwt, 1e-4, max_bad=8)
+
+
+def test_gauss_newton_alignment_of_a_frame_pair():
+    """the whole coarse-to-fine estimateVisualOdometry (visodo.cpp:1041-1263) rebuilt from the mirror's kernels against the oracle's: the two
+    recover the same relative pose (to the float32-vs-float64 difference of two 18-iteration Gauss-Newton runs), and it is the synthetic
+    camera's true motion to sensor-noise accuracy"""
+    from rgbid import synth
+    seq = synth.make_sequence(2, K=K, rows=ROWS, cols=COLS, trans_step=(0.01, 0.015), rot_step_deg=(0.5, 0.8))
+    d = seq["depth"].numpy().astype(np.uint16); c = seq["rgb"].numpy()
+    cfg = O.default_config(rows=ROWS, cols=COLS, fx=K[0], fy=K[1], cx=K[2], cy=K[3], motion_model=O.NO_MM)
+    ok, Ro, to, _ = O.align_pair(cfg, d[0], c[0], d[1], c[1])
+    assert ok
+    Rm, tm = M.align_pair(d[0], c[0], d[1], c[1], K)
+    ang = lambda A, B: float(np.arccos(np.clip((np.trace(A.T @ B) - 1) / 2, -1, 1)))
+    assert ang(Ro, Rm) < 2e-5 and np.linalg.norm(to - tm) < 2e-5, (ang(Ro, Rm), np.linalg.norm(to - tm))
+    # ground truth: pose of camera 1 in camera 0
+    R_wc, t_wc = seq["R_wc"].numpy(), seq["t_wc"].numpy()
+    Rg = R_wc[0].T @ R_wc[1]; tg = R_wc[0].T @ (t_wc[1] - t_wc[0])
+    assert ang(Rm, Rg) < 3e-3 and np.linalg.norm(tm - tg) < 5e-3
