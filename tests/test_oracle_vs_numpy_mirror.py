@@ -141,7 +141,7 @@ def test_gauss_newton_alignment_of_a_frame_pair():
     assert ok
     Rm, tm = M.align_pair(d[0], c[0], d[1], c[1], K)
     ang = lambda A, B: float(np.arccos(np.clip((np.trace(A.T @ B) - 1) / 2, -1, 1)))
-    assert ang(Ro, Rm) < 2e-5 and np.linalg.norm(to - tm) < 2e-5, (ang(Ro, Rm), np.linalg.norm(to - tm))
+    assert ang(Ro, Rm) < 5e-6 and np.linalg.norm(to - tm) < 5e-6, (ang(Ro, Rm), np.linalg.norm(to - tm))     # measured 1e-7 rad / 3e-7 m
     # ground truth: pose of camera 1 in camera 0
     R_wc, t_wc = seq["R_wc"].numpy(), seq["t_wc"].numpy()
     Rg = R_wc[0].T @ R_wc[1]; tg = R_wc[0].T @ (t_wc[1] - t_wc[0])
