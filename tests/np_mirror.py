@@ -367,3 +367,147 @@ def align_pair(depth0, rgb0, depth1, rgb1, K, iters=(10, 5, 3), min_nsamples=100
             t = Rinc @ t - Rinc @ x[:3]
             R = Rinc @ R
     return R, t
+
+
+# ---- SE(3) helpers (src/util_funcs.cpp:31-123, include/util_funcs.h:50-58) and the tracker's per-frame logic -------------------------------
+def _skew(w):
+    return np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], np.float64)
+
+
+def _Q(w):
+    th = np.linalg.norm(w); Om = _skew(w)
+    if th < 1e-5:
+        return np.eye(3) + 0.5 * Om + Om @ Om / 6.0
+    return np.eye(3) + (1 - np.cos(th)) / th ** 2 * Om + (1 - np.sin(th) / th) / th ** 2 * Om @ Om
+
+
+def exp_map(w, v):
+    """expMap, src/util_funcs.cpp:85-123: (R, t) = (exp([w]x), Q(w) v)"""
+    return exp_map_rot(w), _Q(np.asarray(w, np.float64)) @ np.asarray(v, np.float64)
+
+
+def log_map(R, t):
+    """logMap, src/util_funcs.cpp:31-83: twist (v, w) of (R, t)"""
+    U, _, Vt = np.linalg.svd(R)
+    R = U @ Vt
+    r = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    s = np.sqrt((r * r).sum() * 0.25)
+    th = np.arccos(np.clip((np.trace(R) - 1) * 0.5, -1, 1))
+    k = (1.0 + th * th / 6.0 + 7.0 / 360.0 * th ** 4) if s < 1e-5 else th / s
+    w = r * (k / 2.0)
+    return np.linalg.solve(_Q(w), np.asarray(t, np.float64)), w
+
+
+class Tracker:
+    """VisodoTracker::trackNewFrame, src/visodo.cpp:1967-2247, for the shipped configuration (constant-velocity prediction, PYR_FIRST, Student-t,
+    sigma from the residual pdf, independent weights, no gradient filtering), built only from this module's kernels: keyframe bookkeeping
+    (:826-893, 1541-1575), the Gauss-Newton loop and its covariance pass (:944-1479), covisibility (:1481-1514), keyframe switching and fusion
+    (:2172-2215, 1674-1764).  The tracking-lost branch is not mirrored (the sequences used here never lose track)."""
+
+    def __init__(self, K, rows, cols, iters=(10, 5, 3), visratio_odo=0.9, visratio_integr=0.7, delta_t=0.03333, min_nsamples=10000):
+        self.K, self.rows, self.cols, self.iters = tuple(float(v) for v in K), rows, cols, tuple(iters)
+        self.th_odo, self.th_int, self.dt, self.nsamp = visratio_odo, visratio_integr, np.float32(delta_t), min_nsamples
+        self.time = 0
+        self.poses = []
+        self.info = []
+
+    # -- images
+    def _prepare(self, depth, rgb):
+        w, i = [depth_to_invdepth(depth)], [intensity(rgb)]
+        for _ in range(1, len(self.iters)):
+            w.append(pyr_down(w[-1])); i.append(pyr_down(i[-1]))
+        return w, i
+
+    def _save_odo_kf(self):                                            # saveCurrentImagesAsOdoKeyframes :826-878
+        self.kf_w, self.kf_i = [a.copy() for a in self.cur_w], [a.copy() for a in self.cur_i]
+        fw, fi = bilateral(self.kf_w[0], 2 * 0.0025), bilateral(self.kf_i[0], 3.0)
+        self.cov_grads = sobel(fw) + sobel(fi)                          # gWx, gWy, gIx, gIy of the filtered level-0 maps
+        self.grads = [sobel(w) + sobel(i) for w, i in zip(self.kf_w, self.kf_i)]
+
+    def _save_integr_kf(self):                                         # saveCurrentImagesAsIntegrationKeyframes :880-893
+        self.int_w, self.int_raw = self.cur_w[0].copy(), self.cur_w[0].copy()
+        self.int_weight = np.ones_like(self.cur_w[0])
+
+    def _Km(self, level=0):
+        fx, fy, cx, cy = [v / (1 << level) for v in self.K]
+        return np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+
+    def _covis(self, R_ab, t_ab, A, B):                                # computeCovisibility :1481-1514
+        Km = self._Km(); Ki = np.linalg.inv(Km)
+        r_ba, _, _ = visibility_ratio(B, A, Km @ R_ab @ Ki, Km @ t_ab)
+        Ri = np.linalg.inv(R_ab)
+        r_ab, _, _ = visibility_ratio(A, B, Km @ Ri @ Ki, -Km @ Ri @ t_ab)
+        return min(r_ab, r_ba)
+
+    # -- one frame
+    def track(self, depth, rgb):
+        self.cur_w, self.cur_i = self._prepare(depth, rgb)
+        if self.time == 0:                                             # :1994-2045
+            self.time = 1
+            self.odo_R, self.odo_t = np.eye(3), np.zeros(3); self.int_R, self.int_t = np.eye(3), np.zeros(3)
+            self.est_R, self.est_t = np.eye(3), np.zeros(3)
+            self.dR, self.dt_, self.dcov = np.eye(3), np.zeros(3), np.zeros((6, 6))
+            self.vel, self.omega = np.zeros(3), np.zeros(3)
+            self.odo_count = self.int_count = 0
+            self._save_odo_kf(); self._save_integr_kf()
+            self.poses.append((np.eye(3), np.zeros(3)))
+            return
+        # ---- estimateVisualOdometry :944-1479
+        prev_R, prev_t = self.dR, self.dt_
+        if self.time > 1:                                              # constant-velocity prediction :1012-1025
+            dRp, dtp = exp_map(self.omega * self.dt, self.vel * self.dt)
+            R, t = prev_R @ dRp, prev_R @ dtp + prev_t
+        else:
+            R, t = prev_R, prev_t
+        for l in range(len(self.iters) - 1, -1, -1):
+            Kl = tuple(v / (1 << l) for v in self.K); Km = self._Km(l); Ki = np.linalg.inv(Km)
+            gwx, gwy, gix, giy = self.grads[l]
+            for _ in range(self.iters[l]):
+                Ri = np.linalg.inv(R)
+                Rp, tp = Km @ Ri @ Ki, Km @ (-Ri @ t)
+                W1 = warp_invdepth(self.cur_w[l], self.kf_w[l], Rp, tp)
+                I1 = warp_intensity(self.cur_i[l], W1, Rp, tp, tex8=True)
+                bi, si, nui = sigma_nu_student(lattice(I1, self.kf_i[l], self.nsamp), 0.0, 5.0)
+                bd, sd, nud = sigma_nu_student(lattice(W1, self.kf_w[l], self.nsamp), 0.0, 0.0025)
+                nui = max(nui, nud)
+                A, b = build_system(self.kf_w[l], self.kf_i[l], gwx, gwy, gix, giy, W1, I1, Kl, sd, si, bd, bi, nud, nui)
+                x = np.linalg.solve(A, b)
+                Rinc = np.linalg.inv(exp_map_rot(x[3:]))
+                t = Rinc @ t - Rinc @ x[:3]; R = Rinc @ R
+        # covariance pass :1283-1330 (filtered-map gradients, Student-t with 5 dof, reference sigmas)
+        Km = self._Km(0); Ki = np.linalg.inv(Km); Ri = np.linalg.inv(R)
+        Rp, tp = Km @ Ri @ Ki, Km @ (-Ri @ t)
+        W1 = warp_invdepth(self.cur_w[0], self.kf_w[0], Rp, tp)
+        I1 = warp_intensity(self.cur_i[0], W1, Rp, tp, tex8=True)
+        cg = self.cov_grads
+        A, _ = build_system(self.kf_w[0], self.kf_i[0], cg[0], cg[1], cg[2], cg[3], W1, I1, self.K, 0.0025, 5.0, student_nu=False, mestimator=3)
+        self.dR, self.dt_, self.dcov = R, t, np.linalg.inv(A)
+        est_cov = self.dcov.copy()
+        v, w = log_map(prev_R.T @ R, prev_R.T @ (t - prev_t))          # :1459-1468
+        self.vel, self.omega = v / self.dt, w / self.dt
+        # ---- trackNewFrame :2059-2215
+        self.est_t = self.odo_t + self.odo_R @ self.dt_; self.est_R = self.odo_R @ self.dR
+        self.poses.append((self.est_R.copy(), self.est_t.copy()))
+        self.odo_count += 1; self.int_count += 1
+        vis_odo = self._covis(self.dR, self.dt_, self.kf_w[0], self.cur_w[0])
+        sw_odo = vis_odo < self.th_odo
+        if sw_odo:                                                     # resetOdometryKeyframe :1541-1575 (pose part)
+            self.odo_count = 0
+            self.odo_R, self.odo_t = self.est_R.copy(), self.est_t.copy()
+            self.dR, self.dt_, self.dcov = np.eye(3), np.zeros(3), np.zeros((6, 6))
+            self._save_odo_kf()
+        iR = self.int_R.T @ self.est_R; it = self.int_R.T @ (self.est_t - self.int_t)
+        vis_int = self._covis(iR, it, self.int_raw, self.cur_w[0])
+        sw_int = vis_int < self.th_int
+        if sw_int:
+            self.int_count = 0
+            self.int_R, self.int_t = self.est_R.copy(), self.est_t.copy()
+            self._save_integr_kf()
+        else:                                                          # integrateImagesIntoKeyframes :1674-1764
+            Kd = self._Km(0)
+            Rp = Kd @ iR @ np.linalg.inv(Kd); tp = Kd @ it
+            Rpi = np.linalg.inv(Rp)
+            ws, wt = warp_invdepth_weighted(self.cur_w[0], self.int_w, Rpi, -Rpi @ tp)
+            self.int_w, self.int_weight = integrate(ws, np.where(np.isnan(wt), 0.0, wt), self.int_w, self.int_weight)
+        self.info.append(dict(vis_odo=vis_odo, vis_int=vis_int, sw_odo=bool(sw_odo), sw_int=bool(sw_int), cov=est_cov))
+        self.time += 1

@@ -146,3 +146,36 @@ def test_gauss_newton_alignment_of_a_frame_pair():
     R_wc, t_wc = seq["R_wc"].numpy(), seq["t_wc"].numpy()
     Rg = R_wc[0].T @ R_wc[1]; tg = R_wc[0].T @ (t_wc[1] - t_wc[0])
     assert ang(Rm, Rg) < 3e-3 and np.linalg.norm(tm - tg) < 5e-3
+
+
+def test_tracker_frame_loop():
+    """trackNewFrame over a short sequence that switches both keyframes: the mirror's tracker (constant-velocity prediction, Gauss-Newton,
+    covariance pass, covisibility, keyframe switching, keyframe fusion -- all from np_mirror) against the oracle tracker: same keyframe
+    decisions, same covisibility ratios, same poses and fused keyframe map"""
+    from rgbid import synth
+    n = 9
+    seq = synth.make_sequence(n, K=K, rows=ROWS, cols=COLS, trans_step=(0.005, 0.012), rot_step_deg=(0.2, 0.6))
+    d = seq["depth"].numpy().astype(np.uint16); c = seq["rgb"].numpy()
+    th = dict(visratio_odo=0.95, visratio_integr=0.915)          # odometry keyframe switches on 4 frames, integration keyframe on 2, fusion on 6
+    orc = O.Tracker(O.default_config(rows=ROWS, cols=COLS, fx=K[0], fy=K[1], cx=K[2], cy=K[3], **th))
+    mir = M.Tracker(K, ROWS, COLS, **th)
+    ang = lambda A, B: float(np.arccos(np.clip((np.trace(A.T @ B) - 1) / 2, -1, 1)))
+    switches = [0, 0]
+    for k in range(n):
+        orc.track(d[k], c[k]); mir.track(d[k], c[k])
+        if k == 0:
+            continue
+        oi, mi = orc.last_info(), mir.info[-1]
+        assert abs(oi.visratio_odo - mi["vis_odo"]) < 5e-4 and abs(oi.visratio_integr - mi["vis_int"]) < 5e-4, k
+        assert bool(oi.odo_kf_switched) == mi["sw_odo"] and bool(oi.integr_kf_switched) == mi["sw_int"], k
+        switches[0] += mi["sw_odo"]; switches[1] += mi["sw_int"]
+        oc = np.array(oi.delta_cov).reshape(6, 6)                      # covariance of the keyframe-relative pose estimateVisualOdometry returned
+        sc = np.sqrt(np.outer(np.diag(mi["cov"]), np.diag(mi["cov"])))
+        assert (np.abs(oc - mi["cov"]) / sc).max() < 1e-4, k
+    assert 1 <= switches[0] < n - 1 and 1 <= switches[1] < n - 1                      # every branch (switch / keep / fuse) exercised
+    Ro, to = orc.poses()
+    for k in range(n):
+        assert ang(Ro[k], mir.poses[k][0]) < 1e-5 and np.linalg.norm(to[k] - mir.poses[k][1]) < 1e-5, k      # measured 1.4e-6 rad / 2.7e-6 m
+    kd, kw = orc.kf_depthinv(), orc.kf_weight()
+    close(kd, mir.int_w, 1e-4, max_bad=max(16, int(5e-3 * kd.size)))
+    close(kw, mir.int_weight, 1e-3, max_bad=max(16, int(1e-2 * kd.size)))
