@@ -511,3 +511,46 @@ class Tracker:
             self.int_w, self.int_weight = integrate(ws, np.where(np.isnan(wt), 0.0, wt), self.int_w, self.int_weight)
         self.info.append(dict(vis_odo=vis_odo, vis_int=vis_int, sw_odo=bool(sw_odo), sw_int=bool(sw_int), cov=est_cov))
         self.time += 1
+
+
+# ---- custom-calibration front-end (src/cuda/undistortion.cu) ----------------------------------------------------------------------------
+def _distorted_coords(rows, cols, k):
+    """undistortKernel, src/cuda/undistortion.cu:131-160 with distortPixel :96-108: for every undistorted pixel the (x + 0.5, y + 0.5)
+    position in the distorted image (radial k1, k2, k5; tangential k3, k4)"""
+    fx, fy, cx, cy, k1, k2, k3, k4, k5 = [float(v) for v in k]
+    yu, xu = np.mgrid[0:rows, 0:cols].astype(np.float64)
+    u, v = (xu - cx) / fx, (yu - cy) / fy
+    r2 = u * u + v * v
+    fr = 1.0 + k1 * r2 + k2 * r2 * r2 + k5 * r2 ** 3
+    ud = fr * u + 2.0 * k3 * u * v + k4 * (r2 + 2.0 * u * u)
+    vd = fr * v + 2.0 * k4 * u * v + k3 * (r2 + 2.0 * v * v)
+    return fx * ud + cx + 0.5, fy * vd + cy + 0.5
+
+
+def undistort_intensity(src, k, tex8=True):
+    """undistortIntensity, src/cuda/undistortion.cu:208-245: bilinear texture fetch at the distorted position; NaN outside (0, cols) x (0, rows)"""
+    rows, cols = src.shape
+    xd, yd = _distorted_coords(rows, cols, k)
+    ok = ~((xd <= 0) | (yd <= 0) | (xd >= cols) | (yd >= rows))
+    return np.where(ok, bilinear(src, np.where(ok, xd, 0.5), np.where(ok, yd, 0.5), tex8), np.nan)
+
+
+def undistort_depthinv(src, k, c1, c0, q0, q1, xshift, yshift):
+    """undistortDepthInv, src/cuda/undistortion.cu:247-312: per-pixel correction (1 + D1(u, v)) (c1 w + c0) + D0(u, v) of the SHIFTED raw inverse
+    depth (depthinvCorrectionKernel :162-206, polynomials :110-123), then a point-sampled fetch of the corrected map at the distorted position.
+    Returns (corrected, undistorted)."""
+    fx, fy, cx, cy = [float(v) for v in k[:4]]
+    rows, cols = src.shape
+    y, x = np.mgrid[0:rows, 0:cols]
+    u, v = (x - cx) / fx, (y - cy) / fy
+    r2 = u * u + v * v
+    basis = [np.ones_like(u), r2, r2 * r2, r2 ** 3, u, v, u * v, u * u * v, u * v * v]
+    D0 = sum(float(q) * b for q, b in zip(q0, basis)); D1 = sum(float(q) * b for q, b in zip(q1, basis))
+    xs, ys = x - xshift, y - yshift
+    ok = (xs > 0) & (ys > 0)
+    val = src.astype(np.float64)[np.where(ok, ys, 0), np.where(ok, xs, 0)]
+    corr = np.where(ok, (1.0 + D1) * (c1 * val + c0) + D0, np.nan)
+    xd, yd = _distorted_coords(rows, cols, k)
+    inside = ~((xd <= 0) | (yd <= 0) | (xd >= cols) | (yd >= rows))
+    ix = np.clip(np.floor(np.where(inside, xd, 0)), 0, cols - 1).astype(int); iy = np.clip(np.floor(np.where(inside, yd, 0)), 0, rows - 1).astype(int)
+    return corr, np.where(inside, corr[iy, ix], np.nan)

@@ -179,3 +179,19 @@ def test_tracker_frame_loop():
     kd, kw = orc.kf_depthinv(), orc.kf_weight()
     close(kd, mir.int_w, 1e-4, max_bad=max(16, int(5e-3 * kd.size)))
     close(kw, mir.int_weight, 1e-3, max_bad=max(16, int(1e-2 * kd.size)))
+
+
+def test_custom_calibration_front_end():
+    """undistortIntensity / undistortDepthInv (src/cuda/undistortion.cu) with the lens and depth-distortion parameters of the golden fixture"""
+    from tests.golden import make_golden_v2 as G2
+    r, w, _ = maps(31)
+    i = util.rand_intensity(r, ROWS, COLS)
+    krgb = (K[0], K[1], K[2], K[3]) + G2.KD
+    for tex8, mode in ((False, O.INTERP_EXACT), (True, O.INTERP_TEX8)):
+        close(O.undistort_intensity(i, krgb, mode), M.undistort_intensity(i, krgb, tex8), 1e-5, 5e-3 if not tex8 else 1.0, max_bad=8)
+    kd = (K[0] * 1.1, K[1] * 1.1, K[2] - 0.6, K[3] + 0.4) + tuple(-v * 0.5 for v in G2.KD)
+    D = G2.DIST
+    dd = O.depth_dist(c1=D["c1"], c0=D["c0"], q0=D["q0"], q1=D["q1"])
+    ocorr, oout = O.undistort_depthinv(w, kd, dd)
+    mcorr, mout = M.undistort_depthinv(w, kd, D["c1"], D["c0"], D["q0"], D["q1"], 4, 4)
+    close(ocorr, mcorr, 2e-6, 1e-7); close(oout, mout, 2e-6, 1e-7, max_bad=8)
