@@ -241,6 +241,14 @@ def sigma_nu_student(err, bias, sigma, mestimator=3):
         if i > 0 and abs(s - prev) / prev < 0.1:
             break
 
+    return sh_bias, sh_sigma, _nu_bisection(e, sh_bias, sh_sigma)
+
+
+def _nu_bisection(e, bias, sigma):
+    """the second half of computeSigmaAndNuStudent (:934-1039) == computeNuStudent (:1100-1205): e holds the finite residuals"""
+    from scipy.special import digamma
+    sh_bias, sh_sigma = bias, sigma
+
     def C(nu):
         en = (e - sh_bias) / sh_sigma
         w = (nu + 1.0) / (nu + en * en)
@@ -263,7 +271,41 @@ def sigma_nu_student(err, bias, sigma, mestimator=3):
             else:
                 c_down, down = c_new, new
         nu = new
-    return sh_bias, sh_sigma, nu
+    return nu
+
+
+def nu_student(err, bias, sigma):
+    """computeNuStudent, src/cuda/sigmaFuncs.cu:1068-1222: degrees of freedom only, for a given bias and scale"""
+    e = np.asarray(err, np.float64)
+    return _nu_bisection(e[np.isfinite(e)], float(bias), float(sigma))
+
+
+def keyframe_align(iD_ini, grey_ini, iD_end, grey_end, K, R0=None, t0=None):
+    """KeyframeAlign::alignKeyframes, src/keyframe_align.cpp:115-357: dense alignment of two keyframes for the loop closer.  Four pyramid
+    levels with {5, 5, 3, 0} iterations (:43), fixed scales (0.0025, 5) with nu from computeNuStudent on a 19 200-sample lattice, the
+    intensity warp sampled with the KEYFRAME's inverse depth (:233-236), and nu_depthinv passed for both channels (:268).  Returns (R, t, cov)."""
+    iters = (5, 5, 3, 0)
+    a_w, a_i = [np.asarray(iD_ini, np.float64)], [np.asarray(grey_ini, np.float64)]
+    b_w, b_i = [np.asarray(iD_end, np.float64)], [np.asarray(grey_end, np.float64)]
+    for _ in range(1, 4):
+        a_w.append(pyr_down(a_w[-1])); b_w.append(pyr_down(b_w[-1])); a_i.append(pyr_down(a_i[-1])); b_i.append(pyr_down(b_i[-1]))
+    R = np.eye(3) if R0 is None else np.asarray(R0, np.float64); t = np.zeros(3) if t0 is None else np.asarray(t0, np.float64)
+    A = np.eye(6)
+    for l in range(3, -1, -1):
+        Kl = tuple(float(v) / (1 << l) for v in K)
+        Km = np.array([[Kl[0], 0, Kl[2]], [0, Kl[1], Kl[3]], [0, 0, 1.0]]); Ki = np.linalg.inv(Km)
+        gwx, gwy = sobel(a_w[l]); gix, giy = sobel(a_i[l])
+        for _ in range(iters[l]):
+            Ri = np.linalg.inv(R)
+            Rp, tp = Km @ Ri @ Ki, Km @ (-Ri @ t)
+            W1 = warp_invdepth(b_w[l], a_w[l], Rp, tp)
+            I1 = warp_intensity(b_i[l], a_w[l], Rp, tp, tex8=True)
+            nu_d = nu_student(lattice(W1, a_w[l], 19200), 0.0, 0.0025)
+            A, b = build_system(a_w[l], a_i[l], gwx, gwy, gix, giy, W1, I1, Kl, 0.0025, 5.0, 0.0, 0.0, nu_d, nu_d)
+            x = np.linalg.solve(A, b)
+            Rinc = np.linalg.inv(exp_map_rot(x[3:]))
+            t = Rinc @ t - Rinc @ x[:3]; R = Rinc @ R
+    return R, t, np.linalg.inv(A)
 
 
 def vmap(depthinv, K):

@@ -195,3 +195,24 @@ def test_custom_calibration_front_end():
     ocorr, oout = O.undistort_depthinv(w, kd, dd)
     mcorr, mout = M.undistort_depthinv(w, kd, D["c1"], D["c0"], D["q0"], D["q1"], 4, 4)
     close(ocorr, mcorr, 2e-6, 1e-7); close(oout, mout, 2e-6, 1e-7, max_bad=8)
+
+
+def test_keyframe_align():
+    """KeyframeAlign::alignKeyframes (src/keyframe_align.cpp:115-357) rebuilt from the mirror's kernels against the oracle's restatement:
+    same pose and covariance; both find the true relative pose of two frames three steps apart"""
+    from rgbid import synth
+    rows, cols = 240, 320                      # four pyramid levels down to 30 x 40; the finest lattice is 160 x 120 = 19 200 samples
+    Kq = (262.5, 262.5, 159.5, 119.5)
+    seq = synth.make_sequence(4, K=Kq, rows=rows, cols=cols, trans_step=(0.008, 0.015), rot_step_deg=(0.3, 0.8))
+    d = seq["depth"].numpy().astype(np.uint16); c = seq["rgb"].numpy()
+    iD = [O.depth2invdepth(d[k]) for k in (0, 3)]
+    grey = [np.clip(np.rint(O.intensity(c[k])), 0, 255).astype(np.uint8) for k in (0, 3)]
+    Ro, to, covo = O.keyframe_align(iD[0], grey[0], iD[1], grey[1], Kq)
+    Rm, tm, covm = M.keyframe_align(iD[0], grey[0], iD[1], grey[1], Kq)
+    ang = lambda A, B: float(np.arccos(np.clip((np.trace(A.T @ B) - 1) / 2, -1, 1)))
+    assert ang(Ro, Rm) < 1e-5 and np.linalg.norm(to - tm) < 1e-5, (ang(Ro, Rm), np.linalg.norm(to - tm))
+    sc = np.sqrt(np.outer(np.diag(covm), np.diag(covm)))
+    assert (np.abs(covo - covm) / sc).max() < 1e-3
+    R_wc, t_wc = seq["R_wc"].numpy(), seq["t_wc"].numpy()
+    Rg = R_wc[0].T @ R_wc[3]; tg = R_wc[0].T @ (t_wc[3] - t_wc[0])
+    assert ang(Rm, Rg) < 5e-3 and np.linalg.norm(tm - tg) < 1.5e-2
