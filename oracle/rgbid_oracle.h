@@ -13,7 +13,11 @@
  * the reference file:line it follows (paths relative to /root/reference).  Third-party
  * arithmetic that the reference delegates (Eigen LLT/inverse/JacobiSVD, boost::math::digamma,
  * the CUDA texture unit's bilinear filter) is restated from the published algorithm and
- * pinned by analytic known-answer tests and scipy cross-checks in tests/.
+ * pinned by analytic known-answer tests and scipy cross-checks in tests/.  The restatement as a whole is
+ * additionally held to a second one written independently from the reference sources in numpy
+ * (tests/np_mirror.py, tests/test_oracle_vs_numpy_mirror.py: every kernel, the Gauss-Newton loop, the
+ * per-frame tracker logic, KeyframeAlign) -- that guards against transcription errors; it does not pin
+ * the reference's own binary, so the status stays "unpinned".
  *
  * Conventions: images are dense row-major float arrays (step == cols); invalid == NaN;
  * R_proj is a row-major 3x3 float matrix (== reference Mat33: three float3 rows,
