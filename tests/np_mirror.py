@@ -596,3 +596,48 @@ def undistort_depthinv(src, k, c1, c0, q0, q1, xshift, yshift):
     inside = ~((xd <= 0) | (yd <= 0) | (xd >= cols) | (yd >= rows))
     ix = np.clip(np.floor(np.where(inside, xd, 0)), 0, cols - 1).astype(int); iy = np.clip(np.floor(np.where(inside, yd, 0)), 0, rows - 1).astype(int)
     return corr, np.where(inside, corr[iy, ix], np.nan)
+
+
+def register_depthinv(src, dRc_proj, t_dc_proj, cRd_proj, scale=3):
+    """registerDepthinv, src/cuda/warping_registration.cu:720-822: the depth camera's inverse depth re-rendered in the colour camera.
+    (1) translation only (registerPixelTranslationOnly :148-162) splatted with dilation into an enlarged canvas, the nearest surface winning
+    (atomicMax on the bits of the positive inverse depth, :236-288; canvas initialised / converted by :164-203); (2) the remaining rotation
+    as a homography with a point-sampled fetch from the canvas (:597-635).  Returns (canvas, registered)."""
+    s = np.asarray(src, np.float32)
+    rows, cols = s.shape
+    R, C_ = scale * rows, scale * cols
+    ox, oy = (C_ - cols) // 2, (R - rows) // 2
+    t = np.asarray(t_dc_proj, np.float32)
+    canvas = np.zeros((R, C_), np.float32)                     # 0 = empty (the int view of +0.0f)
+    f = np.float32
+    for yd in range(rows):
+        for xd in range(cols):
+            wd = s[yd, xd]
+            if np.isnan(wd):
+                continue
+            zd = f(1) / wd
+            X = np.array([f(xd) * zd, f(yd) * zd, zd], np.float32) - t
+            with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+                wc = f(1) / X[2]
+                xc, yc = X[0] * wc, X[1] * wc
+                if not wc > f(0.01):
+                    continue
+                dil = wc / wd
+                lim = lambda v: int(np.clip(np.rint(v), -2 ** 31, 2 ** 31 - 1))
+                x0, x1 = lim(xc - f(0.5) * dil) + ox, lim(xc + f(0.5) * dil) + ox
+                y0, y1 = lim(yc - f(0.5) * dil) + oy, lim(yc + f(0.5) * dil) + oy
+            for x in range(max(0, x0), min(x1 + 1, C_)):
+                for y in range(max(0, y0), min(y1 + 1, R)):
+                    canvas[y, x] = max(canvas[y, x], wc)
+    inter = np.where(canvas != 0, canvas, np.nan).astype(np.float32)
+    H = np.asarray(dRc_proj, np.float64).reshape(3, 3); Hi = np.asarray(cRd_proj, np.float64).reshape(3, 3)
+    y, x = np.mgrid[0:rows, 0:cols].astype(np.float64)
+    p = np.einsum("ij,jhw->ihw", H, np.stack([x, y, np.ones_like(x)]))
+    p = p / p[2]
+    xs, ys = p[0] + 0.5 + ox, p[1] + 0.5 + oy
+    ix, iy = np.floor(xs), np.floor(ys)
+    inb = (ix >= 0) & (iy >= 0) & (ix < C_) & (iy < R)
+    w = inter.astype(np.float64)[np.where(inb, iy, 0).astype(int), np.where(inb, ix, 0).astype(int)]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        res = w / np.einsum("j,jhw->hw", Hi[2], p)
+        return inter, np.where(inb & (res > 0), res, np.nan)

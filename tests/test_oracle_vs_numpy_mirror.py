@@ -216,3 +216,15 @@ def test_keyframe_align():
     R_wc, t_wc = seq["R_wc"].numpy(), seq["t_wc"].numpy()
     Rg = R_wc[0].T @ R_wc[3]; tg = R_wc[0].T @ (t_wc[3] - t_wc[0])
     assert ang(Rm, Rg) < 5e-3 and np.linalg.norm(tm - tg) < 1.5e-2
+
+
+def test_depth_to_colour_registration():
+    """registerDepthinv (z-buffer splat with dilation + rotation homography) on the golden fixture's stereo calibration"""
+    from tests.golden import make_golden_v2 as G2
+    d, dRc_proj, t_proj, cRd_proj = G2.calib_case()
+    w = d["W0"][:60, :80].copy()                               # the splat is a Python loop here: a crop keeps it to a second
+    ointer, oout = O.register_depthinv(w, dRc_proj, t_proj, cRd_proj)
+    minter, mout = M.register_depthinv(w, dRc_proj, t_proj, cRd_proj)
+    close(ointer, minter, 1e-6, max_bad=4)
+    close(oout, mout, 2e-6, max_bad=4)
+    assert np.isfinite(oout).mean() > 0.5
