@@ -380,7 +380,7 @@ def exp_map_rot(w):
     return np.eye(3) + np.sin(th) / th * Om + (1 - np.cos(th)) / th ** 2 * Om @ Om
 
 
-def align_pair(depth0, rgb0, depth1, rgb1, K, iters=(10, 5, 3), min_nsamples=10000):
+def align_pair(depth0, rgb0, depth1, rgb1, K, iters=(10, 5, 3), min_nsamples=10000, warp_first=False):
     """VisodoTracker::estimateVisualOdometry, src/visodo.cpp:1041-1263 for the shipped configuration (PYR_FIRST, Student-t, sigma from the
     residual pdf, independent weights, no filtering, start at the identity): coarse-to-fine Gauss-Newton of the pose of the current frame
     (1) relative to the keyframe (0).  Built only from the mirror's own kernels.  Returns (R, t)."""
@@ -397,9 +397,17 @@ def align_pair(depth0, rgb0, depth1, rgb1, K, iters=(10, 5, 3), min_nsamples=100
         gwx, gwy = sobel(kf_w[l]); gix, giy = sobel(kf_i[l])
         for _ in range(iters[l]):
             Ri = np.linalg.inv(R); ti = -Ri @ t
-            Rp, tp = Km @ Ri @ np.linalg.inv(Km), Km @ ti                              # :1108-1114
-            W1 = warp_invdepth(cu_w[l], kf_w[l], Rp, tp)
-            I1 = warp_intensity(cu_i[l], W1, Rp, tp, tex8=True)
+            if warp_first:                                                             # WARP_FIRST :1078-1105: warp at level 0, pyrDown the warped maps
+                K0 = np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1.0]])
+                Rp, tp = K0 @ Ri @ np.linalg.inv(K0), K0 @ ti
+                W1 = warp_invdepth(cu_w[0], kf_w[0], Rp, tp)
+                I1 = warp_intensity(cu_i[0], W1, Rp, tp, tex8=True)
+                for _ in range(l):
+                    I1, W1 = pyr_down(I1), pyr_down(W1)
+            else:
+                Rp, tp = Km @ Ri @ np.linalg.inv(Km), Km @ ti                          # :1108-1114
+                W1 = warp_invdepth(cu_w[l], kf_w[l], Rp, tp)
+                I1 = warp_intensity(cu_i[l], W1, Rp, tp, tex8=True)
             bi, si, nui = sigma_nu_student(lattice(I1, kf_i[l], min_nsamples), 0.0, 5.0)        # :1168-1187
             bd, sd, nud = sigma_nu_student(lattice(W1, kf_w[l], min_nsamples), 0.0, 0.0025)
             nui = max(nui, nud)

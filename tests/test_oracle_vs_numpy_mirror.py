@@ -129,17 +129,19 @@ def test_maps_and_weighted_warp():
     close(ow, mw, 2e-5, max_bad=8); close(owt, mwt, 1e-4, max_bad=8)
 
 
-def test_gauss_newton_alignment_of_a_frame_pair():
+@pytest.mark.parametrize("warp_first", [False, True])
+def test_gauss_newton_alignment_of_a_frame_pair(warp_first):
     """the whole coarse-to-fine estimateVisualOdometry (visodo.cpp:1041-1263) rebuilt from the mirror's kernels against the oracle's: the two
     recover the same relative pose (to the float32-vs-float64 difference of two 18-iteration Gauss-Newton runs), and it is the synthetic
     camera's true motion to sensor-noise accuracy"""
     from rgbid import synth
     seq = synth.make_sequence(2, K=K, rows=ROWS, cols=COLS, trans_step=(0.01, 0.015), rot_step_deg=(0.5, 0.8))
     d = seq["depth"].numpy().astype(np.uint16); c = seq["rgb"].numpy()
-    cfg = O.default_config(rows=ROWS, cols=COLS, fx=K[0], fy=K[1], cx=K[2], cy=K[3], motion_model=O.NO_MM)
+    cfg = O.default_config(rows=ROWS, cols=COLS, fx=K[0], fy=K[1], cx=K[2], cy=K[3], motion_model=O.NO_MM,
+                           warping=O.WARP_FIRST if warp_first else O.PYR_FIRST)
     ok, Ro, to, _ = O.align_pair(cfg, d[0], c[0], d[1], c[1])
     assert ok
-    Rm, tm = M.align_pair(d[0], c[0], d[1], c[1], K)
+    Rm, tm = M.align_pair(d[0], c[0], d[1], c[1], K, warp_first=warp_first)
     ang = lambda A, B: float(np.arccos(np.clip((np.trace(A.T @ B) - 1) / 2, -1, 1)))
     assert ang(Ro, Rm) < 5e-6 and np.linalg.norm(to - tm) < 5e-6, (ang(Ro, Rm), np.linalg.norm(to - tm))     # measured 1e-7 rad / 3e-7 m
     # ground truth: pose of camera 1 in camera 0
