@@ -649,3 +649,57 @@ def register_depthinv(src, dRc_proj, t_dc_proj, cRd_proj, scale=3):
     with np.errstate(invalid="ignore", divide="ignore"):
         res = w / np.einsum("j,jhw->hw", Hi[2], p)
         return inter, np.where(inb & (res > 0), res, np.nan)
+
+
+def _m_weight(en, mest):
+    """computeWeight-style M-estimator weights of sigmaFuncs.cu:207-233: returns (weight, is_valid)"""
+    ok = np.ones_like(en)
+    if mest == 1:
+        w = np.where(np.abs(en) > 1.345, 1.345 / np.maximum(np.abs(en), 1e-300), 1.0)
+    elif mest == 2:
+        inside = np.abs(en) < 4.685
+        w = np.where(inside, (1.0 - (en / 4.685) ** 2) ** 2, 0.0); ok = inside.astype(np.float64)
+    elif mest == 3:
+        w = 6.0 / (5.0 + en * en)
+    else:
+        w = np.ones_like(en)
+    return w, ok
+
+
+def sigma_pdf(err, bias, sigma, mestimator=3):
+    """computeSigmaPdf, src/cuda/sigmaFuncs.cu:773-854 with partialBiasAndSigma :179-255: IRLS bias / scale with a fixed M-estimator (first pass
+    least squares), at most 10 passes, stop when sigma changes by < 10 % -- here the comparison is against the PREVIOUS pass's sigma and the
+    returned values are those of the last pass."""
+    e = np.asarray(err, np.float64); e = e[np.isfinite(e)]
+    sh_b, sh_s, mest = float(bias), float(sigma), 0
+    b = s = None
+    for i in range(10):
+        w, ok = _m_weight((e - sh_b) / sh_s, mest)
+        swr, swsr, sw, n = (e * w).sum(), (e * e * w).sum(), w.sum(), ok.sum()
+        b = swr / sw
+        s = np.sqrt((swsr - 2.0 * b * swr + b * b * sw) / n)
+        if i > 0 and abs(s - sh_s) / sh_s < 0.1:
+            break
+        sh_b, sh_s, mest = b, s, mestimator
+    return b, s
+
+
+def chi_square(err_int, err_depth, sigma_int, sigma_depth, mestimator=3):
+    """computeChiSquare, src/cuda/sigmaFuncs.cu:1225-1297 with normalizeAndAppendErrorsKernel :137-150 and partialChiSquared :541-600: mean
+    robust cost rho of the normalised residuals of both channels, the number of finite residuals, and the Gaussian tail test built from them.
+    Returns (chi_squared, chi_test, Ndof)."""
+    from scipy.special import erf
+    en = np.concatenate([np.asarray(err_int, np.float64) / sigma_int, np.asarray(err_depth, np.float64) / sigma_depth])
+    en = en[np.isfinite(en)]
+    rho = en * en / 2.0
+    if mestimator == 1:
+        rho = np.where(np.abs(en) > 1.345, 1.345 * (np.abs(en) - 1.345 / 2.0), rho)
+    elif mestimator == 2:
+        c = 4.685 * 4.685 / 6.0
+        rho = np.where(np.abs(en) < 4.685, c * (1.0 - (1.0 - (en / 4.685) ** 2) ** 3), c)
+    elif mestimator == 3:
+        rho = 3.0 * np.log(1.0 + en * en / 5.0)
+    n = float(en.size)
+    chi = rho.sum() / n
+    z = (chi - n) / np.sqrt(2.0 * n)
+    return chi, 0.5 * (1.0 + erf(z / np.sqrt(2.0))), n

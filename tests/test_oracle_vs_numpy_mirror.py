@@ -230,3 +230,17 @@ def test_depth_to_colour_registration():
     close(ointer, minter, 1e-6, max_bad=4)
     close(oout, mout, 2e-6, max_bad=4)
     assert np.isfinite(oout).mean() > 0.5
+
+
+@pytest.mark.parametrize("mest", [0, 1, 2, 3])
+def test_sigma_pdf_and_chi_square(mest):
+    """the fixed-M-estimator scale estimate (computeSigmaPdf) and the chi-square statistic (computeChiSquare) against the numpy restatement"""
+    r = util.rng(40 + mest)
+    ei = (0.5 + 6.0 * r.standard_t(4, 19200)).astype(np.float32); ed = (0.003 * r.standard_t(4, 19200)).astype(np.float32)
+    ei[r.random(ei.size) < 0.02] = np.nan; ed[:3] = np.inf
+    ob, os_ = O.sigma_pdf(ei, 0.0, 5.0, mest)[:2]
+    mb, ms = M.sigma_pdf(ei, 0.0, 5.0, mest)
+    assert abs(os_ - ms) < 2e-4 * ms and abs(ob - mb) < 2e-4 * ms, (ob, mb, os_, ms)
+    ochi, otest, on = O.chi_square(ei, ed, 5.0, 0.0025, mest)
+    mchi, mtest, mn = M.chi_square(ei, ed, 5.0, 0.0025, mest)
+    assert on == mn and abs(ochi - mchi) < 1e-4 * mchi and abs(otest - mtest) < 1e-6
