@@ -703,3 +703,19 @@ def chi_square(err_int, err_depth, sigma_int, sigma_depth, mestimator=3):
     chi = rho.sum() / n
     z = (chi - n) / np.sqrt(2.0 * n)
     return chi, 0.5 * (1.0 + erf(z / np.sqrt(2.0))), n
+
+
+def generate_image_rgb(vmap_, nmap_, rgb, light):
+    """ImageGeneratorRGB, src/cuda/image_generator.cu:122-180 with one light (getImage, visodo.cpp:559-580): the keyframe colours shaded by
+    |cos| between the normal and the direction to the light, brightness (int)(205 w) + 50 clamped to [0, 255]; black where vertex or normal
+    is invalid."""
+    rows = rgb.shape[0]
+    v = np.asarray(vmap_, np.float64).reshape(3, rows, -1); n = np.asarray(nmap_, np.float64).reshape(3, rows, -1)
+    ok = ~np.isnan(v[0]) & ~np.isnan(n[0])
+    with np.errstate(invalid="ignore"):
+        vec = np.asarray(light, np.float64)[:, None, None] - v
+        vec = vec / np.sqrt((vec * vec).sum(0))
+        w = np.abs((vec * n).sum(0))
+        br = np.clip(np.floor(np.where(ok, 205.0 * w, 0.0)) + 50, 0, 255) / 255.0
+    out = np.rint(rgb.astype(np.float64) * br[..., None])
+    return np.where(ok[..., None], out, 0).astype(np.uint8)

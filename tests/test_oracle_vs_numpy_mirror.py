@@ -244,3 +244,14 @@ def test_sigma_pdf_and_chi_square(mest):
     ochi, otest, on = O.chi_square(ei, ed, 5.0, 0.0025, mest)
     mchi, mtest, mn = M.chi_square(ei, ed, 5.0, 0.0025, mest)
     assert on == mn and abs(ochi - mchi) < 1e-4 * mchi and abs(otest - mtest) < 1e-6
+
+
+def test_preview_shading():
+    """generateImageRGB on the vertex / normal maps of a random surface: identical bytes except where a product lands within rounding of x.5"""
+    r, w, _ = maps(51)
+    rgb = r.integers(0, 256, (ROWS, COLS, 3)).astype(np.uint8)
+    vm = O.vmap(w, K); gx, gy = O.gradient(w); nm = O.nmap_gradients(w, gx, gy, K)
+    light = np.array([0.3, -0.2, -0.5], np.float32)
+    a = O.generate_image_rgb(vm, nm, rgb, light).astype(int); b = M.generate_image_rgb(vm, nm, rgb, light).astype(int)
+    assert np.abs(a - b).max() <= 1 and np.count_nonzero(a != b) <= 1e-3 * a.size
+    assert (a.sum(-1) > 0).mean() > 0.5
