@@ -4,8 +4,12 @@ import numpy as np, torch
 from oracle import oracle as O
 from rgbid import synth, engine as E, device
 def rot_angle(Ra, Rb): return float(np.arccos(np.clip((np.trace(Ra.T @ Rb) - 1) / 2, -1, 1)))
-K = (synth.TUM_K[0] / 4, synth.TUM_K[1] / 4, (synth.TUM_K[2] + 0.5) / 4 - 0.5, (synth.TUM_K[3] + 0.5) / 4 - 0.5)
-n, B, rows, cols = 300, 4, 120, 160
+full = len(sys.argv) > 1 and sys.argv[1] == "full"      # `python tools/soak.py full`: 2 lanes x 60 frames at 640x480 instead of 4 x 300 at 160x120
+if full:
+    K, n, B, rows, cols = synth.TUM_K, 60, 2, 480, 640
+else:
+    K = (synth.TUM_K[0] / 4, synth.TUM_K[1] / 4, (synth.TUM_K[2] + 0.5) / 4 - 0.5, (synth.TUM_K[3] + 0.5) / 4 - 0.5)
+    n, B, rows, cols = 300, 4, 120, 160
 seqs = [synth.make_sequence(n, seed=synth.SEED + 31 * l, K=K, rows=rows, cols=cols, device="cuda", trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8)) for l in range(B)]
 depth = torch.stack([s["depth"] for s in seqs], 1).to(torch.int16).contiguous(); rgb = torch.stack([s["rgb"] for s in seqs], 1).contiguous()
 ctx = device.Context(0)
