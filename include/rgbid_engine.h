@@ -67,6 +67,9 @@ int rgbid_engine_create(rgbid_engine** e, rgbid_ctx* ctx, const rgbid_engine_con
 int rgbid_engine_destroy(rgbid_engine* e);
 /* VisodoTracker::reset() for every lane */
 int rgbid_engine_reset(rgbid_engine* e);
+/* VisodoTracker::reset() for ONE lane (a stream that ends while the others go on): its next frame is a first frame -- pose record
+ * RGBID_ST_FIRST, identity pose, new keyframes, export count back to 0.  Asynchronous on the context's stream. */
+int rgbid_engine_reset_lane(rgbid_engine* e, int lane);
 /* one trackNewFrame for every lane; depth/rgb are device pointers laid out as described above.
  * Asynchronous on the context's stream (sync with rgbid_ctx_sync or a record read).  With use_graph = 0 the step's kernels read the two
  * buffers IN PLACE (no staging copy): keep them valid and unmodified until the step has executed; with use_graph = 1 they are copied into

@@ -877,6 +877,17 @@ int rgbid_engine_reset(rgbid_engine* e) {
   return RGBID_OK;
 }
 
+int rgbid_engine_reset_lane(rgbid_engine* e, int lane) {
+  if (!e || lane < 0 || lane >= e->B) return RGBID_E_INVALID;
+  if (e->steps == 0) return RGBID_OK;   // nothing tracked yet: every lane starts fresh anyway
+  // the lane's next frame takes the first-frame path of k_step_begin (global_time == 0) inside the ordinary step: its Gauss-Newton, covisibility
+  // and fusion kernels are predicated off by the lane flags and the keyframe-creation kernels on, exactly as in the first step after reset()
+  hipError_t he = hipMemsetAsync(&e->state[lane], 0, sizeof(LaneState), e->ctx->stream);
+  if (he != hipSuccess) return (int)he;
+  he = hipMemsetAsync((char*)e->warped_w.base + (size_t)lane * e->warped_w.lane_stride, 0, e->warped_w.lane_stride, e->ctx->stream);
+  return he == hipSuccess ? RGBID_OK : (int)he;
+}
+
 int rgbid_engine_step(rgbid_engine* e, const void* depth_dev, const void* rgb_dev) {
   if (!e || !depth_dev || !rgb_dev) return RGBID_E_INVALID;
   hipStream_t s = e->ctx->stream;

@@ -90,6 +90,9 @@ class Engine:
     def reset(self):
         check(self.L.rgbid_engine_reset(self._h))
 
+    def reset_lane(self, lane):
+        check(self.L.rgbid_engine_reset_lane(self._h, int(lane)))
+
     def step(self, depth, rgb):
         """depth: CUDA tensor [lanes, rows, cols] of 16-bit ints; rgb: CUDA uint8 [lanes, rows, cols, 3] (contiguous)."""
         c = self.cfg

@@ -473,3 +473,39 @@ def test_engine_keyframe_ring_wraps_and_off_by_default(ctx):
     with pytest.raises(Exception):
         off.read_keyframe(0, 0)
     off.close()
+
+
+@pytest.mark.parametrize("use_graph", [0, 1])
+def test_engine_reset_single_lane(ctx, use_graph):
+    """rgbid_engine_reset_lane: one lane starts a NEW sequence in the middle of a run (its stream ended) while its neighbours keep tracking;
+    the restarted lane must behave like a fresh oracle tracker on the new sequence, the others like uninterrupted ones."""
+    K = (synth.TUM_K[0] / 4, synth.TUM_K[1] / 4, (synth.TUM_K[2] + 0.5) / 4 - 0.5, (synth.TUM_K[3] + 0.5) / 4 - 0.5)
+    rows, cols, n, B, cut = 120, 160, 9, 3, 4
+    seqs, depth, rgb = make_lanes(B, n, rows, cols, K, trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8))
+    new = synth.make_sequence(n - cut, seed=synth.SEED + 999, K=K, rows=rows, cols=cols, device="cuda", trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8))
+    depth = depth.clone(); rgb = rgb.clone()
+    depth[cut:, 1] = new["depth"].to(torch.int16); rgb[cut:, 1] = new["rgb"]          # lane 1 switches to another sequence at frame `cut`
+    eng = E.Engine(ctx, E.default_config(rows=rows, cols=cols, lanes=B, K=K, use_graph=use_graph, record_capacity=n, keyframe_capacity=2))
+    for k in range(n):
+        if k == cut:
+            eng.reset_lane(1)
+        eng.step(depth[k], rgb[k])
+    rec = eng.records()
+    assert int(rec[cut, 1]["status"]) & E.ST_FIRST and not int(rec[cut, 0]["status"]) & E.ST_FIRST
+    for l in range(B):
+        spans = [(0, n)] if l != 1 else [(0, cut), (cut, n)]
+        for a, b in spans:
+            trk = O.Tracker(O.default_config(rows=rows, cols=cols, fx=K[0], fy=K[1], cx=K[2], cy=K[3]))
+            d = depth[a:b, l].cpu().numpy().view(np.uint16); c = rgb[a:b, l].cpu().numpy()
+            for k in range(b - a):
+                trk.track(d[k], c[k])
+            Rs, ts = trk.poses()
+            for k in range(1, b - a):
+                assert rot_angle(Rs[k], rec[a + k, l]["R"]) < 1e-4 and np.linalg.norm(ts[k] - rec[a + k, l]["t"]) < 1e-4, (l, a, k)
+            if b == n:
+                kd = eng.keyframe_maps(l)[0]; od = trk.kf_depthinv()
+                m = ~np.isnan(kd) & ~np.isnan(od)
+                assert np.count_nonzero(np.isnan(kd) != np.isnan(od)) <= 2e-3 * od.size
+                assert np.count_nonzero(np.abs(kd[m] - od[m]) / od[m] > 1e-4) <= max(16, 5e-3 * m.sum())
+            trk.close()
+    eng.close()
