@@ -70,6 +70,10 @@ int rgbid_engine_reset(rgbid_engine* e);
 /* VisodoTracker::reset() for ONE lane (a stream that ends while the others go on): its next frame is a first frame -- pose record
  * RGBID_ST_FIRST, identity pose, new keyframes, export count back to 0.  Asynchronous on the context's stream. */
 int rgbid_engine_reset_lane(rgbid_engine* e, int lane);
+/* Lanes fed by the following steps: active[lane] != 0 (host array of `lanes` ints; NULL = all, the default).  A lane that is not fed sits the
+ * step out -- no state of it changes, its pose record repeats the last pose with status 0 -- so streams of different frame rates or
+ * lengths can share an engine.  The input buffers still carry `lanes` frames; the slots of inactive lanes are ignored. */
+int rgbid_engine_set_active(rgbid_engine* e, const int* active);
 /* one trackNewFrame for every lane; depth/rgb are device pointers laid out as described above.
  * Asynchronous on the context's stream (sync with rgbid_ctx_sync or a record read).  With use_graph = 0 the step's kernels read the two
  * buffers IN PLACE (no staging copy): keep them valid and unmodified until the step has executed; with use_graph = 1 they are copied into

@@ -57,6 +57,7 @@ struct StepCfg {  // by-value kernel argument with what the scalar kernels need
   int start_warp_level;  // pyramid level whose intrinsics project the first warp of a frame
   rgbid_keyframe_header* kf_hdr;  // export ring headers [B][kf_cap] (nullptr: no export)
   int kf_cap;
+  const int* active;     // per-lane 0/1: lanes without a new frame this step sit it out (nullptr: every lane is fed)
 };
 
 __device__ void set_warp_from_pose(const StepCfg& c, int level, const double* R, const double* t, WarpParams& wp) {
@@ -142,6 +143,10 @@ __global__ void k_step_begin(LaneState* st, Flags f, WarpParams* wp, SysParams* 
   LaneState& s = st[lane];
   s.status = 0; s.gn_failed = 0; s.vis_odo = 0.f; s.vis_int = 0.f;
   f.vis[lane] = 0; f.overlap[lane] = 0; f.fuse[lane] = 0; f.kf_slot[lane] = -1;
+  if (c.active && !c.active[lane]) {   // no frame for this lane: nothing of its state moves, its record repeats the last pose with status 0
+    f.first[lane] = 0; f.track[lane] = 0; f.gn[lane] = 0; f.sw_odo[lane] = 0; f.sw_int[lane] = 0; f.maps[lane] = 0;
+    return;
+  }
   if (s.global_time == 0) {
     f.first[lane] = 1; f.track[lane] = 0; f.gn[lane] = 0; f.sw_odo[lane] = 1; f.sw_int[lane] = 1; f.maps[lane] = 1;
     s.global_time = 1;
@@ -504,6 +509,7 @@ struct rgbid_engine {
   unsigned int* counts = nullptr;
   rgbid_pose_record* records = nullptr;  // [capacity][B]
   rgbid_pose_record* rec_cur = nullptr;  // [B] staging written by the step, copied into the ring
+  int* active_dev = nullptr;                // [B] lanes fed by the next steps (rgbid_engine_set_active)
   // keyframe export ring (cfg.keyframe_capacity > 0)
   rgbid_keyframe_header* kf_hdr = nullptr;  // [B][cap]
   char* kf_blocks = nullptr;                // [B][cap][kf_block_bytes]
@@ -602,6 +608,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   const int B = e->B, L = e->L;
   StepCfg sc_ = step_cfg(c);
   sc_.kf_hdr = e->kf_hdr; sc_.kf_cap = c.keyframe_capacity;
+  sc_.active = e->active_dev;   // always passed (all ones by default): the captured graphs stay valid when the mask changes
   const StepCfg sc = sc_;
   const IntrP K0{c.fx, c.fy, c.cx, c.cy};
   const int tb = 64, gb = div_up(B, tb);
@@ -839,6 +846,8 @@ int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_c
   if (!r) r = alloc_dev(e, (void**)&e->records, sizeof(rgbid_pose_record) * (size_t)cfg->record_capacity * B);
   if (!r) r = alloc_dev(e, (void**)&e->rec_cur, sizeof(rgbid_pose_record) * B);
   if (!r) r = alloc_dev(e, (void**)&e->flags.kf_slot, sizeof(int) * B);
+  if (!r) r = alloc_dev(e, (void**)&e->active_dev, sizeof(int) * B);
+  if (!r) { std::vector<int> ones(B, 1); if (hipMemcpyAsync(e->active_dev, ones.data(), sizeof(int) * B, hipMemcpyHostToDevice, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) r = RGBID_E_NOMEM; }
   if (!r && cfg->keyframe_capacity > 0) {
     e->kf_block_bytes = 20 * (size_t)rows * cols;   // u8 mask + 3 u8 colours + f32 inverse depth + 3 f32 normals per pixel
     r = alloc_dev(e, (void**)&e->kf_hdr, sizeof(rgbid_keyframe_header) * (size_t)cfg->keyframe_capacity * B);
@@ -875,6 +884,15 @@ int rgbid_engine_reset(rgbid_engine* e) {
   if (he != hipSuccess) return (int)he;
   e->steps = 0;
   return RGBID_OK;
+}
+
+int rgbid_engine_set_active(rgbid_engine* e, const int* active_host) {
+  if (!e) return RGBID_E_INVALID;
+  std::vector<int> m(e->B, 1);
+  if (active_host) for (int i = 0; i < e->B; ++i) m[i] = active_host[i] ? 1 : 0;
+  hipError_t he = hipMemcpyAsync(e->active_dev, m.data(), sizeof(int) * e->B, hipMemcpyHostToDevice, e->ctx->stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(e->ctx->stream);   // m is a temporary
+  return he == hipSuccess ? RGBID_OK : (int)he;
 }
 
 int rgbid_engine_reset_lane(rgbid_engine* e, int lane) {

@@ -90,6 +90,15 @@ class Engine:
     def reset(self):
         check(self.L.rgbid_engine_reset(self._h))
 
+    def set_active(self, active=None):
+        """lanes fed by the following steps (sequence of 0/1 per lane; None = all)"""
+        if active is None:
+            check(self.L.rgbid_engine_set_active(self._h, None))
+        else:
+            a = np.ascontiguousarray(active, np.int32)
+            assert a.shape == (self.cfg.lanes,)
+            check(self.L.rgbid_engine_set_active(self._h, a.ctypes.data_as(C.c_void_p)))
+
     def reset_lane(self, lane):
         check(self.L.rgbid_engine_reset_lane(self._h, int(lane)))
 

@@ -509,3 +509,52 @@ def test_engine_reset_single_lane(ctx, use_graph):
                 assert np.count_nonzero(np.abs(kd[m] - od[m]) / od[m] > 1e-4) <= max(16, 5e-3 * m.sum())
             trk.close()
     eng.close()
+
+
+@pytest.mark.parametrize("use_graph", [0, 1])
+def test_engine_inactive_lanes_sit_steps_out(ctx, use_graph):
+    """rgbid_engine_set_active: streams of different rates share an engine.  Lane 1 gets no frame on steps 0, 4 and 5 (whatever sits in its
+    input slot is ignored): its records on those steps have status 0 and repeat the last pose, and the frames it does get are tracked exactly
+    like an oracle tracker fed only those; lane 0 is fed every step and is unaffected."""
+    K = (synth.TUM_K[0] / 4, synth.TUM_K[1] / 4, (synth.TUM_K[2] + 0.5) / 4 - 0.5, (synth.TUM_K[3] + 0.5) / 4 - 0.5)
+    rows, cols, n, B = 120, 160, 9, 2
+    seqs, depth, rgb = make_lanes(B, n, rows, cols, K, trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8))
+    idle = {0, 4, 5}
+    eng = E.Engine(ctx, E.default_config(rows=rows, cols=cols, lanes=B, K=K, use_graph=use_graph, record_capacity=n))
+    fed = []                                                   # frame index of lane 1's own sequence consumed at each step (None = idle)
+    nxt = 0
+    garbage_d = torch.full_like(depth[0, 1], 1234); garbage_c = torch.zeros_like(rgb[0, 1])
+    for k in range(n):
+        d = depth[k].clone(); c = rgb[k].clone()
+        if k in idle:
+            eng.set_active([1, 0]); d[1] = garbage_d; c[1] = garbage_c; fed.append(None)
+        else:
+            eng.set_active(None); d[1] = depth[nxt, 1]; c[1] = rgb[nxt, 1]; fed.append(nxt); nxt += 1
+        eng.step(d, c)
+    rec = eng.records()
+    trk = [O.Tracker(O.default_config(rows=rows, cols=cols, fx=K[0], fy=K[1], cx=K[2], cy=K[3])) for _ in range(B)]
+    for k in range(n):
+        trk[0].track(depth[k, 0].cpu().numpy().view(np.uint16), rgb[k, 0].cpu().numpy())
+    R0, t0 = trk[0].poses()
+    for k in range(1, n):
+        assert rot_angle(R0[k], rec[k, 0]["R"]) < 1e-4 and np.linalg.norm(t0[k] - rec[k, 0]["t"]) < 1e-4, k
+    for j in range(nxt):
+        trk[1].track(depth[j, 1].cpu().numpy().view(np.uint16), rgb[j, 1].cpu().numpy())
+    R1, t1 = trk[1].poses()
+    last = None
+    for k in range(n):
+        st = int(rec[k, 1]["status"])
+        if fed[k] is None:
+            assert st == 0, (k, st)
+            if last is not None:
+                assert np.array_equal(rec[k, 1]["R"], rec[last, 1]["R"]) and np.array_equal(rec[k, 1]["t"], rec[last, 1]["t"])
+            continue
+        j = fed[k]
+        assert bool(st & E.ST_FIRST) == (j == 0), (k, st)
+        if j:
+            assert st & E.ST_TRACKED
+            assert rot_angle(R1[j], rec[k, 1]["R"]) < 1e-4 and np.linalg.norm(t1[j] - rec[k, 1]["t"]) < 1e-4, (k, j)
+        last = k
+    for t in trk:
+        t.close()
+    eng.close()
