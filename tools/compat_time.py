@@ -1,6 +1,6 @@
 import sys, time
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/rgbid-slam_amd")
-import numpy as np, torch
+import numpy as np
 from rgbid import host, synth
 seq = synth.make_sequence(40, device="cuda")
 d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()

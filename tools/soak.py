@@ -1,4 +1,4 @@
-import sys, time
+import sys
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/rgbid-slam_amd")
 import numpy as np, torch
 from oracle import oracle as O
