@@ -68,11 +68,13 @@ int rgbid_engine_destroy(rgbid_engine* e);
 /* VisodoTracker::reset() for every lane */
 int rgbid_engine_reset(rgbid_engine* e);
 /* VisodoTracker::reset() for ONE lane (a stream that ends while the others go on): its next frame is a first frame -- pose record
- * RGBID_ST_FIRST, identity pose, new keyframes, export count back to 0.  Asynchronous on the context's stream. */
+ * RGBID_ST_FIRST, identity pose, new keyframes, export count back to 0.  Asynchronous on the context's stream.  Until the lane is fed
+ * again (rgbid_engine_set_active) its pose records read all-zero. */
 int rgbid_engine_reset_lane(rgbid_engine* e, int lane);
 /* Lanes fed by the following steps: active[lane] != 0 (host array of `lanes` ints; NULL = all, the default).  A lane that is not fed sits the
- * step out -- no state of it changes, its pose record repeats the last pose with status 0 -- so streams of different frame rates or
- * lengths can share an engine.  The input buffers still carry `lanes` frames; the slots of inactive lanes are ignored. */
+ * step out -- no tracker state of it changes (keyframes, poses, motion model, current-frame pyramids), every kernel of the step is
+ * predicated off for it, and its pose record repeats the last pose with status 0 -- so streams of different frame rates or lengths can
+ * share an engine.  The input buffers still carry `lanes` frames; the slots of inactive lanes are not read. */
 int rgbid_engine_set_active(rgbid_engine* e, const int* active);
 /* one trackNewFrame for every lane; depth/rgb are device pointers laid out as described above.
  * Asynchronous on the context's stream (sync with rgbid_ctx_sync or a record read).  With use_graph = 0 the step's kernels read the two
@@ -113,7 +115,8 @@ int rgbid_engine_keyframes_dev(rgbid_engine* e, void** headers, void** blocks, s
 
 /* Event timing of the dominant kernel: while profiling is on, every launch of the level-0 (full resolution)
  * residual + normal-equation kernel is bracketed by a hipEvent pair on the context's stream (steps run eagerly,
- * not as a graph).  profile_end synchronises and returns the summed kernel time, the number of launches and the
+ * not as a graph; with use_graph = 1 the inputs still go through the staging copy, so the buffer-lifetime rule of
+ * rgbid_engine_step does not change).  profile_end synchronises and returns the summed kernel time, the number of launches and the
  * algorithmic bytes one launch processes (32 B/px x rows x cols x lanes, SURVEY.md section 8d unit U1). */
 int rgbid_engine_profile_begin(rgbid_engine* e, int max_launches);
 int rgbid_engine_profile_end(rgbid_engine* e, double* total_ms, int* n_launches, double* bytes_per_launch);

@@ -56,10 +56,41 @@ class FrameInfo(C.Structure):
         ("sigma_int", C.c_float), ("sigma_depthinv", C.c_float), ("nu_int", C.c_float),
         ("nu_depthinv", C.c_float), ("bias_int", C.c_float), ("bias_depthinv", C.c_float),
         ("delta_R", C.c_double * 9), ("delta_t", C.c_double * 3), ("delta_cov", C.c_double * 36),
+        ("odo_kf_natural", C.c_int), ("integr_kf_natural", C.c_int),
     ]
 
 
 _lib = None
+_lib_cn = None
+_SO_CN = os.path.join(_HERE, "librgbid_oracle_cudanum.so")
+
+
+def _restypes(L):
+    L.orc_tracker_create.restype = C.c_void_p
+    for f in ("kf_depthinv", "kf_weight", "kf_normals", "kf_vertices", "kf_overlap_mask", "cur_depthinv", "cur_intensity"):
+        getattr(L, "orc_tracker_" + f).restype = C.c_void_p
+    return L
+
+
+def cpu_has_fma():
+    try:
+        return " fma " in open("/proc/cpuinfo").read().replace("\n", " ")
+    except OSError:
+        return False
+
+
+def lib_cudanum():
+    """the oracle built under the model of the reference's nvcc numerics (--ftz --prec-div=false --prec-sqrt=false, fmad, __expf):
+    only the Tracker is meant to be driven through it (Tracker(cfg, numerics="cuda")).  Needs a host CPU with FMA."""
+    global _lib_cn
+    if _lib_cn is None:
+        if not cpu_has_fma():
+            raise RuntimeError("librgbid_oracle_cudanum.so is compiled with -mfma and this CPU has no FMA")
+        if not os.path.exists(_SO_CN):
+            subprocess.check_call(["make", "-C", _HERE, "librgbid_oracle_cudanum.so"])
+        _lib_cn = _restypes(C.CDLL(_SO_CN))
+        assert _lib_cn.orc_cuda_numerics() == 1
+    return _lib_cn
 
 
 def lib():
@@ -67,6 +98,7 @@ def lib():
     if _lib is None:
         build()
         _lib = C.CDLL(_SO)
+        _restypes(_lib)
         _lib.orc_visibility_ratio.restype = C.c_float
         _lib.orc_digamma.restype = C.c_float
         _lib.orc_digamma.argtypes = [C.c_float]
@@ -324,13 +356,14 @@ def default_config(**kw):
 class Tracker:
     """orc_tracker: CPU restatement of VisodoTracker::trackNewFrame (src/visodo.cpp:1967-2247)."""
 
-    def __init__(self, cfg=None, **kw):
+    def __init__(self, cfg=None, numerics="ieee", **kw):
         self.cfg = cfg if cfg is not None else default_config(**kw)
-        self._h = C.c_void_p(lib().orc_tracker_create(C.byref(self.cfg)))
+        self._L = lib() if numerics == "ieee" else lib_cudanum()
+        self._h = C.c_void_p(self._L.orc_tracker_create(C.byref(self.cfg)))
 
     def close(self):
-        if self._h and _lib is not None:
-            _lib.orc_tracker_destroy(self._h)
+        if self._h and self._L is not None:
+            self._L.orc_tracker_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -342,25 +375,29 @@ class Tracker:
     def track(self, depth_u16, rgb_u8):
         d = np.ascontiguousarray(depth_u16, np.uint16)
         r = np.ascontiguousarray(rgb_u8, np.uint8)
-        return bool(lib().orc_tracker_track(self._h, _p(d), _p(r)))
+        return bool(self._L.orc_tracker_track(self._h, _p(d), _p(r)))
+
+    def force_kf_decisions(self, odo_switch=-1, integr_switch=-1):
+        """test hook: impose the keyframe decisions of the NEXT tracked frame (-1 natural, 0 keep, 1 switch)"""
+        self._L.orc_tracker_force_kf_decisions(self._h, int(odo_switch), int(integr_switch))
 
     def poses(self):
-        n = lib().orc_tracker_num_poses(self._h)
+        n = self._L.orc_tracker_num_poses(self._h)
         Rs, ts = np.empty((n, 9)), np.empty((n, 3))
         for i in range(n):
-            lib().orc_tracker_get_pose(self._h, i, _p(Rs[i]), _p(ts[i]))
+            self._L.orc_tracker_get_pose(self._h, i, _p(Rs[i]), _p(ts[i]))
         return Rs.reshape(n, 3, 3), ts
 
     def odometry(self):
-        n = lib().orc_tracker_num_odo(self._h)
+        n = self._L.orc_tracker_num_odo(self._h)
         Rs, ts, cs = np.empty((n, 9)), np.empty((n, 3)), np.empty((n, 36))
         for i in range(n):
-            lib().orc_tracker_get_odo(self._h, i, _p(Rs[i]), _p(ts[i]), _p(cs[i]))
+            self._L.orc_tracker_get_odo(self._h, i, _p(Rs[i]), _p(ts[i]), _p(cs[i]))
         return Rs.reshape(n, 3, 3), ts, cs.reshape(n, 6, 6)
 
     def last_info(self):
         info = FrameInfo()
-        lib().orc_tracker_last_info(self._h, C.byref(info))
+        self._L.orc_tracker_last_info(self._h, C.byref(info))
         return info
 
     def _map(self, fn, shape, dtype):
@@ -373,35 +410,35 @@ class Tracker:
         """prepareImagesCustomCalibration path (custom_registration=1); dist = oracle.depth_dist(...)"""
         cc = CustomCalib(IntrK(*[float(v) for v in rgb_k]), IntrK(*[float(v) for v in depth_k]), dist,
                          (C.c_float * 9)(*[float(v) for v in np.asarray(dRc).reshape(9)]), (C.c_float * 3)(*[float(v) for v in t_dc]))
-        lib().orc_tracker_set_custom_calibration(self._h, C.byref(cc))
+        self._L.orc_tracker_set_custom_calibration(self._h, C.byref(cc))
 
     # ---- streams to the back-end (f-3) ----
     def sink_poses(self):
-        n = lib().orc_tracker_num_sink_poses(self._h)
+        n = self._L.orc_tracker_num_sink_poses(self._h)
         ids = np.empty(n, np.int32); Rs = np.empty((n, 9)); ts = np.empty((n, 3))
         for i in range(n):
             v = C.c_int()
-            lib().orc_tracker_get_sink_pose(self._h, i, C.byref(v), _p(Rs[i]), _p(ts[i]))
+            self._L.orc_tracker_get_sink_pose(self._h, i, C.byref(v), _p(Rs[i]), _p(ts[i]))
             ids[i] = v.value
         return ids, Rs.reshape(n, 3, 3), ts
 
     def constraints(self):
         out = []
-        for i in range(lib().orc_tracker_num_constraints(self._h)):
+        for i in range(self._L.orc_tracker_num_constraints(self._h)):
             a, b, ty = C.c_int(), C.c_int(), C.c_int()
             R = np.empty(9); t = np.empty(3); cov = np.empty(36)
-            lib().orc_tracker_get_constraint(self._h, i, C.byref(a), C.byref(b), C.byref(ty), _p(R), _p(t), _p(cov))
+            self._L.orc_tracker_get_constraint(self._h, i, C.byref(a), C.byref(b), C.byref(ty), _p(R), _p(t), _p(cov))
             out.append(dict(ini=a.value, end=b.value, type=ty.value, R=R.reshape(3, 3), t=t, cov=cov.reshape(6, 6)))
         return out
 
     def num_keyframes(self):
-        return lib().orc_tracker_num_keyframes(self._h)
+        return self._L.orc_tracker_num_keyframes(self._h)
 
     def keyframe(self, i):
         rows, cols = self.cfg.rows, self.cfg.cols
         v = C.c_int(); R = np.empty(9); t = np.empty(3); Rr = np.empty(9); tr = np.empty(3)
         pm, pc, pd, pn = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
-        lib().orc_tracker_get_keyframe(self._h, int(i), C.byref(v), _p(R), _p(t), _p(Rr), _p(tr), C.byref(pm), C.byref(pc), C.byref(pd), C.byref(pn))
+        self._L.orc_tracker_get_keyframe(self._h, int(i), C.byref(v), _p(R), _p(t), _p(Rr), _p(tr), C.byref(pm), C.byref(pc), C.byref(pd), C.byref(pn))
         n = rows * cols
         grab = lambda ptr, ct, cnt, shape, dt: np.frombuffer((ct * cnt).from_address(ptr.value), dt).reshape(shape).copy()
         return dict(id=v.value, R=R.reshape(3, 3), t=t, R_rel=Rr.reshape(3, 3), t_rel=tr,
@@ -409,27 +446,25 @@ class Tracker:
                     depthinv=grab(pd, C.c_float, n, (rows, cols), np.float32), normals=grab(pn, C.c_float, 3 * n, (3, rows, cols), np.float32))
 
     def cur_depthinv(self):
-        lib().orc_tracker_cur_depthinv.restype = C.c_void_p
-        return self._map(lib().orc_tracker_cur_depthinv, (self.cfg.rows, self.cfg.cols), np.float32)
+        return self._map(self._L.orc_tracker_cur_depthinv, (self.cfg.rows, self.cfg.cols), np.float32)
 
     def cur_intensity(self):
-        lib().orc_tracker_cur_intensity.restype = C.c_void_p
-        return self._map(lib().orc_tracker_cur_intensity, (self.cfg.rows, self.cfg.cols), np.float32)
+        return self._map(self._L.orc_tracker_cur_intensity, (self.cfg.rows, self.cfg.cols), np.float32)
 
     def kf_depthinv(self):
-        return self._map(lib().orc_tracker_kf_depthinv, (self.cfg.rows, self.cfg.cols), np.float32)
+        return self._map(self._L.orc_tracker_kf_depthinv, (self.cfg.rows, self.cfg.cols), np.float32)
 
     def kf_weight(self):
-        return self._map(lib().orc_tracker_kf_weight, (self.cfg.rows, self.cfg.cols), np.float32)
+        return self._map(self._L.orc_tracker_kf_weight, (self.cfg.rows, self.cfg.cols), np.float32)
 
     def kf_normals(self):
-        return self._map(lib().orc_tracker_kf_normals, (3 * self.cfg.rows, self.cfg.cols), np.float32)
+        return self._map(self._L.orc_tracker_kf_normals, (3 * self.cfg.rows, self.cfg.cols), np.float32)
 
     def kf_vertices(self):
-        return self._map(lib().orc_tracker_kf_vertices, (3 * self.cfg.rows, self.cfg.cols), np.float32)
+        return self._map(self._L.orc_tracker_kf_vertices, (3 * self.cfg.rows, self.cfg.cols), np.float32)
 
     def kf_overlap_mask(self):
-        return self._map(lib().orc_tracker_kf_overlap_mask, (self.cfg.rows, self.cfg.cols), np.uint8)
+        return self._map(self._L.orc_tracker_kf_overlap_mask, (self.cfg.rows, self.cfg.cols), np.uint8)
 
 
 def align_pair(cfg, depth0, rgb0, depth1, rgb1, R0=None, t0=None):

@@ -19,6 +19,63 @@
 
 #define ORC_NAN (nanf(""))
 
+/* ---- numerics of the reference's CUDA build, as a sensitivity model ---------------------------------------------------------
+ * The reference compiles src/cuda with  --ftz=true --prec-div=false --prec-sqrt=false  (CMakeLists.txt:105) on top of nvcc's default
+ * --fmad=true, and calls __expf in its Gaussian taps (pyrdown.cu:116, filters.cu:124): its own results are NOT those of IEEE
+ * arithmetic.  Built with -DORC_CUDA_NUMERICS (oracle/Makefile: librgbid_oracle_cudanum.so, also -ffp-contract=fast -mfma so that
+ * a*b+c contracts into FMAs as nvcc does) every fp32 division, sqrt, rsqrt and exp of the device code goes through the functions
+ * below: the correctly rounded result moved by a deterministic, input-keyed pseudo-random offset within the error bound the CUDA
+ * programming guide states for the approximate instruction (div.full / rcp.approx: 2 ulp, sqrt.approx / rsqrt.approx: 2 ulp,
+ * ex2.approx behind __expf: 2 + floor(|1.16 x|) ulp), subnormal inputs and results flushed to zero.  The GPU hardware this models
+ * is absent, so the offsets are a MODEL of "any result inside the documented bound", not the bits an NVIDIA GPU would return.
+ * tests/test_oracle_cuda_numerics.py runs both libraries over the same sequences and bounds how far poses and keyframe decisions
+ * move: that is what "within tolerance of the reference's CUDA path" can mean in an image without CUDA.  The default build
+ * (ORC_CUDA_NUMERICS undefined) expands the macros to the plain IEEE operators: its bits are unchanged. */
+#ifdef ORC_CUDA_NUMERICS
+#include <float.h>
+static inline uint32_t cn_bits(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
+static inline float cn_from_bits(uint32_t u) { float x; memcpy(&x, &u, 4); return x; }
+static inline float cn_ftz(float x) { return (fabsf(x) < FLT_MIN) ? copysignf(0.f, x) : x; }
+static inline uint32_t cn_mix(uint32_t a, uint32_t b) {
+  uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u + (a << 6) + (a >> 2));
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+  return h;
+}
+/* r moved by k units in the last place (magnitude-wise), kept finite and normal */
+static inline float cn_nudge(float r, int k) {
+  if (!(fabsf(r) >= FLT_MIN) || isinf(r) || k == 0) return r;
+  uint32_t u = cn_bits(r), sign = u & 0x80000000u, mag = u & 0x7fffffffu;
+  int64_t m = (int64_t)mag + k;
+  if (m < 0x00800000) m = 0x00800000;
+  if (m > 0x7f7fffff) m = 0x7f7fffff;
+  return cn_from_bits(sign | (uint32_t)m);
+}
+static inline int cn_off(uint32_t h, int bound) { return (int)(h % (uint32_t)(2 * bound + 1)) - bound; }
+static inline float cn_div(float a, float b) {
+  a = cn_ftz(a); b = cn_ftz(b);
+  return cn_ftz(cn_nudge(a / b, cn_off(cn_mix(cn_bits(a), cn_bits(b)), 2)));
+}
+static inline float cn_sqrt(float x) { x = cn_ftz(x); return cn_ftz(cn_nudge(sqrtf(x), cn_off(cn_mix(cn_bits(x), 0x51u), 2))); }
+static inline float cn_rsqrt(float x) { x = cn_ftz(x); return cn_ftz(cn_nudge((float)(1.0 / sqrt((double)x)), cn_off(cn_mix(cn_bits(x), 0x52u), 2))); }
+static inline float cn_exp(float x) {
+  x = cn_ftz(x);
+  float t = x * 1.44269504088896341f;                       /* __expf(x) = ex2.approx(x * log2 e), the product rounded to fp32 */
+  int bound = 2;
+  return cn_ftz(cn_nudge((float)exp2((double)t), cn_off(cn_mix(cn_bits(x), 0x53u), bound)));
+}
+#define FDIV(a, b) cn_div((a), (b))
+#define FSQRT(x) cn_sqrt(x)
+#define FRSQRT(x) cn_rsqrt(x)
+#define FEXP(x) cn_exp(x)
+int orc_cuda_numerics(void) { return 1; }
+#else
+#define FDIV(a, b) ((a) / (b))
+#define FSQRT(x) sqrtf(x)
+#define FRSQRT(x) (1.0f / sqrtf(x))
+#define FEXP(x) expf(x)
+int orc_cuda_numerics(void) { return 0; }
+#endif
+
 static int g_threads = 0;
 int orc_num_threads(void) {
 #ifdef _OPENMP
@@ -50,7 +107,7 @@ static inline int f2i_rn(float x) {
 static inline int imin(int a, int b) { return a < b ? a : b; }
 static inline int imax(int a, int b) { return a > b ? a : b; }
 /* utils.hpp:153-157 normalized(): v * rsqrt(dot(v,v)) */
-static inline float rsqrt_f(float x) { return 1.0f / sqrtf(x); }
+static inline float rsqrt_f(float x) { return FRSQRT(x); }
 static inline float dot3(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 
 orc_intr orc_intr_level(orc_intr k, int level) {
@@ -68,7 +125,7 @@ void orc_depth2invdepth(const uint16_t* src, float* dst, int rows, int cols, flo
     for (int x = 0; x < cols; ++x) {
       int value = src[(size_t)y * cols + x];
       float r = ORC_NAN;
-      if (value > 0) r = (1.f / factor_depth) * 1000.f / (float)imax(0, imin(value, 10000));
+      if (value > 0) r = FDIV(FDIV(1.f, factor_depth) * 1000.f, (float)imax(0, imin(value, 10000)));
       dst[(size_t)y * cols + x] = r;
     }
 }
@@ -139,7 +196,7 @@ void orc_pyr_down(const float* src, int rows, int cols, float* dst) {
           float val = src[(size_t)cy * cols + cx];
           if (!isnan(val)) {
             float space2 = (float)((2 * x - cx) * (2 * x - cx) + (2 * y - cy) * (2 * y - cy));
-            float weight = expf(-(space2 * sigma_space2_inv_half));
+            float weight = FEXP(-(space2 * sigma_space2_inv_half));
             sum1 += val * weight;
             sum2 += weight;
             ++count;
@@ -147,7 +204,7 @@ void orc_pyr_down(const float* src, int rows, int cols, float* dst) {
         }
       int d = 2 * br + 1;
       int area = d * d;
-      if (count > (area / 2)) res = sum1 / sum2;
+      if (count > (area / 2)) res = FDIV(sum1, sum2);
       dst[(size_t)y * dcols + x] = res;
     }
 }
@@ -172,28 +229,28 @@ void orc_bilateral(const float* src, int rows, int cols, float sigma_floatmap, f
           float tmp = src[(size_t)cy * cols + cx];
           if (!isnan(tmp)) {
             float space2 = (float)((x - cx) * (x - cx) + (y - cy) * (y - cy));
-            float fn = (value - tmp) / sigma_floatmap;
+            float fn = FDIV(value - tmp, sigma_floatmap);
             /* `0.5 / (sigma_space*sigma_space)` and `0.5*fn*fn` are double expressions in the source */
             float s2ih = (float)(0.5 / (double)(sigma_space * sigma_space));
             double arg = (double)(s2ih * space2) + (0.5 * (double)fn) * (double)fn;
-            float weight = expf((float)(-arg));
+            float weight = FEXP((float)(-arg));
             sum1 += tmp * weight;
             sum2 += weight;
           }
         }
-      dst[(size_t)y * cols + x] = sum1 / sum2;
+      dst[(size_t)y * cols + x] = FDIV(sum1, sum2);
     }
 }
 
 /* ------------------------------------------------------------------ warping_registration.cu */
 /* registerPixel, warping_registration.cu:129-146; Mat33*float3 device.hpp:70-74; dot utils.hpp:105-109 */
 static inline float register_pixel(float* xc, float* yc, int xd, int yd, float wd, const float R[9], const float t[3]) {
-  float zd = 1.f / wd;
+  float zd = FDIV(1.f, wd);
   float Xd[3] = { (float)xd * zd, (float)yd * zd, zd };
   float X0 = dot3(R + 0, Xd) + t[0];
   float X1 = dot3(R + 3, Xd) + t[1];
   float X2 = dot3(R + 6, Xd) + t[2];
-  float wc = 1.f / X2;
+  float wc = FDIV(1.f, X2);
   *xc = X0 * wc;
   *yc = X1 * wc;
   return wc;
@@ -219,8 +276,8 @@ void orc_warp_invdepth(const float* src, const float* grid, int rows, int cols,
         if (in_bounds_rd(xs, ys, cols, rows)) {
           float w2 = src[(size_t)f2i_rd(ys) * cols + f2i_rd(xs)];
           float tz = t[2];
-          float v1_z = (1.f / w3 - tz) * w;
-          float res = (v1_z / (1.f - w2 * tz)) * w2;
+          float v1_z = (FDIV(1.f, w3) - tz) * w;
+          float res = FDIV(v1_z, 1.f - w2 * tz) * w2;
           if (res > 0.f) out = res;
         }
       }
@@ -286,11 +343,11 @@ void orc_warp_invdepth_weighted(const float* src, const float* grid, int rows, i
         if (in_bounds_rd(xs, ys, cols, rows)) {
           float w2 = src[(size_t)f2i_rd(ys) * cols + f2i_rd(xs)];
           float tz = t[2];
-          float v1_z = (1.f / w3 - tz) * w;
+          float v1_z = (FDIV(1.f, w3) - tz) * w;
           float w_factor = 1.f - w2 * tz;
           float w_factor2 = w_factor * w_factor;
-          float weight_res = (w_factor2 * w_factor2) / (v1_z * v1_z);
-          float res = (v1_z / w_factor) * w2;
+          float weight_res = FDIV(w_factor2 * w_factor2, v1_z * v1_z);
+          float res = FDIV(v1_z, w_factor) * w2;
           if (res > 0.f) dst[idx] = res;
           if (weight_res > 0.f) weight[idx] = weight_res;
         }
@@ -312,7 +369,7 @@ void orc_integrate_warped(const float* warped, const float* warped_weight,
         kf_weight[i] = warped_weight[i];
       } else if (dw < 3 * TH) {
         float new_weight = kf_weight[i] + warped_weight[i];
-        kf[i] = (w_KF * kf_weight[i] + w_sum * warped_weight[i]) / new_weight;
+        kf[i] = FDIV(w_KF * kf_weight[i] + w_sum * warped_weight[i], new_weight);
         kf_weight[i] = new_weight;
       }
     }
@@ -351,7 +408,7 @@ void orc_vmap(const float* depthinv, int rows, int cols, orc_intr k, float* vmap
   float fx_inv = 1.f / k.fx, fy_inv = 1.f / k.fy;
   for (int v = 0; v < rows; ++v)
     for (int u = 0; u < cols; ++u) {
-      float z = 1.f / depthinv[(size_t)v * cols + u];
+      float z = FDIV(1.f, depthinv[(size_t)v * cols + u]);
       if (!isnan(z)) {
         vmap[(size_t)v * cols + u] = z * (u - k.cx) * fx_inv;
         vmap[(size_t)(v + rows) * cols + u] = z * (v - k.cy) * fy_inv;
@@ -374,7 +431,7 @@ void orc_nmap_gradients(const float* depthinv, const float* gx_, const float* gy
         float n[3] = { gx * k.fx, gy * k.fy, gx * (k.cx - u) + gy * (k.cy - v) + w };
         float rn = rsqrt_f(dot3(n, n));
         n[0] *= rn; n[1] *= rn; n[2] *= rn;
-        float z = 1.f / w;
+        float z = FDIV(1.f, w);
         float vt[3] = { z * (u - k.cx) * (1.f / k.fx), z * (v - k.cy) * (1.f / k.fy), z };
         float rv = rsqrt_f(dot3(vt, vt));
         vt[0] *= rv; vt[1] *= rv; vt[2] *= rv;
@@ -422,7 +479,7 @@ void orc_integrate_warped_rgb(const float* warped, const float* r, const float* 
     } else if (((kf[i] - warped[i]) < TH) && ((warped[i] - kf[i]) < TH)) {
       float new_weight = kfw[i] + wweight[i];
       float q = kfw[i];
-      kf[i] = (kf[i] * q + warped[i] * wweight[i]) / new_weight;
+      kf[i] = FDIV(kf[i] * q + warped[i] * wweight[i], new_weight);
       c[0] = (uint8_t)f2i_rn(((float)c[0] * q + r[i] * wweight[i]) / new_weight);
       c[1] = (uint8_t)f2i_rn(((float)c[1] * q + g[i] * wweight[i]) / new_weight);
       c[2] = (uint8_t)f2i_rn(((float)c[2] * q + b[i] * wweight[i]) / new_weight);
@@ -560,12 +617,12 @@ void orc_register_depthinv(const float* src, int rows, int cols, int irows, int 
     for (int xd = 0; xd < cols; ++xd) {
       float wd = src[(size_t)yd * cols + xd];
       if (wd != wd) continue;
-      float zd = 1.f / wd;                                        /* registerPixelTranslationOnly :148-165 */
+      float zd = FDIV(1.f, wd);                                        /* registerPixelTranslationOnly :148-165 */
       float X0 = (float)xd * zd - t[0], X1 = (float)yd * zd - t[1], X2 = zd - t[2];
-      float wc = 1.f / X2;
+      float wc = FDIV(1.f, X2);
       float xc = X0 * wc, yc = X1 * wc;
       if (wc > 0.01f) {
-        float dilation = wc / wd;
+        float dilation = FDIV(wc, wd);
         int32_t bits; memcpy(&bits, &wc, 4);
         /* the conversions saturate (CUDA semantics); adding the offset / the +1 of the loop bound is done on indices first clamped
          * to [-1, size] so nothing overflows: the clipped loop ranges are the same */
@@ -586,14 +643,14 @@ void orc_register_depthinv(const float* src, int rows, int cols, int irows, int 
       float out = ORC_NAN;
       float pd[3] = { (float)x, (float)y, 1.f }, ps[3];
       for (int r = 0; r < 3; ++r) ps[r] = dot3(dRc_proj + 3 * r, pd);
-      float iz = 1.f / ps[2];
+      float iz = FDIV(1.f, ps[2]);
       ps[0] *= iz; ps[1] *= iz; ps[2] *= iz;
       float x_src = ps[0] + 0.5f + (float)offset_x;
       float y_src = ps[1] + 0.5f + (float)offset_y;
       if (!(f2i_rd(x_src) < 0 || f2i_rd(y_src) < 0 || f2i_rd(x_src) >= icols || f2i_rd(y_src) >= irows)) {
         float w_src = intermediate[(size_t)imin(imax(f2i_rd(y_src), 0), irows - 1) * icols + imin(imax(f2i_rd(x_src), 0), icols - 1)];
         float pz = dot3(cRd_proj + 6, ps);
-        float res = w_src / pz;
+        float res = FDIV(w_src, pz);
         if (res > 0.f) out = res;
       }
       dst[(size_t)y * cols + x] = out;
@@ -652,19 +709,19 @@ static moments4 pass_bias_sigma(const float* err, int n, float bias, float sigma
         is_valid = 1.f;
         if (mest == ORC_LSQ) weight = 1.f;
         else {
-          float en = (e - bias) / sigma;
-          weight = (nu + 1.f) / (nu + en * en);
+          float en = FDIV(e - bias, sigma);
+          weight = FDIV(nu + 1.f, nu + en * en);
         }
       } else { /* partialBiasAndSigma :179-255 */
         weight = 1.f; is_valid = 1.f;
-        float en = (e - bias) / sigma;
-        if ((mest == ORC_HUBER) && (fabsf(en) > TH_HUBER)) weight = TH_HUBER / fabsf(en);
+        float en = FDIV(e - bias, sigma);
+        if ((mest == ORC_HUBER) && (fabsf(en) > TH_HUBER)) weight = FDIV(TH_HUBER, fabsf(en));
         else if (mest == ORC_TUKEY) {
           if (fabsf(en) < TH_TUKEY) {
-            float aux1 = (en / TH_TUKEY) * (en / TH_TUKEY);
+            float aux1 = FDIV(en, TH_TUKEY) * FDIV(en, TH_TUKEY);
             weight = (1.f - aux1) * (1.f - aux1);
           } else { weight = 0.f; is_valid = 0.f; }
-        } else if (mest == ORC_STUDENT) weight = (STUDENT_DOF + 1.f) / (STUDENT_DOF + en * en);
+        } else if (mest == ORC_STUDENT) weight = FDIV(STUDENT_DOF + 1.f, STUDENT_DOF + en * en);
       }
       weighted_res = e * weight;
       weighted_sq_res = weighted_res * e;
@@ -677,9 +734,9 @@ static moments4 pass_bias_sigma(const float* err, int n, float bias, float sigma
 
 static void final_bias_sigma(moments4 m, float* bias, float* sigma) {
   /* finalReductionBiasAndSigma :361-407 (fp32) */
-  float b = m.swr / m.sw;
+  float b = FDIV(m.swr, m.sw);
   *bias = b;
-  *sigma = sqrtf((m.swsr - 2.f * b * m.swr + b * b * m.sw) / m.nel);
+  *sigma = FSQRT(FDIV(m.swsr - 2.f * b * m.swr + b * b * m.sw, m.nel));
 }
 
 static float func_weights_nu(const float* err, int n, float bias, float sigma, float nu) {
@@ -688,8 +745,8 @@ static float func_weights_nu(const float* err, int n, float bias, float sigma, f
   for (int i = 0; i < n; ++i) {
     float e = err[i];
     if (!isinf(e) && !isnan(e)) {
-      float en = (e - bias) / sigma;
-      float weight = (nu + 1.f) / (nu + en * en);
+      float en = FDIV(e - bias, sigma);
+      float weight = FDIV(nu + 1.f, nu + en * en);
       sln += logf(weight); sw += weight; nel += 1.0;
     }
   }
@@ -761,7 +818,7 @@ void orc_chi_square(const float* err_int, const float* err_depth, int n, float s
   double sN = 0, srho = 0;
   for (int half = 0; half < 2; ++half)
     for (int i = 0; i < n; ++i) {
-      float en = half == 0 ? err_int[i] / sigma_int : err_depth[i] / sigma_depth;
+      float en = half == 0 ? FDIV(err_int[i], sigma_int) : FDIV(err_depth[i], sigma_depth);
       float rho = 0.f;
       if (!isinf(en) && !isnan(en)) {
         sN += 1.0;
@@ -769,7 +826,7 @@ void orc_chi_square(const float* err_int, const float* err_depth, int n, float s
         if ((mest == ORC_HUBER) && (fabsf(en) > TH_HUBER)) rho = TH_HUBER * (fabsf(en) - TH_HUBER / 2.f);
         else if (mest == ORC_TUKEY) {
           if (fabsf(en) < TH_TUKEY) {
-            float aux1 = (en / TH_TUKEY) * (en / TH_TUKEY);
+            float aux1 = FDIV(en, TH_TUKEY) * FDIV(en, TH_TUKEY);
             float aux2 = (1.f - aux1) * (1.f - aux1) * (1.f - aux1);
             rho = ((TH_TUKEY * TH_TUKEY) / 6.f) * (1.f - aux2);
           } else rho = ((TH_TUKEY * TH_TUKEY) / 6.f);
@@ -788,11 +845,11 @@ void orc_chi_square(const float* err_int, const float* err_depth, int n, float s
 static inline float compute_weight(float error, int mest) {
   /* computeWeight estimate_VO.cu:141-167 */
   float weight = 1.f;
-  if (mest == ORC_HUBER) { if (fabsf(error) > TH_HUBER) weight = TH_HUBER / fabsf(error); }
+  if (mest == ORC_HUBER) { if (fabsf(error) > TH_HUBER) weight = FDIV(TH_HUBER, fabsf(error)); }
   else if (mest == ORC_TUKEY) {
-    if (fabsf(error) < TH_TUKEY) { float aux1 = (error / TH_TUKEY) * (error / TH_TUKEY); weight = (1.f - aux1) * (1.f - aux1); }
+    if (fabsf(error) < TH_TUKEY) { float aux1 = FDIV(error, TH_TUKEY) * FDIV(error, TH_TUKEY); weight = (1.f - aux1) * (1.f - aux1); }
     else weight = 0.f;
-  } else if (mest == ORC_STUDENT) weight = (STUDENT_DOF + 1.f) / (STUDENT_DOF + error * error);
+  } else if (mest == ORC_STUDENT) weight = FDIV(STUDENT_DOF + 1.f, STUDENT_DOF + error * error);
   return weight;
 }
 
@@ -815,10 +872,10 @@ void orc_build_system(const float* W0, const float* I0, const float* gW0x, const
         /* invDepthConstraint :214-262 */
         float gradx = gW0x[i], grady = gW0y[i];
         if (!(isnan(w0) || isnan(w1) || isnan(gradx) || isnan(grady))) {
-          float p[3] = { ((float)x - k.cx) / k.fx, ((float)y - k.cy) / k.fy, 1.f };
+          float p[3] = { FDIV((float)x - k.cx, k.fx), FDIV((float)y - k.cy, k.fy), 1.f };
           float g[3];
           g[0] = gradx * k.fx; g[1] = grady * k.fy; g[2] = -(g[0] * p[0] + g[1] * p[1]);
-          float inv_w0 = 1.f / w0;
+          float inv_w0 = FDIV(1.f, w0);
           float n[3] = { g[0] * inv_w0, g[1] * inv_w0, g[2] * inv_w0 };
           n[2] += 1.f;
           float rn = rsqrt_f(dot3(n, n));
@@ -826,7 +883,7 @@ void orc_build_system(const float* W0, const float* I0, const float* gW0x, const
           float rp = rsqrt_f(dot3(p, p));
           float pu[3] = { p[0] * rp, p[1] * rp, p[2] * rp };
           n_factor = fabsf(dot3(n, pu));
-          float weight = 1.f / sigma_depthinv;
+          float weight = FDIV(1.f, sigma_depthinv);
           float rt[3] = { g[0] * w0, g[1] * w0, g[2] * w0 };
           rt[2] = rt[2] + w0 * w1;
           g[2] = g[2] + w1;
@@ -835,8 +892,8 @@ void orc_build_system(const float* W0, const float* I0, const float* gW0x, const
           float bb = (w1 - w0);
           for (int c = 0; c < 3; ++c) { row_d[c] = rt[c] * weight; row_d[3 + c] = rr[c] * weight; }
           error_d = -bb * weight;
-          float e_unb = error_d - (bias_depthinv / sigma_depthinv);
-          float wgt = student_nu ? (nu_depthinv + 1.f) / (nu_depthinv + e_unb * e_unb) : compute_weight(e_unb, mestimator);
+          float e_unb = error_d - FDIV(bias_depthinv, sigma_depthinv);
+          float wgt = student_nu ? FDIV(nu_depthinv + 1.f, nu_depthinv + e_unb * e_unb) : compute_weight(e_unb, mestimator);
           weight_d = wgt * (float)(1 - (weighting == ORC_PHOT_ONLY));
         }
       }
@@ -844,17 +901,17 @@ void orc_build_system(const float* W0, const float* I0, const float* gW0x, const
         /* intensityConstraint :176-212 */
         float i0 = I0[i], i1 = I1[i], gradx = gI0x[i], grady = gI0y[i];
         if (!(isnan(w0) || isnan(i0) || isnan(i1) || isnan(gradx) || isnan(grady))) {
-          float p[3] = { ((float)x - k.cx) / k.fx, ((float)y - k.cy) / k.fy, 1.f };
+          float p[3] = { FDIV((float)x - k.cx, k.fx), FDIV((float)y - k.cy, k.fy), 1.f };
           float g[3];
           g[0] = gradx * k.fx; g[1] = grady * k.fy; g[2] = -(g[0] * p[0] + g[1] * p[1]);
-          float weight = 1.f / sigma_int;
+          float weight = FDIV(1.f, sigma_int);
           float rr[3] = { -(g[1] * p[2] - g[2] * p[1]), -(g[2] * p[0] - g[0] * p[2]), -(g[0] * p[1] - g[1] * p[0]) };
           float rt[3] = { g[0] * w0, g[1] * w0, g[2] * w0 };
           float bb = (i1 - i0);
           for (int c = 0; c < 3; ++c) { row_int[c] = rt[c] * weight; row_int[3 + c] = rr[c] * weight; }
           error_int = -bb * weight;
-          float e_unb = error_int - (bias_int / sigma_int);
-          float wgt = student_nu ? (nu_int + 1.f) / (nu_int + e_unb * e_unb) : compute_weight(e_unb, mestimator);
+          float e_unb = error_int - FDIV(bias_int, sigma_int);
+          float wgt = student_nu ? FDIV(nu_int + 1.f, nu_int + e_unb * e_unb) : compute_weight(e_unb, mestimator);
           weight_int = wgt * (float)(1 - (weighting == ORC_GEOM_ONLY));
         }
       }

@@ -191,8 +191,14 @@ typedef struct {
   float visratio_odo, visratio_integr;
   float sigma_int, sigma_depthinv, nu_int, nu_depthinv, bias_int, bias_depthinv; /* last GN iteration */
   double delta_R[9], delta_t[3], delta_cov[36];  /* KF-relative pose + covariance after the frame */
+  int odo_kf_natural, integr_kf_natural;         /* what the two covisibility tests decided on their own (see the hook below) */
 } orc_frame_info;
 void orc_tracker_last_info(const orc_tracker* t, orc_frame_info* info);
+/* TEST HOOK (no counterpart in the reference): impose the two keyframe decisions of the NEXT tracked frame (-1 = decide naturally,
+ * 0 = keep, 1 = switch).  A covisibility ratio that lands within rounding of its threshold may fall on either side in two
+ * implementations whose poses differ by 1e-6; the parity tests then continue the comparison with the decision of the implementation
+ * under test imposed (and assert that the natural decision only differed because the ratio sat on the threshold). */
+void orc_tracker_force_kf_decisions(orc_tracker* t, int odo_switch, int integr_switch);
 /* fused keyframe maps (rows x cols): depthinv_integrKF_, weight_integrKF_ ; nmap/vmap 3*rows x cols */
 const float* orc_tracker_kf_depthinv(const orc_tracker* t);
 const float* orc_tracker_kf_weight(const orc_tracker* t);
@@ -210,6 +216,8 @@ int orc_align_pair(const orc_tracker_config* c, const uint16_t* depth0, const ui
 int orc_keyframe_align(int rows, int cols, const float* depthinv_ini, const uint8_t* grey_ini, const float* depthinv_end,
                        const uint8_t* grey_end, orc_intr k, int interp_mode, double R[9], double t[3], double cov[36]);
 
+/* 1 in the build that models the reference's nvcc numerics (librgbid_oracle_cudanum.so, see rgbid_oracle.c), 0 in the IEEE build */
+int orc_cuda_numerics(void);
 /* number of OpenMP threads the oracle will use (1 when built without -fopenmp) */
 int orc_num_threads(void);
 void orc_set_num_threads(int n);

@@ -237,6 +237,7 @@ struct orc_tracker {
   float *vmap, *nmap, *gxD_integr, *gyD_integr;
   uint8_t* colors_integr; uint8_t* overlap_mask;
   orc_frame_info info;
+  int force_odo, force_integr;   /* test hook (orc_tracker_force_kf_decisions): -1 = decide naturally, 0 / 1 = imposed for the next frame */
 };
 
 void orc_tracker_default_config(orc_tracker_config* c) {
@@ -281,6 +282,7 @@ orc_tracker* orc_tracker_create(const orc_tracker_config* c) {
   t->odo_cov = (double*)malloc(36 * sizeof(double) * t->cap_odo);
   /* reset() visodo.cpp:519-553 */
   t->global_time = 0; t->lost = 0;
+  t->force_odo = t->force_integr = -1;
   m3_id(t->rmats); memset(t->tvecs, 0, 3 * sizeof(double)); t->n_poses = 1;
   m3_id(t->last_est_R); memset(t->last_est_t, 0, sizeof(t->last_est_t));
   return t;
@@ -704,11 +706,27 @@ static int estimate_visual_odometry(orc_tracker* t, double R_io[9], double t_io[
   return 1;
 }
 
+static int tracker_track(orc_tracker* t, const uint16_t* depth, const uint8_t* rgb);
 int orc_tracker_track(orc_tracker* t, const uint16_t* depth, const uint8_t* rgb) {
+#if defined(ORC_CUDA_NUMERICS) && defined(__SSE2__)
+  /* --ftz=true for every fp32 operation of the frame: flush-to-zero + denormals-are-zero in this thread's MXCSR (the image loops of
+   * this build are single-threaded); the host-side double arithmetic never comes near the subnormal range */
+  unsigned int csr = __builtin_ia32_stmxcsr();
+  __builtin_ia32_ldmxcsr(csr | 0x8040u);
+  int r = tracker_track(t, depth, rgb);
+  __builtin_ia32_ldmxcsr(csr);
+  return r;
+#else
+  return tracker_track(t, depth, rgb);
+#endif
+}
+static int tracker_track(orc_tracker* t, const uint16_t* depth, const uint8_t* rgb) {
   /* trackNewFrame visodo.cpp:1967-2247 */
   const orc_tracker_config* c = &t->c;
   t->delta_t = c->delta_t; /* computeInterframeTime :1929-1964 with compute_deltat_flag_ off */
   memset(&t->info, 0, sizeof(t->info));
+  const int force_odo = t->force_odo, force_integr = t->force_integr;   /* one-shot */
+  t->force_odo = t->force_integr = -1;
   prepare_images(t, depth, rgb);
   if (t->global_time == 0) {
     ++t->global_time;
@@ -801,7 +819,10 @@ int orc_tracker_track(orc_tracker* t, const uint16_t* depth, const uint8_t* rgb)
   /* odometry keyframe switch :2172-2180 */
   float vis_odo = compute_covisibility(t, t->delta_R, t->delta_t_, t->iD_kf[0], t->iD_curr[0]);
   t->info.visratio_odo = vis_odo;
-  if ((t->odoKF_count >= c->max_odoKF_count) || (vis_odo < c->visratio_odo)) {
+  int sw_odo = (t->odoKF_count >= c->max_odoKF_count) || (vis_odo < c->visratio_odo);
+  t->info.odo_kf_natural = sw_odo;
+  if (force_odo >= 0) sw_odo = force_odo;
+  if (sw_odo) {
     reset_odometry_keyframe(t);
     save_odo_keyframe(t);
     t->info.odo_kf_switched = 1;
@@ -814,7 +835,10 @@ int orc_tracker_track(orc_tracker* t, const uint16_t* depth, const uint8_t* rgb)
   m3_mulv(iRi, d, dIt);
   float vis_int = compute_covisibility(t, dIR, dIt, t->iD_integr_raw, t->iD_curr[0]);
   t->info.visratio_integr = vis_int;
-  if ((t->integrKF_count >= c->max_integrKF_count) || (vis_int < c->visratio_integr)) {
+  int sw_int = (t->integrKF_count >= c->max_integrKF_count) || (vis_int < c->visratio_integr);
+  t->info.integr_kf_natural = sw_int;
+  if (force_integr >= 0) sw_int = force_integr;
+  if (sw_int) {
     reset_integration_keyframe(t);
     { /* computeOverlapping visodo.cpp:1517-1539 */
       float Rab[9], tab[3];
@@ -840,6 +864,7 @@ void orc_tracker_get_odo(const orc_tracker* t, int i, double R[9], double tv[3],
   memcpy(cov, t->odo_cov + 36 * i, 36 * sizeof(double));
 }
 void orc_tracker_last_info(const orc_tracker* t, orc_frame_info* info) { *info = t->info; }
+void orc_tracker_force_kf_decisions(orc_tracker* t, int odo_switch, int integr_switch) { t->force_odo = odo_switch; t->force_integr = integr_switch; }
 int orc_tracker_num_sink_poses(const orc_tracker* t) { return t->n_sp; }
 void orc_tracker_get_sink_pose(const orc_tracker* t, int i, int* id, double R[9], double tv[3]) {
   *id = t->sp[i].id; memcpy(R, t->sp[i].R, 72); memcpy(tv, t->sp[i].t, 24);

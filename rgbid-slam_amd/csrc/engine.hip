@@ -141,12 +141,15 @@ __global__ void k_step_begin(LaneState* st, Flags f, WarpParams* wp, SysParams* 
   int lane = blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= B) return;
   LaneState& s = st[lane];
-  s.status = 0; s.gn_failed = 0; s.vis_odo = 0.f; s.vis_int = 0.f;
-  f.vis[lane] = 0; f.overlap[lane] = 0; f.fuse[lane] = 0; f.kf_slot[lane] = -1;
-  if (c.active && !c.active[lane]) {   // no frame for this lane: nothing of its state moves, its record repeats the last pose with status 0
+  f.vis[lane] = 0; f.overlap[lane] = 0; f.fuse[lane] = 0; f.kf_slot[lane] = -1;   // per-step launch predicates, not tracker state
+  if (c.active && !c.active[lane]) {
+    // no frame for this lane: nothing of its tracker state moves (only the per-step status word reads 0), every kernel of the step is
+    // predicated off for it, and its record repeats the last pose / covisibility figures with status 0
     f.first[lane] = 0; f.track[lane] = 0; f.gn[lane] = 0; f.sw_odo[lane] = 0; f.sw_int[lane] = 0; f.maps[lane] = 0;
+    s.status = 0;
     return;
   }
+  s.status = 0; s.gn_failed = 0; s.vis_odo = 0.f; s.vis_int = 0.f;
   if (s.global_time == 0) {
     f.first[lane] = 1; f.track[lane] = 0; f.gn[lane] = 0; f.sw_odo[lane] = 1; f.sw_int[lane] = 1; f.maps[lane] = 1;
     s.global_time = 1;
@@ -182,12 +185,12 @@ __global__ void k_step_begin(LaneState* st, Flags f, WarpParams* wp, SysParams* 
 }
 
 // sets the per-level constants of the lane's SysParams before a level's iterations / the covariance pass
-__global__ void k_set_sys(SysParams* sp, LaneState* st, StepCfg c, int level, int cov_pass, int B) {
+__global__ void k_set_sys(SysParams* sp, LaneState* st, const int* track, StepCfg c, int level, int cov_pass, int B) {
   int lane = blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= B) return;
   int div = 1 << level;
   SysParams& p = sp[lane];
-  if (cov_pass) {
+  if (cov_pass && track[lane]) {
     st[lane].rec_sigma_i = p.sigma_i; st[lane].rec_sigma_d = p.sigma_d;
     st[lane].rec_nu_i = fmaxf(p.nu_i, p.nu_d); st[lane].rec_nu_d = p.nu_d;  // nu_int = max(nu_int, nu_depthinv), visodo.cpp:1186
   }
@@ -615,11 +618,12 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   e->launches = 0;
   Flags& f = e->flags;
   // ---- prepareImages (visodo.cpp:760-773)
-  launch_prep_frame(s, B, e->cur_depth, e->cur_rgb, e->iD_curr[0], e->I_curr[0], e->r_curr, e->g_curr, e->b_curr, c.factor_depth, ALL);
+  const LaneMask fed = M(e->active_dev);   // lanes without a frame this step keep their current-frame pyramids untouched
+  launch_prep_frame(s, B, e->cur_depth, e->cur_rgb, e->iD_curr[0], e->I_curr[0], e->r_curr, e->g_curr, e->b_curr, c.factor_depth, fed);
   e->launches += 1;
   for (int i = 1; i < L; ++i) {
-    launch_pyr_down(s, B, e->I_curr[i - 1], e->I_curr[i], ALL);
-    launch_pyr_down(s, B, e->iD_curr[i - 1], e->iD_curr[i], ALL);
+    launch_pyr_down(s, B, e->I_curr[i - 1], e->I_curr[i], fed);
+    launch_pyr_down(s, B, e->iD_curr[i - 1], e->iD_curr[i], fed);
     e->launches += 2;
   }
   hipLaunchKernelGGL(k_step_begin, dim3(gb), dim3(tb), 0, s, e->state, f, e->wp, e->sp, sc, B);
@@ -628,7 +632,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   // keyframe-creation part of the sequence below is enqueued (k_step_begin has set first / sw_odo / sw_int / maps).
   // ---- estimateVisualOdometry (visodo.cpp:1041-1281), PYR_FIRST
   for (int level = L - 1; !first && level >= c.finest_level; --level) {
-    hipLaunchKernelGGL(k_set_sys, dim3(gb), dim3(tb), 0, s, e->sp, e->state, sc, level, 0, B);
+    hipLaunchKernelGGL(k_set_sys, dim3(gb), dim3(tb), 0, s, e->sp, e->state, f.track, sc, level, 0, B);
     e->launches++;
     int iters = c.iters[level];
     for (int it = 0; it < iters; ++it) {
@@ -684,7 +688,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   // ---- covariance pass (visodo.cpp:1283-1409)
   if (!first) {
     int fl = c.finest_level;
-    hipLaunchKernelGGL(k_set_sys, dim3(gb), dim3(tb), 0, s, e->sp, e->state, sc, fl, 1, B);
+    hipLaunchKernelGGL(k_set_sys, dim3(gb), dim3(tb), 0, s, e->sp, e->state, f.track, sc, fl, 1, B);
     bool prof = e->prof_on && fl == 0 && e->prof_used + 2 <= (int)e->prof_ev.size();
     bool fuse_cov = c.fused_gn && !c.chi_square_stats;  // the chi-square statistics need W1 / I1 in memory
     int nblk;
@@ -714,7 +718,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   }
   // ---- covisibility with both keyframes (visodo.cpp:2172-2188), 4 ratio evaluations
   if (!first) {
-    hipMemsetAsync(e->counts, 0, sizeof(unsigned int) * 8 * B, s);
+    if (hipError_t he = hipMemsetAsync(e->counts, 0, sizeof(unsigned int) * 8 * B, s); he != hipSuccess) return (int)he;
     launch_visibility_pair(s, B, e->iD_curr[0], e->iD_kf[0], e->vis_ab, e->vis_ba, e->counts + 0 * 2 * B, e->counts + 1 * 2 * B, M(f.vis));
     launch_visibility_pair(s, B, e->iD_curr[0], e->iD_integr_raw, e->ivis_ab, e->ivis_ba, e->counts + 2 * 2 * B, e->counts + 3 * 2 * B, M(f.vis));
     hipLaunchKernelGGL(k_decide, dim3(gb), dim3(tb), 0, s, e->state, f, e->counts, e->fuse_wp, sc, B);
@@ -736,7 +740,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   }
   // ---- integration keyframe: computeOverlapping (:1517-1539) + saveCurrentImagesAsIntegrationKeyframes (:880-893) ...
   if (!first) {
-    hipMemsetAsync(e->counts, 0, sizeof(unsigned int) * 2 * B, s);
+    if (hipError_t he = hipMemsetAsync(e->counts, 0, sizeof(unsigned int) * 2 * B, s); he != hipSuccess) return (int)he;
     launch_visibility(s, B, e->iD_curr[0], e->iD_integr_raw, e->overlap_mask, nullptr, e->ivis_ab, e->counts, M(f.overlap));
   }
   launch_copy_bytes(s, B, e->iD_curr[0], e->iD_integr, 4, M(f.sw_int));
@@ -877,6 +881,7 @@ int rgbid_engine_destroy(rgbid_engine* e) {
 
 int rgbid_engine_reset(rgbid_engine* e) {
   if (!e) return RGBID_E_INVALID;
+  hipSetDevice(e->ctx->device);
   hipError_t he = hipMemsetAsync(e->state, 0, sizeof(LaneState) * e->B, e->ctx->stream);  // global_time = 0 -> first-frame path
   if (he != hipSuccess) return (int)he;
   // warped_weight_curr_ is never initialised by the reference (uninitialised device memory); the engine defines it as 0
@@ -888,6 +893,7 @@ int rgbid_engine_reset(rgbid_engine* e) {
 
 int rgbid_engine_set_active(rgbid_engine* e, const int* active_host) {
   if (!e) return RGBID_E_INVALID;
+  hipSetDevice(e->ctx->device);
   std::vector<int> m(e->B, 1);
   if (active_host) for (int i = 0; i < e->B; ++i) m[i] = active_host[i] ? 1 : 0;
   hipError_t he = hipMemcpyAsync(e->active_dev, m.data(), sizeof(int) * e->B, hipMemcpyHostToDevice, e->ctx->stream);
@@ -898,11 +904,15 @@ int rgbid_engine_set_active(rgbid_engine* e, const int* active_host) {
 int rgbid_engine_reset_lane(rgbid_engine* e, int lane) {
   if (!e || lane < 0 || lane >= e->B) return RGBID_E_INVALID;
   if (e->steps == 0) return RGBID_OK;   // nothing tracked yet: every lane starts fresh anyway
+  hipSetDevice(e->ctx->device);
   // the lane's next frame takes the first-frame path of k_step_begin (global_time == 0) inside the ordinary step: its Gauss-Newton, covisibility
   // and fusion kernels are predicated off by the lane flags and the keyframe-creation kernels on, exactly as in the first step after reset()
   hipError_t he = hipMemsetAsync(&e->state[lane], 0, sizeof(LaneState), e->ctx->stream);
   if (he != hipSuccess) return (int)he;
   he = hipMemsetAsync((char*)e->warped_w.base + (size_t)lane * e->warped_w.lane_stride, 0, e->warped_w.lane_stride, e->ctx->stream);
+  if (he != hipSuccess) return (int)he;
+  // the lane's staged record goes with its state: while the lane sits steps out before its new first frame, its records read all-zero
+  he = hipMemsetAsync(&e->rec_cur[lane], 0, sizeof(rgbid_pose_record), e->ctx->stream);
   return he == hipSuccess ? RGBID_OK : (int)he;
 }
 
@@ -914,7 +924,7 @@ int rgbid_engine_step(rgbid_engine* e, const void* depth_dev, const void* rgb_de
   // A captured graph bakes its kernel arguments in, so graph replay reads fixed staging buffers (dense [lanes][rows][cols] -> pitched
   // lanes); eager steps read the caller's dense buffers in place (they must stay valid until the step has run, as documented).
   hipError_t he = hipSuccess;
-  if (c.use_graph && !e->prof_on) {
+  if (c.use_graph) {   // also while profiling (which only skips the replay): the buffer-lifetime rule of graph mode does not change
     he = hipMemcpy2DAsync(e->in_depth.base, e->in_depth.pitch, depth_dev, (size_t)c.cols * 2, (size_t)c.cols * 2, (size_t)c.rows * e->B,
                           hipMemcpyDeviceToDevice, s);
     if (he != hipSuccess) return (int)he;
@@ -938,8 +948,10 @@ int rgbid_engine_step(rgbid_engine* e, const void* depth_dev, const void* rgb_de
       if (he != hipSuccess) return (int)he;
       r = enqueue_step(e, s, first);
       he = hipStreamEndCapture(s, &g);
-      if (r) return r;
-      if (he != hipSuccess) return (int)he;
+      if (r || he != hipSuccess) {
+        if (g) hipGraphDestroy(g);
+        return r ? r : (int)he;
+      }
       he = hipGraphInstantiate(&gx, g, nullptr, nullptr, 0);
       hipGraphDestroy(g);
       if (he != hipSuccess) return (int)he;

@@ -148,26 +148,6 @@ class Engine:
             out.update(overlap_mask=mask, colors=colors, depthinv=iD, normals=nrm)
         return out
 
-    def keyframe_counts(self):
-        """keyframes each lane has exported for the back-end so far (cfg.keyframe_capacity > 0)"""
-        out = np.zeros(self.cfg.lanes, np.int32)
-        check(self.L.rgbid_engine_keyframe_counts(self._h, out.ctypes.data_as(C.c_void_p)))
-        return out
-
-    def read_keyframe(self, lane, seq, images=True):
-        """export `seq` of `lane`: header fields + (overlap_mask, colors, depthinv, normals) host arrays"""
-        rows, cols = self.cfg.rows, self.cfg.cols
-        h = KeyframeHeader()
-        mask = np.empty((rows, cols), np.uint8); colors = np.empty((rows, cols, 3), np.uint8)
-        iD = np.empty((rows, cols), np.float32); nrm = np.empty((3, rows, cols), np.float32)
-        ptr = (lambda a: a.ctypes.data_as(C.c_void_p)) if images else (lambda a: None)
-        check(self.L.rgbid_engine_read_keyframe(self._h, int(lane), int(seq), C.byref(h), ptr(mask), ptr(colors), ptr(iD), ptr(nrm)))
-        out = dict(id=h.id, end_id=h.end_id, lane=h.lane, seq=h.seq, R=np.array(h.R).reshape(3, 3), t=np.array(h.t),
-                   R_rel=np.array(h.R_rel).reshape(3, 3), t_rel=np.array(h.t_rel), cov_rel=np.array(h.cov_rel).reshape(6, 6))
-        if images:
-            out.update(overlap_mask=mask, colors=colors, depthinv=iD, normals=nrm)
-        return out
-
     def profile_begin(self, max_launches):
         check(self.L.rgbid_engine_profile_begin(self._h, int(max_launches)))
 

@@ -37,38 +37,40 @@ def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph):
     okw = {k: v for k, v in cfg_kw.items() if k != "fused_gn"}
     okw.update(rows=rows, cols=cols, fx=K[0], fy=K[1], cx=K[2], cy=K[3])
     worst_r = worst_t = 0.0
+    imposed = 0
+    th_o, th_i = cfg_kw.get("visratio_odo", 0.9), cfg_kw.get("visratio_integr", 0.7)
     for l in range(n_lanes):
         trk = O.Tracker(O.default_config(**okw))
         d = depth[:, l].cpu().numpy().view(np.uint16)
         c = rgb[:, l].cpu().numpy()
-        diverged_at = None
         for k in range(n_frames):
+            st = int(rec[k, l]["status"])
+            if k:
+                # EVERY frame of every lane is checked: where a covisibility ratio lands on its threshold the two implementations may decide
+                # differently (their poses differ by ~1e-6); the oracle then continues with the engine's decision imposed (test hook,
+                # oracle/rgbid_oracle.h) -- and the natural decision may only have differed because the ratio sat on the threshold
+                trk.force_kf_decisions(bool(st & E.ST_ODO_KF), bool(st & E.ST_INTEGR_KF))
             ret = trk.track(d[k], c[k])
             info = trk.last_info()
-            st = int(rec[k, l]["status"])
             if k == 0:
                 assert st & E.ST_FIRST
                 continue
             assert bool(st & E.ST_TRACKED) == ret, (l, k, st, ret)
+            if not ret:
+                continue
             # covisibility ratios are counts of gated pixels: ~1e-6 pose differences may flip a handful of them
             assert abs(rec[k, l]["vis_odo"] - info.visratio_odo) < 5e-4 and abs(rec[k, l]["vis_integr"] - info.visratio_integr) < 5e-4
-            same = bool(st & E.ST_ODO_KF) == bool(info.odo_kf_switched) and bool(st & E.ST_INTEGR_KF) == bool(info.integr_kf_switched)
-            if not same:
-                # a keyframe decision may only differ when its ratio sits on the threshold; the lane's trajectory then legitimately parts
-                th_o, th_i = cfg_kw.get("visratio_odo", 0.9), cfg_kw.get("visratio_integr", 0.7)
-                assert abs(info.visratio_odo - th_o) < 5e-4 or abs(info.visratio_integr - th_i) < 5e-4, (l, k, st, info.visratio_odo, info.visratio_integr)
-                diverged_at = k
-                break
+            if bool(st & E.ST_ODO_KF) != bool(info.odo_kf_natural):
+                assert abs(info.visratio_odo - th_o) < 5e-4, (l, k, st, info.visratio_odo)
+                imposed += 1
+            if bool(st & E.ST_INTEGR_KF) != bool(info.integr_kf_natural):
+                assert abs(info.visratio_integr - th_i) < 5e-4, (l, k, st, info.visratio_integr)
+                imposed += 1
             assert rec[k, l]["nu_depthinv"] == info.nu_depthinv and rec[k, l]["nu_int"] == info.nu_int, (l, k)
             # sigma is the scale of the residuals AT the current pose estimate, which itself agrees to ~1e-5: 1e-3 relative
             assert abs(rec[k, l]["sigma_int"] - info.sigma_int) < 1e-3 * info.sigma_int, (l, k, rec[k, l]["sigma_int"], info.sigma_int)
         Rs, ts = trk.poses()
         oR, ot, ocov = trk.odometry()
-        if diverged_at is not None:
-            for k in range(1, diverged_at + 1):
-                assert rot_angle(Rs[k], rec[k, l]["R"]) < 1e-4 and np.linalg.norm(ts[k] - rec[k, l]["t"]) < 1e-4, (l, k)
-            trk.close()
-            continue
         for k in range(1, n_frames):
             er, et = rot_angle(Rs[k], rec[k, l]["R"]), float(np.linalg.norm(ts[k] - rec[k, l]["t"]))
             worst_r, worst_t = max(worst_r, er), max(worst_t, et)
@@ -95,6 +97,8 @@ def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph):
         assert rot_angle(Rg[-1], rec[-1, l]["R"]) < 5e-3 and np.linalg.norm(tg[-1] - rec[-1, l]["t"]) < 2e-2
         trk.close()
     eng.close()
+    if imposed:
+        print(f"keyframe decisions on the threshold, imposed on the oracle: {imposed}")
     return worst_r, worst_t
 
 
@@ -159,6 +163,14 @@ def test_engine_vs_oracle_full_res(ctx):
     """BASELINE config 2 stand-in: 640x480, 3 levels, {10,5,3}, Student-t + sigmaML, pyrFirst, fusion on."""
     wr, wt = run_case(ctx, 480, 640, synth.TUM_K, n_lanes=2, n_frames=5, cfg_kw=dict(), seq_kw=dict(), use_graph=1)
     print("worst pose deviation engine vs oracle (640x480):", wr, wt)
+
+
+def test_engine_vs_oracle_1280x960_four_levels(ctx):
+    """BASELINE config 5: 1280x960 upsampled synthetic stream, 4-level pyramid (the reference's LEVELS is a compile-time constant,
+    include/visodo.h:52; iterations {10,5,3,3} follow src/visodo.cpp:652-655), 2 lanes x 4 frames of the batched engine vs the oracle."""
+    K = (1050.0, 1050.0, 639.5, 479.5)    # TUM factory intrinsics x2 with the half-pixel centre shift ((c + 0.5) * 2 - 0.5)
+    wr, wt = run_case(ctx, 960, 1280, K, n_lanes=2, n_frames=4, cfg_kw=dict(levels=4, iters=[10, 5, 3, 3]), seq_kw=dict(), use_graph=0)
+    print("worst pose deviation engine vs oracle (1280x960, 4 levels):", wr, wt)
 
 
 def test_chunked_sequence_matches_sequential(ctx):

@@ -109,8 +109,9 @@ def test_fuzz_engine_sizes_and_garbage(ctx, seed):
     from rgbid import engine as E, synth
     from tests.test_gpu_engine import run_case
     r = util.rng(3000 + seed)
-    levels = int(r.integers(1, 4))
-    rows = int(r.integers(40 << (levels - 1) if levels < 3 else 120, 140)); cols = int(r.integers(56 << (levels - 1) if levels < 3 else 160, 200))   # coarsest level >= 30 x 40
+    levels = int(r.integers(1, 5))                                         # up to the 4 levels of BASELINE config 5 / KeyframeAlign
+    lo_r, lo_c = max(40, 30 << (levels - 1)), max(56, 40 << (levels - 1))  # coarsest level >= 30 x 40
+    rows = int(r.integers(lo_r, lo_r + 40)); cols = int(r.integers(lo_c, lo_c + 60))
     s = cols / 640.0
     K = (525.0 * s, 525.0 * s * float(r.uniform(0.9, 1.1)), cols / 2.0 - 0.5 + float(r.uniform(-3, 3)), rows / 2.0 - 0.5 + float(r.uniform(-3, 3)))
     iters = [int(r.integers(1, 7)) for _ in range(levels)]
