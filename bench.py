@@ -7,12 +7,15 @@ one frame: frame preparation, 3-level pyramid, {3,5,10} Gauss-Newton iterations 
 estimation, covariance pass, covisibility checks, keyframe inverse-depth fusion.  Inputs are resident in HBM when
 the timed region starts.  `value` = aligned frames / s over all GPUs (weak scaling: lanes per GPU is fixed).
 
-    python bench.py --gpus 1 --steps 8 --warmup 2
+    python bench.py --gpus N --steps 8 --warmup 2        (N > 1 without a launcher: re-executes itself as N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0) with `roofline` (level-0 residual + normal-equation kernel, timed with HIP events
-inside the timed region) and `cpu_baseline` (the CPU oracle -- a scalar/OpenMP port of the reference algorithm --
-on the host cores; baseline, not target).
+Protocol: `--reps` (5) repetitions, each = reset, keyframe frame, W untimed warm-up steps, then EXACTLY K timed steps bracketed by a
+barrier + device synchronisation on both sides (max over ranks); `value` is the median repetition, all of them are listed.  Prints ONE
+JSON line (rank 0) with `roofline` (level-0 residual + normal-equation kernel, timed with HIP events inside the timed regions),
+`parity` (duplicate lanes bit-identical; one lane per checked stream against the CPU oracle over all timed steps -- the oracle is the
+checker here, after the timed regions), `extra_configs` (BASELINE configs 1 and 5) and `cpu_baseline` (the CPU oracle -- a scalar port
+of the reference algorithm -- on the host cores; baseline, not target).
 """
 import argparse
 import json
@@ -29,13 +32,20 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4-copy ceiling is 6290 GB/s
+U3_BYTES_PER_FRAME = 275.6e6   # SURVEY.md section 8d: algorithmic bytes of one aligned 640x480 frame (3 levels, {10,5,3})
 
 
-def make_inputs(lanes, n_frames, rows, cols, K, device, n_unique=4):
+def make_inputs(lanes, n_frames, rows, cols, K, device, n_unique=32):
+    """[T, B] stacks of `n_unique` distinct synthetic streams (different scene seed, different camera path), dealt round-robin onto the
+    lanes: lane l carries stream l % n_unique."""
     from rgbid import synth
-    seqs = [synth.make_sequence(n_frames, seed=synth.SEED + 17 * i, K=K, rows=rows, cols=cols, device=device) for i in range(min(lanes, n_unique))]
-    depth = torch.stack([seqs[l % len(seqs)]["depth"].to(torch.int16) for l in range(lanes)], 1).contiguous()  # [T, B, rows, cols]
-    rgb = torch.stack([seqs[l % len(seqs)]["rgb"] for l in range(lanes)], 1).contiguous()                      # [T, B, rows, cols, 3]
+    n = min(lanes, n_unique)
+    seqs = [synth.make_sequence(n_frames, seed=synth.SEED + 17 * i, K=K, rows=rows, cols=cols, device=device) for i in range(n)]
+    depth_u = torch.stack([s["depth"].to(torch.int16) for s in seqs], 1)   # [T, n, rows, cols]
+    rgb_u = torch.stack([s["rgb"] for s in seqs], 1)
+    idx = torch.arange(lanes, device=depth_u.device) % n
+    depth = depth_u[:, idx].contiguous()                                    # [T, B, rows, cols]
+    rgb = rgb_u[:, idx].contiguous()                                        # [T, B, rows, cols, 3]
     return seqs, depth, rgb
 
 
@@ -108,7 +118,7 @@ def pmc_traffic(lanes, rows, cols, fused):
     """HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in separate
     rocprofv3 --pmc runs by tools/profile_bench.sh, gfx950 corrections applied; committed under profiles/).  Counters
     cannot be read from inside this process, so the figure is only reported when a committed PMC summary matches the
-    configuration being run; otherwise null."""
+    configuration being run (and says which file it came from); otherwise null."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         try:
@@ -116,8 +126,184 @@ def pmc_traffic(lanes, rows, cols, fused):
         except Exception:
             continue
         if (d.get("lanes"), d.get("rows"), d.get("cols"), bool(d.get("fused_gn"))) == (lanes, rows, cols, bool(fused)):
-            return d["traffic_bytes_per_launch"]
-    return None
+            return d["traffic_bytes_per_launch"], "profiles/" + os.path.basename(f) + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)"
+    return None, None
+
+
+def oracle_check(depth, rgb, lanes_to_check, rows, cols, K, levels, iters, rec, first_step, n_steps):
+    # rec: the engine's records of ALL steps [T, B] (status bits of every frame are imposed on the oracle where a ratio sits on its threshold)
+    """Parity of the surface that was just benchmarked: for each lane in `lanes_to_check` run the CPU oracle tracker over the SAME frames
+    (keyframe frame, warm-up, timed steps) and hold the engine's records of the timed steps to 1e-4 rad / 1e-4 m; keyframe decisions
+    must agree unless a covisibility ratio sits on its threshold (the oracle then continues with the engine's decision imposed).
+    The oracle is the checker here and runs after every timed region.  One worker process per lane (the host cores run them in parallel)."""
+    import subprocess
+    import tempfile
+    from rgbid import engine as E
+    T = first_step + n_steps
+    worst_r = worst_t = 0.0
+    imposed = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        procs = []
+        for l in lanes_to_check:
+            npz = os.path.join(tmp, f"lane{l}.npz")
+            np.savez(npz, depth=depth[:T, l].cpu().numpy().view(np.uint16), rgb=rgb[:T, l].cpu().numpy(), K=np.array(K, np.float64),
+                     levels=levels, iters=np.array(iters), status=rec["status"][:, l])
+            env = dict(os.environ, OMP_NUM_THREADS=str(max(1, usable_cores() // max(1, len(lanes_to_check)))))
+            procs.append((l, subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "oracle_lane_worker.py"), npz], stdout=subprocess.PIPE,
+                                              stderr=subprocess.PIPE, text=True, env=env)))
+        for l, p in procs:
+            out, err = p.communicate(timeout=1200)
+            assert p.returncode == 0, f"oracle worker for lane {l} failed: {err[-800:]}"
+            o = json.loads(out.strip().splitlines()[-1])
+            R = np.array(o["R"]); t = np.array(o["t"])
+            imposed += o["imposed"]
+            for k in range(n_steps):
+                g = rec[first_step + k, l]
+                c = (np.trace(R[first_step + k].T @ g["R"]) - 1) / 2
+                er = float(np.arccos(np.clip(c, -1, 1))); et = float(np.linalg.norm(t[first_step + k] - g["t"]))
+                worst_r, worst_t = max(worst_r, er), max(worst_t, et)
+    return worst_r, worst_t, imposed
+
+
+def run_config(ctx, dev, work_stream, rows, cols, levels, iters, B, Kst, W, reps, n_unique, graph, fused, keyframes, K, dist_env, check_streams=0,
+               fast_numerics=1):
+    """the timed protocol on one engine configuration; returns (result dict, inputs kept for the PCIe leg)"""
+    from rgbid import engine as E
+    T = 1 + W + Kst
+    seqs, depth, rgb = make_inputs(B, T, rows, cols, K, dev, n_unique)
+    cfg_kw = dict(rows=rows, cols=cols, levels=levels, lanes=B, K=K, iters=iters, use_graph=graph, fused_gn=fused, record_capacity=T,
+                  keyframe_capacity=keyframes)
+    if hasattr(E.EngineConfig, "fast_numerics"):
+        cfg_kw["fast_numerics"] = fast_numerics
+    eng = E.Engine(ctx, E.default_config(**cfg_kw))
+    gn_l0 = iters[0] + 1                      # level-0 launches of the dominant kernel per step (10 GN + covariance pass)
+    profile_in_timed = not graph
+    use_dist, comm = dist_env["use_dist"], dist_env.get("comm")
+    times, recs, k_ms_tot, k_n_tot, k_bytes = [], [], 0.0, 0, 0.0
+    gathered = None
+    for rep in range(reps):
+        if rep:
+            eng.reset()
+        eng.step(depth[0], rgb[0])                # frame 0: keyframe creation
+        for k in range(1, 1 + W):                 # untimed warm-up steps
+            eng.step(depth[k], rgb[k])
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            import torch.distributed as dist
+            dist.barrier()
+        if profile_in_timed:
+            eng.profile_begin(gn_l0 * Kst)
+        t0 = time.perf_counter()
+        for k in range(1 + W, 1 + W + Kst):       # EXACTLY K timed steps
+            eng.step(depth[k], rgb[k])
+        rec = eng.records(1 + W, Kst)             # synchronises; pose records of the timed steps
+        if use_dist:
+            # the only collective on the path: all-gather of the 392-byte per-frame records of every rank's lanes (RCCL over xGMI)
+            from rgbid import dist as D
+            packed = D.pack_engine_records(eng, 1 + W, Kst)
+            if comm is not None:
+                gathered = comm.gather(packed, B * Kst)
+                ctx.sync()
+            else:
+                ctx.sync()
+                gathered = torch.empty(dist_env["world"] * packed.numel(), dtype=torch.uint8, device=dev)
+                dist.all_gather_into_tensor(gathered, packed)
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if use_dist:
+            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        if profile_in_timed:
+            ms, n, k_bytes = eng.profile_end()
+            k_ms_tot += ms; k_n_tot += n
+        times.append(el)
+        recs.append(rec.copy())
+    if not profile_in_timed:
+        # graph replay cannot be event-bracketed per kernel: time the same kernel in an extra eager pass over the same frames
+        eng.reset()
+        eng.step(depth[0], rgb[0])
+        eng.profile_begin(gn_l0 * (W + Kst))
+        for k in range(1, 1 + W + Kst):
+            eng.step(depth[k], rgb[k])
+        k_ms_tot, k_n_tot, k_bytes = eng.profile_end()
+    world = dist_env["world"]
+    order = np.argsort(times)
+    med = int(order[len(times) // 2])
+    el = times[med]
+    rec = recs[med]
+    tracked = int(np.count_nonzero(rec["status"] & E.ST_TRACKED))
+    avg_s = (k_ms_tot / max(k_n_tot, 1)) * 1e-3
+    achieved = k_bytes / avg_s / 1e9 if k_n_tot else 0.0
+    n_streams = min(B, n_unique)
+    # ---- parity of the benchmarked surface (after the timed regions) ----
+    reps_identical = all(recs[i].tobytes() == recs[0].tobytes() for i in range(1, len(recs)))
+    ref = rec[:, :n_streams]
+    lanes_identical = all(rec[:, l].tobytes() == ref[:, l % n_streams].tobytes() for l in range(B))
+    parity = {"lanes_bit_identical": bool(lanes_identical), "duplicate_lanes_per_stream": B // n_streams if n_streams else 0,
+              "repetitions_bit_identical": bool(reps_identical)}
+    if check_streams > 0:
+        chk = list(range(min(check_streams, n_streams)))
+        full = eng.records(0, T)   # every step of the last repetition (keyframe frame, warm-up, timed steps): the ring holds T records
+        assert full[1 + W:].tobytes() == recs[-1].tobytes()
+        wr, wt, imposed = oracle_check(depth, rgb, chk, rows, cols, K, levels, iters, full, 1 + W, Kst)
+        parity.update({"oracle_checked_lanes": chk, "oracle_checked_steps": Kst, "worst_rot_rad": wr, "worst_trans_m": wt,
+                       "keyframe_decisions_on_threshold_imposed": imposed, "within_1e-4": bool(wr < 1e-4 and wt < 1e-4)})
+    res = {
+        "value": B * Kst * world / el, "ms_per_step": el / Kst * 1e3,
+        "repetitions": {"n": len(times), "frames_per_s": [B * Kst * world / t for t in times], "protocol": "each: reset, keyframe frame, warm-up, K timed steps; value = median"},
+        "launches_per_step": eng.launches_per_step(), "engine_hbm_bytes": eng.bytes(), "tracked": tracked, "expected": B * Kst,
+        "keyframes_exported": int(np.count_nonzero(rec["status"] & E.ST_KF_EXPORTED)), "n_unique_streams": n_streams,
+        "u1": {"achieved": achieved, "avg_launch_us": avg_s * 1e6, "launches_timed": k_n_tot, "bytes_per_launch": k_bytes,
+               "timed_in": "timed regions" if profile_in_timed else "separate eager pass"},
+        "parity": parity,
+    }
+    keep = (seqs, depth, rgb, eng, rec, gathered)
+    return res, keep
+
+
+def extra_config1(ctx, dev, K):
+    """BASELINE config 1 on the GPU: the residual + 27-term normal equations (unit U1) of ONE 640x480 pair through the single-image C-ABI
+    call (cache-resident: 9.8 MB of maps live in L2 / Infinity Cache), device time from the call's own hipEvent pair."""
+    from oracle import oracle as O   # enum values only
+    from tests import util
+    rows, cols = 480, 640
+    r = util.rng(1)
+    maps = [torch.from_numpy(util.rand_invdepth(r, rows, cols)).to(dev) for _ in range(8)]
+    ms = []
+    for _ in range(60):
+        _, _, m = ctx.buildSystemStudentNuGridStride(*maps, O.STUDENT, O.INDEPENDENT, 0.0025, 5.0, 0.0, 0.0, 5.0, 5.0, K, return_ms=True)
+        ms.append(m)
+    us = float(np.median(ms[10:])) * 1e3
+    return {"config": "1: single 640x480 pair, residual + 6x6 normal equations (U1), cache-resident", "u1_device_us": us,
+            "u1_gbs": 32.0 * rows * cols / (us * 1e-6) / 1e9, "calls_timed": len(ms) - 10,
+            "note": "working set 9.8 MB < L2 + Infinity Cache: a latency figure, not an HBM-roofline figure; the batched x512 U1 is `roofline`"}
+
+
+def flush_c_stdio():
+    """RCCL prints its version banner to the C stdout when the first communicator of a process comes up (NCCL_DEBUG=VERSION in this
+    image); pushing it out right then keeps the result line the LAST line of stdout."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside a launcher: become the launcher.  Fails loudly when the node has fewer devices."""
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        sys.stderr.write(f"bench.py --gpus {n}: this node exposes {have} HIP device(s); refusing to run fewer ranks than requested\n")
+        sys.exit(2)
+    from rgbid import dist as D
+    p = D.spawn_local(n, [os.path.abspath(__file__)] + argv)
+    sys.stderr.write(p.stderr)
+    sys.stdout.write(p.stdout)
+    sys.exit(p.returncode)
 
 
 def main():
@@ -125,110 +311,100 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reps", type=int, default=5, help="timed repetitions of the K steps (value = median)")
     ap.add_argument("--lanes", type=int, default=512, help="independent RGB-D streams per GPU")
+    ap.add_argument("--streams", type=int, default=32, help="distinct synthetic input streams dealt onto the lanes")
+    ap.add_argument("--check-streams", type=int, default=4, help="lanes (one per distinct stream) held to the CPU oracle over all timed steps, after the timed regions")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--levels", type=int, default=3)
     ap.add_argument("--graph", type=int, default=0, help="replay each step as one hipGraph (roofline events then need a 2nd pass)")
     ap.add_argument("--fused", type=int, default=0)
+    ap.add_argument("--fast", type=int, default=1, help="engine numerics of the gather kernels: 1 = reference-build class (FMA contraction, v_rcp), 0 = IEEE-exact")
     ap.add_argument("--keyframes", type=int, default=2, help="per-lane capacity of the keyframe export ring: the outgoing keyframe is handed to the back-end at every switch, as trackNewFrame does (0 = no export)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip extra_configs (BASELINE configs 1 and 5)")
+    ap.add_argument("--gather", default="rccl-cabi", choices=["rccl-cabi", "torch"], help="transport of the record all-gather at N > 1")
     ap.add_argument("--h2d", type=int, default=0, help="also time the same steps with the frames streamed from pinned host memory (PCIe-inclusive rate; never `value`)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args.gpus, sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py --gpus {args.gpus}: launched with WORLD_SIZE={world}; the two must agree\n")
+        sys.exit(2)
     use_dist = world > 1 or bool(os.environ.get("RGBID_FORCE_DIST"))  # the env override exercises the RCCL path on one rank
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        sys.stderr.write(f"bench.py --gpus {args.gpus}: rank {rank} needs HIP device {local_rank}, this node exposes "
+                         f"{torch.cuda.device_count() if torch.cuda.is_available() else 0} device(s) (there is no CPU path)\n")
+        sys.exit(2)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU path)"
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from rgbid import device, engine as E, synth
+    from rgbid import device, engine as E
     rows, cols, B, Kst, W = args.rows, args.cols, args.lanes, args.steps, args.warmup
     s = cols / 640.0
     K = (525.0 * s, 525.0 * s, (319.5 + 0.5) * s - 0.5, (239.5 + 0.5) * s - 0.5)
-    T = 1 + W + Kst
-    # frames resident in HBM: at most 48 per lane; longer runs walk the sequence forwards and backwards (a reversed camera path is
-    # an equally valid sequence for the tracker), so --steps can be large without the inputs outgrowing the GPU
-    TF = min(T, 48)
-    seqs, depth_f, rgb_f = make_inputs(B, TF, rows, cols, K, dev)
-
-    class _PingPong:
-        def __init__(self, a):
-            self.a = a
-
-        def __getitem__(self, k):
-            if TF == 1:
-                return self.a[0]
-            p = k % (2 * (TF - 1))
-            return self.a[p if p < TF else 2 * (TF - 1) - p]
-
-        def cpu_frames(self):
-            return torch.stack([self[k].cpu() for k in range(T)])
-
-    depth, rgb = _PingPong(depth_f), _PingPong(rgb_f)
 
     work = torch.cuda.Stream(dev)                 # the engine's HIP stream (a torch stream so torch events can order against it)
     with torch.cuda.stream(work):
         ctx = device.Context(local_rank)
     ctx.set_async(1)
     iters = [10, 5, 3] + [3] * (args.levels - 3) if args.levels >= 3 else [10, 5, 3][:args.levels]
-    eng = E.Engine(ctx, E.default_config(rows=rows, cols=cols, levels=args.levels, lanes=B, K=K, iters=iters, use_graph=args.graph,
-                                         fused_gn=args.fused, record_capacity=T, keyframe_capacity=args.keyframes))
-    eng.step(depth[0], rgb[0])                # frame 0: keyframe creation
-    for k in range(1, 1 + W):                 # untimed warm-up steps
-        eng.step(depth[k], rgb[k])
-    gn_l0 = iters[0] + 1                      # level-0 launches of the dominant kernel per step (10 GN + covariance pass)
-    profile_in_timed = not args.graph
-    torch.cuda.synchronize(dev)
+    dist_env = {"use_dist": use_dist, "world": world, "comm": None}
+    gather_how = None
     if use_dist:
-        dist.barrier()
-    if profile_in_timed:
-        eng.profile_begin(gn_l0 * Kst)
-    t0 = time.perf_counter()
-    for k in range(1 + W, 1 + W + Kst):       # EXACTLY K timed steps
-        eng.step(depth[k], rgb[k])
-    rec = eng.records(1 + W, Kst)             # synchronises; pose records of the timed steps
+        from rgbid import dist as D
+        gather_how = "torch.distributed all_gather_into_tensor (nccl = RCCL)"
+        if args.gather == "rccl-cabi":
+            try:
+                dist_env["comm"] = D.Comm(ctx, world, rank)      # librgbid_dist.so over librccl; the unique id travels through torch's store
+                gather_how = "rgbid_dist_gather_records (C-ABI, ncclAllGather on the engine's stream)"
+            except Exception as e:                               # a transport problem must not cost the scaling record: say so loudly instead
+                sys.stderr.write(f"[bench] WARNING: C-ABI RCCL communicator failed ({e}); gathering through torch.distributed\n")
+                gather_how += f" -- C-ABI RCCL helper FAILED: {e}"
     if use_dist:
-        # the only collective on the path: gather the poses of every rank's lanes (RCCL over xGMI), ~0.9 KB per frame
-        mine = torch.from_numpy(rec.view(np.uint8).reshape(-1)).to(dev)
-        allrec = torch.empty(world * mine.numel(), dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(allrec, mine)
-    torch.cuda.synchronize(dev)
+        import torch.distributed as dist
+        dist.barrier()            # brings torch's communicator up (and RCCL's banner out) before anything is timed or printed
+        if dist_env["comm"] is not None:
+            dist_env["comm"].barrier()
+        flush_c_stdio()
+    res, keep = run_config(ctx, dev, work, rows, cols, args.levels, iters, B, Kst, W, max(1, args.reps), args.streams, args.graph, args.fused,
+                           args.keyframes, K, dist_env, check_streams=args.check_streams if rank == 0 else 0, fast_numerics=args.fast)
+    seqs, depth, rgb, eng, rec, gathered = keep
+    rccl_ranks = None
+    gather_ok = None
     if use_dist:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        el = float(tmax.item())
-
-    if profile_in_timed:
-        k_ms, k_n, k_bytes = eng.profile_end()
-    else:
-        # graph replay cannot be event-bracketed per kernel: time the same kernel in an extra eager pass over the same frames
-        eng.reset()
-        eng.step(depth[0], rgb[0])
-        eng.profile_begin(gn_l0 * (W + Kst))
-        for k in range(1, 1 + W + Kst):
-            eng.step(depth[k], rgb[k])
-        k_ms, k_n, k_bytes = eng.profile_end()
+        import torch.distributed as dist
+        from rgbid import dist as D
+        # cross-check of the gathered records (outside the timed regions): every rank's block equals what torch.distributed gathers
+        packed = D.pack_engine_records(eng, 1 + W, Kst)
+        ctx.sync()
+        ref = torch.empty(world * packed.numel(), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(ref, packed)
+        gather_ok = bool(torch.equal(ref, gathered))
+        rccl_ranks = dist_env["comm"].world() if dist_env["comm"] is not None else dist.get_world_size()
 
     pcie = None
     if args.h2d:
         # PCIe-inclusive leg: frames start in pinned host memory; frame k+1 is uploaded on a copy stream while step k computes
-        depth_h, rgb_h = depth.cpu_frames().pin_memory(), rgb.cpu_frames().pin_memory()
+        T = 1 + W + Kst
+        depth_h, rgb_h = depth.cpu().pin_memory(), rgb.cpu().pin_memory()
         bufs = [(torch.empty_like(depth[0]), torch.empty_like(rgb[0])) for _ in range(2)]
         copy_stream = torch.cuda.Stream(dev)
         ready = [torch.cuda.Event() for _ in range(2)]
         free = [torch.cuda.Event() for _ in range(2)]
-        main = work
 
         def upload(k, slot):
             with torch.cuda.stream(copy_stream):
@@ -239,7 +415,7 @@ def main():
 
         eng.reset()
         for ev in free:
-            ev.record(main)
+            ev.record(work)
         upload(0, 0)
         t1 = None
         for k in range(T):
@@ -249,53 +425,93 @@ def main():
             if k == 1 + W:
                 torch.cuda.synchronize(dev)
                 t1 = time.perf_counter()
-            main.wait_event(ready[slot])
+            work.wait_event(ready[slot])
             eng.step(bufs[slot][0], bufs[slot][1])
-            free[slot].record(main)
+            free[slot].record(work)
         rec_h = eng.records(1 + W, Kst)
         torch.cuda.synchronize(dev)
         el_h = time.perf_counter() - t1
-        same = bool(np.array_equal(rec_h["status"], rec["status"]) and np.allclose(rec_h["t"], rec["t"], atol=1e-12))
+        same = bool(rec_h.tobytes() == rec.tobytes())
         per_step = (depth_h[0].numel() * 2 + rgb_h[0].numel()) / 1e9
         pcie = {"value": B * Kst / el_h, "unit": "frames/s", "ms_per_step": el_h / Kst * 1e3, "h2d_gb_per_step": per_step,
-                "h2d_gbs_needed": per_step / (el_h / Kst), "poses_identical_to_resident_run": same,
+                "h2d_gbs_needed": per_step / (el_h / Kst), "records_identical_to_resident_run": same,
                 "note": "frames streamed from pinned host memory on a copy stream, double-buffered, overlapped with the previous step"}
+        del depth_h, rgb_h, bufs
+    eng.close()
 
-    tracked = int(np.count_nonzero(rec["status"] & E.ST_TRACKED))
-    frames = B * Kst * world
     result = None
     if rank == 0:
-        avg_s = (k_ms / max(k_n, 1)) * 1e-3
-        achieved = k_bytes / avg_s / 1e9 if k_n else 0.0
+        traffic, traffic_from = pmc_traffic(B, rows, cols, args.fused)
+        u1 = res["u1"]
+        headline = rows == 480 and cols == 640 and args.levels == 3
         result = {
             "metric": "aligned RGB-D frames/sec @640x480, 3-level pyr; achieved HBM GB/s vs roofline",
-            "value": frames / el, "unit": "frames/s", "n_gpus": world, "steps": Kst, "warmup": W,
-            "ms_per_step": el / Kst * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": res["value"], "unit": "frames/s", "n_gpus": world, "steps": Kst, "warmup": W,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic TUM-like {cols}x{rows} RGB-D streams (stand-in for TUM fr1/desk: dataset not in image), "
-                                   f"{B} lanes/GPU, {args.levels}-level pyramid, GN iterations {iters}, Student-t + sigmaML, pyrFirst, "
-                                   f"keyframe iD fusion + keyframe export on, preview off, full trackNewFrame per lane per step",
-                       "lanes_per_gpu": B, "graph": bool(args.graph), "fused_gn": bool(args.fused),
-                       "launches_per_step": eng.launches_per_step(), "engine_hbm_bytes": eng.bytes(),
-                       "tracked_frames_rank0": tracked, "expected_rank0": B * Kst,
-                       "keyframe_export_capacity": args.keyframes,
-                       "keyframes_exported_in_timed_steps_rank0": int(np.count_nonzero(rec["status"] & E.ST_KF_EXPORTED))},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(B, rows, cols, args.fused),
+                                   f"{B} lanes/GPU carrying {res['n_unique_streams']} distinct streams, {args.levels}-level pyramid, GN iterations {iters}, "
+                                   f"Student-t + sigmaML, pyrFirst, keyframe iD fusion + keyframe export on, preview off, full trackNewFrame per lane per step",
+                       "lanes_per_gpu": B, "graph": bool(args.graph), "fused_gn": bool(args.fused), "fast_numerics": bool(args.fast),
+                       "launches_per_step": res["launches_per_step"], "engine_hbm_bytes": res["engine_hbm_bytes"],
+                       "tracked_frames_rank0": res["tracked"], "expected_rank0": res["expected"],
+                       "keyframe_export_capacity": args.keyframes, "keyframes_exported_in_timed_steps_rank0": res["keyframes_exported"],
+                       "n_unique_streams": res["n_unique_streams"]},
+            "repetitions": res["repetitions"],
+            "frame_level": ({"bytes_per_frame": U3_BYTES_PER_FRAME, "achieved_gbs": res["value"] / world * U3_BYTES_PER_FRAME / 1e9,
+                             "frac_of_hbm_peak": res["value"] / world * U3_BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS,
+                             "note": "unit U3 (SURVEY 8d): algorithmic bytes of one aligned frame x frames/s per GPU"} if headline else None),
+            "roofline": {"bound": "hbm", "achieved": u1["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": u1["achieved"] / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_from": traffic_from,
                          "kernel": "rgbid::k_build_system<ByLane<SysParams>, true, 0> (level-0 residual + 27-term normal equations)",
-                         "algorithmic_bytes_per_launch": k_bytes, "launches_timed": k_n, "avg_launch_us": avg_s * 1e6,
-                         "timed_in": "timed region" if profile_in_timed else "separate eager pass"},
+                         "algorithmic_bytes_per_launch": u1["bytes_per_launch"], "launches_timed": u1["launches_timed"], "avg_launch_us": u1["avg_launch_us"],
+                         "timed_in": u1["timed_in"]},
+            "parity": res["parity"],
+            "lanes_bit_identical": res["parity"]["lanes_bit_identical"],
         }
+        if use_dist:
+            result["multi_gpu"] = {"rccl_ranks": rccl_ranks, "gather": gather_how, "record_bytes": 392,
+                                   "gathered_bytes_per_rank_per_repetition": B * Kst * 392, "gather_equals_torch_all_gather": gather_ok}
         if pcie is not None:
             result["pcie_inclusive"] = pcie
+    # ---- extra configurations (BASELINE configs 1 and 5), rank 0 of a single-GPU run only ----
+    if rank == 0 and world == 1 and not args.no_extras and rows == 480 and cols == 640:
+        extras = []
+        del depth, rgb, keep, gathered
+        torch.cuda.empty_cache()
+        try:
+            extras.append(extra_config1(ctx, dev, K))
+        except Exception as e:
+            extras.append({"config": "1", "error": f"{type(e).__name__}: {e}"})
+        try:
+            K5 = (1050.0, 1050.0, 639.5, 479.5)
+            it5 = [10, 5, 3, 3]
+            r5, keep5 = run_config(ctx, dev, work, 960, 1280, 4, it5, 128, min(Kst, 8), 1, 1, 8, 0, 0, 0, K5, {"use_dist": False, "world": 1},
+                                   check_streams=0, fast_numerics=args.fast)
+            keep5[3].close()
+            del keep5
+            torch.cuda.empty_cache()
+            extras.append({"config": "5: 1280x960 upsampled synthetic stream, 4-level pyramid, GN iterations [10,5,3,3], 128 lanes (8 distinct streams)",
+                           "value": r5["value"], "unit": "frames/s", "ms_per_step": r5["ms_per_step"], "steps": min(Kst, 8), "warmup": 1,
+                           "tracked": r5["tracked"], "expected": r5["expected"], "lanes_bit_identical": r5["parity"]["lanes_bit_identical"],
+                           "u1_achieved_gbs": r5["u1"]["achieved"], "u1_frac_of_hbm_peak": r5["u1"]["achieved"] / HBM_PEAK_GBS,
+                           "u1_avg_launch_us": r5["u1"]["avg_launch_us"], "u1_bytes_per_launch": r5["u1"]["bytes_per_launch"],
+                           "u1_launches_timed": r5["u1"]["launches_timed"], "engine_hbm_bytes": r5["engine_hbm_bytes"]})
+        except Exception as e:
+            extras.append({"config": "5", "error": f"{type(e).__name__}: {e}"})
+        result["extra_configs"] = extras
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(seqs[0], rows, cols, K)
         else:
             result["cpu_baseline"] = None
-        print(json.dumps(result))
-    eng.close()
+        flush_c_stdio()
+        print(json.dumps(result), flush=True)   # before any teardown: nothing that happens at exit may cost the result line
+    if dist_env.get("comm") is not None:
+        dist_env["comm"].close()
     ctx.close()
     if use_dist:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

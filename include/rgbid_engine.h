@@ -113,6 +113,18 @@ int rgbid_engine_read_keyframe(rgbid_engine* e, int lane, int seq, rgbid_keyfram
 /* device views for zero-copy consumers: header ring [lanes][capacity] and packed blocks [lanes][capacity][20 N bytes] */
 int rgbid_engine_keyframes_dev(rgbid_engine* e, void** headers, void** blocks, size_t* block_bytes);
 
+/* ---- the per-frame record ranks exchange when a sequence is sharded over GPUs (rgbid_dist.h): what
+ * trackNewFrame appends to odo_rmats_/odo_tvecs_/odo_covmats_ (src/visodo.cpp:2150-2152) plus frame id and status.  392 bytes. ---- */
+typedef struct rgbid_gather_record {
+  int32_t frame_id;      /* global_time_ of the frame inside its lane's (chunk's) run: 0 = first frame */
+  int32_t status;        /* RGBID_ST_* bits */
+  double  R[9], t[3];    /* frame-to-frame odometry dT_k: identity on a first frame and on lost frames */
+  double  cov[36];       /* its 6x6 covariance (100 I on lost frames, visodo.cpp:2070-2071; 0 on a first frame) */
+} rgbid_gather_record;
+/* packs steps [first_step, first_step + n_steps) of the pose-record ring into out_dev[lanes][n_steps] (lane-major: a lane's frames are
+ * contiguous, the layout rgbid_dist_compose_trajectory reads) with one kernel on the context's stream; out_dev is DEVICE memory */
+int rgbid_engine_pack_gather_records(rgbid_engine* e, int first_step, int n_steps, rgbid_gather_record* out_dev);
+
 /* Event timing of the dominant kernel: while profiling is on, every launch of the level-0 (full resolution)
  * residual + normal-equation kernel is bracketed by a hipEvent pair on the context's stream (steps run eagerly,
  * not as a graph; with use_graph = 1 the inputs still go through the staging copy, so the buffer-lifetime rule of

@@ -466,6 +466,19 @@ __global__ void k_set_light(const LaneState* st, LightP* light, int B) {
   light[lane] = LightP{(float)st[lane].integrKF_t[0], (float)st[lane].integrKF_t[1], (float)st[lane].integrKF_t[2]};
 }
 
+// pose-record ring -> the 392-byte records of SURVEY 8e, lane-major; one thread per (lane, step)
+__global__ void k_pack_gather(const rgbid_pose_record* ring, int capacity, int B, int first_step, int n_steps, rgbid_gather_record* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * n_steps) return;
+  int lane = i / n_steps, k = i - lane * n_steps;
+  const rgbid_pose_record& r = ring[(size_t)((first_step + k) % capacity) * B + lane];
+  rgbid_gather_record& g = out[i];
+  g.frame_id = r.frame; g.status = r.status;
+  for (int j = 0; j < 9; ++j) g.R[j] = r.odo_R[j];
+  for (int j = 0; j < 3; ++j) g.t[j] = r.odo_t[j];
+  for (int j = 0; j < 36; ++j) g.cov[j] = r.odo_cov[j];
+}
+
 __global__ void k_step_end(LaneState* st, rgbid_pose_record* rec, const int* kf_slot, int B) {
   int lane = blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= B) return;
@@ -981,6 +994,18 @@ int rgbid_engine_read_records(rgbid_engine* e, int first_step, int n_steps, rgbi
     if (he != hipSuccess) return (int)he;
   }
   hipError_t he = hipStreamSynchronize(e->ctx->stream);
+  return he == hipSuccess ? RGBID_OK : (int)he;
+}
+
+int rgbid_engine_pack_gather_records(rgbid_engine* e, int first_step, int n_steps, rgbid_gather_record* out_dev) {
+  static_assert(sizeof(rgbid_gather_record) == 392, "SURVEY 8e record");
+  if (!e || !out_dev || n_steps < 0 || first_step < 0 || first_step + n_steps > e->steps || e->steps - first_step > e->cfg.record_capacity) return RGBID_E_INVALID;
+  if (n_steps == 0) return RGBID_OK;
+  hipSetDevice(e->ctx->device);
+  const int n = e->B * n_steps;
+  hipLaunchKernelGGL(k_pack_gather, dim3(div_up(n, 128)), dim3(128), 0, e->ctx->stream, e->records, e->cfg.record_capacity, e->B, first_step, n_steps, out_dev);
+  hipError_t he = hipGetLastError();
+  if (he == hipSuccess && !e->ctx->async) he = hipStreamSynchronize(e->ctx->stream);
   return he == hipSuccess ? RGBID_OK : (int)he;
 }
 

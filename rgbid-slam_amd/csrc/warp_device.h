@@ -146,4 +146,138 @@ __device__ __forceinline__ float warp_intensity_px(const FMap& src, int x, int y
   return res;
 }
 
+// =====================================================================================================================================
+// "Reference-build-class" numerics for the ENGINE's gather kernels (rgbid_engine_config.fast_numerics, default on).
+//
+// The reference compiles its kernels with --prec-div=false --prec-sqrt=false --ftz=true (CMakeLists.txt:105) and nvcc's default FMA
+// contraction: its own pixel selection is that of approximate reciprocals and fused multiply-adds, not of IEEE arithmetic.  The functions
+// above reproduce the IEEE evaluation of the scalar oracle bit for bit (the compat bridge always uses them); the functions below evaluate
+// the same formulas in the reference build's class of arithmetic -- v_rcp_f32 (1 ulp) for every division, explicit FMAs, the ray
+// q = R (x, y, 1) formed once per pixel and shared by every projection from that pixel (registerPixel, warping_registration.cu:129-146,
+// re-associated: R (x z, y z, z) + t = z q + t), 1 / (1 / X.z) taken as X.z -- which removes ~40 % of the instructions of kernels that
+// are VALU-bound.  What changes: a coordinate that lands within an ulp of a pixel boundary may select the neighbouring pixel.  Measured
+// against the exact kernels (tests/test_gpu_engine.py::test_engine_fast_numerics_vs_exact): a few boundary pixels per map, poses
+// within 1e-6; the oracle's model of the reference's nvcc flags moves poses by the same order (tests/test_oracle_cuda_numerics.py).
+namespace fastnum {
+
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// floor + saturating convert in one instruction (NaN -> 0); verified against v_floor_f32 + v_cvt_i32_f32 by rgbid_selftest_cvt_flr
+__device__ __forceinline__ int cvt_flr(float x) { int r; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+
+struct Ray { float q0, q1, q2; };   // K R^-1 K^-1 (x, y, 1)
+__device__ __forceinline__ Ray ray(const WarpParams& P, float xf, float yf) {
+  Ray r;
+  r.q0 = __builtin_fmaf(P.R[0], xf, __builtin_fmaf(P.R[1], yf, P.R[2]));
+  r.q1 = __builtin_fmaf(P.R[3], xf, __builtin_fmaf(P.R[4], yf, P.R[5]));
+  r.q2 = __builtin_fmaf(P.R[6], xf, __builtin_fmaf(P.R[7], yf, P.R[8]));
+  return r;
+}
+__device__ __forceinline__ Ray ray_step(const Ray& r, float d0, float d1, float d2) { return Ray{r.q0 + d0, r.q1 + d1, r.q2 + d2}; }
+
+// trafo3DKernelInvDepthGridStride (:505-546), one pixel
+__device__ __forceinline__ float warp_invdepth_px(const FMap& src, const Ray& q, float w, const WarpParams& P) {
+  const bool valid = w == w;
+  const float ws = valid ? w : 1.f;
+  const float zd = rcp(ws);
+  const float X0 = __builtin_fmaf(q.q0, zd, P.t[0]), X1 = __builtin_fmaf(q.q1, zd, P.t[1]), X2 = __builtin_fmaf(q.q2, zd, P.t[2]);
+  const float wc = rcp(X2);
+  const float xs = __builtin_fmaf(X0, wc, 0.5f), ys = __builtin_fmaf(X1, wc, 0.5f);
+  const int ix = cvt_flr(xs), iy = cvt_flr(ys);
+  const bool inb = inside(ix, iy, src.cols, src.rows);
+  const float w2 = src.at(clampi(iy, src.rows - 1), clampi(ix, src.cols - 1));
+  const float tz = P.t[2];
+  const float v1_z = (X2 - tz) * ws;                       // 1 / w3 = X.z
+  const float res = (v1_z * rcp(__builtin_fmaf(-w2, tz, 1.f))) * w2;
+  return (valid & inb & (res > 0.f)) ? res : qnan();
+}
+
+// the weighted variant (:549-594): warped inverse depth + weight (1 - w2 tz)^4 / v^2
+__device__ __forceinline__ float warp_invdepth_weighted_px(const FMap& src, const Ray& q, float w, const WarpParams& P, float& weight_res, bool& store_weight) {
+  const bool valid = w == w;
+  const float ws = valid ? w : 1.f;
+  const float zd = rcp(ws);
+  const float X0 = __builtin_fmaf(q.q0, zd, P.t[0]), X1 = __builtin_fmaf(q.q1, zd, P.t[1]), X2 = __builtin_fmaf(q.q2, zd, P.t[2]);
+  const float wc = rcp(X2);
+  const float xs = __builtin_fmaf(X0, wc, 0.5f), ys = __builtin_fmaf(X1, wc, 0.5f);
+  const int ix = cvt_flr(xs), iy = cvt_flr(ys);
+  const bool inb = inside(ix, iy, src.cols, src.rows);
+  const float w2 = src.at(clampi(iy, src.rows - 1), clampi(ix, src.cols - 1));
+  const float tz = P.t[2];
+  const float v1_z = (X2 - tz) * ws;
+  const float w_factor = __builtin_fmaf(-w2, tz, 1.f);
+  const float rv = rcp(v1_z), wf2 = w_factor * w_factor;
+  weight_res = (wf2 * wf2) * (rv * rv);
+  const float res = (v1_z * rcp(w_factor)) * w2;
+  store_weight = valid & inb & (weight_res > 0.f);
+  return (valid & inb & (res > 0.f)) ? res : qnan();
+}
+
+// trafo3DKernelIntensityWithInvDepthGridStride (:465-501), one pixel; bilinear tap in the lerp form
+__device__ __forceinline__ float warp_intensity_px(const FMap& src, const Ray& q, float w, const WarpParams& P, int interp_mode) {
+  const bool valid = w == w;
+  const float ws = valid ? w : 1.f;
+  const float zd = rcp(ws);
+  const float X0 = __builtin_fmaf(q.q0, zd, P.t[0]), X1 = __builtin_fmaf(q.q1, zd, P.t[1]), X2 = __builtin_fmaf(q.q2, zd, P.t[2]);
+  const float wc = rcp(X2);
+  const float xB = X0 * wc, yB = X1 * wc;                  // texel-space coordinates (xs - 0.5 of the reference's tex2D call)
+  // in bounds <=> floor(xB + 0.5) in [0, cols)
+  const bool inb = (xB >= -0.5f) & (xB < (float)src.cols - 0.5f) & (yB >= -0.5f) & (yB < (float)src.rows - 0.5f);
+  const float fx0 = floorf(xB), fy0 = floorf(yB);
+  float a = xB - fx0, b = yB - fy0;
+  if (interp_mode == 1) {
+    a = rintf(a * 256.f) * 0.00390625f;
+    b = rintf(b * 256.f) * 0.00390625f;
+  }
+  const int ic = clamp_from_m1(__float2int_rd(fx0), src.cols - 1), jc = clamp_from_m1(__float2int_rd(fy0), src.rows - 1);
+  const int i1 = min(ic + 1, src.cols - 1), j1 = min(jc + 1, src.rows - 1);
+  const int i0 = max(ic, 0), j0 = max(jc, 0);
+  const unsigned r0 = src.row(j0), r1 = src.row(j1);
+  const float T00 = src.at_off(r0, i0), T10 = src.at_off(r0, i1), T01 = src.at_off(r1, i0), T11 = src.at_off(r1, i1);
+  const float top = __builtin_fmaf(a, T10 - T00, T00), bot = __builtin_fmaf(a, T11 - T01, T01);
+  float res = __builtin_fmaf(b, bot - top, top);
+  res = fmaxf(0.f, fminf(res, 255.f));                     // NaN -> 255, as CUDA's min/max
+  return (valid & inb) ? res : qnan();
+}
+
+// one direction of computeCovisibility's gate (partialVisibilityKernel :297-360)
+__device__ __forceinline__ bool visible_px(const FMap& D, int cols, int rows, const Ray& q, float w, bool valid, const WarpParams& P) {
+  const float zd = rcp(valid ? w : 1.f);
+  const float X0 = __builtin_fmaf(q.q0, zd, P.t[0]), X1 = __builtin_fmaf(q.q1, zd, P.t[1]), X2 = __builtin_fmaf(q.q2, zd, P.t[2]);
+  const float wc = rcp(X2);
+  const float xd = X0 * wc, yd = X1 * wc;
+  const bool inside_img = (xd > 0) & (xd < (float)(cols - 1)) & (yd > 0) & (yd < (float)(rows - 1));
+  const int xi = clampi(__float2int_rn(xd), cols - 1), yi = clampi(__float2int_rn(yd), rows - 1);
+  return valid & inside_img & (fabsf(wc - D.at(yi, xi)) < 0.020f);
+}
+
+}  // namespace fastnum
+
+// Workgroup -> tile mapping that keeps a lane's tiles on ONE XCD.  The hardware deals consecutive workgroup ids round-robin onto the 8
+// XCDs (id % 8), each with its own 4 MiB L2, so with the natural (x, y, lane) order the neighbours of a tile -- whose gather footprints
+// share cache lines with it (a 64-px row segment shifted by the warp touches 3 lines instead of 2, plus a halo row) -- always run on
+// other XCDs and every shared line is fetched once per XCD.  With a 1-D grid and V = (id % 8) * (n / 8) + id / 8, XCD k walks a
+// contiguous slab of (lane, tile) space: spatial neighbours meet in the same L2.  The two divisions by launch constants are
+// multiply-high by host-computed magic numbers (wave-uniform: they stay on the scalar unit; the generic division the compiler emits for
+// `V / nx` costs ~40 VALU instructions per workgroup, more than the sharing gains in a VALU-bound kernel).
+struct TileMap {
+  unsigned nx, tiles, per, n, magic_tiles, magic_nx;
+  __device__ __forceinline__ TileId tile(unsigned id) const {
+    const unsigned V = (id < (per << 3)) ? (id & 7u) * per + (id >> 3) : id;   // tail ids keep their place
+    TileId t;
+    const unsigned lane = __umulhi(V, magic_tiles);
+    const unsigned tl = V - lane * tiles;
+    const unsigned by = __umulhi(tl, magic_nx);
+    t.lane = (int)lane; t.by = (int)by; t.bx = (int)(tl - by * nx);
+    return t;
+  }
+};
+inline bool make_tile_map(int nx, int ny, int B, TileMap* tm) {
+  const unsigned long long tiles = (unsigned long long)nx * ny, n = tiles * B;
+  if (n >= (1ull << 31) || tiles * n >= (1ull << 32) || (unsigned long long)nx * tiles >= (1ull << 32)) return false;   // mulhi-by-magic exactness bound
+  tm->nx = (unsigned)nx; tm->tiles = (unsigned)tiles; tm->n = (unsigned)n; tm->per = (unsigned)(n >> 3);
+  tm->magic_tiles = (unsigned)((1ull << 32) / tiles + 1);
+  tm->magic_nx = (unsigned)((1ull << 32) / (unsigned)nx + 1);
+  return true;
+}
+
 }  // namespace rgbid

@@ -1,60 +1,168 @@
-"""Multi-GPU sharding of a recorded sequence.
+"""Multi-GPU sharding of a recorded sequence -- Python harness over the C-ABI of include/rgbid_dist.h.
 
 The tracker is sequential inside a sequence, so the independent unit is a CHUNK: a contiguous sub-sequence tracked with
 the full keyframe / fusion logic starting from identity.  A sequence of F frames is cut into `n_chunks` chunks that
 overlap by one frame (chunk c ends on the frame chunk c+1 starts on); every chunk is one lane of one GPU's batched
-engine; ranks exchange ONLY pose records (one all_gather over RCCL / xGMI, ~0.9 KB per frame), and every rank (or rank 0)
-composes the global trajectory T_w,k = T_w,start(c) * T_chunk(k).  No image data ever crosses GPUs.
+engine; ranks exchange ONLY the 392-byte per-frame records {frame id, status, frame-to-frame R | t, 6x6 covariance} (one
+all-gather over RCCL / xGMI), and every rank composes the global trajectory T_w,k = T_w,k-1 * dT_k.  No image data crosses GPUs.
 
-One process per GPU: init torch.distributed with backend "nccl" (= RCCL on ROCm); the CPU tests use "gloo".
+Partitioning, the record layout, the RCCL all-gather (`Comm`) and the composition are the C functions of librgbid_dist.so -- what a
+C++ host calls; this module only binds them.  One process per GPU.  Process-group plumbing (launch, barrier, max-over-ranks
+timing) is torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests, where the records travel through
+torch.distributed instead of RCCL because RCCL needs GPUs).
 """
+import ctypes as C
+import os
+import socket
+import subprocess
+import sys
+
 import numpy as np
-import torch
-import torch.distributed as dist
+
+from . import _lib
+
+GATHER_DTYPE = np.dtype([("frame_id", np.int32), ("status", np.int32), ("R", np.float64, (3, 3)), ("t", np.float64, (3,)),
+                         ("cov", np.float64, (6, 6))], align=True)
+assert GATHER_DTYPE.itemsize == 392
+
+DIST_LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "librgbid_dist.so")
+DIST_EXPORTS = ["rgbid_dist_chunk_ranges", "rgbid_dist_rank_chunks", "rgbid_dist_new_id", "rgbid_dist_exchange_id", "rgbid_dist_broadcast_bytes",
+                "rgbid_dist_init", "rgbid_dist_destroy", "rgbid_dist_world", "rgbid_dist_rank", "rgbid_dist_gather_records", "rgbid_dist_barrier",
+                "rgbid_dist_compose_trajectory"]
+_dl = None
+
+
+def dlib():
+    global _dl
+    if _dl is None:
+        if not os.path.exists(DIST_LIB_PATH):
+            raise _lib.RgbidError(f"{DIST_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _lib.lib()                       # librgbid_hip.so first (librgbid_dist.so links against it)
+        _dl = C.CDLL(DIST_LIB_PATH)
+    return _dl
+
+
+def check(err):
+    if err != 0:
+        if err <= -100:
+            raise _lib.RgbidError(f"RCCL error {-100 - err} (ncclResult_t)")
+        if err == -90:
+            raise _lib.RgbidError("rendezvous (socket) failure")
+        _lib.check(err)
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.c_void_p)
 
 
 def chunk_ranges(n_frames, n_chunks):
     """[(first, last)] inclusive frame ranges, consecutive chunks share one frame; lengths differ by at most 1."""
-    assert n_frames >= n_chunks + 1 and n_chunks >= 1
-    steps = n_frames - 1                       # frame-to-frame transitions to distribute
-    base, extra = divmod(steps, n_chunks)
-    out, s = [], 0
-    for c in range(n_chunks):
-        n = base + (1 if c < extra else 0)
-        out.append((s, s + n))
-        s += n
-    return out
+    first = np.zeros(n_chunks, np.int32); last = np.zeros(n_chunks, np.int32)
+    check(dlib().rgbid_dist_chunk_ranges(int(n_frames), int(n_chunks), _ip(first), _ip(last)))
+    return [(int(a), int(b)) for a, b in zip(first, last)]
 
 
 def rank_chunks(n_chunks, world, rank):
     """chunk ids owned by `rank`: contiguous blocks, so neighbouring chunks mostly live on the same GPU."""
-    per, extra = divmod(n_chunks, world)
-    start = rank * per + min(rank, extra)
-    return list(range(start, start + per + (1 if rank < extra else 0)))
+    s, n = C.c_int(), C.c_int()
+    check(dlib().rgbid_dist_rank_chunks(int(n_chunks), int(world), int(rank), C.byref(s), C.byref(n)))
+    return list(range(s.value, s.value + n.value))
 
 
-def gather_pose_records(local, group=None):
-    """all_gather of fixed-size pose records.  local: float64 array [n_local_chunks, chunk_len, 12] (R row-major | t),
-    identical shape on every rank (pad shorter chunks with NaN).  Returns [world * n_local_chunks, chunk_len, 12]."""
+def lanes_per_rank(n_chunks, world):
+    return -(-n_chunks // world)
+
+
+def compose_trajectory(all_records, world, n_chunks, ranges):
+    """all_records: GATHER_DTYPE array [world, lanes_per_rank, chunk_len] (the gathered buffer).
+    Returns global (R [F,3,3], t [F,3], status [F], cov [F,6,6]); frame 0 = identity."""
+    a = np.ascontiguousarray(all_records)
+    assert a.dtype == GATHER_DTYPE and a.ndim == 3 and a.shape[0] == world
+    F = ranges[-1][1] + 1
+    first = np.array([r[0] for r in ranges], np.int32); last = np.array([r[1] for r in ranges], np.int32)
+    R = np.zeros((F, 3, 3)); t = np.zeros((F, 3)); st = np.zeros(F, np.int32); cov = np.zeros((F, 6, 6))
+    check(dlib().rgbid_dist_compose_trajectory(_ip(a), int(world), int(a.shape[1]), int(n_chunks), int(a.shape[2]), _ip(first), _ip(last),
+                                                _ip(R), _ip(t), _ip(st), _ip(cov)))
+    return R, t, st, cov
+
+
+class Comm:
+    """RCCL communicator bound to an rgbid context (rgbid_dist_init); the unique id is created on rank 0 and shipped either through
+    the library's own TCP rendezvous (`addr`, `port`) or through an initialised torch.distributed group (its store / broadcast)."""
+
+    def __init__(self, ctx, world, rank, addr=None, port=None, group=None):
+        import torch
+        self.ctx = ctx
+        ident = (C.c_char * 128)()
+        L = dlib()
+        if addr is not None:
+            check(L.rgbid_dist_exchange_id(addr.encode(), int(port), int(world), int(rank), ident))
+        else:
+            import torch.distributed as dist
+            if rank == 0:
+                check(L.rgbid_dist_new_id(ident))
+            if world > 1:
+                box = [bytes(ident)]
+                dist.broadcast_object_list(box, src=0, group=group)
+                C.memmove(ident, box[0], 128)
+        self._h = C.c_void_p()
+        check(L.rgbid_dist_init(C.byref(self._h), ctx._h, ident, int(world), int(rank)))
+        self._torch = torch
+
+    def world(self):
+        return dlib().rgbid_dist_world(self._h)
+
+    def rank(self):
+        return dlib().rgbid_dist_rank(self._h)
+
+    def gather(self, local_dev, n_local):
+        """local_dev: CUDA uint8 tensor holding n_local records; returns a CUDA uint8 tensor with world * n_local records (async on the ctx stream)"""
+        out = self._torch.empty(self.world() * n_local * 392, dtype=self._torch.uint8, device=local_dev.device)
+        check(dlib().rgbid_dist_gather_records(self._h, C.c_void_p(local_dev.data_ptr()), int(n_local), C.c_void_p(out.data_ptr())))
+        return out
+
+    def barrier(self):
+        check(dlib().rgbid_dist_barrier(self._h))
+
+    def close(self):
+        if self._h:
+            dlib().rgbid_dist_destroy(self._h)
+            self._h = None
+
+
+def pack_engine_records(eng, first_step, n_steps):
+    """device-side pack of an engine's pose-record ring into [lanes][n_steps] gather records -> CUDA uint8 tensor"""
+    import torch
+    out = torch.empty(eng.cfg.lanes * n_steps * 392, dtype=torch.uint8, device="cuda")
+    _lib.check(_lib.lib().rgbid_engine_pack_gather_records(eng._h, int(first_step), int(n_steps), C.c_void_p(out.data_ptr())))
+    return out
+
+
+def gather_records_torch(local, group=None):
+    """the same exchange through torch.distributed (CPU tests with gloo, and the cross-check of the RCCL path): local is a GATHER_DTYPE
+    array [lanes_per_rank, chunk_len], identical shape on every rank.  Returns [world, lanes_per_rank, chunk_len]."""
+    import torch
+    import torch.distributed as dist
     world = dist.get_world_size(group)
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    mine = torch.as_tensor(np.ascontiguousarray(local), dtype=torch.float64).to(dev)
-    out = torch.empty((world,) + tuple(mine.shape), dtype=torch.float64, device=dev)
-    dist.all_gather_into_tensor(out.view(-1), mine.view(-1), group=group)
-    return out.reshape((-1,) + tuple(mine.shape[1:])).cpu().numpy()
+    mine = torch.from_numpy(np.ascontiguousarray(local).view(np.uint8).reshape(-1).copy()).to(dev)
+    out = torch.empty(world * mine.numel(), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return out.cpu().numpy().view(GATHER_DTYPE).reshape((world,) + tuple(local.shape))
 
 
-def compose_trajectory(chunk_poses, ranges):
-    """chunk_poses[c][j] = (R, t) pose of the chunk's j-th frame relative to the chunk's first frame (identity at j = 0).
-    Returns global (R[F,3,3], t[F,3]) with frame 0 = identity."""
-    F = ranges[-1][1] + 1
-    R = np.zeros((F, 3, 3)); t = np.zeros((F, 3))
-    Rw, tw = np.eye(3), np.zeros(3)
-    for c, (a, b) in enumerate(ranges):
-        for j in range(b - a + 1):
-            Rc = np.asarray(chunk_poses[c][j][:9]).reshape(3, 3); tc = np.asarray(chunk_poses[c][j][9:12])
-            R[a + j] = Rw @ Rc
-            t[a + j] = Rw @ tc + tw
-        Rw, tw = R[b].copy(), t[b].copy()
-    return R, t
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def spawn_local(n, argv, env=None, timeout=None):
+    """Launch `argv` (a script + its arguments) as n ranks of ONE node, one process per GPU -- the same command line the driver uses:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port P script args...
+    Returns the CompletedProcess (stdout/stderr captured as text)."""
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port())] + list(argv)
+    return subprocess.run(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)

@@ -66,3 +66,15 @@ def test_host_library_exports_every_declared_symbol():
     assert len(names) >= 15
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
+
+
+def test_dist_library_exports_every_declared_symbol():
+    """librgbid_dist.so (multi-GPU helpers over librccl, include/rgbid_dist.h) loads without a GPU and exports every declared symbol"""
+    from rgbid import dist as D
+    L = D.dlib()
+    names = [n for n in _declared("rgbid_dist.h") if n.startswith("rgbid_dist_")]
+    assert len(names) == 12 and set(names) == set(D.DIST_EXPORTS), names
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    # the 392-byte record of SURVEY 8e, as the Python harness mirrors it
+    assert D.GATHER_DTYPE.itemsize == 392 and D.GATHER_DTYPE.fields["R"][1] == 8 and D.GATHER_DTYPE.fields["cov"][1] == 104

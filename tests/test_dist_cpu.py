@@ -1,24 +1,19 @@
-"""Multi-process CPU test (gloo, world_size 2) of the N>1 path: chunk sharding, the pose all_gather and trajectory
-composition.  The data path has no other collective, so this is everything ranks exchange."""
+"""Multi-process CPU tests (gloo, world_size 2 and 3) of the N>1 path: chunk sharding, the exchange of the 392-byte per-frame records
+(frame id, status, frame-to-frame R | t, 6x6 covariance -- SURVEY.md section 8e) and the trajectory composition, all through the C
+functions of librgbid_dist.so, launched with the SAME launcher bench.py --gpus N uses (rgbid.dist.spawn_local ->
+python -m torch.distributed.run).  The data path has no other collective, so this is everything ranks exchange.  RCCL itself needs
+GPUs: on CPU the records travel through torch.distributed (gloo); the RCCL transport is covered on the GPU box (tests/test_gpu_dist.py)."""
+import json
 import os
-import socket
+import subprocess
+import sys
 
 import numpy as np
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
+import pytest
 
 from rgbid import dist as D
 
-
-def _rand_chain(n, seed):
-    from scipy.spatial.transform import Rotation
-    r = np.random.default_rng(seed)
-    R = [np.eye(3)]; t = [np.zeros(3)]
-    for _ in range(1, n):
-        dR = Rotation.from_rotvec(0.02 * r.standard_normal(3)).as_matrix(); dt = 0.02 * r.standard_normal(3)
-        t.append(R[-1] @ dt + t[-1]); R.append(R[-1] @ dR)
-    return np.array(R), np.array(t)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_chunk_ranges_cover_sequence():
@@ -30,39 +25,49 @@ def test_chunk_ranges_cover_sequence():
         assert max(lens) - min(lens) <= 1 and min(lens) >= 1
     owned = sum((D.rank_chunks(16, 3, r) for r in range(3)), [])
     assert owned == list(range(16))
+    with pytest.raises(Exception):
+        D.chunk_ranges(4, 4)            # needs n_frames >= n_chunks + 1
 
 
-def _worker(rank, world, port, F, n_chunks, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    Rg, tg = _rand_chain(F, 11)
+def test_compose_single_rank_matches_reference_composition():
+    """world = 1: records laid out chunk-major; the composed poses equal the direct product of the frame-to-frame motions"""
+    from scipy.spatial.transform import Rotation
+    r = np.random.default_rng(5)
+    F, n_chunks = 23, 4
+    dR = [np.eye(3)] + [Rotation.from_rotvec(0.03 * r.standard_normal(3)).as_matrix() for _ in range(F - 1)]
+    dt = [np.zeros(3)] + [0.02 * r.standard_normal(3) for _ in range(F - 1)]
+    Rg, tg = [np.eye(3)], [np.zeros(3)]
+    for k in range(1, F):
+        tg.append(Rg[-1] @ dt[k] + tg[-1]); Rg.append(Rg[-1] @ dR[k])
     ranges = D.chunk_ranges(F, n_chunks)
     L = max(b - a + 1 for a, b in ranges)
-    mine = D.rank_chunks(n_chunks, world, rank)
-    local = np.full((len(mine), L, 12), np.nan)
-    for i, c in enumerate(mine):                      # what each rank's engine lanes would produce: chunk-relative poses
-        a, b = ranges[c]
+    rec = np.zeros((1, n_chunks, L), D.GATHER_DTYPE)
+    for c, (a, b) in enumerate(ranges):
         for j in range(b - a + 1):
-            Rc = Rg[a].T @ Rg[a + j]; tc = Rg[a].T @ (tg[a + j] - tg[a])
-            local[i, j, :9] = Rc.reshape(9); local[i, j, 9:] = tc
-    allp = D.gather_pose_records(local)
-    R, t = D.compose_trajectory(allp, ranges)
-    err = max(np.abs(R - Rg).max(), np.abs(t - tg).max())
-    if rank == 0:
-        q.put(float(err))
-    dist.barrier()
-    dist.destroy_process_group()
+            rec[0, c, j]["R"] = dR[a + j] if j else np.eye(3)
+            rec[0, c, j]["t"] = dt[a + j] if j else 0
+            rec[0, c, j]["status"] = 1 if j else 16
+    R, t, st, cov = D.compose_trajectory(rec, 1, n_chunks, ranges)
+    assert np.abs(R - np.array(Rg)).max() < 1e-14 and np.abs(t - np.array(tg)).max() < 1e-14
+    assert st[0] == 16 and (st[1:] == 1).all()
 
 
-def test_pose_gather_and_composition_world2():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 41, 8, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    err = q.get(timeout=120)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert err < 1e-12, err
+@pytest.mark.parametrize("world,chunks", [(2, 8), (2, 7), (3, 7)])
+def test_record_gather_and_composition_multi_rank(world, chunks):
+    """N ranks through the bench launcher; uneven chunk ownership (7 chunks on 2 or 3 ranks) pads with lanes nobody reads"""
+    p = D.spawn_local(world, [os.path.join(ROOT, "tools", "dist_selftest.py"), "--backend", "gloo", "--frames", "41", "--chunks", str(chunks),
+                              "--expect-world", str(world)], timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["world"] == world and res["compose_err"] < 1e-12 and res["cov_ok"] and res["status_ok"] and res["tcp_rendezvous_ok"], res
+
+
+def test_bench_gpus_flag_fails_loudly_without_devices():
+    """`python bench.py --gpus 2` must not quietly run one rank: with fewer than 2 HIP devices it exits non-zero with a clear message
+    (here: no device at all)."""
+    env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "--gpus 2" in p.stderr and "device" in p.stderr, p.stderr[-500:]
+    assert "{" not in p.stdout          # no result line

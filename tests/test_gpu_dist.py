@@ -1,0 +1,69 @@
+"""GPU side of the multi-GPU helpers (include/rgbid_dist.h) on the one GPU a test box has: the RCCL communicator of the C-ABI with
+world = 1 (ncclCommInitRank / ncclAllGather / all-reduce barrier are real RCCL calls on the engine's stream), the device-side record
+pack, and chunk-sharded tracking gathered through it.  world > 1 is covered by the gloo tests (tests/test_dist_cpu.py) and by
+tools/dist_selftest.py --backend nccl on a multi-GPU node."""
+import numpy as np
+import pytest
+import torch
+
+from rgbid import dist as D
+from rgbid import engine as E
+from rgbid import sequence, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rot_angle(Ra, Rb):
+    return float(np.arccos(np.clip((np.trace(Ra.T @ Rb) - 1) / 2, -1, 1)))
+
+
+def test_pack_gather_records_and_rccl_world1(ctx):
+    K = (131.25, 131.25, 79.5, 59.5)
+    B, T = 3, 6
+    seqs = [synth.make_sequence(T, seed=synth.SEED + 17 * l, K=K, rows=120, cols=160, device="cuda", trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8)) for l in range(B)]
+    depth = torch.stack([s["depth"] for s in seqs], 1).to(torch.int16).contiguous()
+    rgb = torch.stack([s["rgb"] for s in seqs], 1).contiguous()
+    eng = E.Engine(ctx, E.default_config(rows=120, cols=160, lanes=B, K=K, use_graph=0, record_capacity=T))
+    for k in range(T):
+        eng.step(depth[k], rgb[k])
+    rec = eng.records()
+    packed = D.pack_engine_records(eng, 1, T - 1)
+    ctx.sync()
+    g = packed.cpu().numpy().view(D.GATHER_DTYPE).reshape(B, T - 1)
+    for l in range(B):
+        for k in range(T - 1):
+            r = rec[1 + k, l]
+            assert g[l, k]["frame_id"] == r["frame"] and g[l, k]["status"] == r["status"]
+            assert np.array_equal(g[l, k]["R"], r["odo_R"]) and np.array_equal(g[l, k]["t"], r["odo_t"]) and np.array_equal(g[l, k]["cov"], r["odo_cov"])
+    comm = D.Comm(ctx, 1, 0)
+    assert comm.world() == 1 and comm.rank() == 0
+    allb = comm.gather(packed, B * (T - 1))
+    comm.barrier()
+    assert torch.equal(allb, packed)
+    comm.close()
+    eng.close()
+
+
+def test_chunked_tracking_through_the_cabi_gather(ctx):
+    """the frame-to-frame records composed by rgbid_dist_compose_trajectory reproduce the engine's own global poses (single chunk), and
+    the 4-chunk run through the RCCL gather equals the 4-chunk run without it"""
+    K = (131.25, 131.25, 79.5, 59.5)
+    T = 13
+    seq = synth.make_sequence(T, K=K, rows=120, cols=160, device="cuda", trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8))
+    depth = seq["depth"].to(torch.int16).contiguous(); rgb = seq["rgb"].contiguous()
+    R1, t1, _ = sequence.track_chunked(ctx, depth, rgb, 1, K)
+    st, cov = sequence.track_chunked.last
+    eng = E.Engine(ctx, E.default_config(rows=120, cols=160, lanes=1, K=K, record_capacity=T))
+    for k in range(T):
+        eng.step(depth[k:k + 1], rgb[k:k + 1])
+    rec = eng.records()
+    eng.close()
+    for k in range(1, T):
+        assert np.abs(R1[k] - rec[k, 0]["R"]).max() < 1e-12 and np.linalg.norm(t1[k] - rec[k, 0]["t"]) < 1e-12, k   # product of the dT_k = the engine's own pose
+        assert st[k] == rec[k, 0]["status"] and np.array_equal(cov[k], rec[k, 0]["odo_cov"])
+    comm = D.Comm(ctx, 1, 0)
+    Ra, ta, ranges = sequence.track_chunked(ctx, depth, rgb, 4, K, comm=comm)
+    Rb, tb, _ = sequence.track_chunked(ctx, depth, rgb, 4, K)
+    comm.close()
+    assert ranges == [(0, 3), (3, 6), (6, 9), (9, 12)]
+    assert np.array_equal(Ra, Rb) and np.array_equal(ta, tb)
