@@ -92,6 +92,10 @@ int rgbid_selftest_rcp(rgbid_ctx* ctx, unsigned long long* mismatches);
  * reciprocal + two FMA corrections) is compared with IEEE x / divisor for all 2^32 x; *mismatches counts the x whose short result is
  * flagged usable and differs (0 for the tracker's two sigmas, 2*0.0025 and 3 -- the only ones the filter uses it for: *used_by_filter). */
 int rgbid_selftest_div_const(rgbid_ctx* ctx, float divisor, unsigned long long* mismatches, int* used_by_filter);
+/* v_cvt_flr_i32_f32 (one-instruction floor + saturating convert of the engine's fast-numerics gather kernels) against v_floor_f32 +
+ * v_cvt_i32_f32 over every `stride`-th of the 2^32 float bit patterns (stride 1 = exhaustive; NaN excluded: the two differ there and
+ * every index is clamped before it addresses memory); *mismatches must come back 0 */
+int rgbid_selftest_cvt_flr(rgbid_ctx* ctx, unsigned stride, unsigned long long* mismatches);
 /* the context's hipStream_t */
 int rgbid_ctx_get_stream(rgbid_ctx* ctx, void** hip_stream);
 /* showGPUMemoryUsage(), src/cuda/misc.cu:526-540 */
@@ -152,6 +156,15 @@ int rgbid_warp_invdepth(rgbid_ctx*, const rgbid_img* src, const rgbid_img* dst, 
 /* warpIntensityWithTrafo3DInvDepth :920-967 */
 int rgbid_warp_intensity(rgbid_ctx*, const rgbid_img* src, const rgbid_img* dst, const rgbid_img* depthinv_prev,
                          const float R_proj[9], const float t_proj[3], float* ms);
+/* Both warps of one Gauss-Newton iteration in one launch (the pair the tracker issues back to back, src/visodo.cpp:1094-1100): dst_iD =
+ * warpInvDepthWithTrafo3D(src_iD, grid), dst_I = warpIntensityWithTrafo3DInvDepth(src_I, dst_iD) with the warped inverse depth consumed from
+ * registers.  numerics EXACT: bit-identical to the two calls above (IEEE evaluation of the oracle); FAST: the reference BUILD's class of
+ * arithmetic -- hardware reciprocal + FMA contraction, what nvcc --prec-div=false and default fmad give the reference's own kernels
+ * (CMakeLists.txt:105) -- in which a coordinate within an ulp of a pixel boundary may select the neighbouring pixel (what the batched
+ * engine runs by default, rgbid_engine_config.fast_numerics). */
+enum { RGBID_NUMERICS_EXACT = 0, RGBID_NUMERICS_FAST = 1 };
+int rgbid_warp_pair(rgbid_ctx*, const rgbid_img* src_iD, const rgbid_img* src_I, const rgbid_img* grid_iD, const rgbid_img* dst_iD, const rgbid_img* dst_I,
+                    const float R_proj[9], const float t_proj[3], int numerics, float* ms);
 /* warpInvDepthWithTrafo3DWeighted :1021-1069 */
 int rgbid_warp_invdepth_weighted(rgbid_ctx*, const rgbid_img* src, const rgbid_img* dst, const rgbid_img* depthinv_prev,
                                  const rgbid_img* weight_warped, const float R_proj[9], const float t_proj[3], float* ms);

@@ -41,6 +41,11 @@ typedef struct rgbid_engine_config {
   int record_capacity;       /* steps of pose records kept on the device (ring) */
   int warping;               /* RGBID_PYR_FIRST (default) or RGBID_WARP_FIRST: warp at level 0 and pyrDown the warped maps (visodo.cpp:1078-1105) */
   int keyframe_capacity;     /* keyframes exported to the back-end kept per lane on the device (ring); 0 = no export (see below) */
+  int fast_numerics;         /* gather kernels (warp pair, covisibility, keyframe fusion) in the reference BUILD's class of arithmetic --
+                              * hardware reciprocal + FMA contraction, what nvcc --prec-div=false + default fmad give the reference
+                              * (CMakeLists.txt:105) -- instead of the IEEE evaluation of the oracle (default 1; 0 = the bit-exact
+                              * kernels of the compat bridge).  A coordinate within an ulp of a pixel boundary may then select the
+                              * neighbouring pixel: a few pixels per map, poses within 1e-6 (csrc/warp_device.h) */
 } rgbid_engine_config;
 
 #define RGBID_ST_TRACKED    1   /* trackNewFrame returned true */

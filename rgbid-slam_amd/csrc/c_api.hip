@@ -156,6 +156,16 @@ int rgbid_selftest_div_const(rgbid_ctx* c, float divisor, unsigned long long* mi
   if (used_by_filter) *used_by_filter = rgbid::div_const_verified(divisor) ? 1 : 0;
   return RGBID_OK;
 }
+int rgbid_selftest_cvt_flr(rgbid_ctx* c, unsigned stride, unsigned long long* mismatches) {
+  if (!c || !mismatches || stride < 1) return RGBID_E_INVALID;
+  unsigned long long* d = static_cast<unsigned long long*>(c->small_dev);
+  RGBID_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), c->stream));
+  rgbid::launch_selftest_cvt_flr(c->stream, d, stride);
+  RGBID_HIP(hipGetLastError());
+  RGBID_HIP(hipMemcpyAsync(mismatches, d, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  RGBID_HIP(hipStreamSynchronize(c->stream));
+  return RGBID_OK;
+}
 int rgbid_ctx_wait_event(rgbid_ctx* c, void* ev) {
   if (!c || !ev) return RGBID_E_INVALID;
   RGBID_HIP(hipStreamWaitEvent(c->stream, (hipEvent_t)ev, 0));
@@ -380,6 +390,17 @@ int rgbid_warp_intensity(rgbid_ctx* c, const rgbid_img* src, const rgbid_img* ds
   WarpParams p = make_wp(R, tv);
   Timed t(c, ms);
   launch_warp_intensity(c->stream, 1, B1(src), B1(prev), B1(dst), &p, nullptr, c->interp_mode, ALL);
+  return t.finish();
+}
+int rgbid_warp_pair(rgbid_ctx* c, const rgbid_img* src_iD, const rgbid_img* src_I, const rgbid_img* grid, const rgbid_img* dst_iD, const rgbid_img* dst_I,
+                    const float R[9], const float tv[3], int numerics, float* ms) {
+  if (!c || !ok_img(src_iD) || !ok_img(src_I) || !ok_img(grid) || !ok_img(dst_iD) || !ok_img(dst_I) || !R || !tv || !same_size(src_iD, src_I) ||
+      !same_size(src_iD, grid) || !same_size(src_iD, dst_iD) || !same_size(src_iD, dst_I) || (numerics != RGBID_NUMERICS_EXACT && numerics != RGBID_NUMERICS_FAST))
+    return RGBID_E_INVALID;
+  WarpParams p = make_wp(R, tv);
+  Timed t(c, ms);
+  if (!(numerics == RGBID_NUMERICS_FAST && launch_warp_pair_fast(c->stream, 1, B1(src_iD), B1(src_I), B1(grid), B1(dst_iD), B1(dst_I), &p, nullptr, c->interp_mode, ALL)))
+    launch_warp_pair(c->stream, 1, B1(src_iD), B1(src_I), B1(grid), B1(dst_iD), B1(dst_I), nullptr, c->interp_mode, ALL, &p);
   return t.finish();
 }
 int rgbid_warp_invdepth_weighted(rgbid_ctx* c, const rgbid_img* src, const rgbid_img* dst, const rgbid_img* prev, const rgbid_img* weight,

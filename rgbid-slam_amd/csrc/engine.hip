@@ -514,6 +514,8 @@ struct rgbid_engine {
   ImgB r_curr, g_curr, b_curr;
   ImgB iD_integr, iD_integr_raw, w_integr, warped_iD_integr, warped_w, vmap, nmap, gxD_integr, gyD_integr, colors_integr, overlap_mask, preview;
   float *res_I = nullptr, *res_D = nullptr;
+  float* lat_res = nullptr;        // fused path: residual lattice of both channels, [B][2 * lat_cap]
+  size_t lat_cap = 0;
   float* chi_out = nullptr;
   double* partials = nullptr;
   int nblk_cap = 0;
@@ -628,6 +630,9 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   const StepCfg sc = sc_;
   const IntrP K0{c.fx, c.fy, c.cx, c.cy};
   const int tb = 64, gb = div_up(B, tb);
+  // fast numerics per pyramid level: the 16-byte / paired 8-byte accesses of the fast kernels need rows of whole 4-pixel groups; levels
+  // that do not have them run the exact kernels in BOTH the fused and the unfused path (so the two stay bit-identical to each other)
+  auto fast_at = [&](int level) { const int cl = c.cols >> level; return c.fast_numerics != 0 && (cl % 4) == 0 && cl >= 4; };
   e->launches = 0;
   Flags& f = e->flags;
   // ---- prepareImages (visodo.cpp:760-773)
@@ -665,17 +670,18 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
       if (c.fused_gn) {
         if (c.sigma_estimator == RGBID_SIGMA_PDF) {
           launch_sigma_pair_fused(s, B, e->iD_curr[level], e->iD_kf[level], e->I_curr[level], e->I_kf[level], e->wp, c.interp_mode, c.nsamples,
-                                  e->sp, c.mestimator, M(f.gn));
-          e->launches++;
+                                  e->sp, c.mestimator, M(f.gn), fast_at(level), e->lat_res, 2 * e->lat_cap);
+          e->launches += 2;
         }
         if (prof) { set_system_kernel_events(e->prof_ev[e->prof_used], e->prof_ev[e->prof_used + 1]); e->prof_used += 2; }
         nblk = launch_gn_fused(s, B, e->iD_kf[level], e->I_kf[level], e->gxD[level], e->gyD[level], e->gxI[level], e->gyI[level],
-                               e->iD_curr[level], e->I_curr[level], e->wp, c.interp_mode, e->sp, e->partials, M(f.gn), level < 2 ? level : 2);
+                               e->iD_curr[level], e->I_curr[level], e->wp, c.interp_mode, e->sp, e->partials, M(f.gn), level < 2 ? level : 2, fast_at(level));
       } else {
         if (c.warping == RGBID_WARP_FIRST) {
           // :1078-1105: warp the full-resolution frame, then reduce the WARPED maps down to the working level
           // (k_step_begin / k_solve_update project the pose with the level-0 intrinsics in this mode)
-          launch_warp_pair(s, B, e->iD_curr[0], e->I_curr[0], e->iD_kf[0], e->wiD[0], e->wI[0], e->wp, c.interp_mode, M(f.gn));
+          if (!(fast_at(0) && launch_warp_pair_fast(s, B, e->iD_curr[0], e->I_curr[0], e->iD_kf[0], e->wiD[0], e->wI[0], nullptr, e->wp, c.interp_mode, M(f.gn))))
+            launch_warp_pair(s, B, e->iD_curr[0], e->I_curr[0], e->iD_kf[0], e->wiD[0], e->wI[0], e->wp, c.interp_mode, M(f.gn));
           e->launches += 1;
           for (int i = 1; i <= level; ++i) {
             launch_pyr_down(s, B, e->wI[i - 1], e->wI[i], M(f.gn));
@@ -683,7 +689,8 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
             e->launches += 2;
           }
         } else {
-          launch_warp_pair(s, B, e->iD_curr[level], e->I_curr[level], e->iD_kf[level], e->wiD[level], e->wI[level], e->wp, c.interp_mode, M(f.gn));
+          if (!(fast_at(level) && launch_warp_pair_fast(s, B, e->iD_curr[level], e->I_curr[level], e->iD_kf[level], e->wiD[level], e->wI[level], nullptr, e->wp, c.interp_mode, M(f.gn))))
+            launch_warp_pair(s, B, e->iD_curr[level], e->I_curr[level], e->iD_kf[level], e->wiD[level], e->wI[level], e->wp, c.interp_mode, M(f.gn));
           e->launches += 1;
         }
         if (c.sigma_estimator == RGBID_SIGMA_PDF) {
@@ -708,10 +715,11 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
     if (fuse_cov) {
       if (prof) { set_system_kernel_events(e->prof_ev[e->prof_used], e->prof_ev[e->prof_used + 1]); e->prof_used += 2; }
       nblk = launch_gn_fused(s, B, e->iD_kf[fl], e->I_kf[fl], e->gxD_c[fl], e->gyD_c[fl], e->gxI_c[fl], e->gyI_c[fl],
-                             e->iD_curr[fl], e->I_curr[fl], e->wp, c.interp_mode, e->sp, e->partials, M(f.gn), fl < 2 ? fl : 2);
+                             e->iD_curr[fl], e->I_curr[fl], e->wp, c.interp_mode, e->sp, e->partials, M(f.gn), fl < 2 ? fl : 2, fast_at(fl));
       e->launches += 2;
     } else {
-      launch_warp_pair(s, B, e->iD_curr[fl], e->I_curr[fl], e->iD_kf[fl], e->wiD[fl], e->wI[fl], e->wp, c.interp_mode, M(f.gn));
+      if (!(fast_at(fl) && launch_warp_pair_fast(s, B, e->iD_curr[fl], e->I_curr[fl], e->iD_kf[fl], e->wiD[fl], e->wI[fl], nullptr, e->wp, c.interp_mode, M(f.gn))))
+        launch_warp_pair(s, B, e->iD_curr[fl], e->I_curr[fl], e->iD_kf[fl], e->wiD[fl], e->wI[fl], e->wp, c.interp_mode, M(f.gn));
       if (prof) { set_system_kernel_events(e->prof_ev[e->prof_used], e->prof_ev[e->prof_used + 1]); e->prof_used += 2; }
       nblk = launch_build_system(s, B, e->iD_kf[fl], e->I_kf[fl], e->gxD_c[fl], e->gyD_c[fl], e->gxI_c[fl], e->gyI_c[fl],
                                  e->wiD[fl], e->wI[fl], nullptr, e->sp, e->partials, M(f.gn), fl < 2 ? fl : 2);
@@ -732,8 +740,8 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   // ---- covisibility with both keyframes (visodo.cpp:2172-2188), 4 ratio evaluations
   if (!first) {
     if (hipError_t he = hipMemsetAsync(e->counts, 0, sizeof(unsigned int) * 8 * B, s); he != hipSuccess) return (int)he;
-    launch_visibility_pair(s, B, e->iD_curr[0], e->iD_kf[0], e->vis_ab, e->vis_ba, e->counts + 0 * 2 * B, e->counts + 1 * 2 * B, M(f.vis));
-    launch_visibility_pair(s, B, e->iD_curr[0], e->iD_integr_raw, e->ivis_ab, e->ivis_ba, e->counts + 2 * 2 * B, e->counts + 3 * 2 * B, M(f.vis));
+    launch_visibility_pair(s, B, e->iD_curr[0], e->iD_kf[0], e->vis_ab, e->vis_ba, e->counts + 0 * 2 * B, e->counts + 1 * 2 * B, M(f.vis), c.fast_numerics != 0);
+    launch_visibility_pair(s, B, e->iD_curr[0], e->iD_integr_raw, e->ivis_ab, e->ivis_ba, e->counts + 2 * 2 * B, e->counts + 3 * 2 * B, M(f.vis), c.fast_numerics != 0);
     hipLaunchKernelGGL(k_decide, dim3(gb), dim3(tb), 0, s, e->state, f, e->counts, e->fuse_wp, sc, B);
     e->launches += 4;
   }
@@ -764,7 +772,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   e->launches += 7;
   // ... or integrateImagesIntoKeyframes (:1674-1764)
   if (!first) {
-    if (launch_fuse_frame(s, B, e->iD_curr[0], e->iD_integr, e->w_integr, e->warped_w, e->fuse_wp, M(f.fuse))) {
+    if (launch_fuse_frame(s, B, e->iD_curr[0], e->iD_integr, e->w_integr, e->warped_w, e->fuse_wp, M(f.fuse), c.fast_numerics != 0)) {
       e->launches -= 1;
     } else {
       launch_warp_invdepth_weighted(s, B, e->iD_curr[0], e->iD_integr, e->warped_iD_integr, e->warped_w, nullptr, e->fuse_wp, M(f.fuse));
@@ -811,6 +819,7 @@ void rgbid_engine_default_config(rgbid_engine_config* c) {
   c->record_capacity = 64;
   c->warping = RGBID_PYR_FIRST;
   c->keyframe_capacity = 0;
+  c->fast_numerics = 1;
 }
 
 int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_config* cfg) {
@@ -848,6 +857,10 @@ int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_c
     if (!r) r = alloc_dev(e, (void**)&e->res_I, sizeof(float) * (size_t)rows * cols * B);
     if (!r) r = alloc_dev(e, (void**)&e->res_D, sizeof(float) * (size_t)rows * cols * B);
     if (!r) r = alloc_dev(e, (void**)&e->chi_out, sizeof(float) * 3 * B);
+  }
+  if (cfg->fused_gn && cfg->sigma_estimator == RGBID_SIGMA_PDF) {
+    for (int l = 0; l < e->L; ++l) { size_t n = (size_t)lattice_samples(rows >> l, cols >> l, cfg->nsamples); if (n > e->lat_cap) e->lat_cap = n; }
+    if (!r) r = alloc_dev(e, (void**)&e->lat_res, sizeof(float) * 2 * e->lat_cap * B);
   }
   e->nblk_cap = system_blocks_per_lane(rows, cols, B);
   for (int l = 1; l < e->L; ++l) { int nb = system_blocks_per_lane(rows >> l, cols >> l, B); if (nb > e->nblk_cap) e->nblk_cap = nb; }

@@ -32,7 +32,12 @@ void launch_intensity(hipStream_t s, int B, ImgB rgb, ImgB dst, LaneMask m);
 void launch_depth_to_float(hipStream_t s, int B, ImgB src_u16, ImgB dst, LaneMask m);
 void launch_float_to_rgb(hipStream_t s, int B, ImgB src, ImgB dst_rgb, LaneMask m);
 // engine: iD warp + intensity warp (sampled on the warped iD) of one GN iteration in one launch, bit-identical to the two kernels
-void launch_warp_pair(hipStream_t s, int B, ImgB src_iD, ImgB src_I, ImgB grid, ImgB dst_iD, ImgB dst_I, const WarpParams* lane_params, int interp_mode, LaneMask m);
+void launch_warp_pair(hipStream_t s, int B, ImgB src_iD, ImgB src_I, ImgB grid, ImgB dst_iD, ImgB dst_I, const WarpParams* lane_params, int interp_mode, LaneMask m,
+                      const WarpParams* host_p = nullptr);
+// same in the reference build's class of arithmetic (engine, fast_numerics); false: geometry outside the tile map's range, nothing launched
+bool launch_warp_pair_fast(hipStream_t s, int B, ImgB src_iD, ImgB src_I, ImgB grid, ImgB dst_iD, ImgB dst_I, const WarpParams* host_p, const WarpParams* lane_params,
+                           int interp_mode, LaneMask m);
+void launch_selftest_cvt_flr(hipStream_t s, unsigned long long* mismatches_dev, unsigned stride);
 void launch_nmap_cross(hipStream_t s, int B, ImgB vmap, ImgB nmap, LaneMask m);
 void launch_integrate_warped_rgb(hipStream_t s, int B, ImgB warped, ImgB r, ImgB g, ImgB b, ImgB wweight, ImgB kf, ImgB colors, ImgB kfw, LaneMask m);
 void launch_decompose_rgb(hipStream_t s, int B, ImgB rgb, ImgB r, ImgB g, ImgB b, LaneMask m);
@@ -56,11 +61,11 @@ void launch_integrate_warped(hipStream_t s, int B, ImgB warped, ImgB wweight, Im
 void launch_visibility(hipStream_t s, int B, ImgB src, ImgB dst, ImgB mask, const WarpParams* host_p, const WarpParams* lane_p, unsigned int* counts, LaneMask m);
 // engine: both directions of computeCovisibility between two maps in one pass (counts_ab: a projected into b; counts_ba: b into a)
 void launch_visibility_pair(hipStream_t s, int B, ImgB a, ImgB b, const WarpParams* p_ab, const WarpParams* p_ba, unsigned int* counts_ab,
-                            unsigned int* counts_ba, LaneMask m);
+                            unsigned int* counts_ba, LaneMask m, bool fast = false);
 void launch_vmap(hipStream_t s, int B, ImgB depthinv, ImgB vmap, IntrP k, LaneMask m);
 void launch_nmap_gradients(hipStream_t s, int B, ImgB depthinv, ImgB gx, ImgB gy, ImgB nmap, IntrP k, LaneMask m);
 // engine: warpInvDepthWithTrafo3DWeighted + integrateWarpedFrame in one pass (false: layout not 16-byte friendly, nothing launched)
-bool launch_fuse_frame(hipStream_t s, int B, ImgB src, ImgB kf, ImgB kfw, ImgB wweight, const WarpParams* lane_params, LaneMask m);
+bool launch_fuse_frame(hipStream_t s, int B, ImgB src, ImgB kf, ImgB kfw, ImgB wweight, const WarpParams* lane_params, LaneMask m, bool fast = false);
 // engine: createVMap + computeGradientDepth + createNMapGradients of one map in one pass (false: layout not 16-byte friendly, nothing launched)
 bool launch_kf_maps(hipStream_t s, int B, ImgB depthinv, ImgB vmap, ImgB nmap, IntrP k, LaneMask m);
 void launch_generate_image(hipStream_t s, int B, ImgB vmap, ImgB nmap, ImgB rgb, ImgB dst, const LightP* host_l, const LightP* lane_l, LaneMask m);
@@ -74,7 +79,9 @@ void launch_sigma(hipStream_t s, int B, int mode, const float* err, size_t err_l
 void launch_sigma_pair(hipStream_t s, int B, ImgB W1, ImgB W0, ImgB I1, ImgB I0, int min_nsamples, SysParams* sp, int mestimator, LaneMask m);
 // same, but W1 / I1 are produced on the fly from the current frame (fused engine path: they are never stored)
 void launch_sigma_pair_fused(hipStream_t s, int B, ImgB Wcur, ImgB W0, ImgB Icur, ImgB I0, const WarpParams* lane_wp, int interp_mode,
-                             int min_nsamples, SysParams* sp, int mestimator, LaneMask m);
+                             int min_nsamples, SysParams* sp, int mestimator, LaneMask m, bool fast = false, float* res = nullptr, size_t res_lane_stride = 0);
+// samples of the residual lattice computeErrorGridStride takes for this geometry (scratch sizing: 2 * n floats per lane for `res` above)
+int lattice_samples(int rows, int cols, int min_nsamples);
 // out: device [B][3] = chi_square, chi_test, ndof
 void launch_chi_square(hipStream_t s, int B, const float* err_int, const float* err_depth, size_t err_lane_stride, int n,
                        float sigma_int, float sigma_depth, int mestimator, float* out, LaneMask m);
@@ -88,7 +95,7 @@ int launch_build_system(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB g
                         const SysParams* host_p, const SysParams* lane_p, double* partials, LaneMask m, int level_tag = 0);
 // fused Gauss-Newton evaluation (engine): warp of the current frame + residual rows + 27-term reduction in one kernel
 int launch_gn_fused(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB Wcur, ImgB Icur,
-                    const WarpParams* lane_wp, int interp_mode, const SysParams* lane_p, double* partials, LaneMask m, int level_tag);
+                    const WarpParams* lane_wp, int interp_mode, const SysParams* lane_p, double* partials, LaneMask m, int level_tag, bool fast = false);
 // the next launch_build_system / launch_gn_fused on this host thread is bracketed by these events (kernel duration)
 void set_system_kernel_events(hipEvent_t start, hipEvent_t stop);
 void launch_reduce_system(hipStream_t s, int B, const double* partials, int nblk, double* sums, LaneMask m);

@@ -400,12 +400,36 @@ struct FusedLatticeGetter {
   WarpParams P;
   int lane, lcols, stride, ch, interp_mode;
   int cy, cx, sy, sx;  // cursor (lattice row / column) and the advance of SIG_T samples
+  int fast;            // the same arithmetic as the normal-equation kernel that follows (warp_device.h fastnum)
   __device__ __forceinline__ float at(int ly, int lx) const {
     int y = ly * stride, x = lx * stride;
     float w0 = px<float>(W0, lane, y, x);
+    if (fast) {
+      // the ray exactly as the normal-equation kernel forms it for this pixel: evaluated at the start of its 4-pixel group, stepped along x
+      fastnum::Ray r = fastnum::ray(P, (float)(x & ~3), (float)y);
+      for (int i = 0; i < (x & 3); ++i) r = fastnum::ray_step(r, P.R[0], P.R[3], P.R[6]);
+      float w1 = fastnum::warp_invdepth_px(FMap(cur_iD, lane), r, w0, P);
+      if (ch == 0) return w1 - w0;
+      return fastnum::warp_intensity_px(FMap(cur_I, lane), r, w1, P, interp_mode) - px<float>(I0, lane, y, x);
+    }
     float w1 = warp_invdepth_px(FMap(cur_iD, lane), x, y, w0, P);
     if (ch == 0) return w1 - w0;
     return warp_intensity_px(FMap(cur_I, lane), x, y, w1, P, interp_mode) - px<float>(I0, lane, y, x);
+  }
+  // both channels of one lattice sample (the inverse-depth warp is shared)
+  __device__ __forceinline__ void both(int ly, int lx, float& rd, float& ri) const {
+    int y = ly * stride, x = lx * stride;
+    float w0 = px<float>(W0, lane, y, x), i0v = px<float>(I0, lane, y, x), w1, i1;
+    if (fast) {
+      fastnum::Ray r = fastnum::ray(P, (float)(x & ~3), (float)y);
+      for (int i = 0; i < (x & 3); ++i) r = fastnum::ray_step(r, P.R[0], P.R[3], P.R[6]);
+      w1 = fastnum::warp_invdepth_px(FMap(cur_iD, lane), r, w0, P);
+      i1 = fastnum::warp_intensity_px(FMap(cur_I, lane), r, w1, P, interp_mode);
+    } else {
+      w1 = warp_invdepth_px(FMap(cur_iD, lane), x, y, w0, P);
+      i1 = warp_intensity_px(FMap(cur_I, lane), x, y, w1, P, interp_mode);
+    }
+    rd = w1 - w0; ri = i1 - i0v;
   }
   __device__ __forceinline__ float operator()(int i) const { int ly = i / lcols; return at(ly, i - ly * lcols); }
   __device__ __forceinline__ void seek(int i) { cy = i / lcols; cx = i - cy * lcols; sy = SIG_T / lcols; sx = SIG_T - sy * lcols; }
@@ -415,12 +439,12 @@ struct FusedLatticeGetter {
 
 template <bool REG>
 __global__ __launch_bounds__(SIG_T) void k_sigma_pair_fused(NuTable T, ImgB Wcur, ImgB W0, ImgB Icur, ImgB I0, const WarpParams* wp, int interp_mode,
-                                                            int lrows, int lcols, int stride, SysParams* sp, int mestimator, LaneMask m) {
+                                                            int lrows, int lcols, int stride, SysParams* sp, int mestimator, LaneMask m, int fast) {
   int lane = blockIdx.x, ch = blockIdx.y;
   if (!m.on(lane)) return;
   __shared__ double sm_[SIG_SM];
   BlockSum sm(sm_);
-  FusedLatticeGetter g{Wcur, Icur, W0, I0, wp[lane], lane, lcols, stride, ch, interp_mode, 0, 0, 0, 0};
+  FusedLatticeGetter g{Wcur, Icur, W0, I0, wp[lane], lane, lcols, stride, ch, interp_mode, 0, 0, 0, 0, fast};
   Samples<REG, FusedLatticeGetter> S(g, lrows * lcols, threadIdx.x);
   float bias = 0.f, sigma = ch == 0 ? 0.0025f : 5.f, nu = 5.f;
   sigma_core(S, T, 0, mestimator, bias, sigma, nu, sm);
@@ -429,14 +453,60 @@ __global__ __launch_bounds__(SIG_T) void k_sigma_pair_fused(NuTable T, ImgB Wcur
     else { sp[lane].bias_i = bias; sp[lane].sigma_i = sigma; sp[lane].nu_i = nu; }
   }
 }
+// The same in two kernels: the register path of k_sigma_pair_fused walks its <= 19 samples per thread one after the other, each through
+// three dependent memory round trips (keyframe iD -> point sample -> bilinear taps) -- ~85 us of exposed latency per launch.  Here one
+// thread per lattice sample warps its pixel (9.8 M independent threads at 512 lanes: the latency hides behind occupancy) and parks both
+// residuals in res[lane][channel][n]; the sigma / nu kernel then reads them as plain coalesced arrays.
+__global__ __launch_bounds__(256) void k_lattice_residuals_fused(ImgB Wcur, ImgB W0, ImgB Icur, ImgB I0, const WarpParams* wp, int interp_mode, int n, int lcols,
+                                                                 int stride, float* res, size_t res_lane_stride, LaneMask m, int fast) {
+  const int lane = blockIdx.y;
+  if (!m.on(lane)) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  FusedLatticeGetter g{Wcur, Icur, W0, I0, wp[lane], lane, lcols, stride, 1, interp_mode, 0, 0, 0, 0, fast};
+  const int ly = i / lcols, lx = i - ly * lcols;
+  float rd, ri;
+  g.both(ly, lx, rd, ri);
+  float* r = res + (size_t)lane * res_lane_stride;
+  r[i] = rd; r[n + i] = ri;
+}
+template <bool REG>
+__global__ __launch_bounds__(SIG_T) void k_sigma_pair_arrays(NuTable T, const float* res, size_t res_lane_stride, int n, SysParams* sp, int mestimator, LaneMask m) {
+  int lane = blockIdx.x, ch = blockIdx.y;
+  if (!m.on(lane)) return;
+  __shared__ double sm_[SIG_SM];
+  BlockSum sm(sm_);
+  Samples<REG, ArrayGetter> S(ArrayGetter{res + (size_t)lane * res_lane_stride + (size_t)ch * n, 0}, n, threadIdx.x);
+  float bias = 0.f, sigma = ch == 0 ? 0.0025f : 5.f, nu = 5.f;
+  sigma_core(S, T, 0, mestimator, bias, sigma, nu, sm);
+  if (threadIdx.x == 0) {
+    if (ch == 0) { sp[lane].bias_d = bias; sp[lane].sigma_d = sigma; sp[lane].nu_d = nu; }
+    else { sp[lane].bias_i = bias; sp[lane].sigma_i = sigma; sp[lane].nu_i = nu; }
+  }
+}
+int lattice_samples(int rows, int cols, int min_nsamples) {
+  int n, lr, lc, st;
+  lattice_geometry(rows, cols, min_nsamples, &n, &lr, &lc, &st);
+  return n;
+}
+
 void launch_sigma_pair_fused(hipStream_t s, int B, ImgB Wcur, ImgB W0, ImgB Icur, ImgB I0, const WarpParams* lane_wp, int interp_mode,
-                             int min_nsamples, SysParams* sp, int mestimator, LaneMask m) {
+                             int min_nsamples, SysParams* sp, int mestimator, LaneMask m, bool fast, float* res, size_t res_lane_stride) {
   int n, lr, lc, st;
   lattice_geometry(W0.rows, W0.cols, min_nsamples, &n, &lr, &lc, &st);
+  const int f = (fast && Icur.cols >= 2) ? 1 : 0;
+  if (res && res_lane_stride >= 2 * (size_t)n) {
+    hipLaunchKernelGGL(k_lattice_residuals_fused, dim3(div_up(n, 256), B), dim3(256), 0, s, Wcur, W0, Icur, I0, lane_wp, interp_mode, n, lc, st, res, res_lane_stride, m, f);
+    if (n <= SIG_T * SIG_MAXPT)
+      hipLaunchKernelGGL(k_sigma_pair_arrays<true>, dim3(B, 2), dim3(SIG_T), 0, s, nu_table(), res, res_lane_stride, n, sp, mestimator, m);
+    else
+      hipLaunchKernelGGL(k_sigma_pair_arrays<false>, dim3(B, 2), dim3(SIG_T), 0, s, nu_table(), res, res_lane_stride, n, sp, mestimator, m);
+    return;
+  }
   if (n <= SIG_T * SIG_MAXPT)
-    hipLaunchKernelGGL(k_sigma_pair_fused<true>, dim3(B, 2), dim3(SIG_T), 0, s, nu_table(), Wcur, W0, Icur, I0, lane_wp, interp_mode, lr, lc, st, sp, mestimator, m);
+    hipLaunchKernelGGL(k_sigma_pair_fused<true>, dim3(B, 2), dim3(SIG_T), 0, s, nu_table(), Wcur, W0, Icur, I0, lane_wp, interp_mode, lr, lc, st, sp, mestimator, m, f);
   else
-    hipLaunchKernelGGL(k_sigma_pair_fused<false>, dim3(B, 2), dim3(SIG_T), 0, s, nu_table(), Wcur, W0, Icur, I0, lane_wp, interp_mode, lr, lc, st, sp, mestimator, m);
+    hipLaunchKernelGGL(k_sigma_pair_fused<false>, dim3(B, 2), dim3(SIG_T), 0, s, nu_table(), Wcur, W0, Icur, I0, lane_wp, interp_mode, lr, lc, st, sp, mestimator, m, f);
 }
 
 // ---- computeChiSquare sigmaFuncs.cu:1225-1297 (+ :137-150, :541-646) --------------------------------

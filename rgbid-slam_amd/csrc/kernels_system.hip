@@ -14,12 +14,16 @@
 // by a second tiny kernel (or by the batched engine's solve kernel), so results are deterministic --
 // no floating-point atomics.  blockIdx is remapped so that the 8 XCDs each stream a contiguous slab.
 #include "kernels.h"
+#include <cstdlib>
 #include "warp_device.h"
 #include <hip/hip_ext.h>
 
 namespace rgbid {
 
 static constexpr int SYS_T = 256;
+#ifndef RGBID_FUSED_WAVES
+#define RGBID_FUSED_WAVES 4   // waves per SIMD the fused fast kernel's register allocation must allow (<= 128 VGPRs)
+#endif
 static constexpr float TH_HUBER = 1.345f, TH_TUKEY = 4.685f, STUDENT_DOF = 5.f;
 
 struct SysConst {  // per-thread derived constants
@@ -172,8 +176,8 @@ struct FusedArgs { const WarpParams* wp; int interp_mode; };
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 void set_system_kernel_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = start; g_ev_stop = stop; }
 
-template <class PS, bool VEC, int LEVEL, bool FUSED>
-__global__ __launch_bounds__(SYS_T) void k_build_system(ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB W1, ImgB I1,
+template <class PS, bool VEC, int LEVEL, int FUSED>
+__global__ __launch_bounds__(SYS_T) __attribute__((amdgpu_waves_per_eu(FUSED == 2 ? RGBID_FUSED_WAVES : 1, 8))) void k_build_system(ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB W1, ImgB I1,
                                                         PS ps, double* partials, int nblk, int upt, LaneMask m, FusedArgs fa) {
   int gb = xcd_slab_block(blockIdx.x, gridDim.x);
   int lane = gb / nblk, blk = gb - lane * nblk;
@@ -196,6 +200,56 @@ __global__ __launch_bounds__(SYS_T) void k_build_system(ImgB W0, ImgB I0, ImgB g
     // (row, unit-in-row) of the thread's units advance by SYS_T units per step: one division up front, then add-and-wrap
     const int step_y = SYS_T / upr, step_x = SYS_T - step_y * upr;   // wave-uniform
     int y = u0 / upr, xu = u0 - y * upr;
+    if (FUSED == 2) {
+      // A unit needs three dependent memory round trips (keyframe inverse depth -> point-sampled current inverse depth -> bilinear taps), and
+      // a wave that walks through them one after the other leaves the HBM stream idle most of its time.  Schedule: the unit's inverse depth
+      // w0 is loaded one unit AHEAD (4 VGPRs); its other five 16-byte streams are issued at the top of the iteration and travel together with
+      // the inverse-depth gathers (they are only needed by the row update at the end); the next w0 goes out behind the tap loads and lands
+      // during the 4 x ~150-instruction row update.  Two exposed waits per unit instead of three, the stream is in flight during both.
+      // The six keyframe maps of a level share their geometry (checked by the launcher): ONE 32-bit byte offset per unit on six wave-uniform
+      // lane bases (global_load ... saddr) instead of six 64-bit row pointers -- the kernel holds ~100 wave-uniform values (8 image
+      // descriptors, intrinsics, scale constants, the warp) and whatever does not fit the 102 SGPRs lives in VGPRs and costs occupancy.
+      const char* const bW0 = static_cast<const char*>(W0.base) + (size_t)lane * W0.lane_stride;
+      const char* const bI0 = static_cast<const char*>(I0.base) + (size_t)lane * I0.lane_stride;
+      const char* const bA = static_cast<const char*>(gWx.base) + (size_t)lane * gWx.lane_stride;
+      const char* const bB = static_cast<const char*>(gWy.base) + (size_t)lane * gWy.lane_stride;
+      const char* const bC = static_cast<const char*>(gIx.base) + (size_t)lane * gIx.lane_stride;
+      const char* const bD = static_cast<const char*>(gIy.base) + (size_t)lane * gIy.lane_stride;
+      const unsigned pitch_b = (unsigned)W0.pitch;
+      auto unit_off = [&](int yy, int xx) { return __umul24((unsigned)yy, pitch_b) + ((unsigned)xx << 2); };
+      bool live = u0 < units;
+      float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live) w0 = ld_stream4(reinterpret_cast<const float*>(bW0 + unit_off(y, xu << 2)));
+#pragma unroll 1
+      for (int j = 0; j < upt && live; ++j) {
+        int yn = y + step_y, xn = xu + step_x;
+        if (xn >= upr) { xn -= upr; ++yn; }
+        const bool live_n = (j + 1 < upt) && (u0 + (j + 1) * SYS_T < units);
+        const int x = xu << 2;
+        const unsigned off = unit_off(y, x);
+        const float4 i0 = ld_stream4(reinterpret_cast<const float*>(bI0 + off)), a = ld_stream4(reinterpret_cast<const float*>(bA + off)),
+                     b = ld_stream4(reinterpret_cast<const float*>(bB + off)), c = ld_stream4(reinterpret_cast<const float*>(bC + off)),
+                     d = ld_stream4(reinterpret_cast<const float*>(bD + off));
+        const fastnum::Ray r0 = fastnum::ray(WP, (float)x, (float)y);
+        const fastnum::Ray r1 = fastnum::ray_step(r0, WP.R[0], WP.R[3], WP.R[6]), r2 = fastnum::ray_step(r1, WP.R[0], WP.R[3], WP.R[6]),
+                           r3 = fastnum::ray_step(r2, WP.R[0], WP.R[3], WP.R[6]);
+        float4 w1;
+        w1.x = fastnum::warp_invdepth_px(Wc, r0, w0.x, WP); w1.y = fastnum::warp_invdepth_px(Wc, r1, w0.y, WP);
+        w1.z = fastnum::warp_invdepth_px(Wc, r2, w0.z, WP); w1.w = fastnum::warp_invdepth_px(Wc, r3, w0.w, WP);
+        const fastnum::IntensityTaps t0 = fastnum::intensity_taps(Ic, r0, w1.x, WP, fa.interp_mode), t1 = fastnum::intensity_taps(Ic, r1, w1.y, WP, fa.interp_mode),
+                                     t2 = fastnum::intensity_taps(Ic, r2, w1.z, WP, fa.interp_mode), t3 = fastnum::intensity_taps(Ic, r3, w1.w, WP, fa.interp_mode);
+        float4 w0n = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live_n) w0n = ld_stream4(reinterpret_cast<const float*>(bW0 + unit_off(yn, xn << 2)));
+        const float i1x = fastnum::intensity_finish(t0), i1y = fastnum::intensity_finish(t1), i1z = fastnum::intensity_finish(t2), i1w = fastnum::intensity_finish(t3);
+        float py_ = ((float)y - C.cy_f) * C.inv_fy, pp_y = fmaf(py_, py_, 1.f);
+        float px0 = ((float)x - C.cx_f) * C.inv_fx;
+        accumulate_pixel(acc, px0, py_, pp_y, w0.x, i0.x, a.x, b.x, c.x, d.x, w1.x, i1x, P, C);
+        accumulate_pixel(acc, px0 + C.inv_fx, py_, pp_y, w0.y, i0.y, a.y, b.y, c.y, d.y, w1.y, i1y, P, C);
+        accumulate_pixel(acc, fmaf(2.f, C.inv_fx, px0), py_, pp_y, w0.z, i0.z, a.z, b.z, c.z, d.z, w1.z, i1z, P, C);
+        accumulate_pixel(acc, fmaf(3.f, C.inv_fx, px0), py_, pp_y, w0.w, i0.w, a.w, b.w, c.w, d.w, w1.w, i1w, P, C);
+        w0 = w0n; live = live_n; y = yn; xu = xn;
+      }
+    } else
 #pragma unroll 1
     for (int j = 0; j < upt; ++j, y += step_y, xu += step_x) {
       if (xu >= upr) { xu -= upr; ++y; }
@@ -235,7 +289,8 @@ __global__ __launch_bounds__(SYS_T) void k_build_system(ImgB W0, ImgB I0, ImgB g
       if (u < units) {
         int y = u / cols, x = u - y * cols;
         float w0 = px<float>(W0, lane, y, x), w1, i1;
-        if (FUSED) { w1 = warp_invdepth_px(Wc, x, y, w0, WP); i1 = warp_intensity_px(Ic, x, y, w1, WP, fa.interp_mode); }
+        if (FUSED == 2) { const fastnum::Ray r = fastnum::ray(WP, (float)x, (float)y); w1 = fastnum::warp_invdepth_px(Wc, r, w0, WP); i1 = fastnum::warp_intensity_px(Ic, r, w1, WP, fa.interp_mode); }
+        else if (FUSED) { w1 = warp_invdepth_px(Wc, x, y, w0, WP); i1 = warp_intensity_px(Ic, x, y, w1, WP, fa.interp_mode); }
         else { w1 = px<float>(W1, lane, y, x); i1 = px<float>(I1, lane, y, x); }
         float py_ = ((float)y - C.cy_f) * C.inv_fy, pp_y = fmaf(py_, py_, 1.f);
         accumulate_pixel(acc, ((float)x - C.cx_f) * C.inv_fx, py_, pp_y, w0, px<float>(I0, lane, y, x), px<float>(gWx, lane, y, x),
@@ -275,7 +330,7 @@ int system_blocks_per_lane(int rows, int cols, int B) {
 }
 
 static int launch_system_impl(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB W1, ImgB I1,
-                              const SysParams* hp, const SysParams* lp, double* partials, LaneMask m, int level_tag, bool fused, FusedArgs fa) {
+                              const SysParams* hp, const SysParams* lp, double* partials, LaneMask m, int level_tag, int fused, FusedArgs fa) {
   bool vec = (W0.cols % 4 == 0) && vec_ok(W0) && vec_ok(I0) && vec_ok(gWx) && vec_ok(gWy) && vec_ok(gIx) && vec_ok(gIy) && (fused || (vec_ok(W1) && vec_ok(I1)));
   int upt, nblk;
   system_plan(W0.rows, W0.cols, B, vec, &upt, &nblk);
@@ -284,11 +339,12 @@ static int launch_system_impl(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, 
 #define RGBID_SYS_LEVELS(PSV, V, F) do { if (level_tag == 0) RGBID_SYS_LAUNCH(PSV, V, 0, F); else if (level_tag == 1) RGBID_SYS_LAUNCH(PSV, V, 1, F); else RGBID_SYS_LAUNCH(PSV, V, 2, F); } while (0)
   if (lp) {
     ByLane<SysParams> p{lp};
-    if (fused) { if (vec) RGBID_SYS_LEVELS(p, true, true); else RGBID_SYS_LAUNCH(p, false, 0, true); }
-    else { if (vec) RGBID_SYS_LEVELS(p, true, false); else RGBID_SYS_LEVELS(p, false, false); }
+    if (fused == 2) { if (vec) RGBID_SYS_LEVELS(p, true, 2); else RGBID_SYS_LAUNCH(p, false, 0, 2); }
+    else if (fused) { if (vec) RGBID_SYS_LEVELS(p, true, 1); else RGBID_SYS_LAUNCH(p, false, 0, 1); }
+    else { if (vec) RGBID_SYS_LEVELS(p, true, 0); else RGBID_SYS_LEVELS(p, false, 0); }
   } else {
     ByValue<SysParams> p{*hp};
-    if (vec) RGBID_SYS_LEVELS(p, true, false); else RGBID_SYS_LAUNCH(p, false, 0, false);
+    if (vec) RGBID_SYS_LEVELS(p, true, 0); else RGBID_SYS_LAUNCH(p, false, 0, 0);
   }
 #undef RGBID_SYS_LEVELS
 #undef RGBID_SYS_LAUNCH
@@ -298,12 +354,17 @@ static int launch_system_impl(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, 
 
 int launch_build_system(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB W1, ImgB I1,
                         const SysParams* hp, const SysParams* lp, double* partials, LaneMask m, int level_tag) {
-  return launch_system_impl(s, B, W0, I0, gWx, gWy, gIx, gIy, W1, I1, hp, lp, partials, m, level_tag, false, FusedArgs{nullptr, 0});
+  return launch_system_impl(s, B, W0, I0, gWx, gWy, gIx, gIy, W1, I1, hp, lp, partials, m, level_tag, 0, FusedArgs{nullptr, 0});
 }
 
 int launch_gn_fused(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB Wcur, ImgB Icur,
-                    const WarpParams* lane_wp, int interp_mode, const SysParams* lane_p, double* partials, LaneMask m, int level_tag) {
-  return launch_system_impl(s, B, W0, I0, gWx, gWy, gIx, gIy, Wcur, Icur, nullptr, lane_p, partials, m, level_tag, true, FusedArgs{lane_wp, interp_mode});
+                    const WarpParams* lane_wp, int interp_mode, const SysParams* lane_p, double* partials, LaneMask m, int level_tag, bool fast) {
+  // the paired bilinear taps need two columns; the pipelined kernel addresses the six keyframe maps through one shared 32-bit row offset
+  const bool same_geom = W0.pitch == I0.pitch && W0.pitch == gWx.pitch && W0.pitch == gWy.pitch && W0.pitch == gIx.pitch && W0.pitch == gIy.pitch &&
+                         (unsigned long long)W0.rows * W0.pitch < (1ull << 32) && W0.pitch < (1u << 24) && W0.rows < (1 << 24);
+  const bool vec = (W0.cols % 4 == 0) && vec_ok(W0) && vec_ok(I0) && vec_ok(gWx) && vec_ok(gWy) && vec_ok(gIx) && vec_ok(gIy);
+  const bool f = fast && Icur.cols >= 2 && same_geom && vec;   // otherwise the exact fused kernel (as the unfused path falls back to the exact warp pair)
+  return launch_system_impl(s, B, W0, I0, gWx, gWy, gIx, gIy, Wcur, Icur, nullptr, lane_p, partials, m, level_tag, f ? 2 : 1, FusedArgs{lane_wp, interp_mode});
 }
 
 // FinalReductionKernel estimate_VO.cu:459-500 (all-double here; the reference's tree is fp32).

@@ -8,6 +8,7 @@
 // unit's 1.8 fixed-point weight quantisation available as RGBID_INTERP_TEX8 (what tex2D computes).
 // The gathers hit L2 / Infinity Cache: a warped tile's footprint in the source frame is compact.
 #include "kernels.h"
+#include <cstdlib>
 #include "warp_device.h"
 
 // Whole file: no FMA contraction, so every fp32 expression is evaluated operation by operation exactly
@@ -19,6 +20,7 @@ namespace rgbid {
 static constexpr int TX = 64, TY = 4, RPB = 4;  // a workgroup sweeps RPB stacked 64x4 tiles (see kernels_prep.hip)
 static inline dim3 grid2d(int cols, int rows, int B) { return dim3(div_up(cols, TX), div_up(rows, TY * RPB), B); }
 static inline dim3 grid2d_full(int cols, int rows, int B) { return dim3(div_up(cols, TX), div_up(rows, TY), B); }
+static inline bool vec4_ok(const ImgB& a) { return ((a.pitch & 15) == 0) && ((a.lane_stride & 15) == 0) && ((((uintptr_t)a.base) & 15) == 0) && (a.cols % 4 == 0); }
 #define RGBID_FOR_ROWS(yv) for (int it_ = 0, yv = blockIdx.y * (TY * RPB) + threadIdx.y; it_ < RPB; ++it_, yv += TY)
 
 // ---- trafo3DKernelInvDepthGridStride (:505-546) ---------------------------------------------------
@@ -119,9 +121,66 @@ __global__ __launch_bounds__(256) void k_warp_pair(ImgB src_iD, ImgB src_I, ImgB
     if (y < dst_iD.rows) { DW.store(y, x, w1[i]); DI.store(y, x, i1[i]); }
   }
 }
-void launch_warp_pair(hipStream_t s, int B, ImgB src_iD, ImgB src_I, ImgB grid, ImgB dst_iD, ImgB dst_I, const WarpParams* lp, int interp_mode, LaneMask m) {
+void launch_warp_pair(hipStream_t s, int B, ImgB src_iD, ImgB src_I, ImgB grid, ImgB dst_iD, ImgB dst_I, const WarpParams* lp, int interp_mode, LaneMask m, const WarpParams* hp) {
   dim3 g = grid2d(dst_iD.cols, dst_iD.rows, B), b(TX, TY);
-  hipLaunchKernelGGL(k_warp_pair<ByLane<WarpParams>>, g, b, 0, s, src_iD, src_I, grid, dst_iD, dst_I, ByLane<WarpParams>{lp}, interp_mode, m);
+  if (lp) hipLaunchKernelGGL(k_warp_pair<ByLane<WarpParams>>, g, b, 0, s, src_iD, src_I, grid, dst_iD, dst_I, ByLane<WarpParams>{lp}, interp_mode, m);
+  else hipLaunchKernelGGL(k_warp_pair<ByValue<WarpParams>>, g, b, 0, s, src_iD, src_I, grid, dst_iD, dst_I, ByValue<WarpParams>{*hp}, interp_mode, m);
+}
+
+// ---- engine, fast numerics (warp_device.h fastnum): the same pair in the reference build's class of arithmetic ------------------------
+// 1-D grid, XCD-contiguous tile order (TileMap): a lane's tiles run on one XCD, so neighbouring tiles share their gather footprints in L2.
+// Per thread: x fixed, RPB rows TY apart -- the ray q = R (x, y, 1) is formed once (6 FMAs) and stepped down the rows with 3 adds, and it
+// serves BOTH projections of every pixel (iD warp with the keyframe inverse depth, intensity warp with the warped inverse depth).
+// Geometry: a workgroup is 16 x 16 threads over a 64 x 16 pixel tile, a thread owns 4 CONSECUTIVE pixels of one row -- the keyframe inverse
+// depth arrives in one 16-byte load, both results leave in one 16-byte store each, and the bilinear taps are two 8-byte loads per pixel:
+// 15 vector-memory instructions per 4 pixels instead of 32.  That count is what bounds a gather kernel on this chip: the texture
+// addresser takes 16 clocks per wave64 instruction (4 lanes per clock) whatever the access width -- the scalar-access version of this kernel
+// ran 626 us per 512-lane launch with 40 % fewer VALU instructions than the exact kernel, with or without its cache over-fetch.
+template <class PS>
+__global__ __launch_bounds__(256) void k_warp_pair_fast(ImgB src_iD, ImgB src_I, ImgB grid, ImgB dst_iD, ImgB dst_I, PS ps, int interp_mode, LaneMask m, TileMap tm) {
+  const TileId t = tm.tile(blockIdx.x);
+  const int lane = t.lane;
+  if (!m.on(lane)) return;
+  const int x = t.bx * 64 + threadIdx.x * 4, y = t.by * 16 + threadIdx.y;
+  if (x >= dst_iD.cols || y >= dst_iD.rows) return;
+  const WarpParams P = ps.get(lane);
+  const FMap SD(src_iD, lane), SI(src_I, lane), G(grid, lane);
+  const FMapW DW(dst_iD, lane), DI(dst_I, lane);
+  const float4 g4 = G.at4(y, x);
+  const float wv[4] = {g4.x, g4.y, g4.z, g4.w};
+  float w1[4], i1[4];
+  fastnum::Ray q[4];
+  q[0] = fastnum::ray(P, (float)x, (float)y);
+#pragma unroll
+  for (int i = 1; i < 4; ++i) q[i] = fastnum::ray_step(q[i - 1], P.R[0], P.R[3], P.R[6]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w1[i] = fastnum::warp_invdepth_px(SD, q[i], wv[i], P);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) i1[i] = fastnum::warp_intensity_px(SI, q[i], w1[i], P, interp_mode);
+  DW.store4(y, x, make_float4(w1[0], w1[1], w1[2], w1[3]));
+  DI.store4(y, x, make_float4(i1[0], i1[1], i1[2], i1[3]));
+}
+bool launch_warp_pair_fast(hipStream_t s, int B, ImgB src_iD, ImgB src_I, ImgB grid, ImgB dst_iD, ImgB dst_I, const WarpParams* hp, const WarpParams* lp, int interp_mode, LaneMask m) {
+  // 16-byte rows on the grid / output side, at least two columns for the paired bilinear taps; otherwise the caller runs the exact kernel
+  if (!(vec4_ok(grid) && vec4_ok(dst_iD) && vec4_ok(dst_I)) || src_I.cols < 2) return false;
+  TileMap tm;
+  if (!make_tile_map(div_up(dst_iD.cols, 64), div_up(dst_iD.rows, 16), B, &tm)) return false;
+  if (lp) hipLaunchKernelGGL(k_warp_pair_fast<ByLane<WarpParams>>, dim3(tm.n), dim3(16, 16), 0, s, src_iD, src_I, grid, dst_iD, dst_I, ByLane<WarpParams>{lp}, interp_mode, m, tm);
+  else hipLaunchKernelGGL(k_warp_pair_fast<ByValue<WarpParams>>, dim3(tm.n), dim3(16, 16), 0, s, src_iD, src_I, grid, dst_iD, dst_I, ByValue<WarpParams>{*hp}, interp_mode, m, tm);
+  return true;
+}
+
+// device self-test of fastnum::cvt_flr (v_cvt_flr_i32_f32) against floor + saturating convert over a stride of the 2^32 float patterns (NaN excluded)
+__global__ void k_selftest_cvt_flr(unsigned long long* mismatches, unsigned stride) {
+  unsigned long long bad = 0;
+  for (unsigned long long u = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u < (1ull << 32); u += (unsigned long long)gridDim.x * blockDim.x * stride) {
+    const float x = __uint_as_float((unsigned)u);
+    if (x == x && fastnum::cvt_flr(x) != cvt_rd(x)) ++bad;   // NaN: v_cvt_i32_f32 gives 0, v_cvt_flr_i32_f32 does not -- every index is clamped before it addresses memory
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+void launch_selftest_cvt_flr(hipStream_t s, unsigned long long* mismatches_dev, unsigned stride) {
+  hipLaunchKernelGGL(k_selftest_cvt_flr, dim3(4096), dim3(256), 0, s, mismatches_dev, stride);
 }
 
 // ---- trafo3DKernelInvDepthWeightedGridStride (:549-594) -------------------------------------------
@@ -186,7 +245,6 @@ __global__ __launch_bounds__(256) void k_integrate(ImgB warped, ImgB wweight, Im
   }
 }
 // 4 pixels per thread (16-byte accesses); pixels that keep their value are simply written back unchanged
-static inline bool vec4_ok(const ImgB& a) { return ((a.pitch & 15) == 0) && ((a.lane_stride & 15) == 0) && ((((uintptr_t)a.base) & 15) == 0) && (a.cols % 4 == 0); }
 __device__ __forceinline__ void integrate_px(float w_sum, float qs, float& w_KF, float& q) {
   if (!isnan(w_sum)) {
     float dw = fabsf(w_sum - w_KF);
@@ -230,7 +288,7 @@ void launch_integrate_warped(hipStream_t s, int B, ImgB warped, ImgB wweight, Im
 // leave it -- written only where the weight is positive, stale elsewhere -- because the fusion reads it wherever the warped value is
 // valid, which can (only with infinite intermediates) include pixels whose weight was not stored: full groups store 16 bytes, mixed groups
 // store their pixels one by one, and the stale value is fetched only in that exotic case.  Same device functions, bit-identical maps.
-template <class PS>
+template <class PS, bool FAST>
 __global__ __launch_bounds__(256) void k_fuse_frame4(ImgB src, ImgB kf, ImgB kfw, ImgB wweight, PS ps, int cols4, int units, LaneMask m) {
   int lane = blockIdx.y;
   if (!m.on(lane)) return;
@@ -244,13 +302,22 @@ __global__ __launch_bounds__(256) void k_fuse_frame4(ImgB src, ImgB kf, ImgB kfw
     float4 k4 = *kp, q4 = *qp;
     float k[4] = {k4.x, k4.y, k4.z, k4.w}, q[4] = {q4.x, q4.y, q4.z, q4.w}, ws[4], wt[4];
     bool st[4];
-    RcpFast fast;
+    if (FAST) {   // reference-build-class numerics (warp_device.h fastnum): the ray of the group's first pixel stepped along x
+      fastnum::Ray r = fastnum::ray(P, (float)x, (float)y);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ws[i] = warp_invdepth_weighted_px_t(S, x + i, y, k[i], P, fast, wt[i], st[i]);
-    if (__builtin_expect(fast.failed(), 0)) {
-      RcpIeee ieee;
+      for (int i = 0; i < 4; ++i) {
+        ws[i] = fastnum::warp_invdepth_weighted_px(S, r, k[i], P, wt[i], st[i]);
+        r = fastnum::ray_step(r, P.R[0], P.R[3], P.R[6]);
+      }
+    } else {
+      RcpFast fast;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ws[i] = warp_invdepth_weighted_px_t(S, x + i, y, k[i], P, ieee, wt[i], st[i]);
+      for (int i = 0; i < 4; ++i) ws[i] = warp_invdepth_weighted_px_t(S, x + i, y, k[i], P, fast, wt[i], st[i]);
+      if (__builtin_expect(fast.failed(), 0)) {
+        RcpIeee ieee;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ws[i] = warp_invdepth_weighted_px_t(S, x + i, y, k[i], P, ieee, wt[i], st[i]);
+      }
     }
     const bool all_st = st[0] & st[1] & st[2] & st[3];
     if (all_st) *reinterpret_cast<float4*>(wp) = make_float4(wt[0], wt[1], wt[2], wt[3]);
@@ -266,10 +333,11 @@ __global__ __launch_bounds__(256) void k_fuse_frame4(ImgB src, ImgB kf, ImgB kfw
     *qp = make_float4(q[0], q[1], q[2], q[3]);
   }
 }
-bool launch_fuse_frame(hipStream_t s, int B, ImgB src, ImgB kf, ImgB kfw, ImgB wweight, const WarpParams* lp, LaneMask m) {
+bool launch_fuse_frame(hipStream_t s, int B, ImgB src, ImgB kf, ImgB kfw, ImgB wweight, const WarpParams* lp, LaneMask m, bool fast) {
   if (!(vec4_ok(kf) && vec4_ok(kfw) && vec4_ok(wweight))) return false;   // caller falls back to the two kernels
   int cols4 = kf.cols / 4, units = cols4 * kf.rows;
-  hipLaunchKernelGGL(k_fuse_frame4<ByLane<WarpParams>>, dim3(div_up(units, 256 * 2), B), dim3(256), 0, s, src, kf, kfw, wweight, ByLane<WarpParams>{lp}, cols4, units, m);
+  if (fast) hipLaunchKernelGGL((k_fuse_frame4<ByLane<WarpParams>, true>), dim3(div_up(units, 256 * 2), B), dim3(256), 0, s, src, kf, kfw, wweight, ByLane<WarpParams>{lp}, cols4, units, m);
+  else hipLaunchKernelGGL((k_fuse_frame4<ByLane<WarpParams>, false>), dim3(div_up(units, 256 * 2), B), dim3(256), 0, s, src, kf, kfw, wweight, ByLane<WarpParams>{lp}, cols4, units, m);
   return true;
 }
 
@@ -364,6 +432,7 @@ __device__ __forceinline__ bool visible_px(const FMap& D, int cols, int rows, in
   int xi = clampi(__float2int_rn(xd), cols - 1), yi = clampi(__float2int_rn(yd), rows - 1);
   return valid && inside_img && (fabsf(w_dst - D.at(yi, xi)) < 0.020f);
 }
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_visibility_pair(ImgB A, ImgB Bm, const WarpParams* p_ab, const WarpParams* p_ba, unsigned int* counts_ab,
                                                          unsigned int* counts_ba, LaneMask m) {
   int lane = blockIdx.z;
@@ -389,8 +458,14 @@ __global__ __launch_bounds__(256) void k_visibility_pair(ImgB A, ImgB Bm, const 
     for (int i = 0; i < 2; ++i) {
       const int y = yb + i * TY;
       const bool va = !isnan(wa[i]), vb = !isnan(wb[i]);
-      const bool sa = visible_px(FB, cols, rows, x, y, wa[i], va, Pab);
-      const bool sb = visible_px(FA, cols, rows, x, y, wb[i], vb, Pba);
+      bool sa, sb;
+      if (FAST) {
+        sa = fastnum::visible_px(FB, cols, rows, fastnum::ray(Pab, (float)x, (float)y), wa[i], va, Pab);
+        sb = fastnum::visible_px(FA, cols, rows, fastnum::ray(Pba, (float)x, (float)y), wb[i], vb, Pba);
+      } else {
+        sa = visible_px(FB, cols, rows, x, y, wa[i], va, Pab);
+        sb = visible_px(FA, cols, rows, x, y, wb[i], vb, Pba);
+      }
       n[0] += (unsigned int)__popcll(__ballot(sa)); n[1] += (unsigned int)__popcll(__ballot(va));
       n[2] += (unsigned int)__popcll(__ballot(sb)); n[3] += (unsigned int)__popcll(__ballot(vb));
     }
@@ -405,9 +480,10 @@ __global__ __launch_bounds__(256) void k_visibility_pair(ImgB A, ImgB Bm, const 
   }
 }
 void launch_visibility_pair(hipStream_t s, int B, ImgB a, ImgB b, const WarpParams* p_ab, const WarpParams* p_ba, unsigned int* counts_ab,
-                            unsigned int* counts_ba, LaneMask m) {
+                            unsigned int* counts_ba, LaneMask m, bool fast) {
   dim3 g(div_up(a.cols, TX), div_up(a.rows, VIS_ROWS), B), blk(TX, TY);
-  hipLaunchKernelGGL(k_visibility_pair, g, blk, 0, s, a, b, p_ab, p_ba, counts_ab, counts_ba, m);
+  if (fast) hipLaunchKernelGGL(k_visibility_pair<true>, g, blk, 0, s, a, b, p_ab, p_ba, counts_ab, counts_ba, m);
+  else hipLaunchKernelGGL(k_visibility_pair<false>, g, blk, 0, s, a, b, p_ab, p_ba, counts_ab, counts_ba, m);
 }
 
 void launch_visibility(hipStream_t s, int B, ImgB src, ImgB dst, ImgB mask, const WarpParams* hp, const WarpParams* lp, unsigned int* counts, LaneMask m) {

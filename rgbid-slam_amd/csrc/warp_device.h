@@ -40,6 +40,14 @@ struct FMap {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, row_b + ((unsigned)x << 2), 0, 0));
   }
   __device__ __forceinline__ float at(int y, int x) const { return at_off(row(y), x); }
+  // two horizontally adjacent texels (x, x + 1) in ONE 8-byte load: the texture addresser handles 4 lanes per clock whatever the access
+  // width, so a gather kernel's time is its number of vector-memory instructions, not its bytes (x + 1 must be a valid column)
+  __device__ __forceinline__ float2 at2_off(unsigned row_b, int x) const {
+    return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, row_b + ((unsigned)x << 2), 0, 0));
+  }
+  __device__ __forceinline__ float4 at4(int y, int x) const {   // x % 4 == 0, 16-byte aligned rows
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, row(y) + ((unsigned)x << 2), 0, 0));
+  }
 };
 
 // writable counterpart (kernel outputs): raw buffer stores with a 32-bit byte offset (a 24-bit multiply-add) on a wave-uniform descriptor
@@ -51,6 +59,10 @@ struct FMapW {
         pitch_b((unsigned)im.pitch) {}
   __device__ __forceinline__ void store(int y, int x, float v) const {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsrc, __umul24((unsigned)y, pitch_b) + ((unsigned)x << 2), 0, 0);
+  }
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  __device__ __forceinline__ void store4(int y, int x, float4 v) const {   // x % 4 == 0, 16-byte aligned rows
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), rsrc, __umul24((unsigned)y, pitch_b) + ((unsigned)x << 2), 0, 0);
   }
 };
 
@@ -212,31 +224,43 @@ __device__ __forceinline__ float warp_invdepth_weighted_px(const FMap& src, cons
   return (valid & inb & (res > 0.f)) ? res : qnan();
 }
 
-// trafo3DKernelIntensityWithInvDepthGridStride (:465-501), one pixel; bilinear tap in the lerp form
-__device__ __forceinline__ float warp_intensity_px(const FMap& src, const Ray& q, float w, const WarpParams& P, int interp_mode) {
+// the same intensity warp in two halves, so that a caller can put other memory traffic between the tap loads and their use:
+// intensity_taps() projects, forms the 1.8 fixed-point weights and ISSUES the two 8-byte tap loads; intensity_finish() blends.
+struct IntensityTaps { float2 p0, p1; float a, b; bool left, right, ok; };
+__device__ __forceinline__ IntensityTaps intensity_taps(const FMap& src, const Ray& q, float w, const WarpParams& P, int interp_mode) {
+  IntensityTaps t;
   const bool valid = w == w;
   const float ws = valid ? w : 1.f;
   const float zd = rcp(ws);
   const float X0 = __builtin_fmaf(q.q0, zd, P.t[0]), X1 = __builtin_fmaf(q.q1, zd, P.t[1]), X2 = __builtin_fmaf(q.q2, zd, P.t[2]);
   const float wc = rcp(X2);
-  const float xB = X0 * wc, yB = X1 * wc;                  // texel-space coordinates (xs - 0.5 of the reference's tex2D call)
-  // in bounds <=> floor(xB + 0.5) in [0, cols)
-  const bool inb = (xB >= -0.5f) & (xB < (float)src.cols - 0.5f) & (yB >= -0.5f) & (yB < (float)src.rows - 0.5f);
+  const float xB = X0 * wc, yB = X1 * wc;
+  t.ok = valid & (xB >= -0.5f) & (xB < (float)src.cols - 0.5f) & (yB >= -0.5f) & (yB < (float)src.rows - 0.5f);
   const float fx0 = floorf(xB), fy0 = floorf(yB);
-  float a = xB - fx0, b = yB - fy0;
+  t.a = xB - fx0; t.b = yB - fy0;
   if (interp_mode == 1) {
-    a = rintf(a * 256.f) * 0.00390625f;
-    b = rintf(b * 256.f) * 0.00390625f;
+    t.a = rintf(t.a * 256.f) * 0.00390625f;
+    t.b = rintf(t.b * 256.f) * 0.00390625f;
   }
   const int ic = clamp_from_m1(__float2int_rd(fx0), src.cols - 1), jc = clamp_from_m1(__float2int_rd(fy0), src.rows - 1);
-  const int i1 = min(ic + 1, src.cols - 1), j1 = min(jc + 1, src.rows - 1);
-  const int i0 = max(ic, 0), j0 = max(jc, 0);
-  const unsigned r0 = src.row(j0), r1 = src.row(j1);
-  const float T00 = src.at_off(r0, i0), T10 = src.at_off(r0, i1), T01 = src.at_off(r1, i0), T11 = src.at_off(r1, i1);
-  const float top = __builtin_fmaf(a, T10 - T00, T00), bot = __builtin_fmaf(a, T11 - T01, T01);
-  float res = __builtin_fmaf(b, bot - top, top);
-  res = fmaxf(0.f, fminf(res, 255.f));                     // NaN -> 255, as CUDA's min/max
-  return (valid & inb) ? res : qnan();
+  const int j1 = min(jc + 1, src.rows - 1), j0 = max(jc, 0);
+  const int c = clampi(ic, src.cols - 2);
+  t.p0 = src.at2_off(src.row(j0), c); t.p1 = src.at2_off(src.row(j1), c);
+  t.left = ic < 0; t.right = ic > src.cols - 2;
+  return t;
+}
+__device__ __forceinline__ float intensity_finish(const IntensityTaps& t) {
+  const float T00 = t.right ? t.p0.y : t.p0.x, T10 = t.left ? t.p0.x : t.p0.y;
+  const float T01 = t.right ? t.p1.y : t.p1.x, T11 = t.left ? t.p1.x : t.p1.y;
+  const float top = __builtin_fmaf(t.a, T10 - T00, T00), bot = __builtin_fmaf(t.a, T11 - T01, T01);
+  float res = __builtin_fmaf(t.b, bot - top, top);
+  res = fmaxf(0.f, fminf(res, 255.f));
+  return t.ok ? res : qnan();
+}
+
+// trafo3DKernelIntensityWithInvDepthGridStride (:465-501), one pixel; bilinear tap in the lerp form
+__device__ __forceinline__ float warp_intensity_px(const FMap& src, const Ray& q, float w, const WarpParams& P, int interp_mode) {
+  return intensity_finish(intensity_taps(src, q, w, P, interp_mode));
 }
 
 // one direction of computeCovisibility's gate (partialVisibilityKernel :297-360)
@@ -264,9 +288,9 @@ struct TileMap {
   __device__ __forceinline__ TileId tile(unsigned id) const {
     const unsigned V = (id < (per << 3)) ? (id & 7u) * per + (id >> 3) : id;   // tail ids keep their place
     TileId t;
-    const unsigned lane = __umulhi(V, magic_tiles);
+    const unsigned lane = tiles == 1 ? V : __umulhi(V, magic_tiles);   // 2^32 / 1 + 1 does not fit the magic: divisor 1 is taken apart
     const unsigned tl = V - lane * tiles;
-    const unsigned by = __umulhi(tl, magic_nx);
+    const unsigned by = nx == 1 ? tl : __umulhi(tl, magic_nx);
     t.lane = (int)lane; t.by = (int)by; t.bx = (int)(tl - by * nx);
     return t;
   }

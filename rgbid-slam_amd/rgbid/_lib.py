@@ -58,14 +58,14 @@ def check(err):
 # every symbol include/rgbid.h declares (checked by the CPU test-suite against the built library)
 EXPORTS = [
     "rgbid_version", "rgbid_error_string", "rgbid_device_count", "rgbid_get_device_prop", "rgbid_set_device", "rgbid_ctx_create", "rgbid_ctx_destroy",
-    "rgbid_ctx_set_stream", "rgbid_ctx_set_async", "rgbid_ctx_set_interp_mode", "rgbid_ctx_sync", "rgbid_selftest_rcp", "rgbid_selftest_div_const", "rgbid_ctx_wait_event", "rgbid_ctx_get_stream", "rgbid_mem_info",
+    "rgbid_ctx_set_stream", "rgbid_ctx_set_async", "rgbid_ctx_set_interp_mode", "rgbid_ctx_sync", "rgbid_selftest_rcp", "rgbid_selftest_div_const", "rgbid_selftest_cvt_flr", "rgbid_ctx_wait_event", "rgbid_ctx_get_stream", "rgbid_mem_info",
     "rgbid_malloc", "rgbid_malloc_pitch", "rgbid_free", "rgbid_memcpy_h2d", "rgbid_memcpy_d2h", "rgbid_memcpy_d2d",
     "rgbid_memcpy2d_h2d", "rgbid_memcpy2d_d2h", "rgbid_memcpy2d_d2d",
     "rgbid_depth_to_float", "rgbid_float_to_rgb", "rgbid_create_nmap", "rgbid_integrate_warped_rgb",
     "rgbid_undistort_intensity", "rgbid_undistort_depthinv", "rgbid_register_depthinv",
     "rgbid_depth_to_invdepth", "rgbid_compute_intensity", "rgbid_decompose_rgb", "rgbid_compute_gradient",
     "rgbid_copy_images", "rgbid_copy_image", "rgbid_copy_image_rgb", "rgbid_init_weight_keyframe", "rgbid_fill_2d",
-    "rgbid_pyr_down", "rgbid_bilateral_filter", "rgbid_warp_invdepth", "rgbid_warp_intensity",
+    "rgbid_pyr_down", "rgbid_bilateral_filter", "rgbid_warp_invdepth", "rgbid_warp_intensity", "rgbid_warp_pair",
     "rgbid_warp_invdepth_weighted", "rgbid_integrate_warped_frame", "rgbid_visibility_ratio",
     "rgbid_create_vmap", "rgbid_create_nmap_gradients", "rgbid_generate_image",
     "rgbid_error_lattice_size", "rgbid_compute_error", "rgbid_sigma_nu_student", "rgbid_nu_student",

@@ -98,6 +98,11 @@ class Context:
         check(self.L.rgbid_selftest_rcp(self._h, C.byref(n)))
         return n.value
 
+    def selftest_cvt_flr(self, stride=1):
+        n = C.c_ulonglong()
+        check(self.L.rgbid_selftest_cvt_flr(self._h, C.c_uint(int(stride)), C.byref(n)))
+        return n.value
+
     def selftest_div_const(self, divisor):
         """(mismatches of the bilateral filter's short division by `divisor` vs IEEE over all 2^32 dividends, whether the filter uses it)"""
         n, used = C.c_ulonglong(1), C.c_int(0)
@@ -213,6 +218,12 @@ class Context:
         ms = C.c_float()
         check(self.L.rgbid_warp_intensity(self._h, C.byref(img(src)), C.byref(img(dst)), C.byref(img(depthinv_prev)),
                                           _fa(R_proj, 9), _fa(t_proj, 3), C.byref(ms)))
+        return ms.value
+
+    def warpPair(self, src_iD, src_I, grid_iD, dst_iD, dst_I, R_proj, t_proj, fast=False):
+        ms = C.c_float()
+        check(self.L.rgbid_warp_pair(self._h, C.byref(img(src_iD)), C.byref(img(src_I)), C.byref(img(grid_iD)), C.byref(img(dst_iD)), C.byref(img(dst_I)),
+                                     _fa(R_proj, 9), _fa(t_proj, 3), int(bool(fast)), C.byref(ms)))
         return ms.value
 
     def warpInvDepthWithTrafo3DWeighted(self, src, dst, depthinv_prev, weight_warped, R_proj, t_proj):

@@ -27,7 +27,7 @@ class EngineConfig(C.Structure):
         ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("factor_depth", C.c_float),
         ("interp_mode", C.c_int), ("delta_t", C.c_float),
         ("use_graph", C.c_int), ("fused_gn", C.c_int), ("chi_square_stats", C.c_int), ("preview", C.c_int),
-        ("record_capacity", C.c_int), ("warping", C.c_int), ("keyframe_capacity", C.c_int),
+        ("record_capacity", C.c_int), ("warping", C.c_int), ("keyframe_capacity", C.c_int), ("fast_numerics", C.c_int),
     ]
 
 

@@ -138,8 +138,29 @@ def test_engine_fused_gn_is_bit_identical(ctx):
     seqs, depth, rgb = make_lanes(3, 6, 120, 160, K, trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8))
     recs = []
     for fused in (0, 1):
-        eng = E.Engine(ctx, E.default_config(rows=120, cols=160, lanes=3, K=K, use_graph=0, fused_gn=fused, record_capacity=6))
+        eng = E.Engine(ctx, E.default_config(rows=120, cols=160, lanes=3, K=K, use_graph=0, fused_gn=fused, record_capacity=6, fast_numerics=0))
         for k in range(6):
+            eng.step(depth[k], rgb[k])
+        recs.append(eng.records())
+        eng.close()
+    for name in ("R", "t", "odo_cov", "status", "nu_int", "sigma_depthinv", "vis_odo"):
+        assert np.array_equal(recs[0][name], recs[1][name]), name
+
+
+@pytest.mark.parametrize("rows,cols,levels", [(120, 160, 3), (122, 164, 2), (480, 640, 3)])
+def test_engine_fused_fast_is_bit_identical_to_unfused_fast(ctx, rows, cols, levels):
+    """fast numerics: the fused kernel (gathers issued pixel-per-lane through the wave's LDS transpose) and the stand-alone fast warp pair
+    evaluate the same device functions on the same pixels and the rows are accumulated in the same order: records must be IDENTICAL.
+    (122 x 164: rows that are not a multiple of the launch geometry, lanes past the end of the image inside a live wave.)"""
+    s = cols / 640.0
+    K = (525.0 * s, 525.0 * s, (319.5 + 0.5) * s - 0.5, (239.5 + 0.5) * rows / 480.0 - 0.5)
+    T, B = (6, 3) if rows < 480 else (3, 2)
+    seqs, depth, rgb = make_lanes(B, T, rows, cols, K, trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8))
+    recs = []
+    for fused in (0, 1):
+        eng = E.Engine(ctx, E.default_config(rows=rows, cols=cols, lanes=B, K=K, levels=levels, iters=[6, 4, 3][:levels], use_graph=0, fused_gn=fused,
+                                             record_capacity=T, fast_numerics=1))
+        for k in range(T):
             eng.step(depth[k], rgb[k])
         recs.append(eng.records())
         eng.close()
@@ -163,6 +184,40 @@ def test_engine_vs_oracle_full_res(ctx):
     """BASELINE config 2 stand-in: 640x480, 3 levels, {10,5,3}, Student-t + sigmaML, pyrFirst, fusion on."""
     wr, wt = run_case(ctx, 480, 640, synth.TUM_K, n_lanes=2, n_frames=5, cfg_kw=dict(), seq_kw=dict(), use_graph=1)
     print("worst pose deviation engine vs oracle (640x480):", wr, wt)
+
+
+@pytest.mark.parametrize("rows,cols", [(120, 160), (480, 640)])
+def test_engine_fast_numerics_vs_exact(ctx, rows, cols):
+    """The engine's default gather kernels (fast_numerics = 1: reference-build-class arithmetic) against its bit-exact ones on the same frames:
+    same keyframe decisions, poses within 1e-5 rad / 1e-5 m (measured ~1e-7..1e-6), fused keyframe maps equal except boundary pixels --
+    the same order the oracle's model of the reference's nvcc flags moves the results (tests/test_oracle_cuda_numerics.py)."""
+    s = cols / 640.0
+    K = (525.0 * s, 525.0 * s, (319.5 + 0.5) * s - 0.5, (239.5 + 0.5) * s - 0.5)
+    T, B = (10, 3) if rows == 120 else (5, 2)
+    kw = dict(trans_step=(0.004, 0.012), rot_step_deg=(0.2, 0.8)) if rows == 120 else dict()
+    seqs, depth, rgb = make_lanes(B, T, rows, cols, K, **kw)
+    out = []
+    for fast in (0, 1):
+        eng = E.Engine(ctx, E.default_config(rows=rows, cols=cols, lanes=B, K=K, use_graph=0, record_capacity=T, fast_numerics=fast))
+        for k in range(T):
+            eng.step(depth[k], rgb[k])
+        out.append((eng.records().copy(), [eng.keyframe_maps(l) for l in range(B)]))
+        eng.close()
+    (ra, ma), (rb, mb) = out
+    assert np.array_equal(ra["status"], rb["status"])
+    assert np.array_equal(ra["nu_int"], rb["nu_int"]) and np.array_equal(ra["nu_depthinv"], rb["nu_depthinv"])
+    wr = max(rot_angle(ra[k, l]["R"], rb[k, l]["R"]) for k in range(1, T) for l in range(B))
+    wt = float(np.abs(ra["t"] - rb["t"]).max())
+    assert np.abs(ra["vis_odo"] - rb["vis_odo"]).max() < 2e-4 and np.abs(ra["vis_integr"] - rb["vis_integr"]).max() < 2e-4
+    print(f"fast vs exact engine {cols}x{rows}: worst pose difference {wr:.2e} rad / {wt:.2e} m")
+    assert wr < 1e-5 and wt < 1e-5
+    for l in range(B):
+        kd_a, kw_a = ma[l][0], ma[l][1]; kd_b, kw_b = mb[l][0], mb[l][1]
+        n = kd_a.size
+        assert np.count_nonzero(np.isnan(kd_a) != np.isnan(kd_b)) <= 1e-3 * n
+        m = ~np.isnan(kd_a) & ~np.isnan(kd_b)
+        rel = np.abs(kd_a[m] - kd_b[m]) / np.abs(kd_a[m])
+        assert np.count_nonzero(rel > 1e-4) <= max(16, 2e-3 * rel.size) and np.median(rel) < 1e-6, (np.count_nonzero(rel > 1e-4), rel.size)
 
 
 def test_engine_vs_oracle_1280x960_four_levels(ctx):

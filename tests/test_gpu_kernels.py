@@ -136,6 +136,52 @@ def test_warp_intensity(ctx, rows, cols, mode):
     assert_bits(dst.cpu().numpy(), O.warp_intensity(inten, grid, Rp, tp, mode), 0, "warp intensity")
 
 
+@pytest.mark.parametrize("rows,cols", SIZES)
+def test_warp_pair_exact_is_the_two_warps(ctx, rows, cols):
+    """rgbid_warp_pair with EXACT numerics: both maps bit-identical to the oracle's two warps (the intensity warp sampled on the WARPED iD)"""
+    K, grid, src, inten, Rp, tp = _warp_case(rows, cols, 6)
+    d1, d2 = new(rows, cols), new(rows, cols)
+    ctx.warpPair(dev(src), dev(inten), dev(grid), d1, d2, Rp, tp, fast=False)
+    w1 = O.warp_invdepth(src, grid, Rp, tp)
+    assert_bits(d1.cpu().numpy(), w1, 0, "pair iD")
+    assert_bits(d2.cpu().numpy(), O.warp_intensity(inten, w1, Rp, tp, O.INTERP_TEX8), 0, "pair intensity")
+
+
+def test_selftest_cvt_flr_exhaustive(ctx):
+    """v_cvt_flr_i32_f32 == v_floor_f32 + v_cvt_i32_f32 (saturating) for every non-NaN one of the 2^32 float bit patterns"""
+    assert ctx.selftest_cvt_flr(1) == 0
+
+
+@pytest.mark.parametrize("rows,cols", SIZES)
+@pytest.mark.parametrize("seed", [6, 21])
+def test_warp_pair_fast_differs_only_at_pixel_boundaries(ctx, rows, cols, seed):
+    """FAST numerics (the reference build's class of arithmetic: v_rcp_f32, FMA contraction, shared ray -- csrc/warp_device.h fastnum) against
+    the IEEE oracle: the pixel-selection parity statement of DESIGN.md section 4.  All but a handful of pixels select the same source pixel
+    (warped iD equal to 1e-5 relative, NaN pattern equal), and the bilinear intensity agrees to rounding except where the 1.8 fixed-point
+    weight lands on the other side of a 1/256 step (bounded by one weight step times the local contrast)."""
+    K, grid, src, inten, Rp, tp = _warp_case(rows, cols, seed)
+    d1, d2 = new(rows, cols), new(rows, cols)
+    ctx.warpPair(dev(src), dev(inten), dev(grid), d1, d2, Rp, tp, fast=True)
+    g1, g2 = d1.cpu().numpy(), d2.cpu().numpy()
+    w1 = O.warp_invdepth(src, grid, Rp, tp)
+    i1 = O.warp_intensity(inten, w1, Rp, tp, O.INTERP_TEX8)
+    n = rows * cols
+    nan_mis = int(np.count_nonzero(np.isnan(g1) != np.isnan(w1)))
+    both = ~np.isnan(g1) & ~np.isnan(w1)
+    rel = np.abs(g1[both] - w1[both]) / np.abs(w1[both])
+    other_px = int(np.count_nonzero(rel > 1e-5))                     # a different source pixel was point-sampled
+    assert nan_mis <= max(4, 2e-4 * n) and other_px <= max(4, 5e-4 * n), (nan_mis, other_px, n)
+    assert np.median(rel) < 2e-7
+    nan_mis_i = int(np.count_nonzero(np.isnan(g2) != np.isnan(i1)))
+    bi = ~np.isnan(g2) & ~np.isnan(i1)
+    di = np.abs(g2[bi] - i1[bi])
+    # the intensity warp samples at the warped iD: pixels whose warped iD came from another source pixel move with it
+    assert nan_mis_i <= max(4, 4e-4 * n), (nan_mis_i, n)
+    assert np.count_nonzero(di > 0.5) <= max(8, 2e-3 * n), (np.count_nonzero(di > 0.5), n)      # 1/256 weight steps x contrast, plus the moved pixels
+    assert np.median(di) < 1e-3
+    print(f"fast vs exact {cols}x{rows}: NaN-pattern {nan_mis}, other source pixel {other_px} of {int(both.sum())}; intensity > 0.5 grey levels: {int(np.count_nonzero(di > 0.5))}, max {di.max():.3f}")
+
+
 @pytest.mark.parametrize("rows,cols", SMALL)
 def test_warp_identity_is_exact(ctx, rows, cols):
     """Analytic KAT: identity transform => W1 == W0 wherever W0 is valid, I1 == I0 (exact bilinear at integer coords)."""
