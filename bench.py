@@ -319,7 +319,7 @@ def main():
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--levels", type=int, default=3)
     ap.add_argument("--graph", type=int, default=0, help="replay each step as one hipGraph (roofline events then need a 2nd pass)")
-    ap.add_argument("--fused", type=int, default=0)
+    ap.add_argument("--fused", type=int, default=1, help="1: one fused warp + residual + normal-equation kernel per GN iteration (engine default); 0: the reference's kernel sequence")
     ap.add_argument("--fast", type=int, default=1, help="engine numerics of the gather kernels: 1 = reference-build class (FMA contraction, v_rcp), 0 = IEEE-exact")
     ap.add_argument("--keyframes", type=int, default=2, help="per-lane capacity of the keyframe export ring: the outgoing keyframe is handed to the back-end at every switch, as trackNewFrame does (0 = no export)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -463,7 +463,9 @@ def main():
                              "note": "unit U3 (SURVEY 8d): algorithmic bytes of one aligned frame x frames/s per GPU"} if headline else None),
             "roofline": {"bound": "hbm", "achieved": u1["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": u1["achieved"] / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_from": traffic_from,
-                         "kernel": "rgbid::k_build_system<ByLane<SysParams>, true, 0> (level-0 residual + 27-term normal equations)",
+                         "kernel": ("rgbid::k_build_system<ByLane<SysParams>, true, 0, 2>: level-0 Gauss-Newton evaluation, FUSED -- warp of the current frame (gathers) + residual rows + "
+                                    "27-term normal equations; reads the same 8 fp32 maps as unit U1 (6 keyframe-side streams + the 2 current-frame maps through the gathers), writes nothing"
+                                    if args.fused else "rgbid::k_build_system<ByLane<SysParams>, true, 0, 0> (level-0 residual + 27-term normal equations on stored W1 / I1)"),
                          "algorithmic_bytes_per_launch": u1["bytes_per_launch"], "launches_timed": u1["launches_timed"], "avg_launch_us": u1["avg_launch_us"],
                          "timed_in": u1["timed_in"]},
             "parity": res["parity"],

@@ -58,6 +58,8 @@ enum { RGBID_NO_FILTERS = 0, RGBID_FILTER_GRADS };
 /* bilinear filter of the intensity warp: exact fp32 weights, or the CUDA texture unit's 1.8
  * fixed-point weights (what the reference's tex2D computes; default) */
 enum { RGBID_INTERP_EXACT = 0, RGBID_INTERP_TEX8 = 1 };
+/* arithmetic class of the gather / filter kernels, see rgbid_ctx_set_numerics and rgbid_warp_pair */
+enum { RGBID_NUMERICS_EXACT = 0, RGBID_NUMERICS_FAST = 1 };
 
 /* ---- library / context ------------------------------------------------------------------- */
 const char* rgbid_version(void);
@@ -83,6 +85,11 @@ int rgbid_ctx_set_stream(rgbid_ctx* ctx, void* stream);
 int rgbid_ctx_set_async(rgbid_ctx* ctx, int async_on);       /* default 0: synchronous on return */
 int rgbid_ctx_set_interp_mode(rgbid_ctx* ctx, int mode);     /* default RGBID_INTERP_TEX8 */
 int rgbid_ctx_sync(rgbid_ctx* ctx);                          /* internal.h:456-457 sync() */
+/* Arithmetic class of the bridge calls that have two implementations (today: rgbid_bilateral_filter; rgbid_warp_pair takes it per call):
+ * RGBID_NUMERICS_EXACT (default) = the IEEE evaluation of the oracle, bit for bit; RGBID_NUMERICS_FAST = the reference BUILD's class of
+ * arithmetic (hardware reciprocal / exp2, FMA contraction -- what nvcc --prec-div=false, default fmad and __expf give the reference's own
+ * kernels, CMakeLists.txt:105, filters.cu:124).  The batched engine selects it with rgbid_engine_config.fast_numerics. */
+int rgbid_ctx_set_numerics(rgbid_ctx* ctx, int numerics);
 /* orders the context's stream after a hipEvent_t recorded on another stream (interop with the caller's framework streams) */
 int rgbid_ctx_wait_event(rgbid_ctx* ctx, void* hip_event);
 /* exhaustive device self-test of the kernels' exact reciprocal (csrc/common.h rcp_exact) against IEEE 1.0f/x over all 2^32 float
@@ -162,7 +169,6 @@ int rgbid_warp_intensity(rgbid_ctx*, const rgbid_img* src, const rgbid_img* dst,
  * arithmetic -- hardware reciprocal + FMA contraction, what nvcc --prec-div=false and default fmad give the reference's own kernels
  * (CMakeLists.txt:105) -- in which a coordinate within an ulp of a pixel boundary may select the neighbouring pixel (what the batched
  * engine runs by default, rgbid_engine_config.fast_numerics). */
-enum { RGBID_NUMERICS_EXACT = 0, RGBID_NUMERICS_FAST = 1 };
 int rgbid_warp_pair(rgbid_ctx*, const rgbid_img* src_iD, const rgbid_img* src_I, const rgbid_img* grid_iD, const rgbid_img* dst_iD, const rgbid_img* dst_I,
                     const float R_proj[9], const float t_proj[3], int numerics, float* ms);
 /* warpInvDepthWithTrafo3DWeighted :1021-1069 */

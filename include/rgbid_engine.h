@@ -35,7 +35,10 @@ typedef struct rgbid_engine_config {
   int interp_mode;
   float delta_t;             /* inter-frame time (0.03333 in eval mode, visodo.cpp:1931) */
   int use_graph;             /* replay each step as one hipGraph */
-  int fused_gn;              /* warp + residual + normal equations in one kernel (W1/I1 never stored) */
+  int fused_gn;              /* warp + residual + normal equations in ONE kernel per Gauss-Newton iteration: the warped maps W1 / I1 are
+                              * produced in registers and never stored (32 instead of 52 B/px of HBM traffic per iteration); default 1.
+                              * 0 = the reference's kernel sequence (warp pair, sigma/nu on the stored maps, normal equations).  Same results
+                              * bit for bit.  Ignored (0) with RGBID_WARP_FIRST, whose pyramid of WARPED maps must exist in memory. */
   int chi_square_stats;      /* also run the (unused-by-the-reference) full-res chi-square of visodo.cpp:1411-1415 */
   int preview;               /* also render the Phong preview (getImage, visodo.cpp:559-580) each step */
   int record_capacity;       /* steps of pose records kept on the device (ring) */

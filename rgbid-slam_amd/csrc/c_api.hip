@@ -121,6 +121,11 @@ int rgbid_ctx_set_interp_mode(rgbid_ctx* c, int mode) {
   c->interp_mode = mode;
   return RGBID_OK;
 }
+int rgbid_ctx_set_numerics(rgbid_ctx* c, int numerics) {
+  if (!c || (numerics != RGBID_NUMERICS_EXACT && numerics != RGBID_NUMERICS_FAST)) return RGBID_E_INVALID;
+  c->numerics = numerics;
+  return RGBID_OK;
+}
 int rgbid_ctx_sync(rgbid_ctx* c) { if (!c) return RGBID_E_INVALID; RGBID_HIP(hipStreamSynchronize(c->stream)); return RGBID_OK; }
 namespace {
 __global__ __launch_bounds__(256) void k_selftest_rcp(unsigned long long* mismatches) {
@@ -344,7 +349,7 @@ int rgbid_pyr_down(rgbid_ctx* c, const rgbid_img* src, const rgbid_img* dst, flo
 int rgbid_bilateral_filter(rgbid_ctx* c, const rgbid_img* src, const rgbid_img* dst, float sigma_floatmap, float* ms) {
   if (!c || !ok_img(src) || !ok_img(dst) || !same_size(src, dst) || src->data == dst->data) return RGBID_E_INVALID;
   Timed t(c, ms);
-  launch_bilateral(c->stream, 1, B1(src), B1(dst), sigma_floatmap, ALL);
+  launch_bilateral(c->stream, 1, B1(src), B1(dst), sigma_floatmap, ALL, c->numerics == RGBID_NUMERICS_FAST);
   return t.finish();
 }
 

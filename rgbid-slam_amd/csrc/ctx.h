@@ -11,6 +11,7 @@ struct rgbid_ctx {
   bool owns_stream = false;
   int async = 0;
   int interp_mode = 1;
+  int numerics = 0;            // RGBID_NUMERICS_EXACT / _FAST for the bridge calls that have a fast variant
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   void* small_dev = nullptr;   // ctx_small_bytes of device scratch
   void* small_host = nullptr;  // pinned mirror

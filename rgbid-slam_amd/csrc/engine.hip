@@ -595,8 +595,8 @@ void enqueue_save_odo_kf(rgbid_engine* e, hipStream_t s) {
     launch_copy_bytes(s, B, e->I_curr[i], e->I_kf[i], 4, m);
     e->launches += 2;
   }
-  launch_bilateral(s, B, e->iD_kf[0], e->iD_kf_f[0], 2.f * 0.0025f, m);
-  launch_bilateral(s, B, e->I_kf[0], e->I_kf_f[0], 3.f, m);
+  launch_bilateral(s, B, e->iD_kf[0], e->iD_kf_f[0], 2.f * 0.0025f, m, e->cfg.fast_numerics != 0);
+  launch_bilateral(s, B, e->I_kf[0], e->I_kf_f[0], 3.f, m, e->cfg.fast_numerics != 0);
   launch_gradient(s, B, e->I_kf_f[0], e->gxI_c[0], e->gyI_c[0], m);
   launch_gradient(s, B, e->iD_kf_f[0], e->gxD_c[0], e->gyD_c[0], m);
   e->launches += 4;
@@ -815,7 +815,7 @@ void rgbid_engine_default_config(rgbid_engine_config* c) {
   c->fx = 525.f; c->fy = 525.f; c->cx = 319.5f; c->cy = 239.5f; c->factor_depth = 1.f;   // calibration_factory.ini
   c->interp_mode = RGBID_INTERP_TEX8;
   c->delta_t = 0.03333f;
-  c->use_graph = 1; c->fused_gn = 0; c->chi_square_stats = 0; c->preview = 0;
+  c->use_graph = 1; c->fused_gn = 1; c->chi_square_stats = 0; c->preview = 0;
   c->record_capacity = 64;
   c->warping = RGBID_PYR_FIRST;
   c->keyframe_capacity = 0;
@@ -828,12 +828,13 @@ int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_c
   if (cfg->rows <= 0 || cfg->cols <= 0 || cfg->levels < 1 || cfg->levels > MAXL || cfg->lanes < 1 || cfg->finest_level < 0 ||
       cfg->finest_level >= cfg->levels || (cfg->rows >> (cfg->levels - 1)) < 4 || (cfg->cols >> (cfg->levels - 1)) < 4 ||
       cfg->record_capacity < 1 || (cfg->warping != RGBID_PYR_FIRST && cfg->warping != RGBID_WARP_FIRST) ||
-      (cfg->warping == RGBID_WARP_FIRST && cfg->fused_gn) || cfg->keyframe_capacity < 0 ||
+      cfg->keyframe_capacity < 0 ||
       cfg->cols > (1 << 20) || (unsigned long long)cfg->rows * 3ull * (((unsigned long long)cfg->cols * 4 + 255) & ~255ull) >= (1ull << 32))  // 24-bit row-offset arithmetic (common.h row_ptr)
     return RGBID_E_INVALID;
   rgbid_engine* e = new (std::nothrow) rgbid_engine();
   if (!e) return RGBID_E_NOMEM;
   e->ctx = ctx; e->cfg = *cfg; e->B = cfg->lanes; e->L = cfg->levels;
+  if (cfg->warping == RGBID_WARP_FIRST) e->cfg.fused_gn = 0;   // warp-first pyramids the WARPED maps: they must exist in memory
   hipSetDevice(ctx->device);
   const int B = e->B, rows = cfg->rows, cols = cfg->cols;
   int r = RGBID_OK;
@@ -858,7 +859,7 @@ int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_c
     if (!r) r = alloc_dev(e, (void**)&e->res_D, sizeof(float) * (size_t)rows * cols * B);
     if (!r) r = alloc_dev(e, (void**)&e->chi_out, sizeof(float) * 3 * B);
   }
-  if (cfg->fused_gn && cfg->sigma_estimator == RGBID_SIGMA_PDF) {
+  if (e->cfg.fused_gn && cfg->sigma_estimator == RGBID_SIGMA_PDF) {
     for (int l = 0; l < e->L; ++l) { size_t n = (size_t)lattice_samples(rows >> l, cols >> l, cfg->nsamples); if (n > e->lat_cap) e->lat_cap = n; }
     if (!r) r = alloc_dev(e, (void**)&e->lat_res, sizeof(float) * 2 * e->lat_cap * B);
   }

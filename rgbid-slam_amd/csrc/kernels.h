@@ -47,7 +47,7 @@ void launch_prep_frame(hipStream_t s, int B, ImgB depth_u16, ImgB rgb, ImgB iD, 
 void launch_copy_bytes(hipStream_t s, int B, ImgB src, ImgB dst, int elem_size, LaneMask m);  // row-wise D2D copy kernel
 void launch_fill(hipStream_t s, int B, ImgB dst, int elem_size, uint32_t bits, LaneMask m);
 void launch_pyr_down(hipStream_t s, int B, ImgB src, ImgB dst, LaneMask m);
-void launch_bilateral(hipStream_t s, int B, ImgB src, ImgB dst, float sigma_floatmap, LaneMask m);
+void launch_bilateral(hipStream_t s, int B, ImgB src, ImgB dst, float sigma_floatmap, LaneMask m, bool fast = false);
 bool div_const_verified(float c);   // constants for which the bilateral filter uses the short exact division
 void launch_selftest_div_const(hipStream_t s, float c, unsigned long long* mismatches_dev);
 

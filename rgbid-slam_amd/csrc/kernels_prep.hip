@@ -443,8 +443,29 @@ __device__ __forceinline__ float bilateral_px(const float (*tile)[TX + 2 * BR + 
     }
   return sum1 / sum2;
 }
-template <bool FAST>
+// reference-build-class numerics (engine fast_numerics / rgbid_ctx_set_numerics): the reference's own tap weight is
+// __expf(-(space2 / 50 + 0.5 fn^2)) = ex2.approx(log2e * arg) (filters.cu:124 under nvcc's fast exp); here the same exponent is formed with
+// the constants folded -- arg2 = c_space[dy][dx] + k d^2, k = 0.5 log2e / sigma^2 -- and handed to v_exp_f32: 8 instructions per tap
+// instead of ~50 (exact division, double-precision exponent, full-range expf), results within a few 1e-7 relative of the exact kernel.
+__device__ __forceinline__ float bilateral_px_fast(const float (*tile)[TX + 2 * BR + 1], int ty, int tx, float value, float k, float cs) {
+  float sum1 = value, sum2 = 1.f;   // centre tap: weight exp(-0) = 1
+#pragma unroll
+  for (int dy = -BR; dy <= BR; ++dy)
+#pragma unroll
+    for (int dx = -BR; dx <= BR; ++dx) {
+      if (dx == 0 && dy == 0) continue;
+      const float tmp = tile[ty + dy][tx + dx];
+      const float d = value - tmp;
+      const float w = __builtin_amdgcn_exp2f(-__builtin_fmaf(k * d, d, cs * (float)(dx * dx + dy * dy)));
+      const bool ok = tmp == tmp;
+      sum1 = __builtin_fmaf(ok ? tmp : 0.f, ok ? w : 0.f, sum1);
+      sum2 += ok ? w : 0.f;
+    }
+  return sum1 * __builtin_amdgcn_rcpf(sum2);
+}
+template <int MODE>   // 0: IEEE division per tap, 1: the verified 3-instruction exact division, 2: reference-build-class numerics
 __global__ __launch_bounds__(256) void k_bilateral(ImgB src, ImgB dst, float sigma_floatmap, DivConst dc, LaneMask m) {
+  constexpr bool FAST = MODE == 1;
   int lane = blockIdx.z;
   if (!m.on(lane)) return;
   __shared__ float tile[TY + 2 * BR][TX + 2 * BR + 1];
@@ -469,7 +490,10 @@ __global__ __launch_bounds__(256) void k_bilateral(ImgB src, ImgB dst, float sig
     const float value = tile[threadIdx.y + BR][threadIdx.x + BR];
     if (isnan(value)) { px<float>(dst, lane, y, x) = qnan(); continue; }
     float res;
-    if (FAST) {
+    if (MODE == 2) {
+      const float log2e = 1.44269504088896341f;
+      res = bilateral_px_fast(tile, threadIdx.y + BR, threadIdx.x + BR, value, 0.5f * log2e / (sigma_floatmap * sigma_floatmap), s2ih * log2e);
+    } else if (FAST) {
       bool all_ok = true;
       res = bilateral_px<true>(tile, threadIdx.y + BR, threadIdx.x + BR, value, sigma_floatmap, dc, s2ih, all_ok);
       if (__builtin_expect(!all_ok, 0)) res = bilateral_px<false>(tile, threadIdx.y + BR, threadIdx.x + BR, value, sigma_floatmap, dc, s2ih, all_ok);
@@ -483,10 +507,12 @@ __global__ __launch_bounds__(256) void k_bilateral(ImgB src, ImgB dst, float sig
 // constants whose 3-instruction division has been verified exhaustively (rgbid_selftest_div_const in the GPU tests): the tracker's two
 // range sigmas, 2 * 0.0025 (inverse depth) and 3 (intensity), visodo.cpp:843-844
 bool div_const_verified(float c) { return c == 2.f * 0.0025f || c == 3.f; }
-void launch_bilateral(hipStream_t s, int B, ImgB src, ImgB dst, float sigma_floatmap, LaneMask m) {
+void launch_bilateral(hipStream_t s, int B, ImgB src, ImgB dst, float sigma_floatmap, LaneMask m, bool fast) {
   const DivConst dc{sigma_floatmap, 1.0f / sigma_floatmap};
-  if (div_const_verified(sigma_floatmap)) hipLaunchKernelGGL(k_bilateral<true>, dim3(div_up(src.cols, TX), div_up(src.rows, TY * BIL_TILES), B), dim3(TX, TY), 0, s, src, dst, sigma_floatmap, dc, m);
-  else hipLaunchKernelGGL(k_bilateral<false>, dim3(div_up(src.cols, TX), div_up(src.rows, TY * BIL_TILES), B), dim3(TX, TY), 0, s, src, dst, sigma_floatmap, dc, m);
+  const dim3 g(div_up(src.cols, TX), div_up(src.rows, TY * BIL_TILES), B), b(TX, TY);
+  if (fast) hipLaunchKernelGGL(k_bilateral<2>, g, b, 0, s, src, dst, sigma_floatmap, dc, m);
+  else if (div_const_verified(sigma_floatmap)) hipLaunchKernelGGL(k_bilateral<1>, g, b, 0, s, src, dst, sigma_floatmap, dc, m);
+  else hipLaunchKernelGGL(k_bilateral<0>, g, b, 0, s, src, dst, sigma_floatmap, dc, m);
 }
 // exhaustive check of div_const_fast for one constant: every x whose fast result is flagged ok must equal x / c bit for bit (a zero result
 // only up to its sign); returns the number of violations over all 2^32 bit patterns of x

@@ -131,42 +131,45 @@ void launch_warp_pair(hipStream_t s, int B, ImgB src_iD, ImgB src_I, ImgB grid, 
 // 1-D grid, XCD-contiguous tile order (TileMap): a lane's tiles run on one XCD, so neighbouring tiles share their gather footprints in L2.
 // Per thread: x fixed, RPB rows TY apart -- the ray q = R (x, y, 1) is formed once (6 FMAs) and stepped down the rows with 3 adds, and it
 // serves BOTH projections of every pixel (iD warp with the keyframe inverse depth, intensity warp with the warped inverse depth).
-// Geometry: a workgroup is 16 x 16 threads over a 64 x 16 pixel tile, a thread owns 4 CONSECUTIVE pixels of one row -- the keyframe inverse
-// depth arrives in one 16-byte load, both results leave in one 16-byte store each, and the bilinear taps are two 8-byte loads per pixel:
-// 15 vector-memory instructions per 4 pixels instead of 32.  That count is what bounds a gather kernel on this chip: the texture
-// addresser takes 16 clocks per wave64 instruction (4 lanes per clock) whatever the access width -- the scalar-access version of this kernel
-// ran 626 us per 512-lane launch with 40 % fewer VALU instructions than the exact kernel, with or without its cache over-fetch.
+// Geometry as the exact kernel (lane <-> pixel: a wave covers 64 consecutive pixels of a row, RPB rows TY apart per thread): measured against
+// a 4-consecutive-pixels-per-thread layout with 16-byte grid loads / stores (15 instead of 32 vector-memory instructions per 4 pixels) this is
+// 15 % FASTER -- a gather instruction whose 64 lanes sit on consecutive pixels touches 2-3 cache lines, strided lanes touch 8-12.
 template <class PS>
 __global__ __launch_bounds__(256) void k_warp_pair_fast(ImgB src_iD, ImgB src_I, ImgB grid, ImgB dst_iD, ImgB dst_I, PS ps, int interp_mode, LaneMask m, TileMap tm) {
   const TileId t = tm.tile(blockIdx.x);
   const int lane = t.lane;
   if (!m.on(lane)) return;
-  const int x = t.bx * 64 + threadIdx.x * 4, y = t.by * 16 + threadIdx.y;
-  if (x >= dst_iD.cols || y >= dst_iD.rows) return;
+  const int x = t.bx * TX + threadIdx.x;
   const WarpParams P = ps.get(lane);
   const FMap SD(src_iD, lane), SI(src_I, lane), G(grid, lane);
   const FMapW DW(dst_iD, lane), DI(dst_I, lane);
-  const float4 g4 = G.at4(y, x);
-  const float wv[4] = {g4.x, g4.y, g4.z, g4.w};
-  float w1[4], i1[4];
-  fastnum::Ray q[4];
-  q[0] = fastnum::ray(P, (float)x, (float)y);
+  if (x >= dst_iD.cols) return;
+  const int yb = t.by * (TY * RPB) + threadIdx.y;
+  float wv[RPB], w1[RPB], i1[RPB];
 #pragma unroll
-  for (int i = 1; i < 4; ++i) q[i] = fastnum::ray_step(q[i - 1], P.R[0], P.R[3], P.R[6]);
+  for (int i = 0; i < RPB; ++i) { int y = yb + i * TY; wv[i] = (y < dst_iD.rows) ? G.at(y, x) : qnan(); }
+  // the ray of a pixel is DEFINED as: evaluated at the first pixel of its 4-pixel group, stepped along x (so that this kernel, the fused
+  // normal-equation kernel -- which owns whole groups -- and the sigma / nu lattice agree bit for bit)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) w1[i] = fastnum::warp_invdepth_px(SD, q[i], wv[i], P);
+  for (int i = 0; i < RPB; ++i) {
+    fastnum::Ray q = fastnum::ray(P, (float)(x & ~3), (float)(yb + i * TY));
+    for (int k = 0; k < (x & 3); ++k) q = fastnum::ray_step(q, P.R[0], P.R[3], P.R[6]);
+    w1[i] = fastnum::warp_invdepth_px(SD, q, wv[i], P);
+    i1[i] = fastnum::warp_intensity_px(SI, q, w1[i], P, interp_mode);
+  }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) i1[i] = fastnum::warp_intensity_px(SI, q[i], w1[i], P, interp_mode);
-  DW.store4(y, x, make_float4(w1[0], w1[1], w1[2], w1[3]));
-  DI.store4(y, x, make_float4(i1[0], i1[1], i1[2], i1[3]));
+  for (int i = 0; i < RPB; ++i) {
+    int y = yb + i * TY;
+    if (y < dst_iD.rows) { DW.store(y, x, w1[i]); DI.store(y, x, i1[i]); }
+  }
 }
 bool launch_warp_pair_fast(hipStream_t s, int B, ImgB src_iD, ImgB src_I, ImgB grid, ImgB dst_iD, ImgB dst_I, const WarpParams* hp, const WarpParams* lp, int interp_mode, LaneMask m) {
-  // 16-byte rows on the grid / output side, at least two columns for the paired bilinear taps; otherwise the caller runs the exact kernel
-  if (!(vec4_ok(grid) && vec4_ok(dst_iD) && vec4_ok(dst_I)) || src_I.cols < 2) return false;
+  if (src_I.cols < 2) return false;   // the paired bilinear taps need two columns; the caller runs the exact kernel
+  dim3 g = grid2d(dst_iD.cols, dst_iD.rows, B);
   TileMap tm;
-  if (!make_tile_map(div_up(dst_iD.cols, 64), div_up(dst_iD.rows, 16), B, &tm)) return false;
-  if (lp) hipLaunchKernelGGL(k_warp_pair_fast<ByLane<WarpParams>>, dim3(tm.n), dim3(16, 16), 0, s, src_iD, src_I, grid, dst_iD, dst_I, ByLane<WarpParams>{lp}, interp_mode, m, tm);
-  else hipLaunchKernelGGL(k_warp_pair_fast<ByValue<WarpParams>>, dim3(tm.n), dim3(16, 16), 0, s, src_iD, src_I, grid, dst_iD, dst_I, ByValue<WarpParams>{*hp}, interp_mode, m, tm);
+  if (!make_tile_map((int)g.x, (int)g.y, B, &tm)) return false;
+  if (lp) hipLaunchKernelGGL(k_warp_pair_fast<ByLane<WarpParams>>, dim3(tm.n), dim3(TX, TY), 0, s, src_iD, src_I, grid, dst_iD, dst_I, ByLane<WarpParams>{lp}, interp_mode, m, tm);
+  else hipLaunchKernelGGL(k_warp_pair_fast<ByValue<WarpParams>>, dim3(tm.n), dim3(TX, TY), 0, s, src_iD, src_I, grid, dst_iD, dst_I, ByValue<WarpParams>{*hp}, interp_mode, m, tm);
   return true;
 }
 

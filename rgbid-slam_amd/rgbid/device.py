@@ -89,6 +89,9 @@ class Context:
     def set_interp_mode(self, mode):
         check(self.L.rgbid_ctx_set_interp_mode(self._h, int(mode)))
 
+    def set_numerics(self, fast):
+        check(self.L.rgbid_ctx_set_numerics(self._h, 1 if fast else 0))
+
     def sync(self):
         check(self.L.rgbid_ctx_sync(self._h))
 

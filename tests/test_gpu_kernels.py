@@ -102,6 +102,25 @@ def test_bilateral(ctx, rows, cols, sigma):
     assert_bits(dst.cpu().numpy(), O.bilateral(src, sigma), 8, "bilateral")
 
 
+@pytest.mark.parametrize("rows,cols", SIZES)
+@pytest.mark.parametrize("sigma", [2.0 * 0.0025, 3.0])
+def test_bilateral_fast_numerics(ctx, rows, cols, sigma):
+    """rgbid_ctx_set_numerics(FAST): the bilateral filter in the reference build's class of arithmetic (v_exp_f32 on a folded exponent, what
+    __expf is on the reference's GPU) agrees with the IEEE oracle to 2e-6 relative, with the same NaN pattern"""
+    r = util.rng(5)
+    src = util.rand_invdepth(r, rows, cols, nan_frac=0.05) if sigma < 1 else util.rand_intensity(r, rows, cols)
+    dst = new(rows, cols)
+    ctx.set_numerics(True)
+    try:
+        ctx.bilateralFilter(dev(src), dst, sigma)
+    finally:
+        ctx.set_numerics(False)
+    got, ref = dst.cpu().numpy(), O.bilateral(src, sigma)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    m = ~np.isnan(ref)
+    assert (np.abs(got[m] - ref[m]) <= 2e-6 * np.abs(ref[m]) + 1e-30).all(), float((np.abs(got[m] - ref[m]) / np.abs(ref[m])).max())
+
+
 def _warp_case(rows, cols, seed, trans=0.03, rot=1.5):
     r = util.rng(seed)
     K = K_for(rows, cols)
