@@ -303,12 +303,28 @@ __global__ __launch_bounds__(SYS_T) __attribute__((amdgpu_waves_per_eu(FUSED == 
 
 static inline bool vec_ok(const ImgB& a) { return ((a.pitch & 15) == 0) && ((a.lane_stride & 15) == 0) && ((((uintptr_t)a.base) & 15) == 0); }
 
+// compute units of the current device (hipDeviceProp_t::multiProcessorCount), cached per device id
+static int device_cus() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!cus[dev]) {
+    int n = 0;
+    cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cus[dev];
+}
+
 // launch plan: units per thread (upt) and workgroups per lane.  The grid is sized to whole "rounds" of the
-// chip's resident capacity (256 CUs x 5 workgroups of 4 waves at <=102 VGPRs) so there is no partially
-// filled tail round; a thread's fp32 partial sums run over at most 16 units (64 px).
+// chip's resident capacity (its compute units x the 4-wave workgroups one CU holds: 5 at <= 102 VGPRs, 4 for the
+// fused fast kernel's 128) so there is no partially filled tail round; a thread's fp32 partial sums run over at most
+// 16 units (64 px).  The plan depends on the geometry and the device only -- never on the kernel variant -- so that
+// every variant sums the same pixels in the same order (fused and unfused results are bit-identical); 5 workgroups
+// per CU divides evenly into the 4-per-CU case for the shipped geometries (10 240 workgroups = 8 rounds of 1 280 =
+// 10 rounds of 1 024 on 256 CUs).
 static void system_plan(int rows, int cols, int B, bool vec, int* upt, int* nblk) {
   const long long units = vec ? (long long)rows * (cols / 4) : (long long)rows * cols;
-  const long long capacity = 256LL * 5;                      // resident workgroups
+  const long long capacity = (long long)device_cus() * 5;    // resident workgroups
   const long long max_upt = vec ? 16 : 64;
   long long rounds = (units * B + capacity * SYS_T * max_upt - 1) / (capacity * SYS_T * max_upt);
   long long nb = (rounds * capacity) / B;                    // workgroups per lane
