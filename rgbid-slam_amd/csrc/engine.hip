@@ -516,6 +516,7 @@ struct rgbid_engine {
   float *res_I = nullptr, *res_D = nullptr;
   float* lat_res = nullptr;        // fused path: residual lattice of both channels, [B][2 * lat_cap]
   size_t lat_cap = 0;
+  float* lat_kf[MAXL] = {};        // fused path: the odometry keyframe's side of each level's lattice (W0 | I0), [B][2 * lat_cap], packed at keyframe switches
   float* chi_out = nullptr;
   double* partials = nullptr;
   int nblk_cap = 0;
@@ -595,6 +596,8 @@ void enqueue_save_odo_kf(rgbid_engine* e, hipStream_t s) {
     launch_copy_bytes(s, B, e->I_curr[i], e->I_kf[i], 4, m);
     e->launches += 2;
   }
+  if (e->lat_res)
+    for (int i = 0; i < L; ++i) { launch_lattice_pack(s, B, e->iD_kf[i], e->I_kf[i], e->cfg.nsamples, e->lat_kf[i], 2 * e->lat_cap, m); e->launches++; }
   launch_bilateral(s, B, e->iD_kf[0], e->iD_kf_f[0], 2.f * 0.0025f, m, e->cfg.fast_numerics != 0);
   launch_bilateral(s, B, e->I_kf[0], e->I_kf_f[0], 3.f, m, e->cfg.fast_numerics != 0);
   launch_gradient(s, B, e->I_kf_f[0], e->gxI_c[0], e->gyI_c[0], m);
@@ -670,7 +673,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
       if (c.fused_gn) {
         if (c.sigma_estimator == RGBID_SIGMA_PDF) {
           launch_sigma_pair_fused(s, B, e->iD_curr[level], e->iD_kf[level], e->I_curr[level], e->I_kf[level], e->wp, c.interp_mode, c.nsamples,
-                                  e->sp, c.mestimator, M(f.gn), fast_at(level), e->lat_res, 2 * e->lat_cap);
+                                  e->sp, c.mestimator, M(f.gn), fast_at(level), e->lat_res, 2 * e->lat_cap, e->lat_kf[level], 2 * e->lat_cap);
           e->launches += 2;
         }
         if (prof) { set_system_kernel_events(e->prof_ev[e->prof_used], e->prof_ev[e->prof_used + 1]); e->prof_used += 2; }
@@ -862,6 +865,7 @@ int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_c
   if (e->cfg.fused_gn && cfg->sigma_estimator == RGBID_SIGMA_PDF) {
     for (int l = 0; l < e->L; ++l) { size_t n = (size_t)lattice_samples(rows >> l, cols >> l, cfg->nsamples); if (n > e->lat_cap) e->lat_cap = n; }
     if (!r) r = alloc_dev(e, (void**)&e->lat_res, sizeof(float) * 2 * e->lat_cap * B);
+    for (int l = 0; l < e->L; ++l) if (!r) r = alloc_dev(e, (void**)&e->lat_kf[l], sizeof(float) * 2 * e->lat_cap * B);
   }
   e->nblk_cap = system_blocks_per_lane(rows, cols, B);
   for (int l = 1; l < e->L; ++l) { int nb = system_blocks_per_lane(rows >> l, cols >> l, B); if (nb > e->nblk_cap) e->nblk_cap = nb; }

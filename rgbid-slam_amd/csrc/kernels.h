@@ -79,7 +79,10 @@ void launch_sigma(hipStream_t s, int B, int mode, const float* err, size_t err_l
 void launch_sigma_pair(hipStream_t s, int B, ImgB W1, ImgB W0, ImgB I1, ImgB I0, int min_nsamples, SysParams* sp, int mestimator, LaneMask m);
 // same, but W1 / I1 are produced on the fly from the current frame (fused engine path: they are never stored)
 void launch_sigma_pair_fused(hipStream_t s, int B, ImgB Wcur, ImgB W0, ImgB Icur, ImgB I0, const WarpParams* lane_wp, int interp_mode,
-                             int min_nsamples, SysParams* sp, int mestimator, LaneMask m, bool fast = false, float* res = nullptr, size_t res_lane_stride = 0);
+                             int min_nsamples, SysParams* sp, int mestimator, LaneMask m, bool fast = false, float* res = nullptr, size_t res_lane_stride = 0,
+                             const float* kf_lat = nullptr, size_t kf_lat_lane_stride = 0);
+// the keyframe side of a level's residual lattice packed as [lane][2][n] = W0 | I0 (once per keyframe; see k_lattice_residuals_fused)
+void launch_lattice_pack(hipStream_t s, int B, ImgB W0, ImgB I0, int min_nsamples, float* out, size_t out_lane_stride, LaneMask m);
 // samples of the residual lattice computeErrorGridStride takes for this geometry (scratch sizing: 2 * n floats per lane for `res` above)
 int lattice_samples(int rows, int cols, int min_nsamples);
 // out: device [B][3] = chi_square, chi_test, ndof

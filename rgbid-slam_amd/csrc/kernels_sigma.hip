@@ -418,8 +418,11 @@ struct FusedLatticeGetter {
   }
   // both channels of one lattice sample (the inverse-depth warp is shared)
   __device__ __forceinline__ void both(int ly, int lx, float& rd, float& ri) const {
+    both_given(ly, lx, px<float>(W0, lane, ly * stride, lx * stride), px<float>(I0, lane, ly * stride, lx * stride), rd, ri);
+  }
+  __device__ __forceinline__ void both_given(int ly, int lx, float w0, float i0v, float& rd, float& ri) const {
     int y = ly * stride, x = lx * stride;
-    float w0 = px<float>(W0, lane, y, x), i0v = px<float>(I0, lane, y, x), w1, i1;
+    float w1, i1;
     if (fast) {
       fastnum::Ray r = fastnum::ray(P, (float)(x & ~3), (float)y);
       for (int i = 0; i < (x & 3); ++i) r = fastnum::ray_step(r, P.R[0], P.R[3], P.R[6]);
@@ -457,8 +460,12 @@ __global__ __launch_bounds__(SIG_T) void k_sigma_pair_fused(NuTable T, ImgB Wcur
 // three dependent memory round trips (keyframe iD -> point sample -> bilinear taps) -- ~85 us of exposed latency per launch.  Here one
 // thread per lattice sample warps its pixel (9.8 M independent threads at 512 lanes: the latency hides behind occupancy) and parks both
 // residuals in res[lane][channel][n]; the sigma / nu kernel then reads them as plain coalesced arrays.
+// kf_lat (nullable): the keyframe side of the lattice, packed once per keyframe by k_lattice_pack -- [lane][2][n] = W0 | I0 at the lattice
+// points.  The lattice takes every stride-th pixel of every stride-th row, i.e. a quarter of the cache lines of each map it samples at
+// level 0; the two keyframe maps do not change between keyframes, so their samples are read here as two coalesced arrays instead.
 __global__ __launch_bounds__(256) void k_lattice_residuals_fused(ImgB Wcur, ImgB W0, ImgB Icur, ImgB I0, const WarpParams* wp, int interp_mode, int n, int lcols,
-                                                                 int stride, float* res, size_t res_lane_stride, LaneMask m, int fast) {
+                                                                 int stride, float* res, size_t res_lane_stride, const float* kf_lat, size_t kf_lat_lane_stride,
+                                                                 LaneMask m, int fast) {
   const int lane = blockIdx.y;
   if (!m.on(lane)) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -466,9 +473,29 @@ __global__ __launch_bounds__(256) void k_lattice_residuals_fused(ImgB Wcur, ImgB
   FusedLatticeGetter g{Wcur, Icur, W0, I0, wp[lane], lane, lcols, stride, 1, interp_mode, 0, 0, 0, 0, fast};
   const int ly = i / lcols, lx = i - ly * lcols;
   float rd, ri;
-  g.both(ly, lx, rd, ri);
+  if (kf_lat) {
+    const float* k = kf_lat + (size_t)lane * kf_lat_lane_stride;
+    g.both_given(ly, lx, k[i], k[n + i], rd, ri);
+  } else {
+    g.both(ly, lx, rd, ri);
+  }
   float* r = res + (size_t)lane * res_lane_stride;
   r[i] = rd; r[n + i] = ri;
+}
+__global__ __launch_bounds__(256) void k_lattice_pack(ImgB W0, ImgB I0, int n, int lcols, int stride, float* out, size_t out_lane_stride, LaneMask m) {
+  const int lane = blockIdx.y;
+  if (!m.on(lane)) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int ly = i / lcols, lx = i - ly * lcols;
+  float* o = out + (size_t)lane * out_lane_stride;
+  o[i] = px<float>(W0, lane, ly * stride, lx * stride);
+  o[n + i] = px<float>(I0, lane, ly * stride, lx * stride);
+}
+void launch_lattice_pack(hipStream_t s, int B, ImgB W0, ImgB I0, int min_nsamples, float* out, size_t out_lane_stride, LaneMask m) {
+  int n, lr, lc, st;
+  lattice_geometry(W0.rows, W0.cols, min_nsamples, &n, &lr, &lc, &st);
+  hipLaunchKernelGGL(k_lattice_pack, dim3(div_up(n, 256), B), dim3(256), 0, s, W0, I0, n, lc, st, out, out_lane_stride, m);
 }
 template <bool REG>
 __global__ __launch_bounds__(SIG_T) void k_sigma_pair_arrays(NuTable T, const float* res, size_t res_lane_stride, int n, SysParams* sp, int mestimator, LaneMask m) {
@@ -491,12 +518,14 @@ int lattice_samples(int rows, int cols, int min_nsamples) {
 }
 
 void launch_sigma_pair_fused(hipStream_t s, int B, ImgB Wcur, ImgB W0, ImgB Icur, ImgB I0, const WarpParams* lane_wp, int interp_mode,
-                             int min_nsamples, SysParams* sp, int mestimator, LaneMask m, bool fast, float* res, size_t res_lane_stride) {
+                             int min_nsamples, SysParams* sp, int mestimator, LaneMask m, bool fast, float* res, size_t res_lane_stride,
+                             const float* kf_lat, size_t kf_lat_lane_stride) {
   int n, lr, lc, st;
   lattice_geometry(W0.rows, W0.cols, min_nsamples, &n, &lr, &lc, &st);
   const int f = (fast && Icur.cols >= 2) ? 1 : 0;
   if (res && res_lane_stride >= 2 * (size_t)n) {
-    hipLaunchKernelGGL(k_lattice_residuals_fused, dim3(div_up(n, 256), B), dim3(256), 0, s, Wcur, W0, Icur, I0, lane_wp, interp_mode, n, lc, st, res, res_lane_stride, m, f);
+    hipLaunchKernelGGL(k_lattice_residuals_fused, dim3(div_up(n, 256), B), dim3(256), 0, s, Wcur, W0, Icur, I0, lane_wp, interp_mode, n, lc, st, res, res_lane_stride,
+                       kf_lat_lane_stride >= 2 * (size_t)n ? kf_lat : nullptr, kf_lat_lane_stride, m, f);
     if (n <= SIG_T * SIG_MAXPT)
       hipLaunchKernelGGL(k_sigma_pair_arrays<true>, dim3(B, 2), dim3(SIG_T), 0, s, nu_table(), res, res_lane_stride, n, sp, mestimator, m);
     else
