@@ -8,6 +8,7 @@
 // frame), runs ALL iterations in-kernel (moments -> wave64 shuffle reduction -> LDS across 16 waves ->
 // broadcast), evaluates digamma on the device, and writes (bias, sigma, nu): one launch, no host trips.
 #include "kernels.h"
+#include <cstdlib>
 #include "warp_device.h"
 #include <type_traits>
 
@@ -457,7 +458,8 @@ __global__ __launch_bounds__(SIG_T) void k_sigma_pair_fused(NuTable T, ImgB Wcur
   }
 }
 // The same in two kernels: the register path of k_sigma_pair_fused walks its <= 19 samples per thread one after the other, each through
-// three dependent memory round trips (keyframe iD -> point sample -> bilinear taps) -- ~85 us of exposed latency per launch.  Here one
+// three dependent memory round trips (keyframe iD -> point sample -> bilinear taps) -- ~85 us of exposed latency per launch (batching the
+// round trips over 3 samples inside one kernel, the most 64 VGPRs allow: 190 us, no better than the pair below).  Here one
 // thread per lattice sample warps its pixel (9.8 M independent threads at 512 lanes: the latency hides behind occupancy) and parks both
 // residuals in res[lane][channel][n]; the sigma / nu kernel then reads them as plain coalesced arrays.
 // kf_lat (nullable): the keyframe side of the lattice, packed once per keyframe by k_lattice_pack -- [lane][2][n] = W0 | I0 at the lattice
