@@ -378,7 +378,12 @@ def main():
         import torch.distributed as dist
         dist.barrier()            # brings torch's communicator up (and RCCL's banner out) before anything is timed or printed
         if dist_env["comm"] is not None:
-            dist_env["comm"].barrier()
+            try:
+                dist_env["comm"].barrier()    # first collective of the C-ABI communicator, outside every timed region
+            except Exception as e:
+                sys.stderr.write(f"[bench] WARNING: C-ABI RCCL communicator failed at its first collective ({e}); gathering through torch.distributed\n")
+                gather_how = f"torch.distributed all_gather_into_tensor (nccl = RCCL) -- C-ABI RCCL helper FAILED: {e}"
+                dist_env["comm"] = None
         flush_c_stdio()
     res, keep = run_config(ctx, dev, work, rows, cols, args.levels, iters, B, Kst, W, max(1, args.reps), args.streams, args.graph, args.fused,
                            args.keyframes, K, dist_env, check_streams=args.check_streams if rank == 0 else 0, fast_numerics=args.fast)

@@ -6,7 +6,7 @@
 
 Frames are read with the product's own dataset reader (librgbid_host.so: association files, 16-bit PNG depth x0.2 -> mm), the
 sequence is cut into `chunks` contiguous chunks with one frame of overlap, every chunk is one lane of a rank's engine, ranks exchange
-pose records only (one all_gather over RCCL), rank 0 writes the trajectory in the TUM format (`stamp tx ty tz qx qy qz qw`)."""
+the 392-byte per-frame records only (one all-gather over RCCL through librgbid_dist.so), rank 0 writes the trajectory in the TUM format (`stamp tx ty tz qx qy qz qw`)."""
 import argparse
 import os
 import sys
@@ -61,8 +61,17 @@ def main():
     ctx.set_async(1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    R, t, ranges = sequence.track_chunked(ctx, depth, rgb, args.chunks, tuple(args.K), use_graph=0)
+    comm = None
+    if use_dist:
+        from rgbid import dist as D
+        try:
+            comm = D.Comm(ctx, world, rank)          # the C-ABI RCCL helper (librgbid_dist.so); the id travels through torch's store
+        except Exception as e:                       # transport problem: say so, gather through torch.distributed instead
+            sys.stderr.write(f"[track_dataset] WARNING: C-ABI RCCL communicator failed ({e}); gathering through torch.distributed\n")
+    R, t, ranges = sequence.track_chunked(ctx, depth, rgb, args.chunks, tuple(args.K), comm=comm, use_graph=0)
     el = time.perf_counter() - t0
+    if comm is not None:
+        comm.close()
     if rank == 0:
         tum.write_trajectory(args.out, stamps, R, t)
         print(f"{len(frames)} frames in {args.chunks} chunks on {world} GPU(s): {el:.3f} s ({len(frames) / el:.1f} frames/s incl. engine set-up) -> {args.out}")
