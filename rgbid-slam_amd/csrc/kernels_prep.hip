@@ -3,6 +3,7 @@
 // the reference (citations per kernel).  Geometry is CDNA4-native: 256-thread workgroups shaped
 // 64x4 so each wave64 covers one 256-byte row segment (fully coalesced), blockIdx.z = lane.
 #include "kernels.h"
+#include "warp_device.h"
 
 // Whole file: no FMA contraction, so every fp32 expression is evaluated operation by operation exactly
 // like the scalar oracle (divisions/sqrt are IEEE by hipcc default).  These kernels are bandwidth-bound.
@@ -363,50 +364,66 @@ static const PyrWeights& pyr_weights() {
 // A thread owns one output column and walks PD_ROWS output rows downwards, keeping the 5x5 source window in registers
 // (two new source rows = ten cached loads per output; out-of-image taps become NaN).  No LDS, no barriers.
 static constexpr int PD_ROWS = 8;
-// a source row of the window: value sanitised to 0 and validity as 0/1, so a tap is `sum1 += v * w; sum2 += m * w; count += m`
-// (adding +0 for an invalid tap leaves the sums bit-identical to skipping it: they start at +0 and can never become -0)
-__device__ __forceinline__ void pyr_load_row(const ImgB& src, int lane, int cy, const int cx[5], const bool cin[5], float r[5], float mk[5]) {
-  const bool row_in = cy >= 0 && cy < src.rows;
-  const float* rp = row_ptr<float>(src, lane, row_in ? cy : 0);
+// a source row of the window: value sanitised to 0 and validity both as 0/1 float (weight sum) and 0/1 int (count), so a tap is
+// `sum1 += v * w; sum2 = fma(m, w, sum2); count += mi` (adding +0 for an invalid tap leaves the sums bit-identical to skipping it: they
+// start at +0 and can never become -0; m * w is exact, so the explicit FMA equals the reference's multiply-then-add bit for bit)
+// Loads: the five columns 2x-2 .. 2x+2 of a window row arrive as THREE 8-byte loads at the even columns 2x-2, 2x, 2x+2 (raw buffer
+// descriptor, 32-bit byte offsets) -- the kernel is bound by its vector-memory instruction count (stride-2 lanes: every load instruction
+// touches 4-5 cache lines), 6 instead of 10 per output.  A column outside the image is never used (cin), so the pair at 2x-2 is simply
+// moved to column 0 for x = 0 and the unused upper half of the pair at 2x+2 may lie beyond the row (inside the descriptor, or 0 beyond it).
+__device__ __forceinline__ void pyr_load_row(const FMap& S, int rows, int cy, const unsigned cxb[3], const bool cin[5], float r[5], float mk[5], int mi[5]) {
+  const bool row_in = cy >= 0 && cy < rows;
+  const unsigned rb = S.row(row_in ? cy : 0);
+  const float2 p0 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(S.rsrc, rb + cxb[0], 0, 0));
+  const float2 p1 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(S.rsrc, rb + cxb[1], 0, 0));
+  const float2 p2 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(S.rsrc, rb + cxb[2], 0, 0));
+  const float v[5] = {p0.x, p0.y, p1.x, p1.y, p2.x};
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
-    float v = rp[cx[i]];
-    bool ok = row_in && cin[i] && !isnan(v);
-    r[i] = ok ? v : 0.f;
+    bool ok = row_in && cin[i] && !isnan(v[i]);
+    r[i] = ok ? v[i] : 0.f;
     mk[i] = ok ? 1.f : 0.f;
+    mi[i] = ok ? 1 : 0;
   }
 }
+// The row loop is fully unrolled (PD_ROWS outputs, rows past the image predicated off): the 5-row window then lives in renamed registers --
+// the rolled loop spent 30 of its ~185 instructions per output on v_mov copies of the three rows it keeps.
 __global__ __launch_bounds__(256) void k_pyr_down_roll(ImgB src, ImgB dst, PyrWeights W, int strips, LaneMask m) {
   int lane = blockIdx.y;
   if (!m.on(lane)) return;
   int u = blockIdx.x * 256 + threadIdx.x;
   if (u >= dst.cols * strips) return;
   int strip = u / dst.cols, x = u - strip * dst.cols;
-  int y_begin = strip * PD_ROWS, y_end = min(y_begin + PD_ROWS, dst.rows);
-  int cx[5]; bool cin[5];
+  const int y_begin = strip * PD_ROWS;
+  const FMap S(src, lane);
+  bool cin[5];
 #pragma unroll
-  for (int i = 0; i < 5; ++i) { int c = 2 * x - 2 + i; cin[i] = c >= 0 && c < src.cols; cx[i] = min(max(c, 0), src.cols - 1); }
-  float win[5][5], msk[5][5];  // source rows 2y-2 .. 2y+2
+  for (int i = 0; i < 5; ++i) { int c = 2 * x - 2 + i; cin[i] = c >= 0 && c < src.cols; }
+  const unsigned cx[3] = {(unsigned)max(2 * x - 2, 0) << 2, (unsigned)(2 * x) << 2, (unsigned)(2 * x + 2) << 2};   // byte offsets of the three column pairs
+  // window rows: slot (2j + r) of a ring over the source rows 2y_begin - 2 ...; all indices are compile-time after unrolling
+  float win[2 * PD_ROWS + 3][5], msk[2 * PD_ROWS + 3][5];
+  int mki[2 * PD_ROWS + 3][5];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) pyr_load_row(src, lane, 2 * y_begin - 2 + r, cx, cin, win[r + 2], msk[r + 2]);
-  for (int y = y_begin; y < y_end; ++y) {
+  for (int r = 0; r < 3; ++r) pyr_load_row(S, src.rows, 2 * y_begin - 2 + r, cx, cin, win[r], msk[r], mki[r]);
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+  for (int j = 0; j < PD_ROWS; ++j) {
+    const int y = y_begin + j;
+    if (y < dst.rows) {   // wave-uniform except in a strip's last rows
+      pyr_load_row(S, src.rows, 2 * y + 1, cx, cin, win[2 * j + 3], msk[2 * j + 3], mki[2 * j + 3]);
+      pyr_load_row(S, src.rows, 2 * y + 2, cx, cin, win[2 * j + 4], msk[2 * j + 4], mki[2 * j + 4]);
+      float sum1 = 0.f, sum2 = 0.f;
+      int count = 0;
 #pragma unroll
-      for (int i = 0; i < 5; ++i) { win[r][i] = win[r + 2][i]; msk[r][i] = msk[r + 2][i]; }
-    pyr_load_row(src, lane, 2 * y + 1, cx, cin, win[3], msk[3]);
-    pyr_load_row(src, lane, 2 * y + 2, cx, cin, win[4], msk[4]);
-    float sum1 = 0.f, sum2 = 0.f, count = 0.f;
+      for (int dy = 0; dy < 5; ++dy)
 #pragma unroll
-    for (int dy = 0; dy < 5; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 5; ++dx) {
-        const float weight = W.w[(dx - 2) * (dx - 2) + (dy - 2) * (dy - 2)];
-        sum1 = sum1 + win[dy][dx] * weight;
-        sum2 = sum2 + msk[dy][dx] * weight;
-        count += msk[dy][dx];
-      }
-    px<float>(dst, lane, y, x) = count > 12.f ? sum1 / sum2 : qnan();
+        for (int dx = 0; dx < 5; ++dx) {
+          const float weight = W.w[(dx - 2) * (dx - 2) + (dy - 2) * (dy - 2)];
+          sum1 = sum1 + win[2 * j + dy][dx] * weight;
+          sum2 = __builtin_fmaf(msk[2 * j + dy][dx], weight, sum2);
+          count += mki[2 * j + dy][dx];
+        }
+      px<float>(dst, lane, y, x) = count > 12 ? sum1 / sum2 : qnan();
+    }
   }
 }
 void launch_pyr_down(hipStream_t s, int B, ImgB src, ImgB dst, LaneMask m) {

@@ -399,24 +399,8 @@ void launch_sigma_pair(hipStream_t s, int B, ImgB W1, ImgB W0, ImgB I1, ImgB I0,
 struct FusedLatticeGetter {
   ImgB cur_iD, cur_I, W0, I0;
   WarpParams P;
-  int lane, lcols, stride, ch, interp_mode;
-  int cy, cx, sy, sx;  // cursor (lattice row / column) and the advance of SIG_T samples
+  int lane, stride, interp_mode;
   int fast;            // the same arithmetic as the normal-equation kernel that follows (warp_device.h fastnum)
-  __device__ __forceinline__ float at(int ly, int lx) const {
-    int y = ly * stride, x = lx * stride;
-    float w0 = px<float>(W0, lane, y, x);
-    if (fast) {
-      // the ray exactly as the normal-equation kernel forms it for this pixel: evaluated at the start of its 4-pixel group, stepped along x
-      fastnum::Ray r = fastnum::ray(P, (float)(x & ~3), (float)y);
-      for (int i = 0; i < (x & 3); ++i) r = fastnum::ray_step(r, P.R[0], P.R[3], P.R[6]);
-      float w1 = fastnum::warp_invdepth_px(FMap(cur_iD, lane), r, w0, P);
-      if (ch == 0) return w1 - w0;
-      return fastnum::warp_intensity_px(FMap(cur_I, lane), r, w1, P, interp_mode) - px<float>(I0, lane, y, x);
-    }
-    float w1 = warp_invdepth_px(FMap(cur_iD, lane), x, y, w0, P);
-    if (ch == 0) return w1 - w0;
-    return warp_intensity_px(FMap(cur_I, lane), x, y, w1, P, interp_mode) - px<float>(I0, lane, y, x);
-  }
   // both channels of one lattice sample (the inverse-depth warp is shared)
   __device__ __forceinline__ void both(int ly, int lx, float& rd, float& ri) const {
     both_given(ly, lx, px<float>(W0, lane, ly * stride, lx * stride), px<float>(I0, lane, ly * stride, lx * stride), rd, ri);
@@ -425,6 +409,7 @@ struct FusedLatticeGetter {
     int y = ly * stride, x = lx * stride;
     float w1, i1;
     if (fast) {
+      // the ray exactly as the normal-equation kernel forms it for this pixel: evaluated at the start of its 4-pixel group, stepped along x
       fastnum::Ray r = fastnum::ray(P, (float)(x & ~3), (float)y);
       for (int i = 0; i < (x & 3); ++i) r = fastnum::ray_step(r, P.R[0], P.R[3], P.R[6]);
       w1 = fastnum::warp_invdepth_px(FMap(cur_iD, lane), r, w0, P);
@@ -435,31 +420,11 @@ struct FusedLatticeGetter {
     }
     rd = w1 - w0; ri = i1 - i0v;
   }
-  __device__ __forceinline__ float operator()(int i) const { int ly = i / lcols; return at(ly, i - ly * lcols); }
-  __device__ __forceinline__ void seek(int i) { cy = i / lcols; cx = i - cy * lcols; sy = SIG_T / lcols; sx = SIG_T - sy * lcols; }
-  __device__ __forceinline__ float load() const { return at(cy, cx); }
-  __device__ __forceinline__ void step() { cy += sy; cx += sx; if (cx >= lcols) { cx -= lcols; ++cy; } }
 };
 
-template <bool REG>
-__global__ __launch_bounds__(SIG_T) void k_sigma_pair_fused(NuTable T, ImgB Wcur, ImgB W0, ImgB Icur, ImgB I0, const WarpParams* wp, int interp_mode,
-                                                            int lrows, int lcols, int stride, SysParams* sp, int mestimator, LaneMask m, int fast) {
-  int lane = blockIdx.x, ch = blockIdx.y;
-  if (!m.on(lane)) return;
-  __shared__ double sm_[SIG_SM];
-  BlockSum sm(sm_);
-  FusedLatticeGetter g{Wcur, Icur, W0, I0, wp[lane], lane, lcols, stride, ch, interp_mode, 0, 0, 0, 0, fast};
-  Samples<REG, FusedLatticeGetter> S(g, lrows * lcols, threadIdx.x);
-  float bias = 0.f, sigma = ch == 0 ? 0.0025f : 5.f, nu = 5.f;
-  sigma_core(S, T, 0, mestimator, bias, sigma, nu, sm);
-  if (threadIdx.x == 0) {
-    if (ch == 0) { sp[lane].bias_d = bias; sp[lane].sigma_d = sigma; sp[lane].nu_d = nu; }
-    else { sp[lane].bias_i = bias; sp[lane].sigma_i = sigma; sp[lane].nu_i = nu; }
-  }
-}
-// The same in two kernels: the register path of k_sigma_pair_fused walks its <= 19 samples per thread one after the other, each through
-// three dependent memory round trips (keyframe iD -> point sample -> bilinear taps) -- ~85 us of exposed latency per launch (batching the
-// round trips over 3 samples inside one kernel, the most 64 VGPRs allow: 190 us, no better than the pair below).  Here one
+// Two kernels.  With the warps inside the sigma / nu kernel a thread walks its <= 19 samples one after the other, each through three dependent
+// memory round trips (keyframe iD -> point sample -> bilinear taps): +85 us of exposed latency per launch (and batching the round trips over 3
+// samples, the most 64 VGPRs allow: 190 us, no better than the pair below).  Here one
 // thread per lattice sample warps its pixel (9.8 M independent threads at 512 lanes: the latency hides behind occupancy) and parks both
 // residuals in res[lane][channel][n]; the sigma / nu kernel then reads them as plain coalesced arrays.
 // kf_lat (nullable): the keyframe side of the lattice, packed once per keyframe by k_lattice_pack -- [lane][2][n] = W0 | I0 at the lattice
@@ -472,7 +437,7 @@ __global__ __launch_bounds__(256) void k_lattice_residuals_fused(ImgB Wcur, ImgB
   if (!m.on(lane)) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  FusedLatticeGetter g{Wcur, Icur, W0, I0, wp[lane], lane, lcols, stride, 1, interp_mode, 0, 0, 0, 0, fast};
+  FusedLatticeGetter g{Wcur, Icur, W0, I0, wp[lane], lane, stride, interp_mode, fast};
   const int ly = i / lcols, lx = i - ly * lcols;
   float rd, ri;
   if (kf_lat) {
@@ -522,22 +487,16 @@ int lattice_samples(int rows, int cols, int min_nsamples) {
 void launch_sigma_pair_fused(hipStream_t s, int B, ImgB Wcur, ImgB W0, ImgB Icur, ImgB I0, const WarpParams* lane_wp, int interp_mode,
                              int min_nsamples, SysParams* sp, int mestimator, LaneMask m, bool fast, float* res, size_t res_lane_stride,
                              const float* kf_lat, size_t kf_lat_lane_stride) {
+  // res: [lane][2][n] scratch of at least 2 * lattice_samples() floats per lane (the engine sizes it at creation)
   int n, lr, lc, st;
   lattice_geometry(W0.rows, W0.cols, min_nsamples, &n, &lr, &lc, &st);
   const int f = (fast && Icur.cols >= 2) ? 1 : 0;
-  if (res && res_lane_stride >= 2 * (size_t)n) {
-    hipLaunchKernelGGL(k_lattice_residuals_fused, dim3(div_up(n, 256), B), dim3(256), 0, s, Wcur, W0, Icur, I0, lane_wp, interp_mode, n, lc, st, res, res_lane_stride,
-                       kf_lat_lane_stride >= 2 * (size_t)n ? kf_lat : nullptr, kf_lat_lane_stride, m, f);
-    if (n <= SIG_T * SIG_MAXPT)
-      hipLaunchKernelGGL(k_sigma_pair_arrays<true>, dim3(B, 2), dim3(SIG_T), 0, s, nu_table(), res, res_lane_stride, n, sp, mestimator, m);
-    else
-      hipLaunchKernelGGL(k_sigma_pair_arrays<false>, dim3(B, 2), dim3(SIG_T), 0, s, nu_table(), res, res_lane_stride, n, sp, mestimator, m);
-    return;
-  }
+  hipLaunchKernelGGL(k_lattice_residuals_fused, dim3(div_up(n, 256), B), dim3(256), 0, s, Wcur, W0, Icur, I0, lane_wp, interp_mode, n, lc, st, res, res_lane_stride,
+                     kf_lat_lane_stride >= 2 * (size_t)n ? kf_lat : nullptr, kf_lat_lane_stride, m, f);
   if (n <= SIG_T * SIG_MAXPT)
-    hipLaunchKernelGGL(k_sigma_pair_fused<true>, dim3(B, 2), dim3(SIG_T), 0, s, nu_table(), Wcur, W0, Icur, I0, lane_wp, interp_mode, lr, lc, st, sp, mestimator, m, f);
+    hipLaunchKernelGGL(k_sigma_pair_arrays<true>, dim3(B, 2), dim3(SIG_T), 0, s, nu_table(), res, res_lane_stride, n, sp, mestimator, m);
   else
-    hipLaunchKernelGGL(k_sigma_pair_fused<false>, dim3(B, 2), dim3(SIG_T), 0, s, nu_table(), Wcur, W0, Icur, I0, lane_wp, interp_mode, lr, lc, st, sp, mestimator, m, f);
+    hipLaunchKernelGGL(k_sigma_pair_arrays<false>, dim3(B, 2), dim3(SIG_T), 0, s, nu_table(), res, res_lane_stride, n, sp, mestimator, m);
 }
 
 // ---- computeChiSquare sigmaFuncs.cu:1225-1297 (+ :137-150, :541-646) --------------------------------
