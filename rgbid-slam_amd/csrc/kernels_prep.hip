@@ -371,23 +371,30 @@ static constexpr int PD_ROWS = 8;
 // descriptor, 32-bit byte offsets) -- the kernel is bound by its vector-memory instruction count (stride-2 lanes: every load instruction
 // touches 4-5 cache lines), 6 instead of 10 per output.  A column outside the image is never used (cin), so the pair at 2x-2 is simply
 // moved to column 0 for x = 0 and the unused upper half of the pair at 2x+2 may lie beyond the row (inside the descriptor, or 0 beyond it).
-__device__ __forceinline__ void pyr_load_row(const FMap& S, int rows, int cy, const unsigned cxb[3], const bool cin[5], float r[5], float mk[5], int mi[5]) {
-  const bool row_in = cy >= 0 && cy < rows;
-  const unsigned rb = S.row(row_in ? cy : 0);
-  const float2 p0 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(S.rsrc, rb + cxb[0], 0, 0));
-  const float2 p1 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(S.rsrc, rb + cxb[1], 0, 0));
-  const float2 p2 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(S.rsrc, rb + cxb[2], 0, 0));
-  const float v[5] = {p0.x, p0.y, p1.x, p1.y, p2.x};
+struct PyrRaw { float2 p0, p1, p2; bool row_in; };
+__device__ __forceinline__ PyrRaw pyr_issue_row(const FMap& S, int rows, int cy, const unsigned cxb[3]) {
+  PyrRaw q;
+  q.row_in = cy >= 0 && cy < rows;
+  const unsigned rb = S.row(q.row_in ? cy : 0);
+  q.p0 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(S.rsrc, rb + cxb[0], 0, 0));
+  q.p1 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(S.rsrc, rb + cxb[1], 0, 0));
+  q.p2 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(S.rsrc, rb + cxb[2], 0, 0));
+  return q;
+}
+__device__ __forceinline__ void pyr_finish_row(const PyrRaw& q, const bool cin[5], float r[5], float mk[5], int mi[5]) {
+  const float v[5] = {q.p0.x, q.p0.y, q.p1.x, q.p1.y, q.p2.x};
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
-    bool ok = row_in && cin[i] && !isnan(v[i]);
+    bool ok = q.row_in && cin[i] && !isnan(v[i]);
     r[i] = ok ? v[i] : 0.f;
     mk[i] = ok ? 1.f : 0.f;
     mi[i] = ok ? 1 : 0;
   }
 }
-// The row loop is fully unrolled (PD_ROWS outputs, rows past the image predicated off): the 5-row window then lives in renamed registers --
-// the rolled loop spent 30 of its ~185 instructions per output on v_mov copies of the three rows it keeps.
+// The row loop is fully unrolled (PD_ROWS outputs, rows past the image predicated off): the 5-row window lives in renamed registers (the
+// rolled loop spent 30 of its ~185 instructions per output on v_mov copies), and it is software-pipelined -- the two source rows of output
+// j + 1 are ISSUED before output j is computed and only unpacked (validity, sanitising) after it, so a wave always has a row pair in flight
+// behind its arithmetic instead of waiting out every pair (the kernel ran at 2.4 TB/s: six loads in flight per wave, then a full stop).
 __global__ __launch_bounds__(256) void k_pyr_down_roll(ImgB src, ImgB dst, PyrWeights W, int strips, LaneMask m) {
   int lane = blockIdx.y;
   if (!m.on(lane)) return;
@@ -400,17 +407,24 @@ __global__ __launch_bounds__(256) void k_pyr_down_roll(ImgB src, ImgB dst, PyrWe
 #pragma unroll
   for (int i = 0; i < 5; ++i) { int c = 2 * x - 2 + i; cin[i] = c >= 0 && c < src.cols; }
   const unsigned cx[3] = {(unsigned)max(2 * x - 2, 0) << 2, (unsigned)(2 * x) << 2, (unsigned)(2 * x + 2) << 2};   // byte offsets of the three column pairs
-  // window rows: slot (2j + r) of a ring over the source rows 2y_begin - 2 ...; all indices are compile-time after unrolling
+  // window rows: slot s holds source row 2 y_begin - 2 + s; all indices are compile-time after unrolling
   float win[2 * PD_ROWS + 3][5], msk[2 * PD_ROWS + 3][5];
   int mki[2 * PD_ROWS + 3][5];
+  PyrRaw raw[2 * PD_ROWS + 3];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) pyr_load_row(S, src.rows, 2 * y_begin - 2 + r, cx, cin, win[r], msk[r], mki[r]);
+  for (int r = 0; r < 5; ++r) raw[r] = pyr_issue_row(S, src.rows, 2 * y_begin - 2 + r, cx);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) pyr_finish_row(raw[r], cin, win[r], msk[r], mki[r]);
 #pragma unroll
   for (int j = 0; j < PD_ROWS; ++j) {
     const int y = y_begin + j;
     if (y < dst.rows) {   // wave-uniform except in a strip's last rows
-      pyr_load_row(S, src.rows, 2 * y + 1, cx, cin, win[2 * j + 3], msk[2 * j + 3], mki[2 * j + 3]);
-      pyr_load_row(S, src.rows, 2 * y + 2, cx, cin, win[2 * j + 4], msk[2 * j + 4], mki[2 * j + 4]);
+      if (j + 1 < PD_ROWS && y + 1 < dst.rows) {   // next output's two new rows: in flight during this output's arithmetic
+        raw[2 * j + 5] = pyr_issue_row(S, src.rows, 2 * y + 3, cx);
+        raw[2 * j + 6] = pyr_issue_row(S, src.rows, 2 * y + 4, cx);
+      }
+      pyr_finish_row(raw[2 * j + 3], cin, win[2 * j + 3], msk[2 * j + 3], mki[2 * j + 3]);
+      pyr_finish_row(raw[2 * j + 4], cin, win[2 * j + 4], msk[2 * j + 4], mki[2 * j + 4]);
       float sum1 = 0.f, sum2 = 0.f;
       int count = 0;
 #pragma unroll
