@@ -18,6 +18,8 @@ checker here, after the timed regions), `extra_configs` (BASELINE configs 1 and 
 of the reference algorithm -- on the host cores; baseline, not target).
 """
 import argparse
+import os
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before the HIP runtime comes up: the host driver only supports dmabuf IPC (RCCL across processes)
 import json
 import os
 import sys

@@ -8,6 +8,8 @@ backend gloo (CPU, used by tests/test_dist_cpu.py): the records travel through t
 the C-ABI helper over RCCL (rgbid_dist_gather_records), cross-checked against torch.distributed's all_gather.  Both also run the
 library's own TCP rendezvous (rgbid_dist_broadcast_bytes).  Rank 0 prints one JSON line."""
 import argparse
+import os
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before the HIP runtime comes up: the host driver only supports dmabuf IPC (RCCL across processes)
 import ctypes as C
 import json
 import os

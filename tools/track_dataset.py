@@ -9,6 +9,8 @@ sequence is cut into `chunks` contiguous chunks with one frame of overlap, every
 the 392-byte per-frame records only (one all-gather over RCCL through librgbid_dist.so), rank 0 writes the trajectory in the TUM format (`stamp tx ty tz qx qy qz qw`)."""
 import argparse
 import os
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before the HIP runtime comes up: the host driver only supports dmabuf IPC (RCCL across processes)
+import os
 import sys
 import time
 
