@@ -177,11 +177,12 @@ int rgbid_dist_init(rgbid_dist** out, rgbid_ctx* ctx, const rgbid_dist_id* id, i
 
 int rgbid_dist_destroy(rgbid_dist* d) {
   if (!d) return RGBID_OK;
-  hipSetDevice(d->device);
-  hipStreamSynchronize(d->stream);
-  if (d->token) hipFree(d->token);
+  hipError_t he = hipSetDevice(d->device);
+  if (he == hipSuccess) he = hipStreamSynchronize(d->stream);
+  if (d->token) (void)hipFree(d->token);
   ncclResult_t nr = d->comm ? ncclCommDestroy(d->comm) : ncclSuccess;
   delete d;
+  if (he != hipSuccess) return (int)he;
   return rccl_err(nr);
 }
 
@@ -200,13 +201,13 @@ int rgbid_dist_gather_records(rgbid_dist* d, const rgbid_gather_record* local_de
   static_assert(sizeof(rgbid_gather_record) == 392, "SURVEY 8e record");
   if (!d || !local_dev || !all_dev || n_local < 0) return RGBID_E_INVALID;
   if (n_local == 0) return RGBID_OK;
-  hipSetDevice(d->device);
+  if (hipError_t he = hipSetDevice(d->device); he != hipSuccess) return (int)he;
   return rccl_err(ncclAllGather(local_dev, all_dev, (size_t)n_local * sizeof(rgbid_gather_record), ncclChar, d->comm, d->stream));
 }
 
 int rgbid_dist_barrier(rgbid_dist* d) {
   if (!d) return RGBID_E_INVALID;
-  hipSetDevice(d->device);
+  if (hipError_t e0 = hipSetDevice(d->device); e0 != hipSuccess) return (int)e0;
   ncclResult_t nr = ncclAllReduce(d->token, d->token, 1, ncclInt, ncclSum, d->comm, d->stream);
   if (nr != ncclSuccess) return rccl_err(nr);
   hipError_t he = hipStreamSynchronize(d->stream);

@@ -96,9 +96,12 @@ int system_blocks_per_lane(int rows, int cols, int B);
 // sums: device double [B][27] (packed upper-tri + b, reference order estimate_VO.cu:774-786)
 int launch_build_system(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB W1, ImgB I1,
                         const SysParams* host_p, const SysParams* lane_p, double* partials, LaneMask m, int level_tag = 0);
-// fused Gauss-Newton evaluation (engine): warp of the current frame + residual rows + 27-term reduction in one kernel
+// fused Gauss-Newton evaluation (engine): warp of the current frame + residual rows + 27-term reduction in one kernel.
+// weight_mode: 1 = the caller guarantees that EVERY lane's parameters have student_nu set and weighting != MIN_WEIGHT (kernel variant without
+// per-pixel configuration branches; same arithmetic), 0 = whatever the lanes' parameters say
 int launch_gn_fused(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB Wcur, ImgB Icur,
-                    const WarpParams* lane_wp, int interp_mode, const SysParams* lane_p, double* partials, LaneMask m, int level_tag, bool fast = false);
+                    const WarpParams* lane_wp, int interp_mode, const SysParams* lane_p, double* partials, LaneMask m, int level_tag, bool fast = false,
+                    int weight_mode = 0);
 // the next launch_build_system / launch_gn_fused on this host thread is bracketed by these events (kernel duration)
 void set_system_kernel_events(hipEvent_t start, hipEvent_t stop);
 void launch_reduce_system(hipStream_t s, int B, const double* partials, int nblk, double* sums, LaneMask m);

@@ -15,6 +15,7 @@
 // no floating-point atomics.  blockIdx is remapped so that the 8 XCDs each stream a contiguous slab.
 #include "kernels.h"
 #include <cstdlib>
+#include <type_traits>
 #include "warp_device.h"
 #include <hip/hip_ext.h>
 
@@ -23,6 +24,11 @@ namespace rgbid {
 static constexpr int SYS_T = 256;
 #ifndef RGBID_FUSED_WAVES
 #define RGBID_FUSED_WAVES 4   // waves per SIMD the fused fast kernel's register allocation must allow (<= 128 VGPRs)
+#endif
+#ifndef RGBID_SYS_NO_FENCE
+#define RGBID_SYS_PIXEL_FENCE __builtin_amdgcn_sched_barrier(0)
+#else
+#define RGBID_SYS_PIXEL_FENCE
 #endif
 static constexpr float TH_HUBER = 1.345f, TH_TUKEY = 4.685f, STUDENT_DOF = 5.f;
 
@@ -54,8 +60,14 @@ __device__ __forceinline__ float m_weight(float e, int mest) {  // computeWeight
 //  * explicit FMAs with shared sub-expressions (the naive `acc += a*J + d*J'` costs three operations per term without reassociation).
 // Invalid constraints are neutralised by sanitising their INPUTS (so every row entry stays finite) and zeroing their weight: they
 // contribute exactly 0, as in the reference (weight 0 times a stale finite row).
+// WM: 1 = the weights are Student-t with estimated nu and the weighting is not MIN_WEIGHT (the shipped configuration), known when the
+// pixel loop is entered -- the per-pixel code then has no wave-uniform branches and the four pixels of a unit schedule as one block;
+// 0 = decided per pixel from P (every other configuration).  Same arithmetic either way.
+template <int WM>
 __device__ __forceinline__ void accumulate_pixel(float acc[SYS_TERMS], float px_, float py_, float pp_y, float w0, float i0, float gwx, float gwy,
                                                  float gix, float giy, float w1, float i1, const SysParams& P, const SysConst& C) {
+  const bool snu = WM == 1 ? true : (P.student_nu != 0);
+  const bool minw = WM == 1 ? false : (P.weighting == 1);
   const bool v0 = !isnan(w0);
   const bool vd = v0 && !(isnan(w1) || isnan(gwx) || isnan(gwy));
   const bool vi = v0 && !(isnan(i0) || isnan(i1) || isnan(gix) || isnan(giy));
@@ -77,7 +89,7 @@ __device__ __forceinline__ void accumulate_pixel(float acc[SYS_TERMS], float px_
   Jd[5] = fmaf(gy, px_, -(gx * py_));
   float ed = w0 - w1;
   float eu = fmaf(ed, C.inv_sd, -C.be_d);
-  float wd = P.student_nu ? C.nud1_m * __builtin_amdgcn_rcpf(fmaf(eu, eu, P.nu_d)) : m_weight(eu, P.mestimator) * C.wmul_d;
+  float wd = snu ? C.nud1_m * __builtin_amdgcn_rcpf(fmaf(eu, eu, P.nu_d)) : m_weight(eu, P.mestimator) * C.wmul_d;
   wd = vd ? wd : 0.f;
   // ---- intensity row (times sigma_i; its weight carries rho2)
   float hx = gix * P.fx, hy = giy * P.fy;
@@ -93,12 +105,12 @@ __device__ __forceinline__ void accumulate_pixel(float acc[SYS_TERMS], float px_
   ei = vi ? ei : 0.f;
   float eiu = fmaf(ei, C.inv_si, -C.be_i);
   float wi;
-  if (P.weighting == 1) {  // MIN_WEIGHT (:403-406): the minimum is taken on the true weights
-    wi = P.student_nu ? C.nui1 * __builtin_amdgcn_rcpf(fmaf(eiu, eiu, P.nu_i)) : m_weight(eiu, P.mestimator);
+  if (minw) {  // MIN_WEIGHT (:403-406): the minimum is taken on the true weights
+    wi = snu ? C.nui1 * __builtin_amdgcn_rcpf(fmaf(eiu, eiu, P.nu_i)) : m_weight(eiu, P.mestimator);
     wi = vi ? wi * C.wmul_i : 0.f;
     wi = fminf(wd, wi) * C.rho2;
   } else {
-    wi = P.student_nu ? C.nui1_s * __builtin_amdgcn_rcpf(fmaf(eiu, eiu, P.nu_i)) : m_weight(eiu, P.mestimator) * C.wmul_i_s;
+    wi = snu ? C.nui1_s * __builtin_amdgcn_rcpf(fmaf(eiu, eiu, P.nu_i)) : m_weight(eiu, P.mestimator) * C.wmul_i_s;
     wi = vi ? wi : 0.f;
   }
   float sd = nfac * wd;
@@ -176,7 +188,7 @@ struct FusedArgs { const WarpParams* wp; int interp_mode; };
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 void set_system_kernel_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = start; g_ev_stop = stop; }
 
-template <class PS, bool VEC, int LEVEL, int FUSED>
+template <class PS, bool VEC, int LEVEL, int FUSED, int WMK = 0>
 __global__ __launch_bounds__(SYS_T) __attribute__((amdgpu_waves_per_eu(FUSED == 2 ? RGBID_FUSED_WAVES : 1, 8))) void k_build_system(ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB W1, ImgB I1,
                                                         PS ps, double* partials, int nblk, int upt, LaneMask m, FusedArgs fa) {
   int gb = xcd_slab_block(blockIdx.x, gridDim.x);
@@ -193,6 +205,8 @@ __global__ __launch_bounds__(SYS_T) __attribute__((amdgpu_waves_per_eu(FUSED == 
 #pragma unroll
   for (int k = 0; k < SYS_TERMS; ++k) acc[k] = 0.f;
   const int rows = W0.rows, cols = W0.cols;
+  auto pixel_loop = [&](auto wm_tag) {
+  constexpr int WM = decltype(wm_tag)::value;
   if (VEC) {
     const int upr = cols >> 2;  // float4 units per row
     const int units = rows * upr;
@@ -240,13 +254,17 @@ __global__ __launch_bounds__(SYS_T) __attribute__((amdgpu_waves_per_eu(FUSED == 
                                      t2 = fastnum::intensity_taps(Ic, r2, w1.z, WP, fa.interp_mode), t3 = fastnum::intensity_taps(Ic, r3, w1.w, WP, fa.interp_mode);
         float4 w0n = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live_n) w0n = ld_stream4(reinterpret_cast<const float*>(bW0 + unit_off(yn, xn << 2)));
-        const float i1x = fastnum::intensity_finish(t0), i1y = fastnum::intensity_finish(t1), i1z = fastnum::intensity_finish(t2), i1w = fastnum::intensity_finish(t3);
         float py_ = ((float)y - C.cy_f) * C.inv_fy, pp_y = fmaf(py_, py_, 1.f);
         float px0 = ((float)x - C.cx_f) * C.inv_fx;
-        accumulate_pixel(acc, px0, py_, pp_y, w0.x, i0.x, a.x, b.x, c.x, d.x, w1.x, i1x, P, C);
-        accumulate_pixel(acc, px0 + C.inv_fx, py_, pp_y, w0.y, i0.y, a.y, b.y, c.y, d.y, w1.y, i1y, P, C);
-        accumulate_pixel(acc, fmaf(2.f, C.inv_fx, px0), py_, pp_y, w0.z, i0.z, a.z, b.z, c.z, d.z, w1.z, i1z, P, C);
-        accumulate_pixel(acc, fmaf(3.f, C.inv_fx, px0), py_, pp_y, w0.w, i0.w, a.w, b.w, c.w, d.w, w1.w, i1w, P, C);
+        // each pixel's taps are waited for where its rows are built (RGBID_SYS_PIXEL_FENCE keeps the scheduler from hoisting all four
+        // waits to the top of the unit when the per-pixel code is branch-free): the later gathers land under the earlier pixels' updates
+        accumulate_pixel<WM>(acc, px0, py_, pp_y, w0.x, i0.x, a.x, b.x, c.x, d.x, w1.x, fastnum::intensity_finish(t0), P, C);
+        RGBID_SYS_PIXEL_FENCE;
+        accumulate_pixel<WM>(acc, px0 + C.inv_fx, py_, pp_y, w0.y, i0.y, a.y, b.y, c.y, d.y, w1.y, fastnum::intensity_finish(t1), P, C);
+        RGBID_SYS_PIXEL_FENCE;
+        accumulate_pixel<WM>(acc, fmaf(2.f, C.inv_fx, px0), py_, pp_y, w0.z, i0.z, a.z, b.z, c.z, d.z, w1.z, fastnum::intensity_finish(t2), P, C);
+        RGBID_SYS_PIXEL_FENCE;
+        accumulate_pixel<WM>(acc, fmaf(3.f, C.inv_fx, px0), py_, pp_y, w0.w, i0.w, a.w, b.w, c.w, d.w, w1.w, fastnum::intensity_finish(t3), P, C);
         w0 = w0n; live = live_n; y = yn; xu = xn;
       }
     } else
@@ -274,10 +292,10 @@ __global__ __launch_bounds__(SYS_T) __attribute__((amdgpu_waves_per_eu(FUSED == 
         }
         float py_ = ((float)y - C.cy_f) * C.inv_fy, pp_y = fmaf(py_, py_, 1.f);
         float px0 = ((float)x - C.cx_f) * C.inv_fx;
-        accumulate_pixel(acc, px0, py_, pp_y, w0.x, i0.x, a.x, b.x, c.x, d.x, w1.x, i1.x, P, C);
-        accumulate_pixel(acc, px0 + C.inv_fx, py_, pp_y, w0.y, i0.y, a.y, b.y, c.y, d.y, w1.y, i1.y, P, C);
-        accumulate_pixel(acc, fmaf(2.f, C.inv_fx, px0), py_, pp_y, w0.z, i0.z, a.z, b.z, c.z, d.z, w1.z, i1.z, P, C);
-        accumulate_pixel(acc, fmaf(3.f, C.inv_fx, px0), py_, pp_y, w0.w, i0.w, a.w, b.w, c.w, d.w, w1.w, i1.w, P, C);
+        accumulate_pixel<WM>(acc, px0, py_, pp_y, w0.x, i0.x, a.x, b.x, c.x, d.x, w1.x, i1.x, P, C);
+        accumulate_pixel<WM>(acc, px0 + C.inv_fx, py_, pp_y, w0.y, i0.y, a.y, b.y, c.y, d.y, w1.y, i1.y, P, C);
+        accumulate_pixel<WM>(acc, fmaf(2.f, C.inv_fx, px0), py_, pp_y, w0.z, i0.z, a.z, b.z, c.z, d.z, w1.z, i1.z, P, C);
+        accumulate_pixel<WM>(acc, fmaf(3.f, C.inv_fx, px0), py_, pp_y, w0.w, i0.w, a.w, b.w, c.w, d.w, w1.w, i1.w, P, C);
       }
     }
   } else {
@@ -293,11 +311,13 @@ __global__ __launch_bounds__(SYS_T) __attribute__((amdgpu_waves_per_eu(FUSED == 
         else if (FUSED) { w1 = warp_invdepth_px(Wc, x, y, w0, WP); i1 = warp_intensity_px(Ic, x, y, w1, WP, fa.interp_mode); }
         else { w1 = px<float>(W1, lane, y, x); i1 = px<float>(I1, lane, y, x); }
         float py_ = ((float)y - C.cy_f) * C.inv_fy, pp_y = fmaf(py_, py_, 1.f);
-        accumulate_pixel(acc, ((float)x - C.cx_f) * C.inv_fx, py_, pp_y, w0, px<float>(I0, lane, y, x), px<float>(gWx, lane, y, x),
+        accumulate_pixel<WM>(acc, ((float)x - C.cx_f) * C.inv_fx, py_, pp_y, w0, px<float>(I0, lane, y, x), px<float>(gWx, lane, y, x),
                          px<float>(gWy, lane, y, x), px<float>(gIx, lane, y, x), px<float>(gIy, lane, y, x), w1, i1, P, C);
       }
     }
   }
+  };
+  pixel_loop(std::integral_constant<int, WMK>{});
   block_reduce_store(acc, out, (double)C.inv_sd * (double)C.inv_sd);
 }
 
@@ -346,7 +366,7 @@ int system_blocks_per_lane(int rows, int cols, int B) {
 }
 
 static int launch_system_impl(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB W1, ImgB I1,
-                              const SysParams* hp, const SysParams* lp, double* partials, LaneMask m, int level_tag, int fused, FusedArgs fa) {
+                              const SysParams* hp, const SysParams* lp, double* partials, LaneMask m, int level_tag, int fused, FusedArgs fa, int wm = 0) {
   bool vec = (W0.cols % 4 == 0) && vec_ok(W0) && vec_ok(I0) && vec_ok(gWx) && vec_ok(gWy) && vec_ok(gIx) && vec_ok(gIy) && (fused || (vec_ok(W1) && vec_ok(I1)));
   int upt, nblk;
   system_plan(W0.rows, W0.cols, B, vec, &upt, &nblk);
@@ -355,7 +375,11 @@ static int launch_system_impl(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, 
 #define RGBID_SYS_LEVELS(PSV, V, F) do { if (level_tag == 0) RGBID_SYS_LAUNCH(PSV, V, 0, F); else if (level_tag == 1) RGBID_SYS_LAUNCH(PSV, V, 1, F); else RGBID_SYS_LAUNCH(PSV, V, 2, F); } while (0)
   if (lp) {
     ByLane<SysParams> p{lp};
-    if (fused == 2) { if (vec) RGBID_SYS_LEVELS(p, true, 2); else RGBID_SYS_LAUNCH(p, false, 0, 2); }
+    if (fused == 2 && vec && wm == 1) {
+#define RGBID_SYS_LAUNCH_WM(T) hipExtLaunchKernelGGL((k_build_system<ByLane<SysParams>, true, T, 2, 1>), g, b, 0, s, g_ev_start, g_ev_stop, 0, W0, I0, gWx, gWy, gIx, gIy, W1, I1, p, partials, nblk, upt, m, fa)
+      if (level_tag == 0) RGBID_SYS_LAUNCH_WM(0); else if (level_tag == 1) RGBID_SYS_LAUNCH_WM(1); else RGBID_SYS_LAUNCH_WM(2);
+#undef RGBID_SYS_LAUNCH_WM
+    } else if (fused == 2) { if (vec) RGBID_SYS_LEVELS(p, true, 2); else RGBID_SYS_LAUNCH(p, false, 0, 2); }
     else if (fused) { if (vec) RGBID_SYS_LEVELS(p, true, 1); else RGBID_SYS_LAUNCH(p, false, 0, 1); }
     else { if (vec) RGBID_SYS_LEVELS(p, true, 0); else RGBID_SYS_LEVELS(p, false, 0); }
   } else {
@@ -374,13 +398,13 @@ int launch_build_system(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB g
 }
 
 int launch_gn_fused(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB Wcur, ImgB Icur,
-                    const WarpParams* lane_wp, int interp_mode, const SysParams* lane_p, double* partials, LaneMask m, int level_tag, bool fast) {
+                    const WarpParams* lane_wp, int interp_mode, const SysParams* lane_p, double* partials, LaneMask m, int level_tag, bool fast, int weight_mode) {
   // the paired bilinear taps need two columns; the pipelined kernel addresses the six keyframe maps through one shared 32-bit row offset
   const bool same_geom = W0.pitch == I0.pitch && W0.pitch == gWx.pitch && W0.pitch == gWy.pitch && W0.pitch == gIx.pitch && W0.pitch == gIy.pitch &&
                          (unsigned long long)W0.rows * W0.pitch < (1ull << 32) && W0.pitch < (1u << 24) && W0.rows < (1 << 24);
   const bool vec = (W0.cols % 4 == 0) && vec_ok(W0) && vec_ok(I0) && vec_ok(gWx) && vec_ok(gWy) && vec_ok(gIx) && vec_ok(gIy);
   const bool f = fast && Icur.cols >= 2 && same_geom && vec;   // otherwise the exact fused kernel (as the unfused path falls back to the exact warp pair)
-  return launch_system_impl(s, B, W0, I0, gWx, gWy, gIx, gIy, Wcur, Icur, nullptr, lane_p, partials, m, level_tag, f ? 2 : 1, FusedArgs{lane_wp, interp_mode});
+  return launch_system_impl(s, B, W0, I0, gWx, gWy, gIx, gIy, Wcur, Icur, nullptr, lane_p, partials, m, level_tag, f ? 2 : 1, FusedArgs{lane_wp, interp_mode}, weight_mode);
 }
 
 // FinalReductionKernel estimate_VO.cu:459-500 (all-double here; the reference's tree is fp32).

@@ -166,7 +166,8 @@ __device__ __forceinline__ float warp_intensity_px(const FMap& src, int x, int y
 // above reproduce the IEEE evaluation of the scalar oracle bit for bit (the compat bridge always uses them); the functions below evaluate
 // the same formulas in the reference build's class of arithmetic -- v_rcp_f32 (1 ulp) for every division, explicit FMAs, the ray
 // q = R (x, y, 1) formed once per pixel and shared by every projection from that pixel (registerPixel, warping_registration.cu:129-146,
-// re-associated: R (x z, y z, z) + t = z q + t), 1 / (1 / X.z) taken as X.z -- which removes ~40 % of the instructions of kernels that
+// re-associated: R (x z, y z, z) + t = z q + t, and projected from the scaled point w X = q + w t so that no reciprocal of the inverse depth
+// is taken), 1 / (1 / X.z) taken as X.z -- which removes ~45 % of the instructions of kernels that
 // are VALU-bound.  What changes: a coordinate that lands within an ulp of a pixel boundary may select the neighbouring pixel.  Measured
 // against the exact kernels (tests/test_gpu_engine.py::test_engine_fast_numerics_vs_exact): a few boundary pixels per map, poses
 // within 1e-6; the oracle's model of the reference's nvcc flags moves poses by the same order (tests/test_oracle_cuda_numerics.py).
@@ -185,21 +186,24 @@ __device__ __forceinline__ Ray ray(const WarpParams& P, float xf, float yf) {
   return r;
 }
 __device__ __forceinline__ Ray ray_step(const Ray& r, float d0, float d1, float d2) { return Ray{r.q0 + d0, r.q1 + d1, r.q2 + d2}; }
+// The back-projected, transformed point X = q / w + t of a pixel with inverse depth w, scaled by w: Y = w X = q + w t.  Y projects to the same
+// pixel as X (Y.x / Y.z = X.x / X.z) and needs no reciprocal of w; the depth along the keyframe ray comes out as (X.z - t_z) w = q_z.
+struct Scaled { float y0, y1, y2; };
+__device__ __forceinline__ Scaled scaled_point(const Ray& q, float w, const WarpParams& P) {
+  return Scaled{__builtin_fmaf(P.t[0], w, q.q0), __builtin_fmaf(P.t[1], w, q.q1), __builtin_fmaf(P.t[2], w, q.q2)};
+}
 
 // trafo3DKernelInvDepthGridStride (:505-546), one pixel
 __device__ __forceinline__ float warp_invdepth_px(const FMap& src, const Ray& q, float w, const WarpParams& P) {
   const bool valid = w == w;
   const float ws = valid ? w : 1.f;
-  const float zd = rcp(ws);
-  const float X0 = __builtin_fmaf(q.q0, zd, P.t[0]), X1 = __builtin_fmaf(q.q1, zd, P.t[1]), X2 = __builtin_fmaf(q.q2, zd, P.t[2]);
-  const float wc = rcp(X2);
-  const float xs = __builtin_fmaf(X0, wc, 0.5f), ys = __builtin_fmaf(X1, wc, 0.5f);
+  const Scaled Y = scaled_point(q, ws, P);
+  const float wc = rcp(Y.y2);
+  const float xs = __builtin_fmaf(Y.y0, wc, 0.5f), ys = __builtin_fmaf(Y.y1, wc, 0.5f);
   const int ix = cvt_flr(xs), iy = cvt_flr(ys);
   const bool inb = inside(ix, iy, src.cols, src.rows);
   const float w2 = src.at(clampi(iy, src.rows - 1), clampi(ix, src.cols - 1));
-  const float tz = P.t[2];
-  const float v1_z = (X2 - tz) * ws;                       // 1 / w3 = X.z
-  const float res = (v1_z * rcp(__builtin_fmaf(-w2, tz, 1.f))) * w2;
+  const float res = (q.q2 * rcp(__builtin_fmaf(-w2, P.t[2], 1.f))) * w2;   // v1_z = (X.z - t_z) w = q_z
   return (valid & inb & (res > 0.f)) ? res : qnan();
 }
 
@@ -207,16 +211,14 @@ __device__ __forceinline__ float warp_invdepth_px(const FMap& src, const Ray& q,
 __device__ __forceinline__ float warp_invdepth_weighted_px(const FMap& src, const Ray& q, float w, const WarpParams& P, float& weight_res, bool& store_weight) {
   const bool valid = w == w;
   const float ws = valid ? w : 1.f;
-  const float zd = rcp(ws);
-  const float X0 = __builtin_fmaf(q.q0, zd, P.t[0]), X1 = __builtin_fmaf(q.q1, zd, P.t[1]), X2 = __builtin_fmaf(q.q2, zd, P.t[2]);
-  const float wc = rcp(X2);
-  const float xs = __builtin_fmaf(X0, wc, 0.5f), ys = __builtin_fmaf(X1, wc, 0.5f);
+  const Scaled Y = scaled_point(q, ws, P);
+  const float wc = rcp(Y.y2);
+  const float xs = __builtin_fmaf(Y.y0, wc, 0.5f), ys = __builtin_fmaf(Y.y1, wc, 0.5f);
   const int ix = cvt_flr(xs), iy = cvt_flr(ys);
   const bool inb = inside(ix, iy, src.cols, src.rows);
   const float w2 = src.at(clampi(iy, src.rows - 1), clampi(ix, src.cols - 1));
-  const float tz = P.t[2];
-  const float v1_z = (X2 - tz) * ws;
-  const float w_factor = __builtin_fmaf(-w2, tz, 1.f);
+  const float v1_z = q.q2;
+  const float w_factor = __builtin_fmaf(-w2, P.t[2], 1.f);
   const float rv = rcp(v1_z), wf2 = w_factor * w_factor;
   weight_res = (wf2 * wf2) * (rv * rv);
   const float res = (v1_z * rcp(w_factor)) * w2;
@@ -231,10 +233,9 @@ __device__ __forceinline__ IntensityTaps intensity_taps(const FMap& src, const R
   IntensityTaps t;
   const bool valid = w == w;
   const float ws = valid ? w : 1.f;
-  const float zd = rcp(ws);
-  const float X0 = __builtin_fmaf(q.q0, zd, P.t[0]), X1 = __builtin_fmaf(q.q1, zd, P.t[1]), X2 = __builtin_fmaf(q.q2, zd, P.t[2]);
-  const float wc = rcp(X2);
-  const float xB = X0 * wc, yB = X1 * wc;
+  const Scaled Y = scaled_point(q, ws, P);
+  const float wc = rcp(Y.y2);
+  const float xB = Y.y0 * wc, yB = Y.y1 * wc;
   t.ok = valid & (xB >= -0.5f) & (xB < (float)src.cols - 0.5f) & (yB >= -0.5f) & (yB < (float)src.rows - 0.5f);
   const float fx0 = floorf(xB), fy0 = floorf(yB);
   t.a = xB - fx0; t.b = yB - fy0;
@@ -265,10 +266,10 @@ __device__ __forceinline__ float warp_intensity_px(const FMap& src, const Ray& q
 
 // one direction of computeCovisibility's gate (partialVisibilityKernel :297-360)
 __device__ __forceinline__ bool visible_px(const FMap& D, int cols, int rows, const Ray& q, float w, bool valid, const WarpParams& P) {
-  const float zd = rcp(valid ? w : 1.f);
-  const float X0 = __builtin_fmaf(q.q0, zd, P.t[0]), X1 = __builtin_fmaf(q.q1, zd, P.t[1]), X2 = __builtin_fmaf(q.q2, zd, P.t[2]);
-  const float wc = rcp(X2);
-  const float xd = X0 * wc, yd = X1 * wc;
+  const float ws = valid ? w : 1.f;
+  const Scaled Y = scaled_point(q, ws, P);
+  const float ry = rcp(Y.y2), wc = ws * ry;                 // inverse depth of the point in the other frame: 1 / X.z = w / Y.z
+  const float xd = Y.y0 * ry, yd = Y.y1 * ry;
   const bool inside_img = (xd > 0) & (xd < (float)(cols - 1)) & (yd > 0) & (yd < (float)(rows - 1));
   const int xi = clampi(__float2int_rn(xd), cols - 1), yi = clampi(__float2int_rn(yd), rows - 1);
   return valid & inside_img & (fabsf(wc - D.at(yi, xi)) < 0.020f);

@@ -28,7 +28,7 @@ def make_lanes(n_lanes, n_frames, rows, cols, K, **kw):
     return seqs, depth, rgb
 
 
-def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, map_outliers=5e-3):
+def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, map_outliers=5e-3, sigma_tol=1e-3):
     seqs, depth, rgb = make_lanes(n_lanes, n_frames, rows, cols, K, **seq_kw)
     eng = E.Engine(ctx, E.default_config(rows=rows, cols=cols, lanes=n_lanes, K=K, use_graph=use_graph, record_capacity=n_frames, **cfg_kw))
     for k in range(n_frames):
@@ -68,7 +68,7 @@ def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, m
                 imposed += 1
             assert rec[k, l]["nu_depthinv"] == info.nu_depthinv and rec[k, l]["nu_int"] == info.nu_int, (l, k)
             # sigma is the scale of the residuals AT the current pose estimate, which itself agrees to ~1e-5: 1e-3 relative
-            assert abs(rec[k, l]["sigma_int"] - info.sigma_int) < 1e-3 * info.sigma_int, (l, k, rec[k, l]["sigma_int"], info.sigma_int)
+            assert abs(rec[k, l]["sigma_int"] - info.sigma_int) < sigma_tol * info.sigma_int, (l, k, rec[k, l]["sigma_int"], info.sigma_int)
         Rs, ts = trk.poses()
         oR, ot, ocov = trk.odometry()
         for k in range(1, n_frames):
@@ -378,9 +378,12 @@ def test_engine_configurations(ctx, name, rows, cols, cfg_kw):
     K = (525.0 * s, 525.0 * s, (319.5 + 0.5) * s - 0.5, (239.5 + 0.5) * rows / 480.0 - 0.5)
     # the geometric-only alignment is the least well conditioned (poses agree with the oracle to ~1e-5 instead of ~1e-6, with the exact and
     # with the fast gather kernels alike), so ~5x more pixels of the fused map sit on the other side of the fusion gate: measured 4..111 of
-    # 18 630 over lanes / numerics modes against 0..2 for every other configuration
+    # 18 630 over lanes / numerics modes against 0..2 for every other configuration.  Its intensity sigma is the scale of residuals the pose
+    # was NOT optimised for, so it follows the pose difference to first order (elsewhere to second order): measured up to 7e-4 relative with the
+    # exact kernels and 2.3e-3 with the fast ones at pose differences of 2e-5 (tools/experiments/geom_only_diag.py), against <= 2e-5 otherwise
+    geom = cfg_kw.get("weighting") == O.GEOM_ONLY
     run_case(ctx, rows, cols, K, n_lanes=2, n_frames=5, cfg_kw=cfg_kw, seq_kw=dict(trans_step=(0.003, 0.01), rot_step_deg=(0.1, 0.6)), use_graph=0,
-             map_outliers=1.5e-2 if cfg_kw.get("weighting") == O.GEOM_ONLY else 5e-3)
+             map_outliers=1.5e-2 if geom else 5e-3, sigma_tol=5e-3 if geom else 1e-3)
 
 
 def test_engine_negative_fy_icl_nuim_calibration(ctx):
