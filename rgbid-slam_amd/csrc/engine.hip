@@ -719,7 +719,8 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
     if (fuse_cov) {
       if (prof) { set_system_kernel_events(e->prof_ev[e->prof_used], e->prof_ev[e->prof_used + 1]); e->prof_used += 2; }
       nblk = launch_gn_fused(s, B, e->iD_kf[fl], e->I_kf[fl], e->gxD_c[fl], e->gyD_c[fl], e->gxI_c[fl], e->gyI_c[fl],
-                             e->iD_curr[fl], e->I_curr[fl], e->wp, c.interp_mode, e->sp, e->partials, M(f.gn), fl < 2 ? fl : 2, fast_at(fl));
+                             e->iD_curr[fl], e->I_curr[fl], e->wp, c.interp_mode, e->sp, e->partials, M(f.gn), fl < 2 ? fl : 2, fast_at(fl),
+                             (getenv("RGBID_NO_WM") || c.weighting == RGBID_MIN_WEIGHT) ? 0 : 2);   // k_set_sys: the covariance pass is fixed-nu STUDENT
       e->launches += 2;
     } else {
       if (!(fast_at(fl) && launch_warp_pair_fast(s, B, e->iD_curr[fl], e->I_curr[fl], e->iD_kf[fl], e->wiD[fl], e->wI[fl], nullptr, e->wp, c.interp_mode, M(f.gn))))

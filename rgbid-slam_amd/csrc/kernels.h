@@ -97,8 +97,8 @@ int system_blocks_per_lane(int rows, int cols, int B);
 int launch_build_system(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB W1, ImgB I1,
                         const SysParams* host_p, const SysParams* lane_p, double* partials, LaneMask m, int level_tag = 0);
 // fused Gauss-Newton evaluation (engine): warp of the current frame + residual rows + 27-term reduction in one kernel.
-// weight_mode: 1 = the caller guarantees that EVERY lane's parameters have student_nu set and weighting != MIN_WEIGHT (kernel variant without
-// per-pixel configuration branches; same arithmetic), 0 = whatever the lanes' parameters say
+// weight_mode: what the caller guarantees about EVERY lane's parameters (kernel variants without per-pixel configuration branches; same
+// arithmetic): 1 = student_nu set, 2 = student_nu clear and mestimator STUDENT, both with weighting != MIN_WEIGHT; 0 = nothing
 int launch_gn_fused(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB Wcur, ImgB Icur,
                     const WarpParams* lane_wp, int interp_mode, const SysParams* lane_p, double* partials, LaneMask m, int level_tag, bool fast = false,
                     int weight_mode = 0);

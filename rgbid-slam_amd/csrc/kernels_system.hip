@@ -60,14 +60,16 @@ __device__ __forceinline__ float m_weight(float e, int mest) {  // computeWeight
 //  * explicit FMAs with shared sub-expressions (the naive `acc += a*J + d*J'` costs three operations per term without reassociation).
 // Invalid constraints are neutralised by sanitising their INPUTS (so every row entry stays finite) and zeroing their weight: they
 // contribute exactly 0, as in the reference (weight 0 times a stale finite row).
-// WM: 1 = the weights are Student-t with estimated nu and the weighting is not MIN_WEIGHT (the shipped configuration), known when the
-// pixel loop is entered -- the per-pixel code then has no wave-uniform branches and the four pixels of a unit schedule as one block;
-// 0 = decided per pixel from P (every other configuration).  Same arithmetic either way.
+// WM: what the LAUNCHER knows about every lane's configuration, so that the per-pixel code has no wave-uniform branches and the four
+// pixels of a unit schedule as one block: 1 = Student-t weights with estimated nu (the Gauss-Newton iterations of the shipped configuration),
+// 2 = the covariance pass's fixed-nu Student-t weights, both with a weighting other than MIN_WEIGHT; 0 = decided per pixel from P (every
+// other configuration).  Same arithmetic either way.
 template <int WM>
 __device__ __forceinline__ void accumulate_pixel(float acc[SYS_TERMS], float px_, float py_, float pp_y, float w0, float i0, float gwx, float gwy,
                                                  float gix, float giy, float w1, float i1, const SysParams& P, const SysConst& C) {
-  const bool snu = WM == 1 ? true : (P.student_nu != 0);
-  const bool minw = WM == 1 ? false : (P.weighting == 1);
+  const bool snu = WM == 1 ? true : WM == 2 ? false : (P.student_nu != 0);
+  const bool minw = WM != 0 ? false : (P.weighting == 1);
+  const int mest = WM == 2 ? 3 : P.mestimator;
   const bool v0 = !isnan(w0);
   const bool vd = v0 && !(isnan(w1) || isnan(gwx) || isnan(gwy));
   const bool vi = v0 && !(isnan(i0) || isnan(i1) || isnan(gix) || isnan(giy));
@@ -89,7 +91,7 @@ __device__ __forceinline__ void accumulate_pixel(float acc[SYS_TERMS], float px_
   Jd[5] = fmaf(gy, px_, -(gx * py_));
   float ed = w0 - w1;
   float eu = fmaf(ed, C.inv_sd, -C.be_d);
-  float wd = snu ? C.nud1_m * __builtin_amdgcn_rcpf(fmaf(eu, eu, P.nu_d)) : m_weight(eu, P.mestimator) * C.wmul_d;
+  float wd = snu ? C.nud1_m * __builtin_amdgcn_rcpf(fmaf(eu, eu, P.nu_d)) : m_weight(eu, mest) * C.wmul_d;
   wd = vd ? wd : 0.f;
   // ---- intensity row (times sigma_i; its weight carries rho2)
   float hx = gix * P.fx, hy = giy * P.fy;
@@ -106,11 +108,11 @@ __device__ __forceinline__ void accumulate_pixel(float acc[SYS_TERMS], float px_
   float eiu = fmaf(ei, C.inv_si, -C.be_i);
   float wi;
   if (minw) {  // MIN_WEIGHT (:403-406): the minimum is taken on the true weights
-    wi = snu ? C.nui1 * __builtin_amdgcn_rcpf(fmaf(eiu, eiu, P.nu_i)) : m_weight(eiu, P.mestimator);
+    wi = snu ? C.nui1 * __builtin_amdgcn_rcpf(fmaf(eiu, eiu, P.nu_i)) : m_weight(eiu, mest);
     wi = vi ? wi * C.wmul_i : 0.f;
     wi = fminf(wd, wi) * C.rho2;
   } else {
-    wi = snu ? C.nui1_s * __builtin_amdgcn_rcpf(fmaf(eiu, eiu, P.nu_i)) : m_weight(eiu, P.mestimator) * C.wmul_i_s;
+    wi = snu ? C.nui1_s * __builtin_amdgcn_rcpf(fmaf(eiu, eiu, P.nu_i)) : m_weight(eiu, mest) * C.wmul_i_s;
     wi = vi ? wi : 0.f;
   }
   float sd = nfac * wd;
@@ -231,6 +233,7 @@ __global__ __launch_bounds__(SYS_T) __attribute__((amdgpu_waves_per_eu(FUSED == 
       const char* const bD = static_cast<const char*>(gIy.base) + (size_t)lane * gIy.lane_stride;
       const unsigned pitch_b = (unsigned)W0.pitch;
       auto unit_off = [&](int yy, int xx) { return __umul24((unsigned)yy, pitch_b) + ((unsigned)xx << 2); };
+      const int im = WM == 1 ? 1 : fa.interp_mode;   // variant 1 also fixes the 1.8 fixed-point bilinear weights (launcher)
       bool live = u0 < units;
       float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (live) w0 = ld_stream4(reinterpret_cast<const float*>(bW0 + unit_off(y, xu << 2)));
@@ -250,8 +253,8 @@ __global__ __launch_bounds__(SYS_T) __attribute__((amdgpu_waves_per_eu(FUSED == 
         float4 w1;
         w1.x = fastnum::warp_invdepth_px(Wc, r0, w0.x, WP); w1.y = fastnum::warp_invdepth_px(Wc, r1, w0.y, WP);
         w1.z = fastnum::warp_invdepth_px(Wc, r2, w0.z, WP); w1.w = fastnum::warp_invdepth_px(Wc, r3, w0.w, WP);
-        const fastnum::IntensityTaps t0 = fastnum::intensity_taps(Ic, r0, w1.x, WP, fa.interp_mode), t1 = fastnum::intensity_taps(Ic, r1, w1.y, WP, fa.interp_mode),
-                                     t2 = fastnum::intensity_taps(Ic, r2, w1.z, WP, fa.interp_mode), t3 = fastnum::intensity_taps(Ic, r3, w1.w, WP, fa.interp_mode);
+        const fastnum::IntensityTaps t0 = fastnum::intensity_taps(Ic, r0, w1.x, WP, im), t1 = fastnum::intensity_taps(Ic, r1, w1.y, WP, im),
+                                     t2 = fastnum::intensity_taps(Ic, r2, w1.z, WP, im), t3 = fastnum::intensity_taps(Ic, r3, w1.w, WP, im);
         float4 w0n = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live_n) w0n = ld_stream4(reinterpret_cast<const float*>(bW0 + unit_off(yn, xn << 2)));
         float py_ = ((float)y - C.cy_f) * C.inv_fy, pp_y = fmaf(py_, py_, 1.f);
@@ -375,9 +378,10 @@ static int launch_system_impl(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, 
 #define RGBID_SYS_LEVELS(PSV, V, F) do { if (level_tag == 0) RGBID_SYS_LAUNCH(PSV, V, 0, F); else if (level_tag == 1) RGBID_SYS_LAUNCH(PSV, V, 1, F); else RGBID_SYS_LAUNCH(PSV, V, 2, F); } while (0)
   if (lp) {
     ByLane<SysParams> p{lp};
-    if (fused == 2 && vec && wm == 1) {
-#define RGBID_SYS_LAUNCH_WM(T) hipExtLaunchKernelGGL((k_build_system<ByLane<SysParams>, true, T, 2, 1>), g, b, 0, s, g_ev_start, g_ev_stop, 0, W0, I0, gWx, gWy, gIx, gIy, W1, I1, p, partials, nblk, upt, m, fa)
-      if (level_tag == 0) RGBID_SYS_LAUNCH_WM(0); else if (level_tag == 1) RGBID_SYS_LAUNCH_WM(1); else RGBID_SYS_LAUNCH_WM(2);
+    if (fused == 2 && vec && (wm == 2 || (wm == 1 && fa.interp_mode == 1))) {
+#define RGBID_SYS_LAUNCH_WM(T, W) hipExtLaunchKernelGGL((k_build_system<ByLane<SysParams>, true, T, 2, W>), g, b, 0, s, g_ev_start, g_ev_stop, 0, W0, I0, gWx, gWy, gIx, gIy, W1, I1, p, partials, nblk, upt, m, fa)
+      if (wm == 1) { if (level_tag == 0) RGBID_SYS_LAUNCH_WM(0, 1); else if (level_tag == 1) RGBID_SYS_LAUNCH_WM(1, 1); else RGBID_SYS_LAUNCH_WM(2, 1); }
+      else { if (level_tag == 0) RGBID_SYS_LAUNCH_WM(0, 2); else if (level_tag == 1) RGBID_SYS_LAUNCH_WM(1, 2); else RGBID_SYS_LAUNCH_WM(2, 2); }
 #undef RGBID_SYS_LAUNCH_WM
     } else if (fused == 2) { if (vec) RGBID_SYS_LEVELS(p, true, 2); else RGBID_SYS_LAUNCH(p, false, 0, 2); }
     else if (fused) { if (vec) RGBID_SYS_LEVELS(p, true, 1); else RGBID_SYS_LAUNCH(p, false, 0, 1); }

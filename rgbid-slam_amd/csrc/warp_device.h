@@ -173,6 +173,9 @@ __device__ __forceinline__ float warp_intensity_px(const FMap& src, int x, int y
 // within 1e-6; the oracle's model of the reference's nvcc flags moves poses by the same order (tests/test_oracle_cuda_numerics.py).
 namespace fastnum {
 
+// Rejected pixels (coordinates outside the image, invalid inverse depth) are not clamped to a legal address first, as the exact functions do:
+// the gathers go through the map's raw buffer descriptor, whose range check returns 0 for any offset outside the lane's image, an offset
+// that wraps lands on some other texel of the same image, and either value is discarded by the pixel's predicate.
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 // floor + saturating convert in one instruction (NaN -> 0); verified against v_floor_f32 + v_cvt_i32_f32 by rgbid_selftest_cvt_flr
 __device__ __forceinline__ int cvt_flr(float x) { int r; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
@@ -202,7 +205,7 @@ __device__ __forceinline__ float warp_invdepth_px(const FMap& src, const Ray& q,
   const float xs = __builtin_fmaf(Y.y0, wc, 0.5f), ys = __builtin_fmaf(Y.y1, wc, 0.5f);
   const int ix = cvt_flr(xs), iy = cvt_flr(ys);
   const bool inb = inside(ix, iy, src.cols, src.rows);
-  const float w2 = src.at(clampi(iy, src.rows - 1), clampi(ix, src.cols - 1));
+  const float w2 = src.at(iy, ix);   // unclamped: see the note on rejected pixels above
   const float res = (q.q2 * rcp(__builtin_fmaf(-w2, P.t[2], 1.f))) * w2;   // v1_z = (X.z - t_z) w = q_z
   return (valid & inb & (res > 0.f)) ? res : qnan();
 }
@@ -216,7 +219,7 @@ __device__ __forceinline__ float warp_invdepth_weighted_px(const FMap& src, cons
   const float xs = __builtin_fmaf(Y.y0, wc, 0.5f), ys = __builtin_fmaf(Y.y1, wc, 0.5f);
   const int ix = cvt_flr(xs), iy = cvt_flr(ys);
   const bool inb = inside(ix, iy, src.cols, src.rows);
-  const float w2 = src.at(clampi(iy, src.rows - 1), clampi(ix, src.cols - 1));
+  const float w2 = src.at(iy, ix);   // unclamped: see the note on rejected pixels above
   const float v1_z = q.q2;
   const float w_factor = __builtin_fmaf(-w2, P.t[2], 1.f);
   const float rv = rcp(v1_z), wf2 = w_factor * w_factor;
@@ -237,14 +240,13 @@ __device__ __forceinline__ IntensityTaps intensity_taps(const FMap& src, const R
   const float wc = rcp(Y.y2);
   const float xB = Y.y0 * wc, yB = Y.y1 * wc;
   t.ok = valid & (xB >= -0.5f) & (xB < (float)src.cols - 0.5f) & (yB >= -0.5f) & (yB < (float)src.rows - 0.5f);
-  const float fx0 = floorf(xB), fy0 = floorf(yB);
-  t.a = xB - fx0; t.b = yB - fy0;
+  t.a = __builtin_amdgcn_fractf(xB); t.b = __builtin_amdgcn_fractf(yB);   // v_fract_f32: x - floor(x), kept below 1
   if (interp_mode == 1) {
     t.a = rintf(t.a * 256.f) * 0.00390625f;
     t.b = rintf(t.b * 256.f) * 0.00390625f;
   }
-  const int ic = clamp_from_m1(__float2int_rd(fx0), src.cols - 1), jc = clamp_from_m1(__float2int_rd(fy0), src.rows - 1);
-  const int j1 = min(jc + 1, src.rows - 1), j0 = max(jc, 0);
+  const int ic = cvt_flr(xB), jc = cvt_flr(yB);   // in [-1, n - 1] whenever t.ok
+  const int j1 = min((int)((unsigned)jc + 1u), src.rows - 1), j0 = max(jc, 0);
   const int c = clampi(ic, src.cols - 2);
   t.p0 = src.at2_off(src.row(j0), c); t.p1 = src.at2_off(src.row(j1), c);
   t.left = ic < 0; t.right = ic > src.cols - 2;
@@ -271,7 +273,7 @@ __device__ __forceinline__ bool visible_px(const FMap& D, int cols, int rows, co
   const float ry = rcp(Y.y2), wc = ws * ry;                 // inverse depth of the point in the other frame: 1 / X.z = w / Y.z
   const float xd = Y.y0 * ry, yd = Y.y1 * ry;
   const bool inside_img = (xd > 0) & (xd < (float)(cols - 1)) & (yd > 0) & (yd < (float)(rows - 1));
-  const int xi = clampi(__float2int_rn(xd), cols - 1), yi = clampi(__float2int_rn(yd), rows - 1);
+  const int xi = __float2int_rn(xd), yi = __float2int_rn(yd);   // inside_img: both already in the image
   return valid & inside_img & (fabsf(wc - D.at(yi, xi)) < 0.020f);
 }
 
