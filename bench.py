@@ -470,9 +470,10 @@ def main():
                              "note": "unit U3 (SURVEY 8d): algorithmic bytes of one aligned frame x frames/s per GPU"} if headline else None),
             "roofline": {"bound": "hbm", "achieved": u1["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": u1["achieved"] / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_from": traffic_from,
-                         "kernel": ("rgbid::k_build_system<ByLane<SysParams>, true, 0, 2>: level-0 Gauss-Newton evaluation, FUSED -- warp of the current frame (gathers) + residual rows + "
+                         "kernel": ("rgbid::k_build_system<ByLane<SysParams>, true, 0, 2, 1> (the level-0 Gauss-Newton iterations) and <..., 0, 2, 2> (the covariance pass: same kernel, fixed-nu weights; "
+                                    "1 launch in 11): level-0 Gauss-Newton evaluation, FUSED -- warp of the current frame (gathers) + residual rows + "
                                     "27-term normal equations; reads the same 8 fp32 maps as unit U1 (6 keyframe-side streams + the 2 current-frame maps through the gathers), writes nothing"
-                                    if args.fused else "rgbid::k_build_system<ByLane<SysParams>, true, 0, 0> (level-0 residual + 27-term normal equations on stored W1 / I1)"),
+                                    if args.fused else "rgbid::k_build_system<ByLane<SysParams>, true, 0, 0, 0> (level-0 residual + 27-term normal equations on stored W1 / I1)"),
                          "algorithmic_bytes_per_launch": u1["bytes_per_launch"], "launches_timed": u1["launches_timed"], "avg_launch_us": u1["avg_launch_us"],
                          "timed_in": u1["timed_in"]},
             "parity": res["parity"],

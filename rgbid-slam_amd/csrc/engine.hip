@@ -679,7 +679,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
         if (prof) { set_system_kernel_events(e->prof_ev[e->prof_used], e->prof_ev[e->prof_used + 1]); e->prof_used += 2; }
         nblk = launch_gn_fused(s, B, e->iD_kf[level], e->I_kf[level], e->gxD[level], e->gyD[level], e->gxI[level], e->gyI[level],
                                e->iD_curr[level], e->I_curr[level], e->wp, c.interp_mode, e->sp, e->partials, M(f.gn), level < 2 ? level : 2, fast_at(level),
-                               (getenv("RGBID_NO_WM") || c.weighting == RGBID_MIN_WEIGHT) ? 0 : 1);   // k_set_sys: GN iterations always estimate nu
+                               c.weighting == RGBID_MIN_WEIGHT ? 0 : 1);   // k_set_sys: the Gauss-Newton iterations always estimate nu
       } else {
         if (c.warping == RGBID_WARP_FIRST) {
           // :1078-1105: warp the full-resolution frame, then reduce the WARPED maps down to the working level
@@ -720,7 +720,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
       if (prof) { set_system_kernel_events(e->prof_ev[e->prof_used], e->prof_ev[e->prof_used + 1]); e->prof_used += 2; }
       nblk = launch_gn_fused(s, B, e->iD_kf[fl], e->I_kf[fl], e->gxD_c[fl], e->gyD_c[fl], e->gxI_c[fl], e->gyI_c[fl],
                              e->iD_curr[fl], e->I_curr[fl], e->wp, c.interp_mode, e->sp, e->partials, M(f.gn), fl < 2 ? fl : 2, fast_at(fl),
-                             (getenv("RGBID_NO_WM") || c.weighting == RGBID_MIN_WEIGHT) ? 0 : 2);   // k_set_sys: the covariance pass is fixed-nu STUDENT
+                             c.weighting == RGBID_MIN_WEIGHT ? 0 : 2);   // k_set_sys: the covariance pass is fixed-nu STUDENT
       e->launches += 2;
     } else {
       if (!(fast_at(fl) && launch_warp_pair_fast(s, B, e->iD_curr[fl], e->I_curr[fl], e->iD_kf[fl], e->wiD[fl], e->wI[fl], nullptr, e->wp, c.interp_mode, M(f.gn))))

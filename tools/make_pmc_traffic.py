@@ -10,7 +10,8 @@ d, out, lanes = sys.argv[1], sys.argv[2], int(sys.argv[3])
 rows, cols = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (480, 640)
 fused = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 # level-0 Gauss-Newton evaluation: the fused kernel (warp + residual + normal equations, template tag 2 = fast numerics) or the unfused one
-KEY = "k_build_system<rgbid::ByLane<rgbid::SysParams>, true, 0, 2>" if fused else "k_build_system<rgbid::ByLane<rgbid::SysParams>, true, 0, 0>"
+# (last template argument 1 = the branch-free variant the Gauss-Newton iterations of the shipped configuration run)
+KEY = "k_build_system<rgbid::ByLane<rgbid::SysParams>, true, 0, 2, 1>" if fused else "k_build_system<rgbid::ByLane<rgbid::SysParams>, true, 0, 0, 0>"
 
 
 def counter(pattern, name):
