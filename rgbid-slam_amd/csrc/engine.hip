@@ -635,7 +635,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   const int tb = 64, gb = div_up(B, tb);
   // fast numerics per pyramid level: the 16-byte / paired 8-byte accesses of the fast kernels need rows of whole 4-pixel groups; levels
   // that do not have them run the exact kernels in BOTH the fused and the unfused path (so the two stay bit-identical to each other)
-  auto fast_at = [&](int level) { const int cl = c.cols >> level; return c.fast_numerics != 0 && (cl % 4) == 0 && cl >= 4; };
+  auto fast_at = [&](int level) { const int cl = c.cols >> level; return c.fast_numerics != 0 && (cl % 4) == 0 && cl >= 4 && (c.rows >> level) >= 2; };
   e->launches = 0;
   Flags& f = e->flags;
   // ---- prepareImages (visodo.cpp:760-773)

@@ -490,7 +490,7 @@ void launch_sigma_pair_fused(hipStream_t s, int B, ImgB Wcur, ImgB W0, ImgB Icur
   // res: [lane][2][n] scratch of at least 2 * lattice_samples() floats per lane (the engine sizes it at creation)
   int n, lr, lc, st;
   lattice_geometry(W0.rows, W0.cols, min_nsamples, &n, &lr, &lc, &st);
-  const int f = (fast && Icur.cols >= 2) ? 1 : 0;
+  const int f = (fast && Icur.cols >= 2 && Icur.rows >= 2) ? 1 : 0;
   hipLaunchKernelGGL(k_lattice_residuals_fused, dim3(div_up(n, 256), B), dim3(256), 0, s, Wcur, W0, Icur, I0, lane_wp, interp_mode, n, lc, st, res, res_lane_stride,
                      kf_lat_lane_stride >= 2 * (size_t)n ? kf_lat : nullptr, kf_lat_lane_stride, m, f);
   if (n <= SIG_T * SIG_MAXPT)

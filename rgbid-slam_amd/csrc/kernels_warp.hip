@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void k_warp_pair_fast(ImgB src_iD, ImgB src_I,
   }
 }
 bool launch_warp_pair_fast(hipStream_t s, int B, ImgB src_iD, ImgB src_I, ImgB grid, ImgB dst_iD, ImgB dst_I, const WarpParams* hp, const WarpParams* lp, int interp_mode, LaneMask m) {
-  if (src_I.cols < 2) return false;   // the paired bilinear taps need two columns; the caller runs the exact kernel
+  if (src_I.cols < 2 || src_I.rows < 2) return false;   // the bilinear taps need a 2 x 2 neighbourhood; the caller runs the exact kernel
   dim3 g = grid2d(dst_iD.cols, dst_iD.rows, B);
   TileMap tm;
   if (!make_tile_map((int)g.x, (int)g.y, B, &tm)) return false;

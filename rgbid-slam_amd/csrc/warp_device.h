@@ -45,6 +45,10 @@ struct FMap {
   __device__ __forceinline__ float2 at2_off(unsigned row_b, int x) const {
     return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, row_b + ((unsigned)x << 2), 0, 0));
   }
+  // the same with the byte offset split into a per-pixel part and a wave-uniform part (the instruction's scalar offset operand)
+  __device__ __forceinline__ float2 at2_raw(unsigned voff, unsigned soff) const {
+    return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0));
+  }
   __device__ __forceinline__ float4 at4(int y, int x) const {   // x % 4 == 0, 16-byte aligned rows
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, row(y) + ((unsigned)x << 2), 0, 0));
   }
@@ -231,7 +235,12 @@ __device__ __forceinline__ float warp_invdepth_weighted_px(const FMap& src, cons
 
 // the same intensity warp in two halves, so that a caller can put other memory traffic between the tap loads and their use:
 // intensity_taps() projects, forms the 1.8 fixed-point weights and ISSUES the two 8-byte tap loads; intensity_finish() blends.
-struct IntensityTaps { float2 p0, p1; float a, b; bool left, right, ok; };
+struct IntensityTaps { float2 p0, p1; float a, b; bool ok; };
+// Clamp addressing without integer clamps or per-tap selects: the sample coordinate itself is clamped to [0, n - 1) (one v_med3_f32 per
+// axis; the upper end is the float just below n - 1), so that floor() is a legal column / row with a legal right / lower neighbour and the
+// two 8-byte loads (row j and row j + 1: the same offset, the pitch in the instruction's scalar offset) ARE the four texels.  Left / top
+// border: the weight becomes 0 on texel 0, as clamp addressing gives; right / bottom border: the weight becomes 1 - 2^-24 (exactly 1 after
+// the 1.8 fixed-point rounding) on the last texel.
 __device__ __forceinline__ IntensityTaps intensity_taps(const FMap& src, const Ray& q, float w, const WarpParams& P, int interp_mode) {
   IntensityTaps t;
   const bool valid = w == w;
@@ -240,22 +249,20 @@ __device__ __forceinline__ IntensityTaps intensity_taps(const FMap& src, const R
   const float wc = rcp(Y.y2);
   const float xB = Y.y0 * wc, yB = Y.y1 * wc;
   t.ok = valid & (xB >= -0.5f) & (xB < (float)src.cols - 0.5f) & (yB >= -0.5f) & (yB < (float)src.rows - 0.5f);
-  t.a = __builtin_amdgcn_fractf(xB); t.b = __builtin_amdgcn_fractf(yB);   // v_fract_f32: x - floor(x), kept below 1
+  const float hx = __builtin_bit_cast(float, __builtin_bit_cast(int, (float)(src.cols - 1)) - 1);   // wave-uniform
+  const float hy = __builtin_bit_cast(float, __builtin_bit_cast(int, (float)(src.rows - 1)) - 1);
+  const float xc = __builtin_amdgcn_fmed3f(xB, 0.f, hx), yc = __builtin_amdgcn_fmed3f(yB, 0.f, hy);
+  t.a = __builtin_amdgcn_fractf(xc); t.b = __builtin_amdgcn_fractf(yc);   // v_fract_f32: x - floor(x), kept below 1
   if (interp_mode == 1) {
     t.a = rintf(t.a * 256.f) * 0.00390625f;
     t.b = rintf(t.b * 256.f) * 0.00390625f;
   }
-  const int ic = cvt_flr(xB), jc = cvt_flr(yB);   // in [-1, n - 1] whenever t.ok
-  const int j1 = min((int)((unsigned)jc + 1u), src.rows - 1), j0 = max(jc, 0);
-  const int c = clampi(ic, src.cols - 2);
-  t.p0 = src.at2_off(src.row(j0), c); t.p1 = src.at2_off(src.row(j1), c);
-  t.left = ic < 0; t.right = ic > src.cols - 2;
+  const unsigned off = src.row(cvt_flr(yc)) + ((unsigned)cvt_flr(xc) << 2);
+  t.p0 = src.at2_raw(off, 0u); t.p1 = src.at2_raw(off, src.pitch_b);
   return t;
 }
 __device__ __forceinline__ float intensity_finish(const IntensityTaps& t) {
-  const float T00 = t.right ? t.p0.y : t.p0.x, T10 = t.left ? t.p0.x : t.p0.y;
-  const float T01 = t.right ? t.p1.y : t.p1.x, T11 = t.left ? t.p1.x : t.p1.y;
-  const float top = __builtin_fmaf(t.a, T10 - T00, T00), bot = __builtin_fmaf(t.a, T11 - T01, T01);
+  const float top = __builtin_fmaf(t.a, t.p0.y - t.p0.x, t.p0.x), bot = __builtin_fmaf(t.a, t.p1.y - t.p1.x, t.p1.x);
   float res = __builtin_fmaf(t.b, bot - top, top);
   res = fmaxf(0.f, fminf(res, 255.f));
   return t.ok ? res : qnan();
