@@ -185,6 +185,14 @@ __device__ __forceinline__ int xcd_slab_block(int b, int n) {
 // instead of 56 B/px (12+12 for the two warp kernels, 32 for this one) and two launches disappear.
 struct FusedArgs { const WarpParams* wp; int interp_mode; };
 
+// Work decomposition of the 16-byte path: the image is cut into tiles of TW x TH units (a unit = 4 consecutive pixels; TW = 2^tw_log2 units wide,
+// TH = SYS_T / TW rows high: 128 px x 8 rows at 640 px), one tile per workgroup per step, thread <-> (unit column, row) inside the tile.  Tiles are
+// numbered DOWN a strip of TW units, then strip by strip, and a workgroup takes `upt` consecutive tiles.  A workgroup therefore reads the current
+// frame's maps (fused variants: the gathers) over 8 neighbouring rows AT THE SAME TIME -- the bilinear taps' lower row is the next pixel row's upper
+// row, and with a row-major walk (1 024 consecutive pixels per step) that second use came one step later, after the L2 had been flushed by
+// ~40 MB of streamed keyframe maps: the intensity map was fetched ~1.6 x, now 9 rows per 8.
+struct SysTiles { int tw_log2, tiles_y, ntiles; };
+
 // optional event pair that brackets exactly the next normal-equation kernel dispatch (hipExtLaunchKernelGGL:
 // the events carry the dispatch's own start / end timestamps, i.e. the kernel duration a profiler reports)
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
@@ -192,7 +200,7 @@ void set_system_kernel_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = 
 
 template <class PS, bool VEC, int LEVEL, int FUSED, int WMK = 0>
 __global__ __launch_bounds__(SYS_T) __attribute__((amdgpu_waves_per_eu(FUSED == 2 ? RGBID_FUSED_WAVES : 1, 8))) void k_build_system(ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB W1, ImgB I1,
-                                                        PS ps, double* partials, int nblk, int upt, LaneMask m, FusedArgs fa) {
+                                                        PS ps, double* partials, int nblk, int upt, LaneMask m, FusedArgs fa, SysTiles tp) {
   int gb = xcd_slab_block(blockIdx.x, gridDim.x);
   int lane = gb / nblk, blk = gb - lane * nblk;
   double* out = partials + ((size_t)lane * nblk + blk) * SYS_TERMS;
@@ -211,11 +219,12 @@ __global__ __launch_bounds__(SYS_T) __attribute__((amdgpu_waves_per_eu(FUSED == 
   constexpr int WM = decltype(wm_tag)::value;
   if (VEC) {
     const int upr = cols >> 2;  // float4 units per row
-    const int units = rows * upr;
-    int u0 = blk * (SYS_T * upt) + threadIdx.x;
-    // (row, unit-in-row) of the thread's units advance by SYS_T units per step: one division up front, then add-and-wrap
-    const int step_y = SYS_T / upr, step_x = SYS_T - step_y * upr;   // wave-uniform
-    int y = u0 / upr, xu = u0 - y * upr;
+    const int L = tp.tw_log2, TH = SYS_T >> L;
+    const int lx = threadIdx.x & ((1 << L) - 1), ly = threadIdx.x >> L;
+    const int T0 = blk * upt;                                  // first tile of the workgroup (wave-uniform)
+    const int nt = min(upt, tp.ntiles - T0);                   // its tiles
+    int sx = T0 / tp.tiles_y, ty = T0 - sx * tp.tiles_y;       // strip and tile-in-strip: one scalar division, then count-and-wrap
+    int xu = (sx << L) + lx, y = ty * TH + ly;
     if (FUSED == 2) {
       // A unit needs three dependent memory round trips (keyframe inverse depth -> point-sampled current inverse depth -> bilinear taps), and
       // a wave that walks through them one after the other leaves the HBM stream idle most of its time.  Schedule: the unit's inverse depth
@@ -234,14 +243,17 @@ __global__ __launch_bounds__(SYS_T) __attribute__((amdgpu_waves_per_eu(FUSED == 
       const unsigned pitch_b = (unsigned)W0.pitch;
       auto unit_off = [&](int yy, int xx) { return __umul24((unsigned)yy, pitch_b) + ((unsigned)xx << 2); };
       const int im = WM == 1 ? 1 : fa.interp_mode;   // variant 1 also fixes the 1.8 fixed-point bilinear weights (launcher)
-      bool live = u0 < units;
+      bool live = nt > 0 && xu < upr && y < rows;               // ragged right / bottom tiles
       float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (live) w0 = ld_stream4(reinterpret_cast<const float*>(bW0 + unit_off(y, xu << 2)));
 #pragma unroll 1
-      for (int j = 0; j < upt && live; ++j) {
-        int yn = y + step_y, xn = xu + step_x;
-        if (xn >= upr) { xn -= upr; ++yn; }
-        const bool live_n = (j + 1 < upt) && (u0 + (j + 1) * SYS_T < units);
+      for (int j = 0; j < nt; ++j) {
+        int tyn = ty + 1, sxn = sx;
+        if (tyn == tp.tiles_y) { tyn = 0; ++sxn; }
+        const int xn = (sxn << L) + lx, yn = tyn * TH + ly;
+        const bool live_n = (j + 1 < nt) && xn < upr && yn < rows;
+        float4 w0n = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
         const int x = xu << 2;
         const unsigned off = unit_off(y, x);
         const float4 i0 = ld_stream4(reinterpret_cast<const float*>(bI0 + off)), a = ld_stream4(reinterpret_cast<const float*>(bA + off)),
@@ -255,7 +267,6 @@ __global__ __launch_bounds__(SYS_T) __attribute__((amdgpu_waves_per_eu(FUSED == 
         w1.z = fastnum::warp_invdepth_px(Wc, r2, w0.z, WP); w1.w = fastnum::warp_invdepth_px(Wc, r3, w0.w, WP);
         const fastnum::IntensityTaps t0 = fastnum::intensity_taps(Ic, r0, w1.x, WP, im), t1 = fastnum::intensity_taps(Ic, r1, w1.y, WP, im),
                                      t2 = fastnum::intensity_taps(Ic, r2, w1.z, WP, im), t3 = fastnum::intensity_taps(Ic, r3, w1.w, WP, im);
-        float4 w0n = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live_n) w0n = ld_stream4(reinterpret_cast<const float*>(bW0 + unit_off(yn, xn << 2)));
         float py_ = ((float)y - C.cy_f) * C.inv_fy, pp_y = fmaf(py_, py_, 1.f);
         float px0 = ((float)x - C.cx_f) * C.inv_fx;
@@ -268,14 +279,17 @@ __global__ __launch_bounds__(SYS_T) __attribute__((amdgpu_waves_per_eu(FUSED == 
         accumulate_pixel<WM>(acc, fmaf(2.f, C.inv_fx, px0), py_, pp_y, w0.z, i0.z, a.z, b.z, c.z, d.z, w1.z, fastnum::intensity_finish(t2), P, C);
         RGBID_SYS_PIXEL_FENCE;
         accumulate_pixel<WM>(acc, fmaf(3.f, C.inv_fx, px0), py_, pp_y, w0.w, i0.w, a.w, b.w, c.w, d.w, w1.w, fastnum::intensity_finish(t3), P, C);
-        w0 = w0n; live = live_n; y = yn; xu = xn;
+        } else if (live_n) w0n = ld_stream4(reinterpret_cast<const float*>(bW0 + unit_off(yn, xn << 2)));
+        w0 = w0n; live = live_n; y = yn; xu = xn; ty = tyn; sx = sxn;
       }
     } else
 #pragma unroll 1
-    for (int j = 0; j < upt; ++j, y += step_y, xu += step_x) {
-      if (xu >= upr) { xu -= upr; ++y; }
-      int u = u0 + j * SYS_T;
-      if (u < units) {
+    for (int j = 0; j < nt; ++j) {
+      if (j) {
+        if (++ty == tp.tiles_y) { ty = 0; ++sx; }
+        xu = (sx << L) + lx; y = ty * TH + ly;
+      }
+      if (xu < upr && y < rows) {
         const int x = xu << 2;
         float4 w0 = ld_stream4(row_ptr<float>(W0, lane, y) + x);
         float4 i0 = ld_stream4(row_ptr<float>(I0, lane, y) + x);
@@ -338,24 +352,36 @@ static int device_cus() {
   return cus[dev];
 }
 
-// launch plan: units per thread (upt) and workgroups per lane.  The grid is sized to whole "rounds" of the
-// chip's resident capacity (its compute units x the 4-wave workgroups one CU holds: 5 at <= 102 VGPRs, 4 for the
-// fused fast kernel's 128) so there is no partially filled tail round; a thread's fp32 partial sums run over at most
-// 16 units (64 px).  The plan depends on the geometry and the device only -- never on the kernel variant -- so that
-// every variant sums the same pixels in the same order (fused and unfused results are bit-identical); 5 workgroups
-// per CU divides evenly into the 4-per-CU case for the shipped geometries (10 240 workgroups = 8 rounds of 1 280 =
-// 10 rounds of 1 024 on 256 CUs).
+// tile shape of the 16-byte path (SysTiles): the widest of 32 / 16 / 8 units that divides the row, else 32 with a ragged last strip
+static SysTiles system_tiles(int rows, int cols) {
+  const int upr = cols / 4;
+  int L = 5;
+  if (upr % 32 != 0) { if (upr % 16 == 0) L = 4; else if (upr % 8 == 0) L = 3; }
+  const int tw = 1 << L, th = SYS_T >> L;
+  SysTiles t;
+  t.tw_log2 = L;
+  t.tiles_y = (rows + th - 1) / th;
+  t.ntiles = ((upr + tw - 1) / tw) * t.tiles_y;
+  return t;
+}
+
+// launch plan: steps per thread (upt; a step = one tile of SYS_T units on the 16-byte path, SYS_T single pixels otherwise) and workgroups per
+// lane.  The grid is sized to whole "rounds" of the chip's resident capacity (its compute units x the 4-wave workgroups one CU holds: 5 at
+// <= 102 VGPRs, 4 for the fused fast kernel's <= 128) so there is no partially filled tail round; a thread's fp32 partial sums run over at
+// most 16 units (64 px).  The plan depends on the geometry and the device only -- never on the kernel variant -- so that every variant sums
+// the same pixels in the same order (fused and unfused results are bit-identical); 5 workgroups per CU divides evenly into the 4-per-CU case
+// for the shipped geometries (10 240 workgroups = 8 rounds of 1 280 = 10 rounds of 1 024 on 256 CUs).
 static void system_plan(int rows, int cols, int B, bool vec, int* upt, int* nblk) {
-  const long long units = vec ? (long long)rows * (cols / 4) : (long long)rows * cols;
+  long long steps = vec ? (long long)system_tiles(rows, cols).ntiles : ((long long)rows * cols + SYS_T - 1) / SYS_T;   // workgroup-steps per lane
+  if (steps < 1) steps = 1;
   const long long capacity = (long long)device_cus() * 5;    // resident workgroups
   const long long max_upt = vec ? 16 : 64;
-  long long rounds = (units * B + capacity * SYS_T * max_upt - 1) / (capacity * SYS_T * max_upt);
+  long long rounds = (steps * B + capacity * max_upt - 1) / (capacity * max_upt);
   long long nb = (rounds * capacity) / B;                    // workgroups per lane
-  long long nb_max = (units + SYS_T - 1) / SYS_T;
   if (nb < 1) nb = 1;
-  if (nb > nb_max) nb = nb_max;
-  long long u = (units + nb * SYS_T - 1) / (nb * SYS_T);
-  nb = (units + u * SYS_T - 1) / (u * SYS_T);                // drop workgroups that would get no unit
+  if (nb > steps) nb = steps;
+  long long u = (steps + nb - 1) / nb;
+  nb = (steps + u - 1) / u;                                  // drop workgroups that would get no step
   *upt = (int)u;
   *nblk = (int)nb;
 }
@@ -374,12 +400,13 @@ static int launch_system_impl(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, 
   int upt, nblk;
   system_plan(W0.rows, W0.cols, B, vec, &upt, &nblk);
   dim3 g(nblk * B), b(SYS_T);
-#define RGBID_SYS_LAUNCH(PSV, V, T, F) hipExtLaunchKernelGGL((k_build_system<decltype(PSV), V, T, F>), g, b, 0, s, g_ev_start, g_ev_stop, 0, W0, I0, gWx, gWy, gIx, gIy, W1, I1, PSV, partials, nblk, upt, m, fa)
+  const SysTiles tp = vec ? system_tiles(W0.rows, W0.cols) : SysTiles{0, 1, 0};
+#define RGBID_SYS_LAUNCH(PSV, V, T, F) hipExtLaunchKernelGGL((k_build_system<decltype(PSV), V, T, F>), g, b, 0, s, g_ev_start, g_ev_stop, 0, W0, I0, gWx, gWy, gIx, gIy, W1, I1, PSV, partials, nblk, upt, m, fa, tp)
 #define RGBID_SYS_LEVELS(PSV, V, F) do { if (level_tag == 0) RGBID_SYS_LAUNCH(PSV, V, 0, F); else if (level_tag == 1) RGBID_SYS_LAUNCH(PSV, V, 1, F); else RGBID_SYS_LAUNCH(PSV, V, 2, F); } while (0)
   if (lp) {
     ByLane<SysParams> p{lp};
     if (fused == 2 && vec && (wm == 2 || (wm == 1 && fa.interp_mode == 1))) {
-#define RGBID_SYS_LAUNCH_WM(T, W) hipExtLaunchKernelGGL((k_build_system<ByLane<SysParams>, true, T, 2, W>), g, b, 0, s, g_ev_start, g_ev_stop, 0, W0, I0, gWx, gWy, gIx, gIy, W1, I1, p, partials, nblk, upt, m, fa)
+#define RGBID_SYS_LAUNCH_WM(T, W) hipExtLaunchKernelGGL((k_build_system<ByLane<SysParams>, true, T, 2, W>), g, b, 0, s, g_ev_start, g_ev_stop, 0, W0, I0, gWx, gWy, gIx, gIy, W1, I1, p, partials, nblk, upt, m, fa, tp)
       if (wm == 1) { if (level_tag == 0) RGBID_SYS_LAUNCH_WM(0, 1); else if (level_tag == 1) RGBID_SYS_LAUNCH_WM(1, 1); else RGBID_SYS_LAUNCH_WM(2, 1); }
       else { if (level_tag == 0) RGBID_SYS_LAUNCH_WM(0, 2); else if (level_tag == 1) RGBID_SYS_LAUNCH_WM(1, 2); else RGBID_SYS_LAUNCH_WM(2, 2); }
 #undef RGBID_SYS_LAUNCH_WM

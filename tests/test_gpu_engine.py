@@ -376,14 +376,15 @@ def test_engine_configurations(ctx, name, rows, cols, cfg_kw):
     """every run-time switch of the tracker through the batched engine, each held to the oracle (1e-4 rad / 1e-4 m, same keyframe decisions)"""
     s = cols / 640.0
     K = (525.0 * s, 525.0 * s, (319.5 + 0.5) * s - 0.5, (239.5 + 0.5) * rows / 480.0 - 0.5)
-    # the geometric-only alignment is the least well conditioned (poses agree with the oracle to ~1e-5 instead of ~1e-6, with the exact and
-    # with the fast gather kernels alike), so ~5x more pixels of the fused map sit on the other side of the fusion gate: measured 4..111 of
-    # 18 630 over lanes / numerics modes against 0..2 for every other configuration.  Its intensity sigma is the scale of residuals the pose
-    # was NOT optimised for, so it follows the pose difference to first order (elsewhere to second order): measured up to 7e-4 relative with the
-    # exact kernels and 2.3e-3 with the fast ones at pose differences of 2e-5 (tools/experiments/geom_only_diag.py), against <= 2e-5 otherwise
+    # The geometric-only alignment is ill-conditioned on these scenes: ANY change of arithmetic class moves its poses by 1e-5 .. 1e-4 instead of
+    # ~1e-6 -- the oracle rebuilt under the model of the reference's own nvcc flags moves them by up to 4.8e-5 rad / 4.0e-5 m, its intensity sigma
+    # (the scale of residuals the pose was NOT optimised for: first-order in the pose difference) by 2.3e-3 and up to 1 % of the fused map beyond
+    # 1e-4 (tests/test_oracle_cuda_numerics.py::test_geometric_only_is_ill_conditioned, same sequences); the engine's fast gather kernels: up to
+    # 8.3e-5 / 8.7e-5, sigma 2.3e-3, 2 % of the map (tools/experiments/geom_only_diag.py; exact kernels: 5e-6 / 1.2e-5).  The pose tolerance stays
+    # 1e-4; the derived quantities get the room that pose difference needs.
     geom = cfg_kw.get("weighting") == O.GEOM_ONLY
     run_case(ctx, rows, cols, K, n_lanes=2, n_frames=5, cfg_kw=cfg_kw, seq_kw=dict(trans_step=(0.003, 0.01), rot_step_deg=(0.1, 0.6)), use_graph=0,
-             map_outliers=1.5e-2 if geom else 5e-3, sigma_tol=5e-3 if geom else 1e-3)
+             map_outliers=4e-2 if geom else 5e-3, sigma_tol=5e-3 if geom else 1e-3)
 
 
 def test_engine_negative_fy_icl_nuim_calibration(ctx):

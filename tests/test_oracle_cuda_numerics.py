@@ -96,6 +96,25 @@ def test_oracle_cuda_numerics_sensitivity():
     assert worst_r < 1e-4 and worst_t < 1e-4
 
 
+@needs_fma
+def test_geometric_only_is_ill_conditioned():
+    """weighting = GEOM_ONLY on the sequences tests/test_gpu_engine.py::test_engine_configurations uses: the modelled nvcc numerics move its poses
+    an order of magnitude more than those of the default weighting (still inside 1e-4) -- the yardstick for the room that test gives the
+    engine's fast-numerics kernels in this configuration."""
+    rows, cols = 120, 160
+    s = cols / 640.0
+    K = (525.0 * s, 525.0 * s, (319.5 + 0.5) * s - 0.5, (239.5 + 0.5) * rows / 480.0 - 0.5)
+    worst = {}
+    for name, w in (("geom", O.GEOM_ONLY), ("indep", O.INDEPENDENT)):
+        ws = [run_pair(rows, cols, K, 5, synth.SEED + 17 * l, cfg_kw=dict(weighting=w), seq_kw=dict(trans_step=(0.003, 0.01), rot_step_deg=(0.1, 0.6)))
+              for l in (0, 1)]
+        worst[name] = (max(x["worst_rot"] for x in ws), max(x["worst_trans"] for x in ws), max(x["map_px_beyond_1e4"] / x["map_px"] for x in ws),
+                       max(x["worst_sigma_rel"] for x in ws))
+        print("cuda-numerics sensitivity,", name, worst[name])
+    assert worst["geom"][0] < 1e-4 and worst["geom"][1] < 1e-4
+    assert worst["geom"][0] > 5 * worst["indep"][0] and worst["geom"][1] > 5 * worst["indep"][1]
+
+
 def test_force_kf_decisions_hook():
     """the test hook imposes exactly one frame's decisions and reports what the tracker would have decided on its own"""
     K = (131.25, 131.25, 79.875, 59.875)
