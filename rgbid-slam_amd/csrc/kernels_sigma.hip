@@ -3,9 +3,9 @@
 //
 // The reference runs every IRLS / bisection step as two kernel launches + two stream syncs + a 4-8 byte
 // D2H copy (16-32 launches and 7 cudaMalloc/cudaFree pairs per call, sigmaFuncs.cu:858-1066), with
-// boost::math::digamma evaluated on the host.  Here one 1024-thread workgroup per lane keeps its
-// <=24 residual samples per thread in VGPRs (19 200 samples at every pyramid level of a 640x480
-// frame), runs ALL iterations in-kernel (moments -> wave64 shuffle reduction -> LDS across 16 waves ->
+// boost::math::digamma evaluated on the host.  Here one 512-thread workgroup per lane keeps its
+// <=40 residual samples per thread in VGPRs (19 200 samples at every pyramid level of a 640x480
+// frame), runs ALL iterations in-kernel (moments -> wave64 shuffle reduction -> LDS across 8 waves ->
 // broadcast), evaluates digamma on the device, and writes (bias, sigma, nu): one launch, no host trips.
 #include "kernels.h"
 #include <cstdlib>
@@ -76,10 +76,17 @@ static const NuTable& nu_table() {
   return T;
 }
 
-static constexpr int SIG_T = 1024, SIG_MAXPT = 24, SIG_W = SIG_T / 64;
+// One workgroup per (lane, channel).  512 threads x <= 40 samples in registers: four workgroups fit a CU, so the 1 024 workgroups of a 512-lane
+// launch are resident in ONE round (1 024 threads x 24 samples needed two rounds of 512 and paid the ~10 block reductions of a pass sequence
+// twice: 81 us; 768 x 26: 57; 512 x 40: 54; 384 x 50: 64; 256 x 76: 59).
+#ifndef RGBID_SIG_T
+#define RGBID_SIG_T 512
+#define RGBID_SIG_MAXPT 40
+#endif
+static constexpr int SIG_T = RGBID_SIG_T, SIG_MAXPT = RGBID_SIG_MAXPT, SIG_W = SIG_T / 64;
 static constexpr float TH_HUBER = 1.345f, TH_TUKEY = 4.685f, STUDENT_DOF = 5.f;
 
-// block-wide sum of 4 per-thread fp32 partials: DPP wave reduction in fp32, then the 16 wave totals are
+// block-wide sum of 4 per-thread fp32 partials: DPP wave reduction in fp32, then the SIG_W wave totals are
 // added in double in a fixed order and broadcast.  Two alternating LDS buffers (the passes are strictly sequential) make the
 // write-after-read barrier of a single buffer unnecessary: 2 barriers per pass.  sm: 2 * (SIG_W*4 + 4) doubles of LDS.
 static constexpr int SIG_SM = 2 * (SIG_W * 4 + 4);
@@ -111,14 +118,14 @@ __device__ __forceinline__ void block_sum4(const float in[4], double out[4], Blo
 }
 
 // Per-thread residual samples, produced by a getter get(i) (a plain array for the bridge calls; a lattice
-// sample of two maps for the batched engine).  REG: <= 24 samples per thread held in VGPRs; otherwise the getter is
+// sample of two maps for the batched engine).  REG: <= SIG_MAXPT samples per thread held in VGPRs; otherwise the getter is
 // re-evaluated on every pass.  Samples are kept SANITISED (an invalid residual -- NaN, infinite or a slot beyond n -- is stored as 0) so
 // the passes run branch-free.  Every sum a pass forms is LINEAR in the validity flag: sum_valid f(e_i) = sum_all f(e_i) - n_invalid f(0).
 // The register path therefore keeps no per-sample flag at all: it sums f over all its slots with flag 1 and then calls f once more on the
-// value an invalid slot holds with flag -n_invalid (24 VGPRs and one multiply per sample, sum and pass less).
+// value an invalid slot holds with flag -n_invalid (SIG_MAXPT VGPRs and one multiply per sample, sum and pass less).
 template <bool REG, class Getter>
 struct Samples {
-  // register path: <= 24 fp32 adds per thread; streaming path (up to a full frame per thread-stride): double
+  // register path: <= SIG_MAXPT fp32 adds per thread; streaming path (up to a full frame per thread-stride): double
   using Acc = typename std::conditional<REG, float, double>::type;
   float e[REG ? SIG_MAXPT : 1];
   float zero_slot;   // what an invalid slot currently holds (0, or its image under to_squared_normalised)
