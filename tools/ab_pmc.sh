@@ -3,7 +3,7 @@
 # usage: COUNTERS="FETCH_SIZE|WRITE_SIZE|TCC_HIT_sum TCC_MISS_sum" FILTER=warp_pair bash tools/ab_pmc.sh "ENV=a" "ENV=b"
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps ${STEPS:-2} --warmup 1 --reps 1 --lanes ${LANES:-512} ${EXTRA:-} --no-cpu-baseline --no-extras --check-streams 0"
+ARGS="--steps ${STEPS:-2} --warmup 1 --reps 1 --lanes ${LANES:-2048} ${EXTRA:-} --no-cpu-baseline --no-extras --check-streams 0"
 i=0
 for cfg in "$@"; do
   i=$((i+1))
@@ -16,7 +16,7 @@ for cfg in "$@"; do
     echo "=== [$i] $cfg  pass: $pass"
     python - <<PY
 import csv
-px = ${LANES:-512} * 480 * 640
+px = ${LANES:-2048} * 480 * 640
 for r in csv.DictReader(open("$OUT/p_pmc_rgbid.csv")):
     if "${FILTER:-rgbid::}" in r["Name"]:
         v = float(r["Max"]); unit = 1024.0 if "SIZE" in r["Counter"] else 1.0

@@ -18,7 +18,7 @@ timeout 600 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace1280 -- python $ROOT/bench.py --rows 960 --cols 1280 --levels 4 --lanes 128 --streams 8 $LIGHT > $OUT/bench1280_under_rocprof.json 2>/dev/null
 rm -f $OUT/*agent_info.csv
 python $ROOT/tools/summarize_prof.py $OUT
-python $ROOT/tools/make_pmc_traffic.py $OUT $OUT/pmc_traffic.json ${LANES:-512} || true
+python $ROOT/tools/make_pmc_traffic.py $OUT $OUT/pmc_traffic.json ${LANES:-2048} || true
 python $ROOT/tools/sq_table.py $OUT > $OUT/sq_table.md || true
 find $OUT -name "*kernel_trace.csv" -size +4M -delete
 ls -la $OUT

@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/quick${TAG:-}
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps ${STEPS:-6} --warmup ${WARMUP:-2} --reps 1 --lanes ${LANES:-512} ${EXTRA:-} --no-cpu-baseline --no-extras --check-streams 0"
+ARGS="--steps ${STEPS:-6} --warmup ${WARMUP:-2} --reps 1 --lanes ${LANES:-2048} ${EXTRA:-} --no-cpu-baseline --no-extras --check-streams 0"
 rocprofv3 --kernel-trace --output-format csv -d $OUT -o trace -- python $ROOT/bench.py $ARGS > $OUT/bench_under_rocprof.json 2>/dev/null
 rm -f $OUT/*agent_info.csv
 python $ROOT/tools/summarize_prof.py $OUT
