@@ -51,6 +51,26 @@ def make_inputs(lanes, n_frames, rows, cols, K, device, n_unique=32):
     return seqs, depth, rgb
 
 
+def auto_lanes(ctx, dev, rows, cols, levels, n_frames, keyframes, world, target=2048):
+    """lanes per GPU: `target`, or the largest multiple of 256 whose engine state + resident input frames (n_frames x lanes x 5 B/px) fit 85 % of
+    the device's free memory (a long --steps run must not run out of HBM); every rank takes the minimum over ranks"""
+    from rgbid import engine as E
+    probe = E.Engine(ctx, E.default_config(rows=rows, cols=cols, levels=levels, lanes=1, K=(525.0, 525.0, 319.5, 239.5), record_capacity=n_frames,
+                                           keyframe_capacity=keyframes))
+    per_lane = probe.bytes() + n_frames * rows * cols * 5 * 1.05      # u16 depth + rgb24 per frame; 5 % for the unique-stream copies
+    probe.close()
+    free, _total = torch.cuda.mem_get_info(dev)
+    lanes = target
+    while lanes > 256 and lanes * per_lane > 0.85 * free:
+        lanes -= 256
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([lanes], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        lanes = int(t.item())
+    return lanes
+
+
 def usable_cores():
     """host cores this process may actually use: affinity mask, capped by the cgroup CPU quota (cpu.max / cfs_quota_us)"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -314,7 +334,8 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reps", type=int, default=5, help="timed repetitions of the K steps (value = median)")
-    ap.add_argument("--lanes", type=int, default=2048, help="independent RGB-D streams per GPU (2 048 x 640x480 lanes = 126 GB of the 288 GB; per-lane cost 512 -> 2 048: -5 %)")
+    ap.add_argument("--lanes", type=int, default=0, help="independent RGB-D streams per GPU; 0 = 2 048 (126 GB of engine state at 640x480; per-lane cost 512 -> 2 048: -5 %), "
+                    "reduced in steps of 256 if the engine + the resident input frames of W + K + 1 steps would not fit the device's free memory")
     ap.add_argument("--streams", type=int, default=32, help="distinct synthetic input streams dealt onto the lanes")
     ap.add_argument("--check-streams", type=int, default=4, help="lanes (one per distinct stream) held to the CPU oracle over all timed steps, after the timed regions")
     ap.add_argument("--rows", type=int, default=480)
@@ -363,6 +384,8 @@ def main():
     with torch.cuda.stream(work):
         ctx = device.Context(local_rank)
     ctx.set_async(1)
+    if B <= 0:
+        B = auto_lanes(ctx, dev, rows, cols, args.levels, 1 + W + Kst, args.keyframes, world)
     iters = [10, 5, 3] + [3] * (args.levels - 3) if args.levels >= 3 else [10, 5, 3][:args.levels]
     dist_env = {"use_dist": use_dist, "world": world, "comm": None}
     gather_how = None
