@@ -382,6 +382,20 @@ def test_build_system_student_nu(ctx, rows, cols, weighting):
     assert np.array_equal(A, A2) and np.array_equal(b, b2)
 
 
+@pytest.mark.parametrize("rows,cols", [(37, 100), (50, 72), (45, 136), (9, 260), (130, 36)])
+def test_build_system_ragged_tiles(ctx, rows, cols):
+    """the 16-byte path's tile decomposition (kernels_system.hip SysTiles) on widths whose unit count no tile width divides (25, 18, 34, 65, 9 units
+    per row: a ragged last strip) and heights that are no multiple of the tile height (ragged bottom tiles)"""
+    K, maps = _system_case(rows, cols, 23)
+    args = dict(sigma_depthinv=0.003, sigma_int=6.0, bias_depthinv=0.0002, bias_int=-0.5, nu_depthinv=3.5, nu_int=6.25)
+    dm = [util.padded(dev(m), 4) for m in maps]
+    assert all(d.stride(0) % 4 == 0 and d.data_ptr() % 16 == 0 for d in dm)     # the 16-byte path is the one taken
+    A, b = ctx.buildSystemStudentNuGridStride(*dm, O.STUDENT, O.INDEPENDENT, args["sigma_depthinv"], args["sigma_int"], args["bias_depthinv"],
+                                              args["bias_int"], args["nu_depthinv"], args["nu_int"], K)
+    oA, ob = O.build_system(*maps, K, student_nu=True, mestimator=O.STUDENT, weighting=O.INDEPENDENT, **args)
+    _check_system(A, b, oA, ob)
+
+
 @pytest.mark.parametrize("rows,cols", SMALL + [(480, 640)])
 @pytest.mark.parametrize("mest", [O.LSQ, O.HUBER, O.TUKEY, O.STUDENT])
 def test_build_system_fixed_nu(ctx, rows, cols, mest):
