@@ -357,6 +357,9 @@ static SysTiles system_tiles(int rows, int cols) {
   const int upr = cols / 4;
   int L = 5;
   if (upr % 32 != 0) { if (upr % 16 == 0) L = 4; else if (upr % 8 == 0) L = 3; }
+#ifdef RGBID_SYS_FORCE_TWLOG2
+  if (upr % (1 << RGBID_SYS_FORCE_TWLOG2) == 0) L = RGBID_SYS_FORCE_TWLOG2;   // experiment hook (tools/ab_build.sh)
+#endif
   const int tw = 1 << L, th = SYS_T >> L;
   SysTiles t;
   t.tw_log2 = L;
