@@ -363,7 +363,13 @@ static const PyrWeights& pyr_weights() {
 }
 // A thread owns one output column and walks PD_ROWS output rows downwards, keeping the 5x5 source window in registers
 // (two new source rows = ten cached loads per output; out-of-image taps become NaN).  No LDS, no barriers.
-static constexpr int PD_ROWS = 8;
+#ifndef RGBID_PD_ROWS
+#define RGBID_PD_ROWS 8
+#endif
+#ifndef RGBID_PD_AHEAD
+#define RGBID_PD_AHEAD 1      // outputs whose two new source rows are in flight ahead of the one being computed
+#endif
+static constexpr int PD_ROWS = RGBID_PD_ROWS, PD_AHEAD = RGBID_PD_AHEAD;
 // a source row of the window: value sanitised to 0 and validity both as 0/1 float (weight sum) and 0/1 int (count), so a tap is
 // `sum1 += v * w; sum2 = fma(m, w, sum2); count += mi` (adding +0 for an invalid tap leaves the sums bit-identical to skipping it: they
 // start at +0 and can never become -0; m * w is exact, so the explicit FMA equals the reference's multiply-then-add bit for bit)
@@ -412,16 +418,16 @@ __global__ __launch_bounds__(256) void k_pyr_down_roll(ImgB src, ImgB dst, PyrWe
   int mki[2 * PD_ROWS + 3][5];
   PyrRaw raw[2 * PD_ROWS + 3];
 #pragma unroll
-  for (int r = 0; r < 5; ++r) raw[r] = pyr_issue_row(S, src.rows, 2 * y_begin - 2 + r, cx);
+  for (int r = 0; r < 3 + 2 * PD_AHEAD; ++r) raw[r] = pyr_issue_row(S, src.rows, 2 * y_begin - 2 + r, cx);
 #pragma unroll
   for (int r = 0; r < 3; ++r) pyr_finish_row(raw[r], cin, win[r], msk[r], mki[r]);
 #pragma unroll
   for (int j = 0; j < PD_ROWS; ++j) {
     const int y = y_begin + j;
     if (y < dst.rows) {   // wave-uniform except in a strip's last rows
-      if (j + 1 < PD_ROWS && y + 1 < dst.rows) {   // next output's two new rows: in flight during this output's arithmetic
-        raw[2 * j + 5] = pyr_issue_row(S, src.rows, 2 * y + 3, cx);
-        raw[2 * j + 6] = pyr_issue_row(S, src.rows, 2 * y + 4, cx);
+      if (j + PD_AHEAD < PD_ROWS && y + PD_AHEAD < dst.rows) {   // a later output's two new rows: in flight during this output's arithmetic
+        raw[2 * (j + PD_AHEAD) + 3] = pyr_issue_row(S, src.rows, 2 * (y + PD_AHEAD) + 1, cx);
+        raw[2 * (j + PD_AHEAD) + 4] = pyr_issue_row(S, src.rows, 2 * (y + PD_AHEAD) + 2, cx);
       }
       pyr_finish_row(raw[2 * j + 3], cin, win[2 * j + 3], msk[2 * j + 3], mki[2 * j + 3]);
       pyr_finish_row(raw[2 * j + 4], cin, win[2 * j + 4], msk[2 * j + 4], mki[2 * j + 4]);
