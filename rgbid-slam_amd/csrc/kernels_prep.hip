@@ -452,7 +452,10 @@ void launch_pyr_down(hipStream_t s, int B, ImgB src, ImgB dst, LaneMask m) {
 }
 
 // ---- bilateralKernel (filters.cu:86-135), clipped 5x5 window -------------------------------------
-static constexpr int BR = 2, BIL_TILES = 4;
+#ifndef RGBID_BIL_TILES
+#define RGBID_BIL_TILES 4
+#endif
+static constexpr int BR = 2, BIL_TILES = RGBID_BIL_TILES;
 // the 24 off-centre taps of one pixel.  FAST: the per-tap division by sigma (a constant of the launch) as the 3-instruction exact sequence of
 // common.h div_const_fast; the caller recomputes the pixel with the IEEE division if any tap left its verified range.  The centre tap is the
 // pixel itself: its weight is expf(-0) = 1 exactly, so it enters the sums as (value, 1) without arithmetic -- at its place in the tap order.
@@ -484,6 +487,10 @@ __device__ __forceinline__ float bilateral_px(const float (*tile)[TX + 2 * BR + 
 // __expf(-(space2 / 50 + 0.5 fn^2)) = ex2.approx(log2e * arg) (filters.cu:124 under nvcc's fast exp); here the same exponent is formed with
 // the constants folded -- arg2 = c_space[dy][dx] + k d^2, k = 0.5 log2e / sigma^2 -- and handed to v_exp_f32: 8 instructions per tap
 // instead of ~50 (exact division, double-precision exponent, full-range expf), results within a few 1e-7 relative of the exact kernel.
+// Invalid taps (NaN in the map, window positions outside the image) are stored in the tile as BIL_SENTINEL, a large FINITE value: the range
+// term k d^2 of such a tap is >= 1e36, v_exp_f32 returns exactly 0 and 0 * sentinel adds exactly 0 to both sums -- the tap drops out without a
+// compare and two selects per tap (a third of the kernel's issue time).  No valid inverse depth or intensity comes near the sentinel.
+static constexpr float BIL_SENTINEL = 1e19f;
 __device__ __forceinline__ float bilateral_px_fast(const float (*tile)[TX + 2 * BR + 1], int ty, int tx, float value, float k, float cs) {
   float sum1 = value, sum2 = 1.f;   // centre tap: weight exp(-0) = 1
 #pragma unroll
@@ -494,9 +501,8 @@ __device__ __forceinline__ float bilateral_px_fast(const float (*tile)[TX + 2 * 
       const float tmp = tile[ty + dy][tx + dx];
       const float d = value - tmp;
       const float w = __builtin_amdgcn_exp2f(-__builtin_fmaf(k * d, d, cs * (float)(dx * dx + dy * dy)));
-      const bool ok = tmp == tmp;
-      sum1 = __builtin_fmaf(ok ? tmp : 0.f, ok ? w : 0.f, sum1);
-      sum2 += ok ? w : 0.f;
+      sum1 = __builtin_fmaf(tmp, w, sum1);
+      sum2 += w;
     }
   return sum1 * __builtin_amdgcn_rcpf(sum2);
 }
@@ -505,38 +511,44 @@ __global__ __launch_bounds__(256) void k_bilateral(ImgB src, ImgB dst, float sig
   constexpr bool FAST = MODE == 1;
   int lane = blockIdx.z;
   if (!m.on(lane)) return;
-  __shared__ float tile[TY + 2 * BR][TX + 2 * BR + 1];
+  // one halo tile of BIL_TILES x TY rows per workgroup (16 + 4 rows x 68 columns: 1.33 loads per output, ONE barrier and ONE exposed memory round
+  // trip per four outputs of a thread; four separate 4-row tiles cost 2.1 loads per output and four round trips)
+  __shared__ float tile[TY * BIL_TILES + 2 * BR][TX + 2 * BR + 1];
   const int x0 = blockIdx.x * TX;
   const float sigma_space = 5.f;
   const float s2ih = (float)(0.5 / (double)(sigma_space * sigma_space));
-  for (int it_ = 0, y0 = blockIdx.y * (TY * BIL_TILES); it_ < BIL_TILES; ++it_, y0 += TY) {   // 4 tiles per workgroup: more workgroups balance this heavy kernel better
-    if (y0 >= src.rows) break;
-    __syncthreads();
-    for (int ty = threadIdx.y; ty < TY + 2 * BR; ty += TY) {
-      const int cy = y0 + ty - BR;
-      const bool row_in = cy >= 0 && cy < src.rows;
-      const float* rp = row_ptr<float>(src, lane, row_in ? cy : 0);
-      for (int tx = threadIdx.x; tx < TX + 2 * BR; tx += TX) {
-        const int cx = x0 + tx - BR;
-        tile[ty][tx] = (row_in && cx >= 0 && cx < src.cols) ? rp[cx] : qnan();
-      }
+  const int y0 = blockIdx.y * (TY * BIL_TILES);
+  for (int ty = threadIdx.y; ty < TY * BIL_TILES + 2 * BR; ty += TY) {
+    const int cy = y0 + ty - BR;
+    const bool row_in = cy >= 0 && cy < src.rows;
+    const float* rp = row_ptr<float>(src, lane, row_in ? cy : 0);
+    for (int tx = threadIdx.x; tx < TX + 2 * BR; tx += TX) {
+      const int cx = x0 + tx - BR;
+      float v = (row_in && cx >= 0 && cx < src.cols) ? rp[cx] : qnan();
+      if (MODE == 2) v = v == v ? v : BIL_SENTINEL;
+      tile[ty][tx] = v;
     }
-    __syncthreads();
-    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
-    if (x >= src.cols || y >= src.rows) continue;
-    const float value = tile[threadIdx.y + BR][threadIdx.x + BR];
-    if (isnan(value)) { px<float>(dst, lane, y, x) = qnan(); continue; }
+  }
+  __syncthreads();
+  const int x = x0 + threadIdx.x;
+  if (x >= src.cols) return;
+#pragma unroll
+  for (int it_ = 0; it_ < BIL_TILES; ++it_) {
+    const int ly = it_ * TY + threadIdx.y, y = y0 + ly;
+    if (y >= src.rows) break;
+    const float value = tile[ly + BR][threadIdx.x + BR];
+    if (MODE == 2 ? value == BIL_SENTINEL : isnan(value)) { px<float>(dst, lane, y, x) = qnan(); continue; }
     float res;
     if (MODE == 2) {
       const float log2e = 1.44269504088896341f;
-      res = bilateral_px_fast(tile, threadIdx.y + BR, threadIdx.x + BR, value, 0.5f * log2e / (sigma_floatmap * sigma_floatmap), s2ih * log2e);
+      res = bilateral_px_fast(tile, ly + BR, threadIdx.x + BR, value, 0.5f * log2e / (sigma_floatmap * sigma_floatmap), s2ih * log2e);
     } else if (FAST) {
       bool all_ok = true;
-      res = bilateral_px<true>(tile, threadIdx.y + BR, threadIdx.x + BR, value, sigma_floatmap, dc, s2ih, all_ok);
-      if (__builtin_expect(!all_ok, 0)) res = bilateral_px<false>(tile, threadIdx.y + BR, threadIdx.x + BR, value, sigma_floatmap, dc, s2ih, all_ok);
+      res = bilateral_px<true>(tile, ly + BR, threadIdx.x + BR, value, sigma_floatmap, dc, s2ih, all_ok);
+      if (__builtin_expect(!all_ok, 0)) res = bilateral_px<false>(tile, ly + BR, threadIdx.x + BR, value, sigma_floatmap, dc, s2ih, all_ok);
     } else {
       bool unused = true;
-      res = bilateral_px<false>(tile, threadIdx.y + BR, threadIdx.x + BR, value, sigma_floatmap, dc, s2ih, unused);
+      res = bilateral_px<false>(tile, ly + BR, threadIdx.x + BR, value, sigma_floatmap, dc, s2ih, unused);
     }
     px<float>(dst, lane, y, x) = res;
   }
