@@ -6,7 +6,7 @@ from rgbid import synth, engine as E, device
 def rot_angle(Ra, Rb): return float(np.arccos(np.clip((np.trace(Ra.T @ Rb) - 1) / 2, -1, 1)))
 full = len(sys.argv) > 1 and sys.argv[1] == "full"      # `python tools/soak.py full`: 2 lanes x 60 frames at 640x480 instead of 4 x 300 at 160x120
 if full:
-    K, n, B, rows, cols = synth.TUM_K, 60, 2, 480, 640
+    K, n, B, rows, cols = synth.TUM_K, (int(sys.argv[2]) if len(sys.argv) > 2 else 60), 2, 480, 640   # `python tools/soak.py full 200`: longer
 else:
     K = (synth.TUM_K[0] / 4, synth.TUM_K[1] / 4, (synth.TUM_K[2] + 0.5) / 4 - 0.5, (synth.TUM_K[3] + 0.5) / 4 - 0.5)
     n, B, rows, cols = 300, 4, 120, 160
