@@ -98,6 +98,8 @@ int rgbid_ctx_destroy(rgbid_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->partials) hipFree(c->partials);
+  if (c->lane_dev) hipFree(c->lane_dev);
+  if (c->lane_host) hipHostFree(c->lane_host);
   if (c->small_dev) hipFree(c->small_dev);
   if (c->small_host) hipHostFree(c->small_host);
   if (c->ev0) hipEventDestroy(c->ev0);
@@ -277,6 +279,24 @@ int rgbid::ctx_reserve_partials(rgbid_ctx* c, size_t n_doubles) {
   hipError_t e = hipMalloc((void**)&c->partials, n_doubles * sizeof(double));
   if (e != hipSuccess) return e == hipErrorOutOfMemory ? RGBID_E_NOMEM : (int)e;
   c->partials_cap = n_doubles;
+  return RGBID_OK;
+}
+
+int rgbid::ctx_reserve_lane(rgbid_ctx* c, size_t bytes) {
+  if (c->lane_cap >= bytes) return RGBID_OK;
+  hipStreamSynchronize(c->stream);
+  if (c->lane_dev) hipFree(c->lane_dev);
+  if (c->lane_host) hipHostFree(c->lane_host);
+  c->lane_dev = c->lane_host = nullptr; c->lane_cap = 0;
+  bytes = (bytes + 4095) & ~(size_t)4095;
+  hipError_t e = hipMalloc(&c->lane_dev, bytes);
+  if (e == hipSuccess) e = hipHostMalloc(&c->lane_host, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    if (c->lane_dev) { hipFree(c->lane_dev); c->lane_dev = nullptr; }
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? RGBID_E_NOMEM : (int)e;
+  }
+  c->lane_cap = bytes;
   return RGBID_OK;
 }
 

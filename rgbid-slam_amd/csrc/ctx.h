@@ -17,6 +17,9 @@ struct rgbid_ctx {
   void* small_host = nullptr;  // pinned mirror
   double* partials = nullptr;  // [nblk][27] workgroup partial sums of the normal equations
   size_t partials_cap = 0;     // in doubles
+  void* lane_dev = nullptr;    // per-lane parameter / result scratch of the batched C-ABI (rgbid_batched.h), grown on demand
+  void* lane_host = nullptr;   // pinned mirror
+  size_t lane_cap = 0;         // bytes
 };
 
 namespace rgbid {
@@ -26,4 +29,5 @@ constexpr size_t ctx_off_sigma = 320;   // SigmaIO
 constexpr size_t ctx_off_chi = 384;     // 3 floats
 constexpr size_t ctx_small_bytes = 1024;
 int ctx_reserve_partials(rgbid_ctx* c, size_t n_doubles);
+int ctx_reserve_lane(rgbid_ctx* c, size_t bytes);
 }  // namespace rgbid

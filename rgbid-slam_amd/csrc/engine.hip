@@ -633,9 +633,12 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   const StepCfg sc = sc_;
   const IntrP K0{c.fx, c.fy, c.cx, c.cy};
   const int tb = 64, gb = div_up(B, tb);
-  // fast numerics per pyramid level: the 16-byte / paired 8-byte accesses of the fast kernels need rows of whole 4-pixel groups; levels
-  // that do not have them run the exact kernels in BOTH the fused and the unfused path (so the two stay bit-identical to each other)
-  auto fast_at = [&](int level) { const int cl = c.cols >> level; return c.fast_numerics != 0 && (cl % 4) == 0 && cl >= 4 && (c.rows >> level) >= 2; };
+  // fast numerics per pyramid level, decided ONCE here for every gather kernel of the level (lattice pre-pass, warp pair, fused normal
+  // equations; kernels.h gn_fast_supported): levels whose geometry does not allow the 16-byte / paired 8-byte accesses run the exact
+  // kernels in BOTH the fused and the unfused path, so the two stay bit-identical to each other
+  auto fast_at = [&](int level) {
+    return c.fast_numerics != 0 && gn_fast_supported(e->iD_kf[level], e->I_kf[level], e->gxD[level], e->gyD[level], e->gxI[level], e->gyI[level], e->I_curr[level]);
+  };
   e->launches = 0;
   Flags& f = e->flags;
   // ---- prepareImages (visodo.cpp:760-773)
@@ -680,6 +683,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
         nblk = launch_gn_fused(s, B, e->iD_kf[level], e->I_kf[level], e->gxD[level], e->gyD[level], e->gxI[level], e->gyI[level],
                                e->iD_curr[level], e->I_curr[level], e->wp, c.interp_mode, e->sp, e->partials, M(f.gn), level < 2 ? level : 2, fast_at(level),
                                c.weighting == RGBID_MIN_WEIGHT ? 0 : 1);   // k_set_sys: the Gauss-Newton iterations always estimate nu
+        if (nblk < 0) return RGBID_E_INVALID;
       } else {
         if (c.warping == RGBID_WARP_FIRST) {
           // :1078-1105: warp the full-resolution frame, then reduce the WARPED maps down to the working level
@@ -721,6 +725,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
       nblk = launch_gn_fused(s, B, e->iD_kf[fl], e->I_kf[fl], e->gxD_c[fl], e->gyD_c[fl], e->gxI_c[fl], e->gyI_c[fl],
                              e->iD_curr[fl], e->I_curr[fl], e->wp, c.interp_mode, e->sp, e->partials, M(f.gn), fl < 2 ? fl : 2, fast_at(fl),
                              c.weighting == RGBID_MIN_WEIGHT ? 0 : 2);   // k_set_sys: the covariance pass is fixed-nu STUDENT
+      if (nblk < 0) return RGBID_E_INVALID;
       e->launches += 2;
     } else {
       if (!(fast_at(fl) && launch_warp_pair_fast(s, B, e->iD_curr[fl], e->I_curr[fl], e->iD_kf[fl], e->wiD[fl], e->wI[fl], nullptr, e->wp, c.interp_mode, M(f.gn))))

@@ -81,6 +81,10 @@ void launch_sigma_pair(hipStream_t s, int B, ImgB W1, ImgB W0, ImgB I1, ImgB I0,
 void launch_sigma_pair_fused(hipStream_t s, int B, ImgB Wcur, ImgB W0, ImgB Icur, ImgB I0, const WarpParams* lane_wp, int interp_mode,
                              int min_nsamples, SysParams* sp, int mestimator, LaneMask m, bool fast = false, float* res = nullptr, size_t res_lane_stride = 0,
                              const float* kf_lat = nullptr, size_t kf_lat_lane_stride = 0);
+// the two halves of launch_sigma_pair_fused on their own (C-ABI rgbid_lattice_residuals_batched / rgbid_sigma_pair_batched)
+void launch_lattice_residuals_fused(hipStream_t s, int B, ImgB Wcur, ImgB W0, ImgB Icur, ImgB I0, const WarpParams* lane_wp, int interp_mode, int min_nsamples,
+                                    LaneMask m, bool fast, float* res, size_t res_lane_stride, const float* kf_lat, size_t kf_lat_lane_stride);
+void launch_sigma_pair_arrays(hipStream_t s, int B, const float* res, size_t res_lane_stride, int n, SysParams* sp, int mestimator, LaneMask m);
 // the keyframe side of a level's residual lattice packed as [lane][2][n] = W0 | I0 (once per keyframe; see k_lattice_residuals_fused)
 void launch_lattice_pack(hipStream_t s, int B, ImgB W0, ImgB I0, int min_nsamples, float* out, size_t out_lane_stride, LaneMask m);
 // samples of the residual lattice computeErrorGridStride takes for this geometry (scratch sizing: 2 * n floats per lane for `res` above)
@@ -97,11 +101,16 @@ int system_blocks_per_lane(int rows, int cols, int B);
 int launch_build_system(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB W1, ImgB I1,
                         const SysParams* host_p, const SysParams* lane_p, double* partials, LaneMask m, int level_tag = 0);
 // fused Gauss-Newton evaluation (engine): warp of the current frame + residual rows + 27-term reduction in one kernel.
+// fast: the resolved class of the level -- must imply gn_fast_supported() (returns -1 and launches nothing otherwise).
 // weight_mode: what the caller guarantees about EVERY lane's parameters (kernel variants without per-pixel configuration branches; same
 // arithmetic): 1 = student_nu set, 2 = student_nu clear and mestimator STUDENT, both with weighting != MIN_WEIGHT; 0 = nothing
 int launch_gn_fused(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB Wcur, ImgB Icur,
                     const WarpParams* lane_wp, int interp_mode, const SysParams* lane_p, double* partials, LaneMask m, int level_tag, bool fast = false,
                     int weight_mode = 0);
+// THE predicate for "this level's gather kernels run in the fast numerics class" (engine / C-ABI decide it once per level and hand the
+// resolved bool to the lattice pre-pass, the warp pair and the fused normal equations, so the three always agree): rows of whole 4-pixel
+// groups, a 2 x 2 neighbourhood for the paired bilinear taps, six keyframe maps of one geometry with 16-byte aligned rows
+bool gn_fast_supported(ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB Icur);
 // the next launch_build_system / launch_gn_fused on this host thread is bracketed by these events (kernel duration)
 void set_system_kernel_events(hipEvent_t start, hipEvent_t stop);
 void launch_reduce_system(hipStream_t s, int B, const double* partials, int nblk, double* sums, LaneMask m);

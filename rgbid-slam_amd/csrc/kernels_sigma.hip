@@ -491,19 +491,28 @@ int lattice_samples(int rows, int cols, int min_nsamples) {
   return n;
 }
 
-void launch_sigma_pair_fused(hipStream_t s, int B, ImgB Wcur, ImgB W0, ImgB Icur, ImgB I0, const WarpParams* lane_wp, int interp_mode,
-                             int min_nsamples, SysParams* sp, int mestimator, LaneMask m, bool fast, float* res, size_t res_lane_stride,
-                             const float* kf_lat, size_t kf_lat_lane_stride) {
-  // res: [lane][2][n] scratch of at least 2 * lattice_samples() floats per lane (the engine sizes it at creation)
+// the lattice pre-pass of the fused path alone: both channels' residuals of every lattice sample into res[lane][2][n].  `fast` is the RESOLVED
+// numerics class of the level (kernels.h gn_fast_supported): the caller decides it once for the lattice and the normal equations.
+void launch_lattice_residuals_fused(hipStream_t s, int B, ImgB Wcur, ImgB W0, ImgB Icur, ImgB I0, const WarpParams* lane_wp, int interp_mode, int min_nsamples,
+                                    LaneMask m, bool fast, float* res, size_t res_lane_stride, const float* kf_lat, size_t kf_lat_lane_stride) {
   int n, lr, lc, st;
   lattice_geometry(W0.rows, W0.cols, min_nsamples, &n, &lr, &lc, &st);
-  const int f = (fast && Icur.cols >= 2 && Icur.rows >= 2) ? 1 : 0;
   hipLaunchKernelGGL(k_lattice_residuals_fused, dim3(div_up(n, 256), B), dim3(256), 0, s, Wcur, W0, Icur, I0, lane_wp, interp_mode, n, lc, st, res, res_lane_stride,
-                     kf_lat_lane_stride >= 2 * (size_t)n ? kf_lat : nullptr, kf_lat_lane_stride, m, f);
+                     kf_lat_lane_stride >= 2 * (size_t)n ? kf_lat : nullptr, kf_lat_lane_stride, m, fast ? 1 : 0);
+}
+// computeSigmaAndNuStudent of both channels on res[lane][2][n] (start values of visodo.cpp:1168-1173), results into sp[lane]
+void launch_sigma_pair_arrays(hipStream_t s, int B, const float* res, size_t res_lane_stride, int n, SysParams* sp, int mestimator, LaneMask m) {
   if (n <= SIG_T * SIG_MAXPT)
     hipLaunchKernelGGL(k_sigma_pair_arrays<true>, dim3(B, 2), dim3(SIG_T), 0, s, nu_table(), res, res_lane_stride, n, sp, mestimator, m);
   else
     hipLaunchKernelGGL(k_sigma_pair_arrays<false>, dim3(B, 2), dim3(SIG_T), 0, s, nu_table(), res, res_lane_stride, n, sp, mestimator, m);
+}
+void launch_sigma_pair_fused(hipStream_t s, int B, ImgB Wcur, ImgB W0, ImgB Icur, ImgB I0, const WarpParams* lane_wp, int interp_mode,
+                             int min_nsamples, SysParams* sp, int mestimator, LaneMask m, bool fast, float* res, size_t res_lane_stride,
+                             const float* kf_lat, size_t kf_lat_lane_stride) {
+  // res: [lane][2][n] scratch of at least 2 * lattice_samples() floats per lane (the engine sizes it at creation)
+  launch_lattice_residuals_fused(s, B, Wcur, W0, Icur, I0, lane_wp, interp_mode, min_nsamples, m, fast, res, res_lane_stride, kf_lat, kf_lat_lane_stride);
+  launch_sigma_pair_arrays(s, B, res, res_lane_stride, lattice_samples(W0.rows, W0.cols, min_nsamples), sp, mestimator, m);
 }
 
 // ---- computeChiSquare sigmaFuncs.cu:1225-1297 (+ :137-150, :541-646) --------------------------------

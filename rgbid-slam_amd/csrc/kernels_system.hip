@@ -431,14 +431,18 @@ int launch_build_system(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB g
   return launch_system_impl(s, B, W0, I0, gWx, gWy, gIx, gIy, W1, I1, hp, lp, partials, m, level_tag, 0, FusedArgs{nullptr, 0});
 }
 
-int launch_gn_fused(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB Wcur, ImgB Icur,
-                    const WarpParams* lane_wp, int interp_mode, const SysParams* lane_p, double* partials, LaneMask m, int level_tag, bool fast, int weight_mode) {
-  // the paired bilinear taps need two columns; the pipelined kernel addresses the six keyframe maps through one shared 32-bit row offset
+bool gn_fast_supported(ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB Icur) {
+  // the pipelined kernel addresses the six keyframe maps through one shared 32-bit row offset; the paired bilinear taps read (x, x + 1) of rows (y, y + 1)
   const bool same_geom = W0.pitch == I0.pitch && W0.pitch == gWx.pitch && W0.pitch == gWy.pitch && W0.pitch == gIx.pitch && W0.pitch == gIy.pitch &&
                          (unsigned long long)W0.rows * W0.pitch < (1ull << 32) && W0.pitch < (1u << 24) && W0.rows < (1 << 24);
-  const bool vec = (W0.cols % 4 == 0) && vec_ok(W0) && vec_ok(I0) && vec_ok(gWx) && vec_ok(gWy) && vec_ok(gIx) && vec_ok(gIy);
-  const bool f = fast && Icur.cols >= 2 && same_geom && vec;   // otherwise the exact fused kernel (as the unfused path falls back to the exact warp pair)
-  return launch_system_impl(s, B, W0, I0, gWx, gWy, gIx, gIy, Wcur, Icur, nullptr, lane_p, partials, m, level_tag, f ? 2 : 1, FusedArgs{lane_wp, interp_mode}, weight_mode);
+  const bool vec = (W0.cols % 4 == 0) && W0.cols >= 4 && vec_ok(W0) && vec_ok(I0) && vec_ok(gWx) && vec_ok(gWy) && vec_ok(gIx) && vec_ok(gIy);
+  return same_geom && vec && Icur.cols >= 2 && Icur.rows >= 2;
+}
+
+int launch_gn_fused(hipStream_t s, int B, ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB Wcur, ImgB Icur,
+                    const WarpParams* lane_wp, int interp_mode, const SysParams* lane_p, double* partials, LaneMask m, int level_tag, bool fast, int weight_mode) {
+  if (fast && !gn_fast_supported(W0, I0, gWx, gWy, gIx, gIy, Icur)) return -1;   // the caller resolves the class once per level (kernels.h)
+  return launch_system_impl(s, B, W0, I0, gWx, gWy, gIx, gIy, Wcur, Icur, nullptr, lane_p, partials, m, level_tag, fast ? 2 : 1, FusedArgs{lane_wp, interp_mode}, weight_mode);
 }
 
 // FinalReductionKernel estimate_VO.cu:459-500 (all-double here; the reference's tree is fp32).

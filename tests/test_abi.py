@@ -19,9 +19,12 @@ def test_library_exports_every_declared_symbol():
     _lib.build()
     L = ctypes.CDLL(_lib.LIB_PATH)
     names = _declared("rgbid.h")
-    if os.path.exists(os.path.join(ROOT, "include", "rgbid_engine.h")):
-        names += _declared("rgbid_engine.h")
-    assert len(names) >= 40
+    names += _declared("rgbid_engine.h")
+    batched = _declared("rgbid_batched.h")
+    from rgbid import batched as BT
+    assert set(batched) == set(BT.BATCHED_EXPORTS), set(batched) ^ set(BT.BATCHED_EXPORTS)
+    names += batched
+    assert len(names) >= 90
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
     # the Python binding's own list must not drift from the header
