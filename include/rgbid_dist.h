@@ -16,6 +16,7 @@
  *     rgbid_engine_pack_gather_records(engine, 0, chunk_len, local_dev)  // device-side: pose-record ring -> [lanes][chunk_len] records
  *     rgbid_dist_gather_records(d, local_dev, lanes * chunk_len, all_dev)// ncclAllGather on the context's stream
  *     rgbid_dist_compose_trajectory(all_host, ...)                       // after one D2H of world * lanes * chunk_len * 392 bytes
+ * -- or calls rgbid_dist_track_sequence, which is exactly that sequence (tools/rgbid_track_sequence.cpp is its command line).
  * Functions return 0, a positive hipError_t, a negative RGBID_E_* code, or RGBID_E_RCCL - ncclResult_t.
  */
 #ifndef RGBID_DIST_H_
@@ -46,8 +47,17 @@ int rgbid_dist_rank_chunks(int n_chunks, int world, int rank, int* start, int* c
  * rgbid_dist_new_id on rank 0, ship the 128 bytes, rgbid_dist_init everywhere. ---- */
 int rgbid_dist_new_id(rgbid_dist_id* id);
 int rgbid_dist_exchange_id(const char* addr, int port, int world, int rank, rgbid_dist_id* id);
-/* the transport alone (rank 0's `blob` of n bytes reaches every rank); exposed so that it can be tested without RCCL */
+/* the transport alone (rank 0's `blob` of n bytes reaches every rank); exposed so that it can be tested without RCCL.
+ * addr: IPv4 / IPv6 literal or a host name (getaddrinfo).  Rank 0 listens until every rank 1..world-1 has been served ONCE or the
+ * deadline passes (RGBID_DIST_TIMEOUT_S, default 120 s); a connection that does not present the job's hello -- magic, the job nonce
+ * (RGBID_DIST_NONCE, else a hash of TORCHELASTIC_RUN_ID, else 0: set one per job on a shared network, the blob goes to whoever
+ * presents it), a rank in 1..world-1 that has not been served yet -- is dropped and rank 0 keeps accepting.  One node / a trusted
+ * cluster network is the intended scope: there is no encryption. */
 int rgbid_dist_broadcast_bytes(const char* addr, int port, int world, int rank, void* blob, size_t n);
+/* every rank's n bytes reach every rank over the same TCP rendezvous: all[world][n], rank-major.  A TEST / bring-up transport for hosts
+ * without a working RCCL (two processes on one GPU, CPU-only checks of the driver below) -- the product's exchange is
+ * rgbid_dist_gather_records over RCCL. */
+int rgbid_dist_allgather_bytes_tcp(const char* addr, int port, int world, int rank, const void* mine, size_t n, void* all);
 
 /* ---- communicator bound to a context (its device and HIP stream) ---- */
 int rgbid_dist_init(rgbid_dist** d, rgbid_ctx* ctx, const rgbid_dist_id* id, int world, int rank);
@@ -69,6 +79,35 @@ int rgbid_dist_barrier(rgbid_dist* d);
  * (nullable) [n_frames][36] the frame-to-frame covariances (zero for frame 0). ---- */
 int rgbid_dist_compose_trajectory(const rgbid_gather_record* all, int world, int lanes_per_rank, int n_chunks, int chunk_len,
                                   const int* first, const int* last, double* R, double* t, int* status, double* cov);
+
+/* ---- the whole sharded-sequence driver (BASELINE config 4; the C++ counterpart of the reference's eval loop tools/RGBID_SLAMapp.cpp:360-433
+ * + tools/evaluation.cpp:380-439 for ONE sequence cut into chunks): partition -> one engine lane per owned chunk -> frames staged lane-major
+ * and uploaded on a copy stream behind the previous step -> chunk_len lock-step engine steps -> device-side record pack -> ONE all-gather
+ * -> trajectory composition.  One process per GPU calls it with the SAME arguments except `rank`. ---- */
+enum { RGBID_EXCHANGE_RCCL = 0, RGBID_EXCHANGE_TCP = 1 };
+typedef struct rgbid_seq_config {
+  rgbid_engine_config engine;   /* geometry, calibration, schedule, numerics; lanes / record_capacity are set by the driver */
+  int n_chunks;                 /* >= world; chunk c is tracked by lane (c - start) of rank rgbid_dist_rank_chunks owns it */
+  int world, rank;              /* 1, 0 for a single process */
+  int exchange;                 /* RGBID_EXCHANGE_RCCL: ncclAllGather on the context's stream; RGBID_EXCHANGE_TCP: the test transport above */
+  const char* master_addr;      /* rank 0's address for the rendezvous (world > 1) */
+  int master_port;
+} rgbid_seq_config;
+typedef struct rgbid_seq_report {
+  int lanes, chunk_len, n_chunks, world, rccl_ranks;
+  double setup_ms;      /* communicator + engine creation, staging allocation (not part of the per-sequence cost of a resident service) */
+  double track_ms;      /* uploads + chunk_len engine steps + record pack, until the engine's stream is idle */
+  double gather_ms;     /* the all-gather + the D2H of the gathered records */
+  double compose_ms;    /* host composition of the trajectory */
+  double total_ms;      /* track + gather + compose */
+  unsigned long long staged_bytes, engine_bytes;
+} rgbid_seq_report;
+/* depth_host [n_frames][rows][cols] u16 millimetres, rgb_host [n_frames][rows][cols][3] (host memory; pinned memory uploads asynchronously).
+ * inject (nullable): [n_chunks][chunk_len] records to use INSTEAD of running the engine (chunk_len = the longest chunk) -- exercises
+ * partition / exchange / composition without a GPU; needs world == 1 or RGBID_EXCHANGE_TCP, ctx may then be NULL.
+ * Outputs as rgbid_dist_compose_trajectory: R [n_frames][9], t [n_frames][3], status / cov nullable.  Every rank receives the trajectory. */
+int rgbid_dist_track_sequence(rgbid_ctx* ctx, const rgbid_seq_config* cfg, const uint16_t* depth_host, const uint8_t* rgb_host, int n_frames,
+                              const rgbid_gather_record* inject, double* R, double* t, int* status, double* cov, rgbid_seq_report* report);
 
 #ifdef __cplusplus
 }

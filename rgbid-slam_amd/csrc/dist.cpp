@@ -10,15 +10,21 @@
 #include <rccl/rccl.h>
 
 #include <arpa/inet.h>
+#include <netdb.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cerrno>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 struct rgbid_dist {
@@ -51,6 +57,116 @@ bool recv_all(int fd, void* p, size_t n) {
     c += k; n -= (size_t)k;
   }
   return true;
+}
+
+// ---- TCP rendezvous ------------------------------------------------------------------------------------------------------------------
+// One listening socket on rank 0, one short connection per other rank.  hello = {magic, nonce, rank}; anything else that connects (a port
+// scanner, a stale process of another job, a rank that has been served already) is dropped and rank 0 keeps accepting until every rank
+// 1..world-1 has been served once or the deadline passes.
+constexpr uint32_t HELLO_MAGIC = 0x52474244u;   // "RGBD"
+struct Hello { uint32_t magic; int32_t rank; uint64_t nonce; };
+
+uint64_t job_nonce() {
+  if (const char* e = getenv("RGBID_DIST_NONCE")) return strtoull(e, nullptr, 0);
+  uint64_t h = 0;
+  if (const char* e = getenv("TORCHELASTIC_RUN_ID")) { h = 1469598103934665603ull; for (const char* p = e; *p; ++p) { h ^= (unsigned char)*p; h *= 1099511628211ull; } }
+  return h;
+}
+int timeout_s() {
+  if (const char* e = getenv("RGBID_DIST_TIMEOUT_S")) { int v = atoi(e); if (v > 0) return v; }
+  return 120;
+}
+using Clock = std::chrono::steady_clock;
+int ms_left(Clock::time_point deadline) {
+  auto d = std::chrono::duration_cast<std::chrono::milliseconds>(deadline - Clock::now()).count();
+  return d < 0 ? 0 : (int)d;
+}
+void set_io_timeout(int fd, int seconds) {
+  timeval tv{seconds, 0};
+  setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+  setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
+}
+
+// rank 0: blob -> every rank (gather == false), or every rank's n bytes -> all[world][n] on every rank (gather == true)
+int tcp_exchange(const char* addr, int port, int world, int rank, void* blob, size_t n, void* all, bool gather) {
+  if (!addr || port <= 0 || port > 65535) return RGBID_E_INVALID;
+  addrinfo hints{};
+  hints.ai_family = AF_UNSPEC; hints.ai_socktype = SOCK_STREAM;
+  if (rank == 0) hints.ai_flags = AI_PASSIVE;
+  addrinfo* res = nullptr;
+  const std::string ports = std::to_string(port);
+  if (getaddrinfo(addr, ports.c_str(), &hints, &res) != 0 || !res) return RGBID_E_NET;
+  const uint64_t nonce = job_nonce();
+  const auto deadline = Clock::now() + std::chrono::seconds(timeout_s());
+  int rc = RGBID_E_NET;
+  if (rank == 0) {
+    int ls = -1;
+    for (addrinfo* a = res; a && ls < 0; a = a->ai_next) {
+      ls = ::socket(a->ai_family, a->ai_socktype, a->ai_protocol);
+      if (ls < 0) continue;
+      int one = 1;
+      setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+      if (::bind(ls, a->ai_addr, a->ai_addrlen) != 0 || ::listen(ls, world + 8) != 0) { ::close(ls); ls = -1; }
+    }
+    freeaddrinfo(res);
+    if (ls < 0) return RGBID_E_NET;
+    std::vector<int> fds(world, -1);        // gather: connections stay open until every rank's block has arrived
+    std::vector<char> served(world, 0);
+    if (gather) memcpy(all, blob, n);
+    int n_served = 0;
+    rc = RGBID_OK;
+    while (n_served < world - 1) {
+      pollfd pf{ls, POLLIN, 0};
+      const int left = ms_left(deadline);
+      if (left == 0) { rc = RGBID_E_NET; break; }
+      const int pr = ::poll(&pf, 1, left);
+      if (pr < 0) { if (errno == EINTR) continue; rc = RGBID_E_NET; break; }
+      if (pr == 0) { rc = RGBID_E_NET; break; }
+      int fd = ::accept(ls, nullptr, nullptr);
+      if (fd < 0) { if (errno == EINTR || errno == EAGAIN || errno == ECONNABORTED) continue; rc = RGBID_E_NET; break; }
+      set_io_timeout(fd, 5);                // a peer that connects and says nothing costs 5 s, not the job
+      Hello h{};
+      const bool hello_ok = recv_all(fd, &h, sizeof(h)) && h.magic == HELLO_MAGIC && h.nonce == nonce && h.rank > 0 && h.rank < world && !served[h.rank];
+      if (!hello_ok) { ::close(fd); continue; }           // not one of ours (or a duplicate): drop it, keep listening
+      set_io_timeout(fd, timeout_s());
+      bool ok;
+      if (gather) ok = recv_all(fd, (char*)all + (size_t)h.rank * n, n);
+      else ok = send_all(fd, blob, n);
+      if (!ok) { ::close(fd); continue; }                  // the rank may reconnect until the deadline
+      served[h.rank] = 1; ++n_served;
+      if (gather) fds[h.rank] = fd; else ::close(fd);
+    }
+    if (gather) {
+      for (int r = 1; r < world; ++r) {
+        if (fds[r] < 0) continue;
+        if (rc == RGBID_OK && !send_all(fds[r], all, (size_t)world * n)) rc = RGBID_E_NET;
+        ::close(fds[r]);
+      }
+    }
+    ::close(ls);
+    return rc;
+  }
+  // ranks > 0: rank 0 may not be listening yet -- retry until the deadline
+  while (ms_left(deadline) > 0) {
+    for (addrinfo* a = res; a; a = a->ai_next) {
+      int fd = ::socket(a->ai_family, a->ai_socktype, a->ai_protocol);
+      if (fd < 0) continue;
+      if (::connect(fd, a->ai_addr, a->ai_addrlen) == 0) {
+        set_io_timeout(fd, timeout_s());
+        Hello h{HELLO_MAGIC, rank, nonce};
+        bool ok = send_all(fd, &h, sizeof(h));
+        if (ok && gather) ok = send_all(fd, blob, n) && recv_all(fd, all, (size_t)world * n);
+        else if (ok) ok = recv_all(fd, blob, n);
+        ::close(fd);
+        freeaddrinfo(res);
+        return ok ? RGBID_OK : RGBID_E_NET;
+      }
+      ::close(fd);
+    }
+    usleep(100 * 1000);
+  }
+  freeaddrinfo(res);
+  return RGBID_E_NET;
 }
 
 void mat3_mul(const double* A, const double* B, double* C) {
@@ -88,47 +204,13 @@ int rgbid_dist_rank_chunks(int n_chunks, int world, int rank, int* start, int* c
 int rgbid_dist_broadcast_bytes(const char* addr, int port, int world, int rank, void* blob, size_t n) {
   if (!blob || world < 1 || rank < 0 || rank >= world) return RGBID_E_INVALID;
   if (world == 1) return RGBID_OK;
-  if (!addr || port <= 0 || port > 65535) return RGBID_E_INVALID;
-  sockaddr_in sa{};
-  sa.sin_family = AF_INET;
-  sa.sin_port = htons((uint16_t)port);
-  if (inet_pton(AF_INET, addr, &sa.sin_addr) != 1) return RGBID_E_NET;
-  if (rank == 0) {
-    int ls = ::socket(AF_INET, SOCK_STREAM, 0);
-    if (ls < 0) return RGBID_E_NET;
-    int one = 1;
-    setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
-    if (::bind(ls, (sockaddr*)&sa, sizeof(sa)) != 0 || ::listen(ls, world) != 0) { ::close(ls); return RGBID_E_NET; }
-    timeval tv{120, 0};   // a rank that never shows up must not hang the job forever
-    setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
-    int served = 0, rc = RGBID_OK;
-    while (served < world - 1) {
-      int fd = ::accept(ls, nullptr, nullptr);
-      if (fd < 0) { if (errno == EINTR) continue; rc = RGBID_E_NET; break; }
-      int peer = -1;
-      bool ok = recv_all(fd, &peer, sizeof(peer)) && peer > 0 && peer < world && send_all(fd, blob, n);
-      ::close(fd);
-      if (!ok) { rc = RGBID_E_NET; break; }
-      ++served;
-    }
-    ::close(ls);
-    return rc;
-  }
-  // ranks > 0: rank 0 may not be listening yet -- retry for up to ~60 s
-  for (int attempt = 0; attempt < 600; ++attempt) {
-    int fd = ::socket(AF_INET, SOCK_STREAM, 0);
-    if (fd < 0) return RGBID_E_NET;
-    if (::connect(fd, (sockaddr*)&sa, sizeof(sa)) == 0) {
-      timeval tv{120, 0};
-      setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
-      bool ok = send_all(fd, &rank, sizeof(rank)) && recv_all(fd, blob, n);
-      ::close(fd);
-      return ok ? RGBID_OK : RGBID_E_NET;
-    }
-    ::close(fd);
-    usleep(100 * 1000);
-  }
-  return RGBID_E_NET;
+  return tcp_exchange(addr, port, world, rank, blob, n, nullptr, false);
+}
+
+int rgbid_dist_allgather_bytes_tcp(const char* addr, int port, int world, int rank, const void* mine, size_t n, void* all) {
+  if (!mine || !all || world < 1 || rank < 0 || rank >= world) return RGBID_E_INVALID;
+  if (world == 1) { memcpy(all, mine, n); return RGBID_OK; }
+  return tcp_exchange(addr, port, world, rank, const_cast<void*>(mine), n, all, true);
 }
 
 int rgbid_dist_new_id(rgbid_dist_id* id) {
@@ -234,6 +316,13 @@ int rgbid_dist_compose_trajectory(const rgbid_gather_record* all, int world, int
     }
     if (owner < 0 || local >= lanes_per_rank) return RGBID_E_INVALID;
     const rgbid_gather_record* rec = all + ((size_t)owner * lanes_per_rank + local) * chunk_len;
+    // a lane that really tracked chunk c numbers its frames 0, 1, 2, ... (rgbid_gather_record.frame_id = global_time_ of the frame inside the
+    // lane's run; a frame that stays lost repeats the id, visodo.cpp:2051-2117): non-decreasing, 0 exactly on the first frame, never ahead
+    // of the frame's position.  A padded lane, a zeroed buffer or a lane that tracked another chunk length fails this.
+    for (int j = 0; j < n; ++j) {
+      const int id = rec[j].frame_id;
+      if (j == 0 ? id != 0 : (id < 1 || id > j || id < rec[j - 1].frame_id)) return RGBID_E_INVALID;
+    }
     if (c == 0 && status) status[0] = rec[0].status;
     // the chunk's first frame IS the previous chunk's last frame: its pose is already composed; continue from there
     for (int j = 1; j < n; ++j) {
@@ -248,6 +337,141 @@ int rgbid_dist_compose_trajectory(const rgbid_gather_record* all, int world, int
       if (cov) memcpy(cov + (size_t)k * 36, g.cov, sizeof(g.cov));
     }
   }
+  return RGBID_OK;
+}
+
+// ---- the sharded-sequence driver ----------------------------------------------------------------------------------------------------------
+namespace {
+struct SeqScratch {   // everything the driver allocates, released on every exit path
+  rgbid_engine* eng = nullptr;
+  rgbid_dist* comm = nullptr;
+  void *d_depth = nullptr, *d_rgb = nullptr, *d_local = nullptr, *d_all = nullptr;
+  hipStream_t copy = nullptr;
+  std::vector<hipEvent_t> ev;
+  ~SeqScratch() {
+    if (eng) rgbid_engine_destroy(eng);
+    if (comm) rgbid_dist_destroy(comm);
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    if (copy) (void)hipStreamDestroy(copy);
+    for (void* p : {d_depth, d_rgb, d_local, d_all}) if (p) (void)hipFree(p);
+  }
+};
+inline double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+}  // namespace
+
+int rgbid_dist_track_sequence(rgbid_ctx* ctx, const rgbid_seq_config* cfg, const uint16_t* depth_host, const uint8_t* rgb_host, int n_frames,
+                              const rgbid_gather_record* inject, double* R, double* t, int* status, double* cov, rgbid_seq_report* report) {
+  if (!cfg || !R || !t || cfg->world < 1 || cfg->rank < 0 || cfg->rank >= cfg->world || cfg->n_chunks < cfg->world || n_frames < cfg->n_chunks + 1 ||
+      (cfg->exchange != RGBID_EXCHANGE_RCCL && cfg->exchange != RGBID_EXCHANGE_TCP))
+    return RGBID_E_INVALID;
+  if (!inject && (!ctx || !depth_host || !rgb_host)) return RGBID_E_INVALID;
+  if (inject && cfg->world > 1 && cfg->exchange != RGBID_EXCHANGE_TCP) return RGBID_E_INVALID;   // no GPU side: nothing for RCCL to gather from
+  if (cfg->world > 1 && (!cfg->master_addr || cfg->master_port <= 0)) return RGBID_E_INVALID;
+  const int world = cfg->world, rank = cfg->rank, n_chunks = cfg->n_chunks;
+  const auto t_setup = Clock::now();
+  std::vector<int> first(n_chunks), last(n_chunks);
+  int r = rgbid_dist_chunk_ranges(n_frames, n_chunks, first.data(), last.data());
+  if (r) return r;
+  int start = 0, count = 0;
+  rgbid_dist_rank_chunks(n_chunks, world, rank, &start, &count);
+  const int lanes = (n_chunks + world - 1) / world;
+  int L = 0;
+  for (int c = 0; c < n_chunks; ++c) L = std::max(L, last[c] - first[c] + 1);
+  // lane -> chunk: the rank's block of chunks; a rank that owns one chunk fewer pads with a lane that re-tracks its last chunk (never read)
+  std::vector<int> owned(lanes);
+  for (int l = 0; l < lanes; ++l) owned[l] = count ? start + std::min(l, count - 1) : 0;
+  const size_t n_local = (size_t)lanes * L;
+  std::vector<rgbid_gather_record> all((size_t)world * n_local);
+  SeqScratch S;
+  rgbid_seq_report rep{};
+  rep.lanes = lanes; rep.chunk_len = L; rep.n_chunks = n_chunks; rep.world = world; rep.rccl_ranks = 0;
+  double track_ms = 0.0, gather_ms = 0.0;
+
+  if (inject) {
+    rep.setup_ms = ms_since(t_setup);
+    const auto t0 = Clock::now();
+    std::vector<rgbid_gather_record> local(n_local);
+    for (int l = 0; l < lanes; ++l) memcpy(&local[(size_t)l * L], inject + (size_t)owned[l] * L, sizeof(rgbid_gather_record) * L);
+    if (count < lanes) for (int l = count; l < lanes; ++l) for (int j = 0; j < L; ++j) local[(size_t)l * L + j].frame_id = -1;   // padding lanes are not chunks
+    track_ms = ms_since(t0);
+    const auto t1 = Clock::now();
+    r = rgbid_dist_allgather_bytes_tcp(cfg->master_addr, cfg->master_port, world, rank, local.data(), n_local * sizeof(rgbid_gather_record), all.data());
+    if (r) return r;
+    gather_ms = ms_since(t1);
+  } else {
+    const rgbid_engine_config& ec = cfg->engine;
+    if (ec.rows <= 0 || ec.cols <= 0) return RGBID_E_INVALID;
+    void* sv = nullptr;
+    if ((r = rgbid_ctx_get_stream(ctx, &sv))) return r;
+    hipStream_t es = (hipStream_t)sv;
+    int dev = 0;
+    if (hipError_t he = hipStreamGetDevice(es, &dev); he != hipSuccess) return (int)he;
+    if (hipError_t he = hipSetDevice(dev); he != hipSuccess) return (int)he;
+    if (world > 1 && cfg->exchange == RGBID_EXCHANGE_RCCL) {
+      rgbid_dist_id id;
+      if ((r = rgbid_dist_exchange_id(cfg->master_addr, cfg->master_port, world, rank, &id))) return r;
+      if ((r = rgbid_dist_init(&S.comm, ctx, &id, world, rank))) return r;
+      rep.rccl_ranks = rgbid_dist_world(S.comm);
+    }
+    rgbid_engine_config e2 = ec;
+    e2.lanes = lanes; e2.record_capacity = L; e2.use_graph = 0;   // eager steps read the staged frames in place
+    if ((r = rgbid_engine_create(&S.eng, ctx, &e2))) return r;
+    size_t eb = 0; rgbid_engine_bytes(S.eng, &eb); rep.engine_bytes = eb;
+    const size_t fd = (size_t)ec.rows * ec.cols * 2, fc = (size_t)ec.rows * ec.cols * 3;
+    rep.staged_bytes = (fd + fc) * n_local;
+    hipError_t he = hipMalloc(&S.d_depth, fd * n_local);
+    if (he == hipSuccess) he = hipMalloc(&S.d_rgb, fc * n_local);
+    if (he == hipSuccess) he = hipMalloc(&S.d_local, sizeof(rgbid_gather_record) * n_local);
+    if (he == hipSuccess && world > 1 && S.comm) he = hipMalloc(&S.d_all, sizeof(rgbid_gather_record) * n_local * world);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&S.copy, hipStreamNonBlocking);
+    S.ev.resize(L, nullptr);
+    for (int j = 0; j < L && he == hipSuccess; ++j) he = hipEventCreateWithFlags(&S.ev[j], hipEventDisableTiming);
+    if (he != hipSuccess) { (void)hipGetLastError(); return he == hipErrorOutOfMemory ? RGBID_E_NOMEM : (int)he; }
+    rgbid_ctx_set_async(ctx, 1);
+    rgbid_ctx_sync(ctx);
+    rep.setup_ms = ms_since(t_setup);
+    if (S.comm && (r = rgbid_dist_barrier(S.comm))) return r;   // ranks start their clocks together
+    // ---- uploads on the copy stream, one event per step; step j waits for its frames only, so step j + 1's frames travel while step j runs
+    const auto t0 = Clock::now();
+    for (int j = 0; j < L; ++j) {
+      for (int l = 0; l < lanes; ++l) {
+        const int c = owned[l];
+        const size_t k = (size_t)std::min(first[c] + j, last[c]);   // a shorter chunk repeats its last frame (its records past the chunk are not read)
+        he = hipMemcpyAsync((char*)S.d_depth + ((size_t)j * lanes + l) * fd, (const char*)depth_host + k * fd, fd, hipMemcpyHostToDevice, S.copy);
+        if (he == hipSuccess) he = hipMemcpyAsync((char*)S.d_rgb + ((size_t)j * lanes + l) * fc, rgb_host + k * fc, fc, hipMemcpyHostToDevice, S.copy);
+        if (he != hipSuccess) { (void)hipGetLastError(); return (int)he; }
+      }
+      he = hipEventRecord(S.ev[j], S.copy);
+      if (he != hipSuccess) { (void)hipGetLastError(); return (int)he; }
+      if ((r = rgbid_ctx_wait_event(ctx, S.ev[j]))) return r;
+      if ((r = rgbid_engine_step(S.eng, (char*)S.d_depth + (size_t)j * lanes * fd, (char*)S.d_rgb + (size_t)j * lanes * fc))) return r;
+    }
+    if ((r = rgbid_engine_pack_gather_records(S.eng, 0, L, (rgbid_gather_record*)S.d_local))) return r;
+    if ((r = rgbid_ctx_sync(ctx))) return r;
+    track_ms = ms_since(t0);
+    // ---- the exchange: ONE all-gather of the records
+    const auto t1 = Clock::now();
+    if (world > 1 && S.comm) {
+      if ((r = rgbid_dist_gather_records(S.comm, (const rgbid_gather_record*)S.d_local, (int)n_local, (rgbid_gather_record*)S.d_all))) return r;
+      he = hipMemcpyAsync(all.data(), S.d_all, sizeof(rgbid_gather_record) * n_local * world, hipMemcpyDeviceToHost, es);
+      if (he == hipSuccess) he = hipStreamSynchronize(es);
+      if (he != hipSuccess) { (void)hipGetLastError(); return (int)he; }
+    } else {
+      std::vector<rgbid_gather_record> local(n_local);
+      he = hipMemcpyAsync(local.data(), S.d_local, sizeof(rgbid_gather_record) * n_local, hipMemcpyDeviceToHost, es);
+      if (he == hipSuccess) he = hipStreamSynchronize(es);
+      if (he != hipSuccess) { (void)hipGetLastError(); return (int)he; }
+      if (count < lanes) for (int l = count; l < lanes; ++l) for (int j = 0; j < L; ++j) local[(size_t)l * L + j].frame_id = -1;
+      if ((r = rgbid_dist_allgather_bytes_tcp(cfg->master_addr, cfg->master_port, world, rank, local.data(), n_local * sizeof(rgbid_gather_record), all.data()))) return r;
+    }
+    gather_ms = ms_since(t1);
+  }
+  const auto t2 = Clock::now();
+  r = rgbid_dist_compose_trajectory(all.data(), world, lanes, n_chunks, L, first.data(), last.data(), R, t, status, cov);
+  if (r) return r;
+  rep.track_ms = track_ms; rep.gather_ms = gather_ms; rep.compose_ms = ms_since(t2);
+  rep.total_ms = rep.track_ms + rep.gather_ms + rep.compose_ms;
+  if (report) *report = rep;
   return RGBID_OK;
 }
 

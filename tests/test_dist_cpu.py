@@ -47,9 +47,17 @@ def test_compose_single_rank_matches_reference_composition():
             rec[0, c, j]["R"] = dR[a + j] if j else np.eye(3)
             rec[0, c, j]["t"] = dt[a + j] if j else 0
             rec[0, c, j]["status"] = 1 if j else 16
+            rec[0, c, j]["frame_id"] = j
     R, t, st, cov = D.compose_trajectory(rec, 1, n_chunks, ranges)
     assert np.abs(R - np.array(Rg)).max() < 1e-14 and np.abs(t - np.array(tg)).max() < 1e-14
     assert st[0] == 16 and (st[1:] == 1).all()
+    # a lane that did not track its chunk (zeroed / padded / shifted records) is refused, not composed silently
+    bad = rec.copy(); bad[0, 2]["frame_id"] = 0
+    with pytest.raises(Exception):
+        D.compose_trajectory(bad, 1, n_chunks, ranges)
+    lost = rec.copy(); lost[0, 1, 3]["frame_id"] = 2       # a frame that stayed lost repeats its id: accepted
+    lost[0, 1, 4:]["frame_id"] -= 1
+    D.compose_trajectory(lost, 1, n_chunks, ranges)
 
 
 @pytest.mark.parametrize("world,chunks", [(2, 8), (2, 7), (3, 7)])

@@ -97,7 +97,7 @@ def check_system(A, b, oA, ob, extraA=None, extrab=None, rtol_b=2e-5):
     return ra, rb
 
 
-FAST_RTOL_B = 1e-4
+FAST_RTOL_B = 2e-5
 ARGS = dict(sigma_depthinv=0.003, sigma_int=6.0, bias_depthinv=0.0002, bias_int=-0.5, nu_depthinv=3.5, nu_int=6.25)
 COV_ARGS = dict(sigma_depthinv=0.0025, sigma_int=5.0, bias_depthinv=0.0, bias_int=0.0, nu_depthinv=5.0, nu_int=5.0)
 
@@ -181,8 +181,8 @@ def test_gn_fused_fast_vs_oracle(bt, rows, cols, lanes, cfg):
         mAo, mbo = O.build_system(W0m, *kf[1:], d["W1"], d["I1"], K, **okw)
         mAf, mbf = O.build_system(W0m, *kf[1:], W1f[l], I1f[l], K, **okw)
         oA, ob = O.build_system(*kf, d["W1"], d["I1"], K, **okw)
-        # the remaining pixels' bilinear weights are 1.8 fixed point: a coordinate that moves by an ulp flips a 1/256 weight step at ~1 % of
-        # them (|dI1| <= local contrast / 256, random sign), which reaches b (linear in the residual) but not A: b is held to FAST_RTOL_B
+        # (the other pixels' 1.8 fixed-point bilinear weights flip a 1/256 step at ~1 % of them -- |dI1| <= local contrast / 256, random sign --
+        # which reaches b, linear in the residual; measured on the MI355X: db <= 9e-6 of the scale at every size, inside the plain 2e-5)
         ra, rb = check_system(A[l], b[l], oA, ob, np.abs(mAo) + np.abs(mAf), np.abs(mbo) + np.abs(mbf), rtol_b=FAST_RTOL_B)   # (b)
         print(f"{name} {cols}x{rows} lane {l}: {nb} boundary pixels of {rows * cols}; vs pure oracle chain: dA {ra:.2e}, db {rb:.2e} (before the boundary allowance)")
 
