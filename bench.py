@@ -13,9 +13,11 @@ the timed region starts.  `value` = aligned frames / s over all GPUs (weak scali
 Protocol: `--reps` (5) repetitions, each = reset, keyframe frame, W untimed warm-up steps, then EXACTLY K timed steps bracketed by a
 barrier + device synchronisation on both sides (max over ranks); `value` is the median repetition, all of them are listed.  Prints ONE
 JSON line (rank 0) with `roofline` (level-0 residual + normal-equation kernel, timed with HIP events inside the timed regions),
-`parity` (duplicate lanes bit-identical; one lane per checked stream against the CPU oracle over all timed steps -- the oracle is the
-checker here, after the timed regions), `extra_configs` (BASELINE configs 1 and 5) and `cpu_baseline` (the CPU oracle -- a scalar port
-of the reference algorithm -- on the host cores; baseline, not target).
+`parity` (duplicate lanes bit-identical; one lane of EVERY distinct stream against the CPU oracle over all timed steps -- the oracle is the
+checker here, after the timed regions), `extra_configs` (the headline workload in the EXACT numerics class, fused and as the reference's kernel
+sequence; BASELINE configs 1, 4 and 5) and `cpu_baseline` (the CPU oracle -- a scalar port of the reference algorithm -- on the host cores;
+baseline, not target).  Config 4 (ONE long sequence cut into chunks, strong-scaled over the ranks) runs through the C++ driver
+rgbid_dist_track_sequence (csrc/dist.cpp; command line: rgbid-slam_amd/bin/rgbid_track_sequence).
 """
 import argparse
 import os
@@ -188,11 +190,11 @@ def oracle_check(depth, rgb, lanes_to_check, rows, cols, K, levels, iters, rec, 
 
 
 def run_config(ctx, dev, work_stream, rows, cols, levels, iters, B, Kst, W, reps, n_unique, graph, fused, keyframes, K, dist_env, check_streams=0,
-               fast_numerics=1):
+               fast_numerics=1, inputs=None):
     """the timed protocol on one engine configuration; returns (result dict, inputs kept for the PCIe leg)"""
     from rgbid import engine as E
     T = 1 + W + Kst
-    seqs, depth, rgb = make_inputs(B, T, rows, cols, K, dev, n_unique)
+    seqs, depth, rgb = inputs if inputs is not None else make_inputs(B, T, rows, cols, K, dev, n_unique)
     cfg_kw = dict(rows=rows, cols=cols, levels=levels, lanes=B, K=K, iters=iters, use_graph=graph, fused_gn=fused, record_capacity=T,
                   keyframe_capacity=keyframes)
     if hasattr(E.EngineConfig, "fast_numerics"):
@@ -203,6 +205,7 @@ def run_config(ctx, dev, work_stream, rows, cols, levels, iters, B, Kst, W, reps
     use_dist, comm = dist_env["use_dist"], dist_env.get("comm")
     times, recs, k_ms_tot, k_n_tot, k_bytes = [], [], 0.0, 0, 0.0
     gathered = None
+    gather_us, rank_times = [], []
     for rep in range(reps):
         if rep:
             eng.reset()
@@ -223,14 +226,18 @@ def run_config(ctx, dev, work_stream, rows, cols, levels, iters, B, Kst, W, reps
             # the only collective on the path: all-gather of the 392-byte per-frame records of every rank's lanes (RCCL over xGMI)
             from rgbid import dist as D
             packed = D.pack_engine_records(eng, 1 + W, Kst)
+            ctx.sync()
+            tg = time.perf_counter()
             if comm is not None:
                 gathered = comm.gather(packed, B * Kst)
                 ctx.sync()
-            else:
-                ctx.sync()
+            else:                                  # --gather torch (asked for explicitly): the same exchange through torch.distributed
                 gathered = torch.empty(dist_env["world"] * packed.numel(), dtype=torch.uint8, device=dev)
                 dist.all_gather_into_tensor(gathered, packed)
+                torch.cuda.synchronize(dev)
+            gather_us.append((time.perf_counter() - tg) * 1e6)
         torch.cuda.synchronize(dev)
+        el_own = time.perf_counter() - t0          # this rank's own clock, before it waits for the others
         if use_dist:
             dist.barrier()
         el = time.perf_counter() - t0
@@ -238,6 +245,9 @@ def run_config(ctx, dev, work_stream, rows, cols, levels, iters, B, Kst, W, reps
             tmax = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el = float(tmax.item())
+            own = torch.zeros(dist_env["world"], dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(own, torch.tensor([el_own], dtype=torch.float64, device=dev))
+            rank_times.append([float(v) for v in own.cpu()])
         if profile_in_timed:
             ms, n, k_bytes = eng.profile_end()
             k_ms_tot += ms; k_n_tot += n
@@ -273,8 +283,17 @@ def run_config(ctx, dev, work_stream, rows, cols, levels, iters, B, Kst, W, reps
         wr, wt, imposed = oracle_check(depth, rgb, chk, rows, cols, K, levels, iters, full, 1 + W, Kst)
         parity.update({"oracle_checked_lanes": chk, "oracle_checked_steps": Kst, "worst_rot_rad": wr, "worst_trans_m": wt,
                        "keyframe_decisions_on_threshold_imposed": imposed, "within_1e-4": bool(wr < 1e-4 and wt < 1e-4)})
+    # what the engine's own launch list has to move per frame (rgbid_engine_step_bytes) at the switch rates of these records
+    sbytes = eng.step_bytes()
+    st_all = rec["status"]
+    n_tr = max(1, int(np.count_nonzero(st_all & E.ST_TRACKED)))
+    p_odo = float(np.count_nonzero((st_all & E.ST_TRACKED) & ((st_all & E.ST_ODO_KF) != 0))) / n_tr
+    p_int = float(np.count_nonzero((st_all & E.ST_TRACKED) & ((st_all & E.ST_INTEGR_KF) != 0))) / n_tr
+    engine_bytes_per_frame = sbytes[0] + p_odo * sbytes[1] + p_int * sbytes[2] + (1.0 - p_int) * sbytes[3]
     res = {
         "value": B * Kst * world / el, "ms_per_step": el / Kst * 1e3,
+        "engine_bytes_per_frame": engine_bytes_per_frame, "odo_kf_switch_rate": p_odo, "integr_kf_switch_rate": p_int, "step_bytes_model": sbytes,
+        "gather_us": gather_us, "rank_seconds": rank_times,
         "repetitions": {"n": len(times), "frames_per_s": [B * Kst * world / t for t in times], "protocol": "each: reset, keyframe frame, warm-up, K timed steps; value = median"},
         "launches_per_step": eng.launches_per_step(), "engine_hbm_bytes": eng.bytes(), "tracked": tracked, "expected": B * Kst,
         "keyframes_exported": int(np.count_nonzero(rec["status"] & E.ST_KF_EXPORTED)), "n_unique_streams": n_streams,
@@ -289,19 +308,124 @@ def run_config(ctx, dev, work_stream, rows, cols, levels, iters, B, Kst, W, reps
 def extra_config1(ctx, dev, K):
     """BASELINE config 1 on the GPU: the residual + 27-term normal equations (unit U1) of ONE 640x480 pair through the single-image C-ABI
     call (cache-resident: 9.8 MB of maps live in L2 / Infinity Cache), device time from the call's own hipEvent pair."""
-    from oracle import oracle as O   # enum values only
-    from tests import util
+    from rgbid import device as DV
     rows, cols = 480, 640
-    r = util.rng(1)
-    maps = [torch.from_numpy(util.rand_invdepth(r, rows, cols)).to(dev) for _ in range(8)]
+    g = torch.Generator(device="cpu").manual_seed(1)
+    maps = []
+    for _ in range(8):       # smooth positive maps with 5 % invalid pixels: the kernel's time does not depend on the values
+        m = 0.25 + torch.rand((rows, cols), generator=g)
+        m[torch.rand((rows, cols), generator=g) < 0.05] = float("nan")
+        maps.append(m.to(dev))
     ms = []
     for _ in range(60):
-        _, _, m = ctx.buildSystemStudentNuGridStride(*maps, O.STUDENT, O.INDEPENDENT, 0.0025, 5.0, 0.0, 0.0, 5.0, 5.0, K, return_ms=True)
+        _, _, m = ctx.buildSystemStudentNuGridStride(*maps, DV.STUDENT, DV.INDEPENDENT, 0.0025, 5.0, 0.0, 0.0, 5.0, 5.0, K, return_ms=True)
         ms.append(m)
     us = float(np.median(ms[10:])) * 1e3
     return {"config": "1: single 640x480 pair, residual + 6x6 normal equations (U1), cache-resident", "u1_device_us": us,
             "u1_gbs": 32.0 * rows * cols / (us * 1e-6) / 1e9, "calls_timed": len(ms) - 10,
             "note": "working set 9.8 MB < L2 + Infinity Cache: a latency figure, not an HBM-roofline figure; the batched U1 (all lanes of the headline run) is `roofline`"}
+
+
+def _ate_rmse(t_est, t_gt):
+    """RMSE of the translational residual after the least-squares rigid alignment of the estimate onto the ground truth (Horn; tools/ate.py)"""
+    mu_e, mu_g = t_est.mean(0), t_gt.mean(0)
+    U, _, Vt = np.linalg.svd((t_est - mu_e).T @ (t_gt - mu_g))
+    S = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        S[2, 2] = -1
+    R = Vt.T @ S @ U.T
+    res = (t_est @ R.T + (mu_g - R @ mu_e)) - t_gt
+    return float(np.sqrt((res ** 2).sum(1).mean()))
+
+
+def _rot_angle(Ra, Rb):
+    return float(np.arccos(np.clip((np.trace(Ra.T @ Rb) - 1) / 2, -1, 1)))
+
+
+def extra_config4(ctx, dev, K, world, rank, n_frames, chunks_per_gpu, fused, fast):
+    """BASELINE config 4 as a workload: ONE long 640x480 sequence (stand-in for TUM fr3/long_office, ~2 500 frames) cut into chunks_per_gpu x N
+    chunks, STRONG-scaled over the N ranks through the C++ driver (rgbid_dist_track_sequence: partition -> uploads from pinned host memory behind
+    the previous step -> lock-step engine steps -> record pack -> ONE RCCL all-gather -> composition), timed end to end per call.  Rank 0 also tracks
+    the sequence unsharded (one lane, every frame in turn) and reports what sharding costs at the chunk heads (no velocity prior, fresh keyframe)
+    and the ATE of both against the synthetic ground truth."""
+    from rgbid import dist as D, engine as E, synth
+    rows, cols = 480, 640
+    t0 = time.perf_counter()
+    seq = synth.make_long_sequence(n_frames, seed=synth.SEED + 4, K=K, rows=rows, cols=cols, device=dev)
+    depth_h = seq["depth"].cpu().pin_memory(); rgb_h = seq["rgb"].cpu().pin_memory()
+    Rg, tg = seq["R_wc"].numpy(), seq["t_wc"].numpy()
+    del seq
+    torch.cuda.empty_cache()
+    render_s = time.perf_counter() - t0
+    cfg = E.default_config(rows=rows, cols=cols, K=K, fused_gn=fused, fast_numerics=fast)
+    chunks = chunks_per_gpu * world
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1"); port = int(os.environ.get("MASTER_PORT", "29541")) + 2
+    runs = []
+    for i in range(2):     # the first call also pays the first touch of the freshly allocated engine / staging memory; the second is the steady figure
+        R, t, st, cov, rep = D.track_sequence(ctx, cfg, depth_h, rgb_h, chunks, world, rank, D.EXCHANGE_RCCL, addr, port + i)
+        runs.append(rep)
+    out = None
+    if rank == 0:
+        Rs, ts, sts, _, rep1 = D.track_sequence(ctx, cfg, depth_h, rgb_h, 1)       # unsharded: one lane, n_frames sequential steps
+        ranges = D.chunk_ranges(n_frames, chunks)
+        head_r = head_t = 0.0
+        for (a, b) in ranges[1:]:          # frame-to-frame motion of the first tracked frame of every chunk, sharded vs unsharded
+            k = a + 1
+            dRc, dtc = R[k - 1].T @ R[k], R[k - 1].T @ (t[k] - t[k - 1])
+            dRs, dts = Rs[k - 1].T @ Rs[k], Rs[k - 1].T @ (ts[k] - ts[k - 1])
+            head_r = max(head_r, _rot_angle(dRc, dRs)); head_t = max(head_t, float(np.linalg.norm(dtc - dts)))
+        lost = int(np.count_nonzero(st & E.ST_LOST))
+        best = runs[-1]
+        out = {"config": f"4: ONE {n_frames}-frame synthetic 640x480 sequence (stand-in for TUM fr3/long_office: dataset not in image) cut into {chunks} chunks "
+                         f"({chunks_per_gpu} per GPU), strong-scaled over {world} GPU(s); C++ driver rgbid_dist_track_sequence, frames uploaded from pinned host memory",
+               "scaling": "strong", "value": 1e3 * n_frames / best["total_ms"], "unit": "frames/s", "frames": n_frames, "chunks": chunks,
+               "lanes_per_gpu": best["lanes"], "chunk_len": best["chunk_len"], "world": world, "rccl_ranks": best["rccl_ranks"],
+               "timing_ms": {k_: best[k_] for k_ in ("setup_ms", "track_ms", "gather_ms", "compose_ms", "total_ms")},
+               "first_call_total_ms": runs[0]["total_ms"], "staged_bytes_per_gpu": best["staged_bytes"], "engine_hbm_bytes": best["engine_bytes"],
+               "timed": "total_ms = uploads + chunk_len engine steps + record pack + all-gather + D2H + composition (setup_ms -- communicator, engine, staging allocation -- listed, not included)",
+               "frames_lost": lost,
+               "unsharded": {"frames_per_s": 1e3 * n_frames / rep1["total_ms"], "total_ms": rep1["total_ms"], "note": "one lane, every frame in turn (latency-bound: ~126 dependent launches per frame)"},
+               "chunk_head_deviation_vs_unsharded": {"max_rot_rad": head_r, "max_trans_m": head_t, "note": "frame-to-frame motion of each chunk's first tracked frame: no velocity prior, fresh keyframe"},
+               "trajectory_vs_unsharded": {"max_rot_rad": max(_rot_angle(R[k], Rs[k]) for k in range(n_frames)), "max_trans_m": float(np.abs(t - ts).max())},
+               "ate_rmse_m": {"sharded": _ate_rmse(t, tg), "unsharded": _ate_rmse(ts, tg), "vs": "synthetic ground truth (exact camera path)"},
+               "render_s": render_s}
+    del depth_h, rgb_h
+    return out
+
+
+def dataset_configs(K_default):
+    """BASELINE configs 2-4 on the REAL sequences, the moment they are mounted (RGBID_TUM_DIR: folders with depth_associated.txt, rgb_associated.txt,
+    groundtruth.txt): tracked by the C++ driver (rgbid-slam_amd/bin/rgbid_track_sequence, 8 chunks and unsharded) and scored with tools/ate.py --
+    the external pin of the trajectory.  None when nothing is mounted."""
+    base = os.environ.get("RGBID_TUM_DIR", "")
+    if not base or not os.path.isdir(base):
+        return None
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ate as A
+    from rgbid import dist as D
+    cands = [base] + [os.path.join(base, d) for d in sorted(os.listdir(base))]
+    out = []
+    for s_ in [c for c in cands if os.path.exists(os.path.join(c, "depth_associated.txt")) and os.path.exists(os.path.join(c, "groundtruth.txt"))]:
+        name = os.path.basename(os.path.normpath(s_))
+        Kd = (481.2, -480.0, 319.5, 239.5) if "kt" in name.lower() else K_default      # config_data/calibration_syntheticHanda.ini
+        entry = {"sequence": name}
+        with tempfile.TemporaryDirectory() as tmp:
+            for chunks in (1, 8):
+                traj = os.path.join(tmp, f"{name}_{chunks}.txt")
+                p = subprocess.run([D.TRACK_SEQUENCE_BIN, "-eval", s_ + "/", "-chunks", str(chunks), "-out", traj, "-K"] + [str(v) for v in Kd],
+                                   capture_output=True, text=True, timeout=3600)
+                if p.returncode != 0:
+                    entry[f"chunks_{chunks}"] = {"error": (p.stdout + p.stderr)[-400:]}
+                    continue
+                rep = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+                gt, est = A.read_trajectory(os.path.join(s_, "groundtruth.txt")), A.read_trajectory(traj)
+                a, r = A.ate(gt, est, 0.02), A.rpe(gt, est, 1, "f", 0.02)
+                entry[f"chunks_{chunks}"] = {"frames": rep["frames"], "frames_per_s": rep["frames_per_s"], "ate_rmse_m": a["rmse"],
+                                             "rpe_trans_rmse_m": r["trans_rmse"], "rpe_rot_rmse_deg": float(np.degrees(r["rot_rmse"]))}
+        out.append(entry)
+    return {"config": "2-4 on the mounted sequences (RGBID_TUM_DIR): C++ driver, ATE / RPE against the published ground truth", "sequences": out}
 
 
 def flush_c_stdio():
@@ -337,7 +461,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="independent RGB-D streams per GPU; 0 = 2 048 (126 GB of engine state at 640x480; per-lane cost 512 -> 2 048: -5 %), "
                     "reduced in steps of 256 if the engine + the resident input frames of W + K + 1 steps would not fit the device's free memory")
     ap.add_argument("--streams", type=int, default=32, help="distinct synthetic input streams dealt onto the lanes")
-    ap.add_argument("--check-streams", type=int, default=4, help="lanes (one per distinct stream) held to the CPU oracle over all timed steps, after the timed regions")
+    ap.add_argument("--check-streams", type=int, default=32, help="lanes (one per distinct stream) held to the CPU oracle over all timed steps, after the timed regions (default: every distinct stream)")
+    ap.add_argument("--seq-frames", type=int, default=2500, help="frames of the ONE long sequence of extra config 4 (BASELINE config 4: fr3/long_office has ~2 500)")
+    ap.add_argument("--seq-chunks-per-gpu", type=int, default=64, help="chunks (= engine lanes) per GPU of extra config 4")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--levels", type=int, default=3)
@@ -347,7 +473,8 @@ def main():
     ap.add_argument("--keyframes", type=int, default=2, help="per-lane capacity of the keyframe export ring: the outgoing keyframe is handed to the back-end at every switch, as trackNewFrame does (0 = no export)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip extra_configs (BASELINE configs 1 and 5)")
-    ap.add_argument("--gather", default="rccl-cabi", choices=["rccl-cabi", "torch"], help="transport of the record all-gather at N > 1")
+    ap.add_argument("--gather", default="rccl-cabi", choices=["rccl-cabi", "torch"], help="transport of the record all-gather at N > 1: the product's C-ABI helper over RCCL "
+                    "(a failure of it ENDS the run with a non-zero exit code), or torch.distributed when asked for explicitly")
     ap.add_argument("--h2d", type=int, default=0, help="also time the same steps with the frames streamed from pinned host memory (PCIe-inclusive rate; never `value`)")
     args = ap.parse_args()
 
@@ -390,30 +517,29 @@ def main():
     dist_env = {"use_dist": use_dist, "world": world, "comm": None}
     gather_how = None
     if use_dist:
-        from rgbid import dist as D
-        gather_how = "torch.distributed all_gather_into_tensor (nccl = RCCL)"
-        if args.gather == "rccl-cabi":
-            try:
-                dist_env["comm"] = D.Comm(ctx, world, rank)      # librgbid_dist.so over librccl; the unique id travels through torch's store
-                gather_how = "rgbid_dist_gather_records (C-ABI, ncclAllGather on the engine's stream)"
-            except Exception as e:                               # a transport problem must not cost the scaling record: say so loudly instead
-                sys.stderr.write(f"[bench] WARNING: C-ABI RCCL communicator failed ({e}); gathering through torch.distributed\n")
-                gather_how += f" -- C-ABI RCCL helper FAILED: {e}"
-    if use_dist:
         import torch.distributed as dist
+        from rgbid import dist as D
+        gather_how = "torch.distributed all_gather_into_tensor (nccl = RCCL) -- asked for with --gather torch"
         dist.barrier()            # brings torch's communicator up (and RCCL's banner out) before anything is timed or printed
-        if dist_env["comm"] is not None:
+        if args.gather == "rccl-cabi":
+            # The product's exchange is the C-ABI helper (librgbid_dist.so over librccl).  If it cannot come up, the scaling figure would be
+            # measured through a transport that is not the product's: that is a FAILED run, not a degraded one.
             try:
-                dist_env["comm"].barrier()    # first collective of the C-ABI communicator, outside every timed region
+                if os.environ.get("RGBID_BENCH_FORCE_COMM_FAILURE"):
+                    raise RuntimeError("forced by RGBID_BENCH_FORCE_COMM_FAILURE (test hook)")
+                dist_env["comm"] = D.Comm(ctx, world, rank)      # the unique id travels through torch's store
+                dist_env["comm"].barrier()                       # first collective of the communicator, outside every timed region
+                gather_how = "rgbid_dist_gather_records (C-ABI, ncclAllGather on the engine's stream)"
             except Exception as e:
-                sys.stderr.write(f"[bench] WARNING: C-ABI RCCL communicator failed at its first collective ({e}); gathering through torch.distributed\n")
-                gather_how = f"torch.distributed all_gather_into_tensor (nccl = RCCL) -- C-ABI RCCL helper FAILED: {e}"
-                dist_env["comm"] = None
+                sys.stderr.write(f"[bench] rank {rank}: the C-ABI RCCL communicator failed ({type(e).__name__}: {e}); refusing to report a multi-GPU number "
+                                 f"through another transport (rerun with --gather torch to measure torch.distributed's all-gather instead)\n")
+                sys.stderr.flush()
+                os._exit(3)
         flush_c_stdio()
     res, keep = run_config(ctx, dev, work, rows, cols, args.levels, iters, B, Kst, W, max(1, args.reps), args.streams, args.graph, args.fused,
                            args.keyframes, K, dist_env, check_streams=args.check_streams if rank == 0 else 0, fast_numerics=args.fast)
     seqs, depth, rgb, eng, rec, gathered = keep
-    rccl_ranks = None
+    rccl_ranks = rccl_ranks_all = None
     gather_ok = None
     if use_dist:
         import torch.distributed as dist
@@ -425,6 +551,9 @@ def main():
         dist.all_gather_into_tensor(ref, packed)
         gather_ok = bool(torch.equal(ref, gathered))
         rccl_ranks = dist_env["comm"].world() if dist_env["comm"] is not None else dist.get_world_size()
+        rr = torch.zeros(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(rr, torch.tensor([rccl_ranks], dtype=torch.int64, device=dev))
+        rccl_ranks_all = [int(v) for v in rr.cpu()]
 
     pcie = None
     if args.h2d:
@@ -488,9 +617,19 @@ def main():
                        "keyframe_export_capacity": args.keyframes, "keyframes_exported_in_timed_steps_rank0": res["keyframes_exported"],
                        "n_unique_streams": res["n_unique_streams"]},
             "repetitions": res["repetitions"],
-            "frame_level": ({"bytes_per_frame": U3_BYTES_PER_FRAME, "achieved_gbs": res["value"] / world * U3_BYTES_PER_FRAME / 1e9,
-                             "frac_of_hbm_peak": res["value"] / world * U3_BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS,
-                             "note": "unit U3 (SURVEY 8d): algorithmic bytes of one aligned frame x frames/s per GPU"} if headline else None),
+            "frame_level": ({"engine_bytes_per_frame": res["engine_bytes_per_frame"],
+                             "engine_gbs": res["value"] / world * res["engine_bytes_per_frame"] / 1e9,
+                             "engine_frac_of_hbm_peak": res["value"] / world * res["engine_bytes_per_frame"] / 1e9 / HBM_PEAK_GBS,
+                             "engine_bytes_model": {"every_tracked_frame": res["step_bytes_model"][0], "per_odometry_kf_switch": res["step_bytes_model"][1],
+                                                    "per_integration_kf_switch": res["step_bytes_model"][2], "per_fused_frame": res["step_bytes_model"][3],
+                                                    "odo_kf_switch_rate": res["odo_kf_switch_rate"], "integr_kf_switch_rate": res["integr_kf_switch_rate"],
+                                                    "from": "rgbid_engine_step_bytes: algorithmic bytes of the engine's own launch list, per lane"},
+                             "u3_bytes_per_frame": U3_BYTES_PER_FRAME,
+                             "u3_equivalent_gbs": res["value"] / world * U3_BYTES_PER_FRAME / 1e9,
+                             "u3_equivalent_frac_of_hbm_peak": res["value"] / world * U3_BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS,
+                             "note": "engine_*: what the (fused) engine actually has to move per aligned frame x frames/s per GPU -- the fraction of the HBM roofline "
+                                     "a step draws; u3_equivalent_*: frames/s priced at SURVEY 8d's UNFUSED budget U3 (275.6 MB/frame), i.e. the rate an unfused "
+                                     "implementation would need -- not traffic that happened"} if headline else None),
             "roofline": {"bound": "hbm", "achieved": u1["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": u1["achieved"] / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_from": traffic_from,
                          "kernel": ("rgbid::k_build_system<ByLane<SysParams>, true, 0, 2, 1> (the level-0 Gauss-Newton iterations) and <..., 0, 2, 2> (the covariance pass: same kernel, fixed-nu weights; "
@@ -503,13 +642,35 @@ def main():
             "lanes_bit_identical": res["parity"]["lanes_bit_identical"],
         }
         if use_dist:
-            result["multi_gpu"] = {"rccl_ranks": rccl_ranks, "gather": gather_how, "record_bytes": 392,
-                                   "gathered_bytes_per_rank_per_repetition": B * Kst * 392, "gather_equals_torch_all_gather": gather_ok}
+            med_i = int(np.argsort(res["repetitions"]["frames_per_s"])[::-1][len(res["repetitions"]["frames_per_s"]) // 2])
+            result["multi_gpu"] = {"rccl_ranks": rccl_ranks, "rccl_ranks_per_rank": rccl_ranks_all, "gather": gather_how, "record_bytes": 392,
+                                   "gathered_bytes_per_rank_per_repetition": B * Kst * 392, "gather_equals_torch_all_gather": gather_ok,
+                                   "gather_us_per_repetition_rank0": res["gather_us"],
+                                   "per_rank_frames_per_s": [B * Kst / t_ for t_ in res["rank_seconds"][med_i]] if res["rank_seconds"] else None,
+                                   "per_rank_note": "each rank's own frames / its own wall time of the median repetition, before the closing barrier; `value` uses the max over ranks"}
         if pcie is not None:
             result["pcie_inclusive"] = pcie
-    # ---- extra configurations (BASELINE configs 1 and 5), rank 0 of a single-GPU run only ----
-    if rank == 0 and world == 1 and not args.no_extras and rows == 480 and cols == 640:
-        extras = []
+    # ---- extra configurations.  Single-GPU run: the headline workload in the EXACT numerics class (fused, and as the reference's kernel
+    # sequence), BASELINE configs 1, 5 and 4, the mounted datasets.  Multi-GPU run: config 4 only (every rank takes part: it is strong-scaled).
+    headline_shape = rows == 480 and cols == 640 and args.levels == 3
+    extras = []
+    if world == 1 and rank == 0 and not args.no_extras and headline_shape:
+        inputs = (seqs, depth, rgb)
+        for name, fu, fa in (("exact-fused: the headline workload with the gather / filter kernels in the EXACT numerics class (bit-exact pixel selection; the fused kernel k_build_system<..., 1, 0>)", 1, 0),
+                             ("exact-unfused: the reference's kernel sequence (warp pair, sigma / nu on stored maps, normal equations k_build_system<..., 0, 0>) in the EXACT class", 0, 0)):
+            try:
+                rx, keepx = run_config(ctx, dev, work, rows, cols, args.levels, iters, B, Kst, W, 1, args.streams, args.graph, fu, args.keyframes, K,
+                                       {"use_dist": False, "world": 1}, check_streams=min(2, args.check_streams), fast_numerics=fa, inputs=inputs)
+                keepx[3].close()
+                del keepx
+                extras.append({"config": name, "value": rx["value"], "unit": "frames/s", "ms_per_step": rx["ms_per_step"], "steps": Kst, "warmup": W, "repetitions": 1,
+                               "lanes": B, "fused_gn": bool(fu), "fast_numerics": bool(fa), "tracked": rx["tracked"], "expected": rx["expected"],
+                               "u1_achieved_gbs": rx["u1"]["achieved"], "u1_frac_of_hbm_peak": rx["u1"]["achieved"] / HBM_PEAK_GBS, "u1_avg_launch_us": rx["u1"]["avg_launch_us"],
+                               "engine_bytes_per_frame": rx["engine_bytes_per_frame"], "parity": rx["parity"]})
+            except Exception as e:
+                extras.append({"config": name, "error": f"{type(e).__name__}: {e}"})
+        del inputs
+    if rank == 0 and world == 1 and not args.no_extras and headline_shape:
         del depth, rgb, keep, gathered
         torch.cuda.empty_cache()
         try:
@@ -520,18 +681,39 @@ def main():
             K5 = (1050.0, 1050.0, 639.5, 479.5)
             it5 = [10, 5, 3, 3]
             r5, keep5 = run_config(ctx, dev, work, 960, 1280, 4, it5, 128, min(Kst, 8), 1, 1, 8, args.graph, args.fused, args.keyframes, K5,
-                                   {"use_dist": False, "world": 1}, check_streams=0, fast_numerics=args.fast)
+                                   {"use_dist": False, "world": 1}, check_streams=min(2, args.check_streams), fast_numerics=args.fast)
             keep5[3].close()
             del keep5
             torch.cuda.empty_cache()
             extras.append({"config": "5: 1280x960 upsampled synthetic stream, 4-level pyramid, GN iterations [10,5,3,3], 128 lanes (8 distinct streams), same engine switches as the headline run",
                            "value": r5["value"], "unit": "frames/s", "ms_per_step": r5["ms_per_step"], "steps": min(Kst, 8), "warmup": 1,
-                           "tracked": r5["tracked"], "expected": r5["expected"], "lanes_bit_identical": r5["parity"]["lanes_bit_identical"],
+                           "tracked": r5["tracked"], "expected": r5["expected"], "lanes_bit_identical": r5["parity"]["lanes_bit_identical"], "parity": r5["parity"],
                            "u1_achieved_gbs": r5["u1"]["achieved"], "u1_frac_of_hbm_peak": r5["u1"]["achieved"] / HBM_PEAK_GBS,
                            "u1_avg_launch_us": r5["u1"]["avg_launch_us"], "u1_bytes_per_launch": r5["u1"]["bytes_per_launch"],
                            "u1_launches_timed": r5["u1"]["launches_timed"], "engine_hbm_bytes": r5["engine_hbm_bytes"]})
         except Exception as e:
             extras.append({"config": "5", "error": f"{type(e).__name__}: {e}"})
+    if not args.no_extras and headline_shape and args.seq_frames > 0:
+        if world > 1:
+            del depth, rgb, keep, gathered
+            torch.cuda.empty_cache()
+        try:
+            c4 = extra_config4(ctx, dev, K, world, rank, args.seq_frames, args.seq_chunks_per_gpu, args.fused, args.fast)
+            if rank == 0:
+                extras.append(c4)
+        except Exception as e:
+            if world > 1:       # a rank that drops out of a collective leaves the others hanging: end the job loudly
+                sys.stderr.write(f"[bench] rank {rank}: extra config 4 failed ({type(e).__name__}: {e})\n"); sys.stderr.flush()
+                os._exit(4)
+            extras.append({"config": "4", "error": f"{type(e).__name__}: {e}"})
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:
+            ds = dataset_configs(K)
+            if ds is not None:
+                extras.append(ds)
+        except Exception as e:
+            extras.append({"config": "2-4 (RGBID_TUM_DIR)", "error": f"{type(e).__name__}: {e}"})
+    if rank == 0 and extras:
         result["extra_configs"] = extras
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

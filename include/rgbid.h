@@ -112,6 +112,9 @@ int rgbid_mem_info(size_t* free_bytes, size_t* total_bytes);
 int rgbid_malloc(void** ptr, size_t bytes);
 int rgbid_malloc_pitch(void** ptr, size_t* step, size_t width_bytes, size_t rows); /* step is 256-B aligned */
 int rgbid_free(void* ptr);
+/* pinned (page-locked) host memory: uploads from it run asynchronously on a stream (frame staging of the batched drivers) */
+int rgbid_malloc_host(void** ptr, size_t bytes);
+int rgbid_free_host(void* ptr);
 int rgbid_memcpy_h2d(rgbid_ctx* ctx, void* dst, const void* src, size_t bytes);
 int rgbid_memcpy_d2h(rgbid_ctx* ctx, void* dst, const void* src, size_t bytes);
 int rgbid_memcpy_d2d(rgbid_ctx* ctx, void* dst, const void* src, size_t bytes);

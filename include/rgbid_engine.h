@@ -144,6 +144,12 @@ int rgbid_engine_profile_end(rgbid_engine* e, double* total_ms, int* n_launches,
 int rgbid_engine_bytes(const rgbid_engine* e, size_t* bytes);
 /* name + launch count of every kernel enqueued by the last step (for DESIGN.md / profiling); returns #launches */
 int rgbid_engine_launches_per_step(const rgbid_engine* e);
+/* Algorithmic HBM bytes PER LANE of the launch list of the last (non-first) step, summed over the engine's own launches as each launcher's
+ * DESIGN.md figure (bytes every kernel must read / write once): out[0] every tracked frame; out[1] in addition per odometry-keyframe switch;
+ * out[2] per integration-keyframe switch; out[3] per frame fused into the integration keyframe.  bytes/frame = out[0] + p_odo out[1] +
+ * p_int out[2] + (1 - p_int) out[3] with the switch rates of the records -- what the engine actually has to move, against which frames/s
+ * is a fraction of the HBM roofline (the unfused SURVEY budget U3 = 275.6 MB no longer applies to the fused path). */
+int rgbid_engine_step_bytes(const rgbid_engine* e, double out[4]);
 
 #ifdef __cplusplus
 }

@@ -197,6 +197,15 @@ int rgbid_malloc_pitch(void** p, size_t* step, size_t width_bytes, size_t rows) 
   return rgbid_malloc(p, st * rows);
 }
 int rgbid_free(void* p) { if (p) RGBID_HIP(hipFree(p)); return RGBID_OK; }
+int rgbid_malloc_host(void** p, size_t bytes) {
+  if (!p) return RGBID_E_INVALID;
+  *p = nullptr;
+  if (bytes == 0) return RGBID_OK;
+  hipError_t e = hipHostMalloc(p, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return e == hipErrorOutOfMemory ? RGBID_E_NOMEM : (int)e; }
+  return RGBID_OK;
+}
+int rgbid_free_host(void* p) { if (p) RGBID_HIP(hipHostFree(p)); return RGBID_OK; }
 
 static int copy1d(rgbid_ctx* c, void* d, const void* s, size_t n, hipMemcpyKind k) {
   if (!c || (n && (!d || !s))) return RGBID_E_INVALID;

@@ -537,6 +537,9 @@ struct rgbid_engine {
   int* kf_counts_host = nullptr;            // pinned host [B]
   int steps = 0;
   int launches = 0;
+  // algorithmic HBM bytes of the launch list, per lane (rgbid_engine_step_bytes): [0] every tracked frame, [1] extra per odometry-keyframe
+  // switch, [2] extra per integration-keyframe switch, [3] extra per frame fused into the integration keyframe
+  double step_bytes[4] = {0, 0, 0, 0};
   hipGraphExec_t graph_first = nullptr, graph_next = nullptr;
   bool graph_ready_first = false, graph_ready_next = false;
   // event timing of the dominant kernel (level-0 normal equations), see rgbid_engine_profile_begin
@@ -588,9 +591,26 @@ StepCfg step_cfg(const rgbid_engine_config& c) {
 }
 
 // saveCurrentImagesAsOdoKeyframes (visodo.cpp:826-878) for the lanes flagged sw_odo
+inline double npx(const ImgB& im) { return (double)im.rows * im.cols; }
+
 void enqueue_save_odo_kf(rgbid_engine* e, hipStream_t s) {
   const int B = e->B, L = e->L;
   LaneMask m = M(e->flags.sw_odo);
+  {
+    // algorithmic bytes of a keyframe switch (bucket 1): 2 copies per level (4 B read + 4 B written per pixel), the lattice pack, two
+    // bilateral filters (8 B/px), the pyramid of the filtered maps, Sobel (12 B/px) of the filtered and of the unfiltered maps
+    double b = 0.0;
+    for (int i = 0; i < L; ++i) {
+      const double n = npx(e->iD_kf[i]);
+      b += 2 * 8 * n;
+      if (e->lat_res) b += 16.0 * lattice_samples(e->iD_kf[i].rows, e->iD_kf[i].cols, e->cfg.nsamples);
+      b += 2 * 12 * n;                                                            // gradients of the filtered maps
+      if (i) b += 2 * (4 * npx(e->iD_kf_f[i - 1]) + 4 * n);                       // pyrDown of the filtered maps
+      b += (e->cfg.image_filtering == RGBID_FILTER_GRADS) ? 4 * 8 * n : 2 * 12 * n;
+    }
+    b += 2 * 8 * npx(e->iD_kf[0]);
+    e->step_bytes[1] = b;
+  }
   for (int i = 0; i < L; ++i) {
     launch_copy_bytes(s, B, e->iD_curr[i], e->iD_kf[i], 4, m);
     launch_copy_bytes(s, B, e->I_curr[i], e->I_kf[i], 4, m);
@@ -640,15 +660,20 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
     return c.fast_numerics != 0 && gn_fast_supported(e->iD_kf[level], e->I_kf[level], e->gxD[level], e->gyD[level], e->gxI[level], e->gyI[level], e->I_curr[level]);
   };
   e->launches = 0;
+  double* const sb = e->step_bytes;
+  sb[0] = sb[2] = sb[3] = 0.0;
+  const double N0 = (double)c.rows * c.cols;
   Flags& f = e->flags;
   // ---- prepareImages (visodo.cpp:760-773)
   const LaneMask fed = M(e->active_dev);   // lanes without a frame this step keep their current-frame pyramids untouched
   launch_prep_frame(s, B, e->cur_depth, e->cur_rgb, e->iD_curr[0], e->I_curr[0], e->r_curr, e->g_curr, e->b_curr, c.factor_depth, fed);
   e->launches += 1;
+  sb[0] += 25 * N0;                                                               // 2 + 3 B/px read, five fp32 planes written
   for (int i = 1; i < L; ++i) {
     launch_pyr_down(s, B, e->I_curr[i - 1], e->I_curr[i], fed);
     launch_pyr_down(s, B, e->iD_curr[i - 1], e->iD_curr[i], fed);
     e->launches += 2;
+    sb[0] += 2 * (4 * npx(e->I_curr[i - 1]) + 4 * npx(e->I_curr[i]));
   }
   hipLaunchKernelGGL(k_step_begin, dim3(gb), dim3(tb), 0, s, e->state, f, e->wp, e->sp, sc, B);
   e->launches++;
@@ -673,6 +698,15 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
       if (c.warping == RGBID_WARP_FIRST) next_level = more_gn ? 0 : c.finest_level;
       bool prof = e->prof_on && level == 0 && e->prof_used + 2 <= (int)e->prof_ev.size();
       int nblk;
+      {
+        // one Gauss-Newton iteration: the 8 maps of unit U1 (32 B/px); unfused additionally the warp pair (12 B/px read, 8 written); the
+        // residual lattice: 36 B/sample fused (packed keyframe side 8, gathers 20, residuals written 8) + 8 read by the sigma / nu kernel,
+        // 16 B/sample read from the stored maps otherwise
+        const double nl = npx(e->iD_kf[level]);
+        const double ns = c.sigma_estimator == RGBID_SIGMA_PDF ? (double)lattice_samples(e->iD_kf[level].rows, e->iD_kf[level].cols, c.nsamples) : 0.0;
+        if (c.fused_gn) sb[0] += 32 * nl + 44 * ns;
+        else sb[0] += (c.warping == RGBID_WARP_FIRST ? 20 * N0 : 20 * nl) + 32 * nl + 16 * ns;
+      }
       if (c.fused_gn) {
         if (c.sigma_estimator == RGBID_SIGMA_PDF) {
           launch_sigma_pair_fused(s, B, e->iD_curr[level], e->iD_kf[level], e->I_curr[level], e->I_kf[level], e->wp, c.interp_mode, c.nsamples,
@@ -719,6 +753,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
     hipLaunchKernelGGL(k_set_sys, dim3(gb), dim3(tb), 0, s, e->sp, e->state, f.track, sc, fl, 1, B);
     bool prof = e->prof_on && fl == 0 && e->prof_used + 2 <= (int)e->prof_ev.size();
     bool fuse_cov = c.fused_gn && !c.chi_square_stats;  // the chi-square statistics need W1 / I1 in memory
+    sb[0] += (fuse_cov ? 32 : 52) * npx(e->iD_kf[fl]);
     int nblk;
     if (fuse_cov) {
       if (prof) { set_system_kernel_events(e->prof_ev[e->prof_used], e->prof_ev[e->prof_used + 1]); e->prof_used += 2; }
@@ -754,6 +789,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
     launch_visibility_pair(s, B, e->iD_curr[0], e->iD_integr_raw, e->ivis_ab, e->ivis_ba, e->counts + 2 * 2 * B, e->counts + 3 * 2 * B, M(f.vis), c.fast_numerics != 0);
     hipLaunchKernelGGL(k_decide, dim3(gb), dim3(tb), 0, s, e->state, f, e->counts, e->fuse_wp, sc, B);
     e->launches += 4;
+    sb[0] += 2 * 16 * N0;                                                         // two covisibility pairs: both maps read + both gathered
   }
   // ---- odometry keyframe switch
   enqueue_save_odo_kf(e, s);
@@ -768,6 +804,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
     hipLaunchKernelGGL(k_export_keyframe, dim3(min(c.rows, 8), 4, B), dim3(256), 0, s, ks, e->kf_blocks, e->kf_block_bytes, c.keyframe_capacity,
                        f.kf_slot);
     e->launches++;
+    sb[2] += 40 * N0;                                                             // 20 B/px of keyframe images read and written
   }
   // ---- integration keyframe: computeOverlapping (:1517-1539) + saveCurrentImagesAsIntegrationKeyframes (:880-893) ...
   if (!first) {
@@ -780,18 +817,23 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   launch_fill(s, B, e->w_integr, 4, 0x3f800000u, M(f.sw_int));
   launch_fill(s, B, e->overlap_mask, 1, 0u, M(f.first));  // initialiseDeviceMemory2D(overlap_mask, 0) :2021
   e->launches += 7;
+  sb[2] += (9 + 8 + 8 + 6 + 4) * N0;                                              // overlap mask pass, three copies, weight fill
   // ... or integrateImagesIntoKeyframes (:1674-1764)
   if (!first) {
     if (launch_fuse_frame(s, B, e->iD_curr[0], e->iD_integr, e->w_integr, e->warped_w, e->fuse_wp, M(f.fuse), c.fast_numerics != 0)) {
       e->launches -= 1;
+      sb[3] += 24 * N0;                                                           // keyframe map + weight read and written, gather, warped weight written
     } else {
+      sb[3] += 40 * N0;
       launch_warp_invdepth_weighted(s, B, e->iD_curr[0], e->iD_integr, e->warped_iD_integr, e->warped_w, nullptr, e->fuse_wp, M(f.fuse));
       launch_integrate_warped(s, B, e->warped_iD_integr, e->warped_w, e->iD_integr, e->w_integr, M(f.fuse));
     }
   }
   if (launch_kf_maps(s, B, e->iD_integr, e->vmap, e->nmap, K0, M(f.maps))) {
     e->launches += 3;
+    sb[0] += 28 * N0;
   } else {
+    sb[0] += (16 + 12 + 24) * N0;
     launch_vmap(s, B, e->iD_integr, e->vmap, K0, M(f.maps));
     launch_gradient(s, B, e->iD_integr, e->gxD_integr, e->gyD_integr, M(f.maps));
     launch_nmap_gradients(s, B, e->iD_integr, e->gxD_integr, e->gyD_integr, e->nmap, K0, M(f.maps));
@@ -1151,5 +1193,10 @@ int rgbid_engine_profile_end(rgbid_engine* e, double* total_ms, int* n_launches,
 
 int rgbid_engine_bytes(const rgbid_engine* e, size_t* bytes) { if (!e || !bytes) return RGBID_E_INVALID; *bytes = e->bytes; return RGBID_OK; }
 int rgbid_engine_launches_per_step(const rgbid_engine* e) { return e ? e->launches : 0; }
+int rgbid_engine_step_bytes(const rgbid_engine* e, double out[4]) {
+  if (!e || !out) return RGBID_E_INVALID;
+  for (int i = 0; i < 4; ++i) out[i] = e->step_bytes[i];
+  return RGBID_OK;
+}
 
 }  // extern "C"

@@ -27,8 +27,10 @@ assert GATHER_DTYPE.itemsize == 392
 
 DIST_LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "librgbid_dist.so")
 DIST_EXPORTS = ["rgbid_dist_chunk_ranges", "rgbid_dist_rank_chunks", "rgbid_dist_new_id", "rgbid_dist_exchange_id", "rgbid_dist_broadcast_bytes",
-                "rgbid_dist_init", "rgbid_dist_destroy", "rgbid_dist_world", "rgbid_dist_rank", "rgbid_dist_gather_records", "rgbid_dist_barrier",
-                "rgbid_dist_compose_trajectory"]
+                "rgbid_dist_allgather_bytes_tcp", "rgbid_dist_init", "rgbid_dist_destroy", "rgbid_dist_world", "rgbid_dist_rank", "rgbid_dist_gather_records",
+                "rgbid_dist_barrier", "rgbid_dist_compose_trajectory", "rgbid_dist_track_sequence"]
+TRACK_SEQUENCE_BIN = os.path.join(os.path.dirname(os.path.dirname(_lib.LIB_PATH)), "bin", "rgbid_track_sequence")
+EXCHANGE_RCCL, EXCHANGE_TCP = 0, 1
 _dl = None
 
 
@@ -128,6 +130,45 @@ class Comm:
         if self._h:
             dlib().rgbid_dist_destroy(self._h)
             self._h = None
+
+
+class SeqReport(C.Structure):
+    _fields_ = [("lanes", C.c_int), ("chunk_len", C.c_int), ("n_chunks", C.c_int), ("world", C.c_int), ("rccl_ranks", C.c_int),
+                ("setup_ms", C.c_double), ("track_ms", C.c_double), ("gather_ms", C.c_double), ("compose_ms", C.c_double), ("total_ms", C.c_double),
+                ("staged_bytes", C.c_ulonglong), ("engine_bytes", C.c_ulonglong)]
+
+
+def track_sequence(ctx, engine_cfg, depth_host, rgb_host, n_chunks, world=1, rank=0, exchange=EXCHANGE_RCCL, master_addr="127.0.0.1", master_port=0,
+                   inject=None, n_frames=None):
+    """rgbid_dist_track_sequence: the C++ sharded-sequence driver (csrc/dist.cpp) on host frames depth [T, rows, cols] uint16 / rgb [T, rows, cols, 3]
+    uint8 (numpy arrays, or CPU torch tensors -- pinned ones upload asynchronously).  inject (GATHER_DTYPE [n_chunks, chunk_len]) + n_frames: compose
+    the given per-chunk records instead of running the engine (ctx / frames may be None).  Returns (R [T,3,3], t [T,3], status [T], cov [T,6,6], report)."""
+    from .engine import EngineConfig
+
+    class SeqConfig(C.Structure):
+        _fields_ = [("engine", EngineConfig), ("n_chunks", C.c_int), ("world", C.c_int), ("rank", C.c_int), ("exchange", C.c_int),
+                    ("master_addr", C.c_char_p), ("master_port", C.c_int)]
+
+    def ptr(a):
+        if a is None:
+            return None
+        return C.c_void_p(a.data_ptr()) if hasattr(a, "data_ptr") else a.ctypes.data_as(C.c_void_p)
+
+    cfg = SeqConfig()
+    C.memmove(C.byref(cfg.engine), C.byref(engine_cfg), C.sizeof(EngineConfig))
+    cfg.n_chunks = int(n_chunks); cfg.world = int(world); cfg.rank = int(rank); cfg.exchange = int(exchange)
+    cfg.master_addr = master_addr.encode(); cfg.master_port = int(master_port)
+    T = int(n_frames) if n_frames is not None else int(depth_host.shape[0])
+    inj = None
+    if inject is not None:
+        inject = np.ascontiguousarray(inject)
+        assert inject.dtype == GATHER_DTYPE and inject.ndim == 2 and inject.shape[0] == n_chunks
+        inj = _ip(inject)
+    R = np.zeros((T, 3, 3)); t = np.zeros((T, 3)); st = np.zeros(T, np.int32); cov = np.zeros((T, 6, 6))
+    rep = SeqReport()
+    check(dlib().rgbid_dist_track_sequence(ctx._h if ctx is not None else None, C.byref(cfg), ptr(depth_host), ptr(rgb_host), T, inj,
+                                           _ip(R), _ip(t), _ip(st), _ip(cov), C.byref(rep)))
+    return R, t, st, cov, {n: getattr(rep, n) for n, _ in SeqReport._fields_}
 
 
 def pack_engine_records(eng, first_step, n_steps):

@@ -165,6 +165,13 @@ class Engine:
     def launches_per_step(self):
         return self.L.rgbid_engine_launches_per_step(self._h)
 
+    def step_bytes(self):
+        """algorithmic HBM bytes per lane of the last step's launch list: [every tracked frame, + per odometry-KF switch, + per integration-KF
+        switch, + per fused frame] (rgbid_engine_step_bytes)"""
+        out = (C.c_double * 4)()
+        check(self.L.rgbid_engine_step_bytes(self._h, out))
+        return [float(v) for v in out]
+
     def preview(self, lane):
         """Host copies of a lane's preview image and keyframe colours (u8 [rows, cols, 3]); needs cfg.preview = 1."""
         imgs = [Img(), Img()]

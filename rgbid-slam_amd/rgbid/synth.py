@@ -138,6 +138,40 @@ def make_sequence(n_frames, seed=SEED, K=TUM_K, rows=480, cols=640, device="cpu"
     return {"depth": torch.stack(depths), "rgb": torch.stack(rgbs), "R_wc": Rs, "t_wc": ts, "K": K}
 
 
+def make_long_sequence(n_frames, seed=SEED, K=TUM_K, rows=480, cols=640, device="cuda", batch=25, dropout=0.03,
+                       trans_step=(0.005, 0.03), rot_step_deg=(0.1, 1.5)):
+    """A long sequence (thousands of frames: BASELINE config 4) of the same scene / camera-path / sensor model as make_sequence, rendered `batch`
+    frames at a time with the noise drawn on the device -- a few milliseconds per frame instead of ~25.  Same dict as make_sequence; the noise
+    realisation differs from make_sequence's (CPU generator), so the two are different sequences of the same distribution."""
+    scene = Scene(seed=seed, device=device)
+    Rs, ts = camera_path(n_frames, seed=seed, trans_step=trans_step, rot_step_deg=rot_step_deg)
+    fx, fy, cx, cy = K
+    v, u = torch.meshgrid(torch.arange(rows, dtype=torch.float64, device=device), torch.arange(cols, dtype=torch.float64, device=device), indexing="ij")
+    dc = torch.stack([(u - cx) / fx, (v - cy) / fy, torch.ones_like(u)], dim=-1)          # [rows, cols, 3]
+    g = torch.Generator(device=device).manual_seed(SEED + 977 * seed)
+    depth_out = torch.empty((n_frames, rows, cols), dtype=torch.int16, device=device)
+    rgb_out = torch.empty((n_frames, rows, cols, 3), dtype=torch.uint8, device=device)
+    for k0 in range(0, n_frames, batch):
+        k1 = min(n_frames, k0 + batch)
+        R = Rs[k0:k1].to(device); t = ts[k0:k1].to(device)
+        dw = torch.einsum("hwc,fdc->fhwd", dc, R)                                           # ray directions in the world frame
+        t_ = t[:, None, None, :]
+        lam = torch.full((k1 - k0, rows, cols), scene.z0, dtype=torch.float64, device=device)
+        for _ in range(40):
+            P = t_ + lam[..., None] * dw
+            lam = (scene.depth(P[..., 0], P[..., 1]) - t_[..., 2]) / dw[..., 2]
+        P = t_ + lam[..., None] * dw
+        rgb = scene.albedo(P[..., 0], P[..., 1])
+        depth = lam + (1.4e-3 * lam ** 2) * torch.randn(lam.shape, generator=g, dtype=torch.float64, device=device)
+        rgb = rgb + 2.0 * torch.randn(rgb.shape, generator=g, dtype=torch.float64, device=device)
+        d_mm = torch.clamp(torch.round(depth * 1000.0), 0, 65535)
+        if dropout > 0:
+            d_mm = torch.where(torch.rand(lam.shape, generator=g, dtype=torch.float64, device=device) < dropout, torch.zeros_like(d_mm), d_mm)
+        depth_out[k0:k1] = d_mm.to(torch.int32).to(torch.int16)      # u16 bit pattern
+        rgb_out[k0:k1] = torch.clamp(torch.round(rgb), 0, 255).to(torch.uint8)
+    return {"depth": depth_out, "rgb": rgb_out, "R_wc": Rs, "t_wc": ts, "K": K}
+
+
 def relative_pose(R_wa, t_wa, R_wb, t_wb):
     """Pose of camera b in the frame of camera a (X_a = R X_b + t) -- the tracker's KF-relative convention."""
     R = R_wa.T @ R_wb

@@ -70,6 +70,103 @@ def test_record_gather_and_composition_multi_rank(world, chunks):
     assert res["world"] == world and res["compose_err"] < 1e-12 and res["cov_ok"] and res["status_ok"] and res["tcp_rendezvous_ok"], res
 
 
+def _chain_records(F, n_chunks, seed=11):
+    """what the engine lanes of a sharded run would produce for a random ground-truth chain: [n_chunks][L] records + the chain"""
+    from scipy.spatial.transform import Rotation
+    r = np.random.default_rng(seed)
+    Rg, tg = [np.eye(3)], [np.zeros(3)]
+    for _ in range(1, F):
+        dR = Rotation.from_rotvec(0.02 * r.standard_normal(3)).as_matrix(); dt = 0.02 * r.standard_normal(3)
+        tg.append(Rg[-1] @ dt + tg[-1]); Rg.append(Rg[-1] @ dR)
+    Rg, tg = np.array(Rg), np.array(tg)
+    ranges = D.chunk_ranges(F, n_chunks)
+    L = max(b - a + 1 for a, b in ranges)
+    rec = np.zeros((n_chunks, L), D.GATHER_DTYPE)
+    rec["R"] = np.eye(3); rec["frame_id"] = -1
+    for c, (a, b) in enumerate(ranges):
+        for j in range(b - a + 1):
+            rec[c, j]["frame_id"] = j; rec[c, j]["status"] = 16 if j == 0 else 1
+            if j:
+                rec[c, j]["R"] = Rg[a + j - 1].T @ Rg[a + j]; rec[c, j]["t"] = Rg[a + j - 1].T @ (tg[a + j] - tg[a + j - 1])
+                rec[c, j]["cov"] = np.eye(6) * (a + j)
+    return rec, Rg, tg, ranges, L
+
+
+@pytest.mark.parametrize("world,chunks", [(1, 5), (2, 8), (2, 7), (3, 7)])
+def test_cpp_sequence_driver_partition_exchange_compose(world, chunks, tmp_path):
+    """The C++ sharded-sequence driver (tools/rgbid_track_sequence.cpp -> rgbid_dist_track_sequence) as `world` PROCESSES with the per-chunk records
+    injected (no GPU here): its partition (uneven ownership, padded lanes), its exchange (the library's TCP rendezvous: hello / nonce, all-gather)
+    and its composition give the trajectory file rgbid/dist.py + rgbid/tum.py give for the same records, byte for byte.  RCCL itself needs one
+    GPU per rank and stays unmeasured here (tests/test_gpu_dist.py covers world 1; tools/dist_selftest.py --backend nccl a multi-GPU node)."""
+    from rgbid import tum
+    F = 41
+    rec, Rg, tg, ranges, L = _chain_records(F, chunks)
+    inj = tmp_path / "records.bin"
+    rec.tofile(str(inj))
+    port = D.free_port()
+    env = dict(os.environ, RGBID_DIST_NONCE="12345", RGBID_DIST_TIMEOUT_S="60")
+    outs = [tmp_path / f"traj_{r}.txt" for r in range(world)]
+    procs = [subprocess.Popen([D.TRACK_SEQUENCE_BIN, "-inject", str(inj), "-frames", str(F), "-chunks", str(chunks), "-world", str(world), "-rank", str(r),
+                               "-exchange", "tcp", "-master_addr", "localhost", "-master_port", str(port), "-out", str(outs[r])],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in reversed(range(world))]   # rank 0 last: the others retry
+    res = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [r[1][-500:] for r in res]
+    rep = json.loads([l for l in res[-1][0].splitlines() if l.startswith("{")][-1])
+    assert rep["world"] == world and rep["chunks"] == chunks and rep["lanes_per_gpu"] == D.lanes_per_rank(chunks, world) and rep["chunk_len"] == L
+    # the Python harness on the same records: the layout a gather would produce, composed and written by the same library functions
+    lanes = D.lanes_per_rank(chunks, world)
+    allrec = np.zeros((world, lanes, L), D.GATHER_DTYPE)
+    for r in range(world):
+        for i, c in enumerate(D.rank_chunks(chunks, world, r)):
+            allrec[r, i] = rec[c]
+    R, t, st, cov = D.compose_trajectory(allrec, world, chunks, ranges)
+    assert np.abs(R - Rg).max() < 1e-12 and np.abs(t - tg).max() < 1e-12
+    ref = tmp_path / "ref.txt"
+    tum.write_trajectory(str(ref), [k / 30.0 for k in range(F)], R, t)
+    assert outs[0].read_bytes() == ref.read_bytes()
+    assert not any(o.exists() for o in outs[1:])          # rank 0 writes
+
+
+def test_tcp_rendezvous_ignores_strangers_and_duplicates():
+    """rank 0 keeps accepting when something that is not a rank of this job connects (a port scanner, a stale process with another nonce, a
+    rank that was served already); host names resolve (getaddrinfo)"""
+    import ctypes as C
+    import socket
+    import struct
+    import threading
+    import time
+    L = D.dlib()
+    port = D.free_port()
+    os.environ["RGBID_DIST_NONCE"] = "777"; os.environ["RGBID_DIST_TIMEOUT_S"] = "30"
+    try:
+        out = {}
+
+        def rank0():
+            blob = (C.c_char * 16)(*b"0123456789abcdef")
+            out["rc0"] = L.rgbid_dist_broadcast_bytes(b"localhost", port, 2, 0, blob, C.c_size_t(16))
+        th = threading.Thread(target=rank0); th.start()
+        time.sleep(0.3)
+        for hello in (b"GET / HTTP/1.0\r\n\r\n", struct.pack("<IiQ", 0x52474244, 1, 999), struct.pack("<IiQ", 0x52474244, 7, 777), b""):
+            s = socket.create_connection(("127.0.0.1", port)); s.sendall(hello); time.sleep(0.05); s.close()
+        blob = (C.c_char * 16)()
+        rc1 = L.rgbid_dist_broadcast_bytes(b"localhost", port, 2, 1, blob, C.c_size_t(16))
+        th.join(60)
+        assert out.get("rc0") == 0 and rc1 == 0 and bytes(blob) == b"0123456789abcdef"
+        # all-gather transport, 3 ranks in threads
+        port2 = D.free_port()
+        allb = [np.zeros(3 * 8, np.uint8) for _ in range(3)]
+        rcs = [None] * 3
+
+        def rk(r):
+            mine = np.full(8, r + 1, np.uint8)
+            rcs[r] = L.rgbid_dist_allgather_bytes_tcp(b"127.0.0.1", port2, 3, r, mine.ctypes.data_as(C.c_void_p), C.c_size_t(8), allb[r].ctypes.data_as(C.c_void_p))
+        ths = [threading.Thread(target=rk, args=(r,)) for r in (2, 1, 0)]
+        [t_.start() for t_ in ths]; [t_.join(60) for t_ in ths]
+        assert rcs == [0, 0, 0] and all(np.array_equal(a, np.repeat([1, 2, 3], 8)) for a in allb)
+    finally:
+        os.environ.pop("RGBID_DIST_NONCE"); os.environ.pop("RGBID_DIST_TIMEOUT_S")
+
+
 def test_bench_gpus_flag_fails_loudly_without_devices():
     """`python bench.py --gpus 2` must not quietly run one rank: with fewer than 2 HIP devices it exits non-zero with a clear message
     (here: no device at all)."""

@@ -67,6 +67,47 @@ def test_synthetic_sequence_through_the_dataset_chain(tmp_path):
     assert r1["trans_rmse"] < 1.5e-3 and r1["rot_rmse"] < 1e-3
 
 
+def run_cpp_driver(folder, out, chunks, K=None, max_frames=-1, world=1, extra=()):
+    """tools/rgbid_track_sequence (C++: dataset reader -> rgbid_dist_track_sequence -> trajectory file) as `world` processes on this box's one GPU
+    (world > 1: records exchanged over the library's TCP transport -- RCCL refuses two ranks on one device)"""
+    from rgbid import dist as D
+    port = D.free_port()
+    procs = []
+    for r in reversed(range(world)):
+        cmd = [D.TRACK_SEQUENCE_BIN, "-eval", str(folder) + "/", "-chunks", str(chunks), "-out", str(out), "-max_frames", str(max_frames), "-gpu", "0",
+               "-world", str(world), "-rank", str(r), "-master_addr", "127.0.0.1", "-master_port", str(port)] + (["-exchange", "tcp"] if world > 1 else []) + list(extra)
+        if K is not None:
+            cmd += ["-K"] + [str(v) for v in K]
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = [p.communicate(timeout=3600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [r_[0][-800:] + r_[1][-800:] for r_ in res]
+    return json.loads([l for l in res[-1][0].splitlines() if l.startswith("{")][-1])
+
+
+def test_cpp_sequence_driver_equals_the_python_harness(tmp_path):
+    """the C++ host of the sharded path (tools/rgbid_track_sequence.cpp over rgbid_engine.h + rgbid_dist.h) writes, byte for byte, the trajectory
+    file tools/track_dataset.py writes for the same TUM-layout folder and chunk count; cut over two processes (a 2-rank run on the one GPU) it
+    composes the same poses"""
+    n = 25
+    seq = synth.make_sequence(n, seed=synth.SEED + 3, device="cuda")
+    root = tmp_path / "synth_office"
+    write_tum_layout(root, seq)
+    a_py, _, n_py = track_and_score(root, tmp_path / "py4.txt", 4)
+    rep = run_cpp_driver(root, tmp_path / "cpp4.txt", 4)
+    assert rep["frames"] == n and rep["chunks"] == 4 and rep["lanes_per_gpu"] == 4 and rep["world"] == 1
+    assert (tmp_path / "cpp4.txt").read_bytes() == (tmp_path / "py4.txt").read_bytes()
+    rep1 = run_cpp_driver(root, tmp_path / "cpp1.txt", 1)
+    track_and_score(root, tmp_path / "py1.txt", 1)
+    assert (tmp_path / "cpp1.txt").read_bytes() == (tmp_path / "py1.txt").read_bytes()
+    rep2 = run_cpp_driver(root, tmp_path / "cpp4w2.txt", 4, world=2)
+    assert rep2["world"] == 2 and rep2["lanes_per_gpu"] == 2
+    e1, e2 = A.read_trajectory(str(tmp_path / "cpp4.txt")), A.read_trajectory(str(tmp_path / "cpp4w2.txt"))
+    assert np.abs(np.asarray(e1[1]) - np.asarray(e2[1])).max() < 2e-6          # 6-decimal text; lanes per launch differ (partial-sum grouping)
+    gt = A.read_trajectory(str(root / "groundtruth.txt"))
+    assert A.ate(gt, e2, 0.02)["rmse"] < 5e-3
+    print("C++ driver:", rep, rep2)
+
+
 def _sequences():
     base = os.environ.get("RGBID_TUM_DIR", "")
     if not base or not os.path.isdir(base):
@@ -90,6 +131,8 @@ def test_real_sequences_ate_against_published_ground_truth(tmp_path):
         K = (481.2, -480.0, 319.5, 239.5) if icl else None          # config_data/calibration_syntheticHanda.ini
         a1, r1, n1 = track_and_score(s, tmp_path / f"{name}_1.txt", 1, K)
         a8, r8, n8 = track_and_score(s, tmp_path / f"{name}_8.txt", 8, K)
+        run_cpp_driver(s, tmp_path / f"{name}_8_cpp.txt", 8, K)                       # the C++ host of the same path: identical file
+        assert (tmp_path / f"{name}_8_cpp.txt").read_bytes() == (tmp_path / f"{name}_8.txt").read_bytes()
         report[name] = dict(frames=n1, ate_rmse_sequential=a1["rmse"], ate_rmse_8_chunks=a8["rmse"], rpe_trans_rmse=r1["trans_rmse"], rpe_rot_rmse_deg=float(np.degrees(r1["rot_rmse"])))
         assert a1["rmse"] < 0.25 and r1["trans_rmse"] < 0.03, (name, a1["rmse"], r1["trans_rmse"])
     print(json.dumps(report))

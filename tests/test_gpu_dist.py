@@ -67,3 +67,45 @@ def test_chunked_tracking_through_the_cabi_gather(ctx):
     comm.close()
     assert ranges == [(0, 3), (3, 6), (6, 9), (9, 12)]
     assert np.array_equal(Ra, Rb) and np.array_equal(ta, tb)
+
+
+def _run_bench(extra_args, env_extra=None, timeout=1500):
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **(env_extra or {}))
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra_args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+def test_bench_small_run_reports_every_section():
+    """bench.py end to end on a small batch: the result line carries roofline, the engine's own bytes per frame, the oracle check of every
+    distinct stream, the EXACT-class variants, configs 1 / 5 and config 4 through the C++ sequence driver"""
+    import json
+    p = _run_bench(["--lanes", "8", "--streams", "4", "--steps", "3", "--warmup", "1", "--reps", "2", "--seq-frames", "61", "--seq-chunks-per-gpu", "4", "--no-cpu-baseline"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["roofline"]["frac"] > 0 and r["roofline"]["bound"] == "hbm"
+    fl = r["frame_level"]
+    assert 1.2e8 < fl["engine_bytes_per_frame"] < 2.4e8 and "u3_equivalent_gbs" in fl and "achieved_gbs" not in fl
+    assert r["parity"]["oracle_checked_lanes"] == [0, 1, 2, 3] and r["parity"]["within_1e-4"] and r["parity"]["lanes_bit_identical"]
+    ex = {e["config"].split(":")[0]: e for e in r["extra_configs"]}
+    assert not any("error" in e for e in r["extra_configs"]), [e for e in r["extra_configs"] if "error" in e]
+    assert ex["exact-fused"]["parity"]["within_1e-4"] and ex["exact-unfused"]["parity"]["within_1e-4"]
+    assert ex["5"]["parity"]["within_1e-4"]
+    c4 = ex["4"]
+    assert c4["scaling"] == "strong" and c4["frames"] == 61 and c4["chunks"] == 4 and c4["lanes_per_gpu"] == 4 and c4["frames_lost"] == 0
+    assert c4["ate_rmse_m"]["sharded"] < 5e-3 and c4["ate_rmse_m"]["unsharded"] < 5e-3
+    assert c4["chunk_head_deviation_vs_unsharded"]["max_rot_rad"] < 5e-3 and c4["chunk_head_deviation_vs_unsharded"]["max_trans_m"] < 1e-2
+
+
+def test_bench_fails_loudly_when_the_cabi_communicator_fails():
+    """the product's record exchange is the C-ABI RCCL helper: if it cannot come up the run ENDS non-zero instead of reporting a number measured
+    through torch.distributed; asked for explicitly (--gather torch) that transport is allowed"""
+    args = ["--lanes", "4", "--streams", "2", "--steps", "1", "--warmup", "0", "--reps", "1", "--no-extras", "--no-cpu-baseline", "--check-streams", "0"]
+    p = _run_bench(args, {"RGBID_FORCE_DIST": "1", "RGBID_BENCH_FORCE_COMM_FAILURE": "1"})
+    assert p.returncode == 3 and "refusing to report" in p.stderr and "{" not in p.stdout, (p.returncode, p.stderr[-800:])
+    p = _run_bench(args + ["--gather", "torch"], {"RGBID_FORCE_DIST": "1", "RGBID_BENCH_FORCE_COMM_FAILURE": "1"})
+    assert p.returncode == 0, p.stderr[-1500:]
+    import json
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert "asked for with --gather torch" in r["multi_gpu"]["gather"] and r["multi_gpu"]["gather_equals_torch_all_gather"]
