@@ -489,8 +489,11 @@ __device__ __forceinline__ float bilateral_px(const float (*tile)[TX + 2 * BR + 
 // instead of ~50 (exact division, double-precision exponent, full-range expf), results within a few 1e-7 relative of the exact kernel.
 // Invalid taps (NaN in the map, window positions outside the image) are stored in the tile as BIL_SENTINEL, a large FINITE value: the range
 // term k d^2 of such a tap is >= 1e36, v_exp_f32 returns exactly 0 and 0 * sentinel adds exactly 0 to both sums -- the tap drops out without a
-// compare and two selects per tap (a third of the kernel's issue time).  No valid inverse depth or intensity comes near the sentinel.
-static constexpr float BIL_SENTINEL = 1e19f;
+// compare and two selects per tap (a third of the kernel's issue time).  So that no VALID value can collide with the sentinel or overflow the
+// range term on its own, this class treats |v| >= BIL_MAXABS (and +-inf) as invalid when the tile is loaded -- one compare per loaded value,
+// nothing per tap; inverse depths (<= 1e3 m^-1) and intensities (<= 255) are six orders below it.  Stated domain of the FAST filter: the
+// oracle's result on the map with such values replaced by NaN (tests/test_gpu_fuzz.py).
+static constexpr float BIL_SENTINEL = 1e19f, BIL_MAXABS = 1e9f;
 __device__ __forceinline__ float bilateral_px_fast(const float (*tile)[TX + 2 * BR + 1], int ty, int tx, float value, float k, float cs) {
   float sum1 = value, sum2 = 1.f;   // centre tap: weight exp(-0) = 1
 #pragma unroll
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(256) void k_bilateral(ImgB src, ImgB dst, float sig
     for (int tx = threadIdx.x; tx < TX + 2 * BR; tx += TX) {
       const int cx = x0 + tx - BR;
       float v = (row_in && cx >= 0 && cx < src.cols) ? rp[cx] : qnan();
-      if (MODE == 2) v = v == v ? v : BIL_SENTINEL;
+      if (MODE == 2) v = fabsf(v) < BIL_MAXABS ? v : BIL_SENTINEL;   // NaN fails the compare too
       tile[ty][tx] = v;
     }
   }

@@ -9,7 +9,8 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ROOT = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_PKG, "lib", "librgbid_hip.so")
+# RGBID_HIP_LIB: an alternative build of the same library (A/B experiments with other -D flags: tools/kernel_bench.py); never a CPU path
+LIB_PATH = os.environ.get("RGBID_HIP_LIB") or os.path.join(_PKG, "lib", "librgbid_hip.so")
 CSRC = os.path.join(_PKG, "csrc")
 
 

@@ -138,13 +138,30 @@ def make_sequence(n_frames, seed=SEED, K=TUM_K, rows=480, cols=640, device="cpu"
     return {"depth": torch.stack(depths), "rgb": torch.stack(rgbs), "R_wc": Rs, "t_wc": ts, "K": K}
 
 
-def make_long_sequence(n_frames, seed=SEED, K=TUM_K, rows=480, cols=640, device="cuda", batch=25, dropout=0.03,
+def camera_path_bounded(n_frames, seed=SEED):
+    """A long hand-held-scan path that STAYS in front of the textured surface (the random walk of camera_path drifts away over thousands of
+    frames): position and orientation are sums of two incommensurate sinusoids per axis -- the camera sweeps about +-0.8 m sideways, +-0.5 m
+    up / down, +-0.25 m in depth and pans / tilts by about +-17 / +-10 degrees -- with per-frame steps of 0.5-3 cm and 0.1-1 degree, the range
+    SURVEY 8d asks for.  Frame 0 = identity (the path is expressed relative to its first pose)."""
+    g = torch.Generator().manual_seed(seed + 2000)
+    ph = 2 * math.pi * torch.rand(12, generator=g, dtype=torch.float64)
+    k = torch.arange(n_frames, dtype=torch.float64)
+    amp_t = [(0.60, 397.0, 0.20, 89.0), (0.35, 311.0, 0.15, 71.0), (0.18, 523.0, 0.07, 113.0)]
+    amp_r = [(0.17, 283.0, 0.04, 61.0), (0.25, 353.0, 0.05, 53.0), (0.06, 431.0, 0.02, 97.0)]       # tilt (x), pan (y), roll (z) in radians
+    tw = torch.stack([a * torch.sin(2 * math.pi * k / p_ + ph[2 * i]) + b * torch.sin(2 * math.pi * k / q + ph[2 * i + 1]) for i, (a, p_, b, q) in enumerate(amp_t)], 1)
+    rw = torch.stack([a * torch.sin(2 * math.pi * k / p_ + ph[6 + 2 * i]) + b * torch.sin(2 * math.pi * k / q + ph[7 + 2 * i]) for i, (a, p_, b, q) in enumerate(amp_r)], 1)
+    Rs = torch.stack([rodrigues(rw[i]) for i in range(n_frames)])
+    R0i = Rs[0].T
+    return torch.stack([R0i @ Rs[i] for i in range(n_frames)]), torch.stack([R0i @ (tw[i] - tw[0]) for i in range(n_frames)])
+
+
+def make_long_sequence(n_frames, seed=SEED, K=TUM_K, rows=480, cols=640, device="cuda", batch=25, dropout=0.03, path="bounded",
                        trans_step=(0.005, 0.03), rot_step_deg=(0.1, 1.5)):
     """A long sequence (thousands of frames: BASELINE config 4) of the same scene / camera-path / sensor model as make_sequence, rendered `batch`
     frames at a time with the noise drawn on the device -- a few milliseconds per frame instead of ~25.  Same dict as make_sequence; the noise
     realisation differs from make_sequence's (CPU generator), so the two are different sequences of the same distribution."""
     scene = Scene(seed=seed, device=device)
-    Rs, ts = camera_path(n_frames, seed=seed, trans_step=trans_step, rot_step_deg=rot_step_deg)
+    Rs, ts = camera_path_bounded(n_frames, seed=seed) if path == "bounded" else camera_path(n_frames, seed=seed, trans_step=trans_step, rot_step_deg=rot_step_deg)
     fx, fy, cx, cy = K
     v, u = torch.meshgrid(torch.arange(rows, dtype=torch.float64, device=device), torch.arange(cols, dtype=torch.float64, device=device), indexing="ij")
     dc = torch.stack([(u - cx) / fx, (v - cy) / fy, torch.ones_like(u)], dim=-1)          # [rows, cols, 3]

@@ -101,6 +101,37 @@ def test_fuzz_stencils_and_fusion(ctx, seed):
     assert_bits(kfd.cpu().numpy(), ok_, 0, "fused iD"); assert_bits(qd.cpu().numpy(), oq, 0, "fused weight")
 
 
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RGBID_FUZZ_N", "12"))))
+def test_fuzz_bilateral_fast_numerics(ctx, seed):
+    """the engine's FAST bilateral filter (k_bilateral<2>: invalid taps as a finite sentinel) on odd sizes with +-inf, +-3e38, the sentinel value
+    itself (1e19), 1e10, values either side of its validity bound 1e9, zeros, denormals and dense NaN.  Its stated domain: the oracle's result
+    (filters.cu:86-135) on the map with |v| >= 1e9 and +-inf replaced by NaN -- same NaN pattern, 2e-6 relative."""
+    r = util.rng(2500 + seed)
+    rows, cols = int(r.integers(5, 90)), int(r.integers(5, 130))
+    sigma = (2 * 0.0025, 3.0)[seed % 2]
+    a = util.rand_invdepth(r, rows, cols, nan_frac=float(r.uniform(0, 0.6)), smooth=bool(r.integers(0, 2))) if sigma < 1 else util.rand_intensity(r, rows, cols, nan_frac=float(r.uniform(0, 0.3)))
+    specials = np.array([np.inf, -np.inf, 3e38, -3e38, 1e19, -1e19, 1e10, -1e10, 1e9, 9.9e8, -9.9e8, 1e8, 0.0, -0.0, 1e-45, 1e-39, 7.5], np.float32)
+    idx = r.integers(0, a.size, size=max(1, a.size // 25))
+    a.reshape(-1)[idx] = specials[r.integers(0, specials.size, size=idx.size)]
+    dst = torch.empty((rows, cols), device="cuda")
+    ctx.set_numerics(True)
+    try:
+        ctx.bilateralFilter(dev(a), dst, sigma)
+    finally:
+        ctx.set_numerics(False)
+    dom = a.copy()
+    with np.errstate(invalid="ignore"):
+        dom[~(np.abs(dom) < 1e9)] = np.nan
+    with np.errstate(all="ignore"):
+        ref = O.bilateral(dom, sigma)
+    got = dst.cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(ref)), (int(np.count_nonzero(np.isnan(got) != np.isnan(ref))), rows, cols)
+    m = ~np.isnan(ref)
+    assert np.isfinite(got[m]).all()
+    err = np.abs(got[m].astype(np.float64) - ref[m]) - (2e-6 * np.abs(ref[m].astype(np.float64)) + 1e-36)
+    assert (err <= 0).all(), float(err.max())
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RGBID_FUZZ_ENGINE_N", "10"))))
 def test_fuzz_engine_sizes_and_garbage(ctx, seed):
     """The batched engine at random odd sizes / pyramid depths: (1) parity with the oracle tracker on a benign synthetic sequence,
