@@ -95,7 +95,8 @@ int rgbid_sigma_pair_batched(rgbid_ctx*, int lanes, const float* res_dev, size_t
 
 /* ---- keyframe fusion / maps / covisibility -------------------------------------------------------------------------------------------- */
 /* warpInvDepthWithTrafo3DWeighted + integrateWarpedFrame (warping_registration.cu:549-669) in one pass: kf_depthinv / kf_weight updated
- * in place, warped_weight left exactly as the two kernels leave it.  16-byte geometry. */
+ * in place; EXACT: warped_weight left exactly as the two kernels leave it; FAST: warped_weight is neither read nor written (it only exists between
+ * the reference's two kernels) -- a warped value whose weight is not positive, i.e. an infinite intermediate, fuses with weight 0.  16-byte geometry. */
 int rgbid_fuse_frame_batched(rgbid_ctx*, int lanes, const rgbid_imgb* cur_depthinv, const rgbid_imgb* kf_depthinv,
                              const rgbid_imgb* kf_weight, const rgbid_imgb* warped_weight, const float* R_proj, const float* t_proj,
                              int numerics, float* ms);

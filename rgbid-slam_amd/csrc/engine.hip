@@ -822,7 +822,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   if (!first) {
     if (launch_fuse_frame(s, B, e->iD_curr[0], e->iD_integr, e->w_integr, e->warped_w, e->fuse_wp, M(f.fuse), c.fast_numerics != 0)) {
       e->launches -= 1;
-      sb[3] += 24 * N0;                                                           // keyframe map + weight read and written, gather, warped weight written
+      sb[3] += (c.fast_numerics ? 20 : 24) * N0;                                  // keyframe map + weight read and written, gather (+ the warped-weight buffer in the exact class)
     } else {
       sb[3] += 40 * N0;
       launch_warp_invdepth_weighted(s, B, e->iD_curr[0], e->iD_integr, e->warped_iD_integr, e->warped_w, nullptr, e->fuse_wp, M(f.fuse));

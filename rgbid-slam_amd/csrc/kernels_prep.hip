@@ -247,6 +247,8 @@ void launch_gradient(hipStream_t s, int B, ImgB src, ImgB gx, ImgB gy, LaneMask 
 // gradients stay in registers, and the six output planes are written with full 16-byte stores (24 B/px).  Per-pixel arithmetic is that
 // of the three kernels, so every value the reference defines is bit-identical.  One deliberate difference: planes 1 and 2 of an INVALID
 // pixel (plane 0 = NaN), which the reference leaves untouched -- i.e. stale or uninitialised -- are written as NaN here.
+// (The reciprocal / normalisations as v_rcp_f32 / v_rsq_f32 instead of the exact sequences change nothing: 1.76 vs 1.69 us per lane at 1 024
+// lanes -- the kernel is bound by its 24 B/px of stores -- so there is only the exact class.)
 __global__ __launch_bounds__(256) void k_kf_maps4(ImgB src, ImgB vmap, ImgB nmap, IntrP k, int cols4, int strips, LaneMask m) {
   int lane = blockIdx.y;
   if (!m.on(lane)) return;
@@ -446,9 +448,84 @@ __global__ __launch_bounds__(256) void k_pyr_down_roll(ImgB src, ImgB dst, PyrWe
     }
   }
 }
+// ---- the same reduction with the window columns SHARED between neighbouring lanes (DPP) -----------------------------------------------------
+// In k_pyr_down_roll every thread loads and sanitises all five columns of each window row itself: three 8-byte loads and 15 compare / select
+// instructions per source row, although its neighbours hold four of the five values.  Here lane l of a wave owns the source column pair
+// (2x, 2x + 1) of output column x = 62 wave + l - 1: ONE coalesced 8-byte load per lane and row (a wave reads 512 contiguous bytes), two values
+// sanitised, and the other three window columns arrive by DPP wave shifts from lanes l - 1 (columns 2x - 2, 2x - 1) and l + 1 (column 2x + 2).
+// Lanes 0 and 63 of a wave are halo providers only (62 outputs per wave), so no lane ever needs data of another wave.  Same tap order, same
+// unfused sum1, exact-FMA mask sum and integer-valued count as the reference / k_pyr_down_roll: bit-identical results.
+template <int CTRL>
+__device__ __forceinline__ float dpp_shift(float v) {   // 0x138 = wave_shr:1 (lane l reads lane l - 1), 0x130 = wave_shl:1 (lane l reads lane l + 1); edge lanes get 0
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+struct PyrRow { float v[5], m[5]; };
+__device__ __forceinline__ float2 pyr_issue_pair(const FMap& S, int rows, int cy, unsigned colb) {
+  const unsigned rb = S.row((cy >= 0 && cy < rows) ? cy : 0);
+  return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(S.rsrc, rb + colb, 0, 0));
+}
+__device__ __forceinline__ void pyr_finish_shared(float2 p, bool row_in, bool c0, bool c1, PyrRow& r) {
+  const bool ok0 = row_in && c0 && !isnan(p.x), ok1 = row_in && c1 && !isnan(p.y);
+  const float v0 = ok0 ? p.x : 0.f, v1 = ok1 ? p.y : 0.f, m0 = ok0 ? 1.f : 0.f, m1 = ok1 ? 1.f : 0.f;
+  r.v[2] = v0; r.v[3] = v1; r.m[2] = m0; r.m[3] = m1;
+  r.v[0] = dpp_shift<0x138>(v0); r.v[1] = dpp_shift<0x138>(v1); r.m[0] = dpp_shift<0x138>(m0); r.m[1] = dpp_shift<0x138>(m1);
+  r.v[4] = dpp_shift<0x130>(v0); r.m[4] = dpp_shift<0x130>(m0);
+}
+static constexpr int PD_WAVE_OUT = 62;   // outputs per wave (lanes 1 .. 62)
+#ifndef RGBID_PD_WAVES
+#define RGBID_PD_WAVES 1
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RGBID_PD_WAVES, 8))) void k_pyr_down_dpp(ImgB src, ImgB dst, PyrWeights W, int strips, int wpr, LaneMask m) {
+  const int lane = blockIdx.y;
+  if (!m.on(lane)) return;
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lid = threadIdx.x & 63;
+  if (wave >= strips * wpr) return;                       // whole waves only: every lane of a live wave takes part in the shifts
+  const int strip = wave / wpr, wx = wave - strip * wpr;
+  const int x = wx * PD_WAVE_OUT + lid - 1;                // -1 and >= dst.cols: halo / idle lanes (they still provide their column pair)
+  const int y_begin = strip * PD_ROWS;
+  const FMap S(src, lane);
+  const bool c0 = x >= 0 && 2 * x < src.cols, c1 = x >= 0 && 2 * x + 1 < src.cols;
+  const unsigned colb = (unsigned)max(2 * x, 0) << 3 >> 1;   // byte offset of column 2x (0 for the halo lane left of the image, whose values are masked off)
+  const bool writer = lid >= 1 && lid <= PD_WAVE_OUT && x < dst.cols;
+  PyrRow win[2 * PD_ROWS + 3];
+  float2 raw[2 * PD_ROWS + 3];
+#pragma unroll
+  for (int r = 0; r < 3 + 2 * PD_AHEAD; ++r) raw[r] = pyr_issue_pair(S, src.rows, 2 * y_begin - 2 + r, colb);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { const int cy = 2 * y_begin - 2 + r; pyr_finish_shared(raw[r], cy >= 0 && cy < src.rows, c0, c1, win[r]); }
+#pragma unroll
+  for (int j = 0; j < PD_ROWS; ++j) {
+    const int y = y_begin + j;
+    if (y < dst.rows) {   // wave-uniform
+      if (j + PD_AHEAD < PD_ROWS && y + PD_AHEAD < dst.rows) {
+        raw[2 * (j + PD_AHEAD) + 3] = pyr_issue_pair(S, src.rows, 2 * (y + PD_AHEAD) + 1, colb);
+        raw[2 * (j + PD_AHEAD) + 4] = pyr_issue_pair(S, src.rows, 2 * (y + PD_AHEAD) + 2, colb);
+      }
+      pyr_finish_shared(raw[2 * j + 3], 2 * y + 1 < src.rows, c0, c1, win[2 * j + 3]);
+      pyr_finish_shared(raw[2 * j + 4], 2 * y + 2 < src.rows, c0, c1, win[2 * j + 4]);
+      // (a per-row tap count shared by the outputs that hold the row saves 12 adds per output but costs 6 VGPRs: 7 -> 6 waves / SIMD, 0.34 -> 0.43 us per lane)
+      float sum1 = 0.f, sum2 = 0.f, count = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+          const float weight = W.w[(dx - 2) * (dx - 2) + (dy - 2) * (dy - 2)];
+          sum1 = sum1 + win[2 * j + dy].v[dx] * weight;
+          sum2 = __builtin_fmaf(win[2 * j + dy].m[dx], weight, sum2);
+          count += win[2 * j + dy].m[dx];                  // small integers: exact in fp32
+        }
+      if (writer) px<float>(dst, lane, y, x) = count > 12.f ? sum1 / sum2 : qnan();
+    }
+  }
+}
 void launch_pyr_down(hipStream_t s, int B, ImgB src, ImgB dst, LaneMask m) {
   int strips = div_up(dst.rows, PD_ROWS);
+#ifndef RGBID_PD_NO_DPP
+  const int wpr = div_up(dst.cols, PD_WAVE_OUT);
+  hipLaunchKernelGGL(k_pyr_down_dpp, dim3(div_up(strips * wpr, 4), B), dim3(256), 0, s, src, dst, pyr_weights(), strips, wpr, m);
+#else
   hipLaunchKernelGGL(k_pyr_down_roll, dim3(div_up(dst.cols * strips, 256), B), dim3(256), 0, s, src, dst, pyr_weights(), strips, m);
+#endif
 }
 
 // ---- bilateralKernel (filters.cu:86-135), clipped 5x5 window -------------------------------------

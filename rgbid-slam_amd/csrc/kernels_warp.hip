@@ -291,56 +291,96 @@ void launch_integrate_warped(hipStream_t s, int B, ImgB warped, ImgB wweight, Im
 // leave it -- written only where the weight is positive, stale elsewhere -- because the fusion reads it wherever the warped value is
 // valid, which can (only with infinite intermediates) include pixels whose weight was not stored: full groups store 16 bytes, mixed groups
 // store their pixels one by one, and the stale value is fetched only in that exotic case.  Same device functions, bit-identical maps.
+// FUSE_UNITS 4-pixel groups per thread, all loads of the thread's groups issued first, then all projections and gathers, then the blends and
+// stores.  Measured at 1 024 lanes (tools/kernel_bench.py): 1 group 1.75-1.79 us per lane, 2 groups 1.87-1.94, 4 groups 1.84-1.92 (the
+// round-2 grid-stride loop of 2 groups per thread: 1.83) -- the kernel is not bound by the latency of its chain but by its traffic: half of its
+// 24 B/px are writes, read-modify-write of two maps in place.  One group per thread; and the FAST class does not carry the reference's
+// warped-weight buffer at all (20 B/px): that buffer only exists between the reference's two kernels, and the one case in which the fused
+// kernel reads it back -- a valid warped value whose weight was not positive, i.e. an infinite intermediate -- takes weight 0 there.
+#ifndef RGBID_FUSE_UNITS
+#define RGBID_FUSE_UNITS 1
+#endif
+static constexpr int FUSE_UNITS = RGBID_FUSE_UNITS;
 template <class PS, bool FAST>
 __global__ __launch_bounds__(256) void k_fuse_frame4(ImgB src, ImgB kf, ImgB kfw, ImgB wweight, PS ps, int cols4, int units, LaneMask m) {
   int lane = blockIdx.y;
   if (!m.on(lane)) return;
   const WarpParams P = ps.get(lane);
   const FMap S(src, lane);
-  for (int u = blockIdx.x * 256 + threadIdx.x; u < units; u += gridDim.x * 256) {
-    int y = u / cols4, x = (u - y * cols4) * 4;
-    float4* kp = reinterpret_cast<float4*>(row_ptr<float>(kf, lane, y) + x);
-    float4* qp = reinterpret_cast<float4*>(row_ptr<float>(kfw, lane, y) + x);
-    float* wp = row_ptr<float>(wweight, lane, y) + x;
-    float4 k4 = *kp, q4 = *qp;
-    float k[4] = {k4.x, k4.y, k4.z, k4.w}, q[4] = {q4.x, q4.y, q4.z, q4.w}, ws[4], wt[4];
-    bool st[4];
-    if (FAST) {   // reference-build-class numerics (warp_device.h fastnum): the ray of the group's first pixel stepped along x
-      fastnum::Ray r = fastnum::ray(P, (float)x, (float)y);
+  const int u0 = blockIdx.x * (256 * FUSE_UNITS) + threadIdx.x;   // the thread's groups: u0, u0 + 256, ... (a wave's loads stay contiguous)
+  float4 k4[FUSE_UNITS], q4[FUSE_UNITS];
+  int xs_[FUSE_UNITS], ys_[FUSE_UNITS];
+  bool on[FUSE_UNITS];
+#pragma unroll
+  for (int g = 0; g < FUSE_UNITS; ++g) {
+    const int u = u0 + g * 256;
+    on[g] = u < units;
+    const int y = on[g] ? u / cols4 : 0, x = on[g] ? (u - y * cols4) * 4 : 0;
+    xs_[g] = x; ys_[g] = y;
+    k4[g] = *reinterpret_cast<const float4*>(row_ptr<float>(kf, lane, y) + x);
+    q4[g] = *reinterpret_cast<const float4*>(row_ptr<float>(kfw, lane, y) + x);
+  }
+  float ws[FUSE_UNITS][4], wt[FUSE_UNITS][4];
+  bool st[FUSE_UNITS][4];
+  if (FAST) {   // reference-build-class numerics (warp_device.h fastnum): the ray of the group's first pixel stepped along x
+#pragma unroll
+    for (int g = 0; g < FUSE_UNITS; ++g) {
+      const float k[4] = {k4[g].x, k4[g].y, k4[g].z, k4[g].w};
+      fastnum::Ray r = fastnum::ray(P, (float)xs_[g], (float)ys_[g]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        ws[i] = fastnum::warp_invdepth_weighted_px(S, r, k[i], P, wt[i], st[i]);
+        ws[g][i] = fastnum::warp_invdepth_weighted_px(S, r, k[i], P, wt[g][i], st[g][i]);
         r = fastnum::ray_step(r, P.R[0], P.R[3], P.R[6]);
       }
-    } else {
-      RcpFast fast;
+    }
+  } else {
+    RcpFast fast;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ws[i] = warp_invdepth_weighted_px_t(S, x + i, y, k[i], P, fast, wt[i], st[i]);
-      if (__builtin_expect(fast.failed(), 0)) {
-        RcpIeee ieee;
+    for (int g = 0; g < FUSE_UNITS; ++g) {
+      const float k[4] = {k4[g].x, k4[g].y, k4[g].z, k4[g].w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ws[i] = warp_invdepth_weighted_px_t(S, x + i, y, k[i], P, ieee, wt[i], st[i]);
+      for (int i = 0; i < 4; ++i) ws[g][i] = warp_invdepth_weighted_px_t(S, xs_[g] + i, ys_[g], k[i], P, fast, wt[g][i], st[g][i]);
+    }
+    if (__builtin_expect(fast.failed(), 0)) {
+      RcpIeee ieee;
+#pragma unroll
+      for (int g = 0; g < FUSE_UNITS; ++g) {
+        const float k[4] = {k4[g].x, k4[g].y, k4[g].z, k4[g].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ws[g][i] = warp_invdepth_weighted_px_t(S, xs_[g] + i, ys_[g], k[i], P, ieee, wt[g][i], st[g][i]);
       }
     }
-    const bool all_st = st[0] & st[1] & st[2] & st[3];
-    if (all_st) *reinterpret_cast<float4*>(wp) = make_float4(wt[0], wt[1], wt[2], wt[3]);
+  }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float qs = wt[i];
-      if (!st[i]) {
-        if (!isnan(ws[i])) qs = wp[i];   // valid warped value whose weight was not stored: the reference fuses with the stale weight
-      } else if (!all_st) wp[i] = wt[i];
-      integrate_px(ws[i], qs, k[i], q[i]);
+  for (int g = 0; g < FUSE_UNITS; ++g) {
+    if (!on[g]) continue;
+    float k[4] = {k4[g].x, k4[g].y, k4[g].z, k4[g].w}, q[4] = {q4[g].x, q4[g].y, q4[g].z, q4[g].w};
+    if (FAST) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) integrate_px(ws[g][i], st[g][i] ? wt[g][i] : 0.f, k[i], q[i]);
+    } else {
+      float* wp = row_ptr<float>(wweight, lane, ys_[g]) + xs_[g];
+      const bool all_st = st[g][0] & st[g][1] & st[g][2] & st[g][3];
+      if (all_st) *reinterpret_cast<float4*>(wp) = make_float4(wt[g][0], wt[g][1], wt[g][2], wt[g][3]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float qs = wt[g][i];
+        if (!st[g][i]) {
+          if (!isnan(ws[g][i])) qs = wp[i];   // valid warped value whose weight was not stored: the reference fuses with the stale weight
+        } else if (!all_st) wp[i] = wt[g][i];
+        integrate_px(ws[g][i], qs, k[i], q[i]);
+      }
     }
-    *kp = make_float4(k[0], k[1], k[2], k[3]);
-    *qp = make_float4(q[0], q[1], q[2], q[3]);
+    *reinterpret_cast<float4*>(row_ptr<float>(kf, lane, ys_[g]) + xs_[g]) = make_float4(k[0], k[1], k[2], k[3]);
+    *reinterpret_cast<float4*>(row_ptr<float>(kfw, lane, ys_[g]) + xs_[g]) = make_float4(q[0], q[1], q[2], q[3]);
   }
 }
 bool launch_fuse_frame(hipStream_t s, int B, ImgB src, ImgB kf, ImgB kfw, ImgB wweight, const WarpParams* lp, LaneMask m, bool fast) {
   if (!(vec4_ok(kf) && vec4_ok(kfw) && vec4_ok(wweight))) return false;   // caller falls back to the two kernels
   int cols4 = kf.cols / 4, units = cols4 * kf.rows;
-  if (fast) hipLaunchKernelGGL((k_fuse_frame4<ByLane<WarpParams>, true>), dim3(div_up(units, 256 * 2), B), dim3(256), 0, s, src, kf, kfw, wweight, ByLane<WarpParams>{lp}, cols4, units, m);
-  else hipLaunchKernelGGL((k_fuse_frame4<ByLane<WarpParams>, false>), dim3(div_up(units, 256 * 2), B), dim3(256), 0, s, src, kf, kfw, wweight, ByLane<WarpParams>{lp}, cols4, units, m);
+  const dim3 g(div_up(units, 256 * FUSE_UNITS), B);
+  if (fast) hipLaunchKernelGGL((k_fuse_frame4<ByLane<WarpParams>, true>), g, dim3(256), 0, s, src, kf, kfw, wweight, ByLane<WarpParams>{lp}, cols4, units, m);
+  else hipLaunchKernelGGL((k_fuse_frame4<ByLane<WarpParams>, false>), g, dim3(256), 0, s, src, kf, kfw, wweight, ByLane<WarpParams>{lp}, cols4, units, m);
   return true;
 }
 

@@ -125,7 +125,8 @@ def main():
             timed("sigma_pair (both channels)", sig, 8 * ns)
     if want("fuse"):
         kf = W[0].clone(); kfw = torch.ones_like(kf); ww = torch.zeros_like(kf)
-        timed("fuse_frame FAST", lambda: bt.fuse_frame(W[1], kf, kfw, ww, Rs, ts, fast=True), 24 * N0, reps=8)
+        timed("fuse_frame FAST", lambda: bt.fuse_frame(W[1], kf, kfw, ww, Rs, ts, fast=True), 20 * N0, reps=8)
+        timed("fuse_frame EXACT", lambda: bt.fuse_frame(W[1], kf, kfw, ww, Rs, ts, fast=False), 24 * N0, reps=8)
         del kf, kfw, ww
     if want("maps"):
         vm, nm = f32(B, 3 * rows, cols), f32(B, 3 * rows, cols)
