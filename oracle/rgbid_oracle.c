@@ -60,7 +60,8 @@ static inline float cn_rsqrt(float x) { x = cn_ftz(x); return cn_ftz(cn_nudge((f
 static inline float cn_exp(float x) {
   x = cn_ftz(x);
   float t = x * 1.44269504088896341f;                       /* __expf(x) = ex2.approx(x * log2 e), the product rounded to fp32 */
-  int bound = 2;
+  int bound = 2 + (int)floorf(fabsf(1.16f * x));            /* CUDA C Programming Guide, intrinsic __expf: max ulp error 2 + floor(abs(1.16 x)) */
+  if (bound > 4096) bound = 4096;                            /* results that far out are flushed to 0 / saturate anyway */
   return cn_ftz(cn_nudge((float)exp2((double)t), cn_off(cn_mix(cn_bits(x), 0x53u), bound)));
 }
 #define FDIV(a, b) cn_div((a), (b))

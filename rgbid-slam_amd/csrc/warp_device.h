@@ -24,8 +24,10 @@ __device__ __forceinline__ int clamp_from_m1(int v, int hi) { int r; asm("v_med3
 
 // lane-local view of a float map for gathers: a raw buffer descriptor over the lane's image (wave-uniform: the lane is a block index) and
 // 32-bit BYTE offsets formed with 24-bit multiplies.  v_mul_lo_u32 issues at quarter rate and a 64-bit flat address costs two more VALU
-// instructions per access, which matters in the VALU-bound warps (rows, pitch < 2^24 and the image < 4 GB: checked at the C-ABI; coordinates
-// are clamped to the image before they get here, so every offset is inside the descriptor's range).
+// instructions per access, which matters in the VALU-bound warps (rows, pitch < 2^24 and the image < 4 GB: checked at the C-ABI).  The EXACT
+// functions clamp every coordinate to the image before it gets here; the fastnum functions do NOT clamp the coordinates of pixels they
+// reject anyway and rely on the descriptor's range check (an offset outside the lane's image reads 0, a wrapped one some other texel of the
+// same image: either value is discarded by the pixel's predicate).
 struct FMap {
   const float* base;
   int pitch, rows, cols;
@@ -202,7 +204,7 @@ __device__ __forceinline__ Scaled scaled_point(const Ray& q, float w, const Warp
 
 // trafo3DKernelInvDepthGridStride (:505-546), one pixel
 __device__ __forceinline__ float warp_invdepth_px(const FMap& src, const Ray& q, float w, const WarpParams& P) {
-  const bool valid = w == w;
+  const bool valid = w > 0.f;   // an inverse depth of 0 (a point at infinity) is rejected like NaN, as the exact path ends up doing
   const float ws = valid ? w : 1.f;
   const Scaled Y = scaled_point(q, ws, P);
   const float wc = rcp(Y.y2);
@@ -216,7 +218,7 @@ __device__ __forceinline__ float warp_invdepth_px(const FMap& src, const Ray& q,
 
 // the weighted variant (:549-594): warped inverse depth + weight (1 - w2 tz)^4 / v^2
 __device__ __forceinline__ float warp_invdepth_weighted_px(const FMap& src, const Ray& q, float w, const WarpParams& P, float& weight_res, bool& store_weight) {
-  const bool valid = w == w;
+  const bool valid = w > 0.f;   // an inverse depth of 0 (a point at infinity) is rejected like NaN, as the exact path ends up doing
   const float ws = valid ? w : 1.f;
   const Scaled Y = scaled_point(q, ws, P);
   const float wc = rcp(Y.y2);
@@ -239,11 +241,13 @@ struct IntensityTaps { float2 p0, p1; float a, b; bool ok; };
 // Clamp addressing without integer clamps or per-tap selects: the sample coordinate itself is clamped to [0, n - 1) (one v_med3_f32 per
 // axis; the upper end is the float just below n - 1), so that floor() is a legal column / row with a legal right / lower neighbour and the
 // two 8-byte loads (row j and row j + 1: the same offset, the pitch in the instruction's scalar offset) ARE the four texels.  Left / top
-// border: the weight becomes 0 on texel 0, as clamp addressing gives; right / bottom border: the weight becomes 1 - 2^-24 (exactly 1 after
-// the 1.8 fixed-point rounding) on the last texel.
+// border: the weight becomes 0 on texel 0, as clamp addressing gives; right / bottom border: the coordinate is the float just below n - 1, so
+// the weight of the last texel is 1 - ulp(n - 1) (1 - 2^-14 at 640 columns) -- exactly 1 after the 1.8 fixed-point rounding of
+// RGBID_INTERP_TEX8, the engine's mode; with RGBID_INTERP_EXACT the last texel is blended with its neighbour by that 2^-14 (at most 0.016 grey
+// levels), a bound of the FAST class only (the exact functions above clamp the texel indices instead).
 __device__ __forceinline__ IntensityTaps intensity_taps(const FMap& src, const Ray& q, float w, const WarpParams& P, int interp_mode) {
   IntensityTaps t;
-  const bool valid = w == w;
+  const bool valid = w > 0.f;   // an inverse depth of 0 (a point at infinity) is rejected like NaN, as the exact path ends up doing
   const float ws = valid ? w : 1.f;
   const Scaled Y = scaled_point(q, ws, P);
   const float wc = rcp(Y.y2);

@@ -73,7 +73,10 @@ def test_host_library_exports_every_declared_symbol():
 
 def test_dist_library_exports_every_declared_symbol():
     """librgbid_dist.so (multi-GPU helpers over librccl, include/rgbid_dist.h) loads without a GPU and exports every declared symbol"""
+    import pytest
     from rgbid import dist as D
+    if not os.path.exists(D.DIST_LIB_PATH) and not os.path.exists("/opt/rocm/include/rccl/rccl.h"):
+        pytest.skip("librgbid_dist.so is not built on hosts without RCCL (csrc/Makefile says so); every other library is")
     L = D.dlib()
     names = [n for n in _declared("rgbid_dist.h") if n.startswith("rgbid_dist_")]
     assert len(names) == 14 and set(names) == set(D.DIST_EXPORTS), names

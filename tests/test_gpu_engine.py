@@ -149,8 +149,9 @@ def test_engine_fused_gn_is_bit_identical(ctx):
 
 @pytest.mark.parametrize("rows,cols,levels", [(120, 160, 3), (122, 164, 2), (480, 640, 3)])
 def test_engine_fused_fast_is_bit_identical_to_unfused_fast(ctx, rows, cols, levels):
-    """fast numerics: the fused kernel (gathers issued pixel-per-lane through the wave's LDS transpose) and the stand-alone fast warp pair
-    evaluate the same device functions on the same pixels and the rows are accumulated in the same order: records must be IDENTICAL.
+    """REGRESSION test (the parity evidence for the fused kernel is tests/test_gpu_batched.py, kernel against oracle): the fused kernel and the
+    stand-alone fast warp pair + normal equations evaluate the same device functions on the same pixels and accumulate the rows in the same
+    order (same launch plan): records must be IDENTICAL.
     (122 x 164: rows that are not a multiple of the launch geometry, lanes past the end of the image inside a live wave.)"""
     s = cols / 640.0
     K = (525.0 * s, 525.0 * s, (319.5 + 0.5) * s - 0.5, (239.5 + 0.5) * rows / 480.0 - 0.5)
