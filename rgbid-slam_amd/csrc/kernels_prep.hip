@@ -363,98 +363,19 @@ static const PyrWeights& pyr_weights() {
   static const PyrWeights W = [] { PyrWeights t; for (int d2 = 0; d2 < 9; ++d2) t.w[d2] = expf(-((float)d2 * 0.5f)); return t; }();
   return W;
 }
-// A thread owns one output column and walks PD_ROWS output rows downwards, keeping the 5x5 source window in registers
-// (two new source rows = ten cached loads per output; out-of-image taps become NaN).  No LDS, no barriers.
-#ifndef RGBID_PD_ROWS
-#define RGBID_PD_ROWS 8
-#endif
-#ifndef RGBID_PD_AHEAD
-#define RGBID_PD_AHEAD 1      // outputs whose two new source rows are in flight ahead of the one being computed
-#endif
-static constexpr int PD_ROWS = RGBID_PD_ROWS, PD_AHEAD = RGBID_PD_AHEAD;
-// a source row of the window: value sanitised to 0 and validity both as 0/1 float (weight sum) and 0/1 int (count), so a tap is
-// `sum1 += v * w; sum2 = fma(m, w, sum2); count += mi` (adding +0 for an invalid tap leaves the sums bit-identical to skipping it: they
-// start at +0 and can never become -0; m * w is exact, so the explicit FMA equals the reference's multiply-then-add bit for bit)
-// Loads: the five columns 2x-2 .. 2x+2 of a window row arrive as THREE 8-byte loads at the even columns 2x-2, 2x, 2x+2 (raw buffer
-// descriptor, 32-bit byte offsets) -- the kernel is bound by its vector-memory instruction count (stride-2 lanes: every load instruction
-// touches 4-5 cache lines), 6 instead of 10 per output.  A column outside the image is never used (cin), so the pair at 2x-2 is simply
-// moved to column 0 for x = 0 and the unused upper half of the pair at 2x+2 may lie beyond the row (inside the descriptor, or 0 beyond it).
-struct PyrRaw { float2 p0, p1, p2; bool row_in; };
-__device__ __forceinline__ PyrRaw pyr_issue_row(const FMap& S, int rows, int cy, const unsigned cxb[3]) {
-  PyrRaw q;
-  q.row_in = cy >= 0 && cy < rows;
-  const unsigned rb = S.row(q.row_in ? cy : 0);
-  q.p0 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(S.rsrc, rb + cxb[0], 0, 0));
-  q.p1 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(S.rsrc, rb + cxb[1], 0, 0));
-  q.p2 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(S.rsrc, rb + cxb[2], 0, 0));
-  return q;
-}
-__device__ __forceinline__ void pyr_finish_row(const PyrRaw& q, const bool cin[5], float r[5], float mk[5], int mi[5]) {
-  const float v[5] = {q.p0.x, q.p0.y, q.p1.x, q.p1.y, q.p2.x};
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    bool ok = q.row_in && cin[i] && !isnan(v[i]);
-    r[i] = ok ? v[i] : 0.f;
-    mk[i] = ok ? 1.f : 0.f;
-    mi[i] = ok ? 1 : 0;
-  }
-}
-// The row loop is fully unrolled (PD_ROWS outputs, rows past the image predicated off): the 5-row window lives in renamed registers (the
-// rolled loop spent 30 of its ~185 instructions per output on v_mov copies), and it is software-pipelined -- the two source rows of output
-// j + 1 are ISSUED before output j is computed and only unpacked (validity, sanitising) after it, so a wave always has a row pair in flight
-// behind its arithmetic instead of waiting out every pair (the kernel ran at 2.4 TB/s: six loads in flight per wave, then a full stop).
-__global__ __launch_bounds__(256) void k_pyr_down_roll(ImgB src, ImgB dst, PyrWeights W, int strips, LaneMask m) {
-  int lane = blockIdx.y;
-  if (!m.on(lane)) return;
-  int u = blockIdx.x * 256 + threadIdx.x;
-  if (u >= dst.cols * strips) return;
-  int strip = u / dst.cols, x = u - strip * dst.cols;
-  const int y_begin = strip * PD_ROWS;
-  const FMap S(src, lane);
-  bool cin[5];
-#pragma unroll
-  for (int i = 0; i < 5; ++i) { int c = 2 * x - 2 + i; cin[i] = c >= 0 && c < src.cols; }
-  const unsigned cx[3] = {(unsigned)max(2 * x - 2, 0) << 2, (unsigned)(2 * x) << 2, (unsigned)(2 * x + 2) << 2};   // byte offsets of the three column pairs
-  // window rows: slot s holds source row 2 y_begin - 2 + s; all indices are compile-time after unrolling
-  float win[2 * PD_ROWS + 3][5], msk[2 * PD_ROWS + 3][5];
-  int mki[2 * PD_ROWS + 3][5];
-  PyrRaw raw[2 * PD_ROWS + 3];
-#pragma unroll
-  for (int r = 0; r < 3 + 2 * PD_AHEAD; ++r) raw[r] = pyr_issue_row(S, src.rows, 2 * y_begin - 2 + r, cx);
-#pragma unroll
-  for (int r = 0; r < 3; ++r) pyr_finish_row(raw[r], cin, win[r], msk[r], mki[r]);
-#pragma unroll
-  for (int j = 0; j < PD_ROWS; ++j) {
-    const int y = y_begin + j;
-    if (y < dst.rows) {   // wave-uniform except in a strip's last rows
-      if (j + PD_AHEAD < PD_ROWS && y + PD_AHEAD < dst.rows) {   // a later output's two new rows: in flight during this output's arithmetic
-        raw[2 * (j + PD_AHEAD) + 3] = pyr_issue_row(S, src.rows, 2 * (y + PD_AHEAD) + 1, cx);
-        raw[2 * (j + PD_AHEAD) + 4] = pyr_issue_row(S, src.rows, 2 * (y + PD_AHEAD) + 2, cx);
-      }
-      pyr_finish_row(raw[2 * j + 3], cin, win[2 * j + 3], msk[2 * j + 3], mki[2 * j + 3]);
-      pyr_finish_row(raw[2 * j + 4], cin, win[2 * j + 4], msk[2 * j + 4], mki[2 * j + 4]);
-      float sum1 = 0.f, sum2 = 0.f;
-      int count = 0;
-#pragma unroll
-      for (int dy = 0; dy < 5; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 5; ++dx) {
-          const float weight = W.w[(dx - 2) * (dx - 2) + (dy - 2) * (dy - 2)];
-          sum1 = sum1 + win[2 * j + dy][dx] * weight;
-          sum2 = __builtin_fmaf(msk[2 * j + dy][dx], weight, sum2);
-          count += mki[2 * j + dy][dx];
-        }
-      px<float>(dst, lane, y, x) = count > 12 ? sum1 / sum2 : qnan();
-    }
-  }
-}
-// ---- the same reduction with the window columns SHARED between neighbouring lanes (DPP) -----------------------------------------------------
-// In k_pyr_down_roll every thread loads and sanitises all five columns of each window row itself: three 8-byte loads and 15 compare / select
-// instructions per source row, although its neighbours hold four of the five values.  Here lane l of a wave owns the source column pair
+static constexpr int PD_ROWS = 8;    // output rows a thread walks down (16 rows: < 4 % either way)
+static constexpr int PD_AHEAD = 1;   // outputs whose two new source rows are in flight ahead of the one being computed (deeper: < 4 %)
+// A thread owns one output column and walks PD_ROWS output rows downwards with the 5-row source window in registers (no LDS, no barriers); the
+// row loop is fully unrolled (the window lives in renamed registers) and software-pipelined: the two source rows of output j + 1 are ISSUED
+// before output j is computed and only unpacked after it.  The window COLUMNS are shared between neighbouring lanes: a thread that loaded and
+// sanitised all five columns of each row itself (round 2: three 8-byte loads and 15 compare / select instructions per source row, 0.47 us per
+// lane) repeats what its neighbours hold.  Here lane l of a wave owns the source column pair
 // (2x, 2x + 1) of output column x = 62 wave + l - 1: ONE coalesced 8-byte load per lane and row (a wave reads 512 contiguous bytes), two values
 // sanitised, and the other three window columns arrive by DPP wave shifts from lanes l - 1 (columns 2x - 2, 2x - 1) and l + 1 (column 2x + 2).
-// Lanes 0 and 63 of a wave are halo providers only (62 outputs per wave), so no lane ever needs data of another wave.  Same tap order, same
-// unfused sum1, exact-FMA mask sum and integer-valued count as the reference / k_pyr_down_roll: bit-identical results.
+// Lanes 0 and 63 of a wave are halo providers only (62 outputs per wave), so no lane ever needs data of another wave.  Same tap order, unfused
+// sum1, exact-FMA mask sum (adding +0 for an invalid tap leaves the sums bit-identical to skipping it: they start at +0 and can never become
+// -0; m * w is exact) and an integer-valued tap count: bit-identical to the oracle's validity pattern.  0.34 us per lane (0.56 of the HBM peak
+// on 5 B per source pixel), VALU-bound at 170 instructions per output.
 template <int CTRL>
 __device__ __forceinline__ float dpp_shift(float v) {   // 0x138 = wave_shr:1 (lane l reads lane l - 1), 0x130 = wave_shl:1 (lane l reads lane l + 1); edge lanes get 0
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
@@ -472,10 +393,7 @@ __device__ __forceinline__ void pyr_finish_shared(float2 p, bool row_in, bool c0
   r.v[4] = dpp_shift<0x130>(v0); r.m[4] = dpp_shift<0x130>(m0);
 }
 static constexpr int PD_WAVE_OUT = 62;   // outputs per wave (lanes 1 .. 62)
-#ifndef RGBID_PD_WAVES
-#define RGBID_PD_WAVES 1
-#endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RGBID_PD_WAVES, 8))) void k_pyr_down_dpp(ImgB src, ImgB dst, PyrWeights W, int strips, int wpr, LaneMask m) {
+__global__ __launch_bounds__(256) void k_pyr_down_dpp(ImgB src, ImgB dst, PyrWeights W, int strips, int wpr, LaneMask m) {
   const int lane = blockIdx.y;
   if (!m.on(lane)) return;
   const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lid = threadIdx.x & 63;
@@ -503,7 +421,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RGBID_PD_WA
       }
       pyr_finish_shared(raw[2 * j + 3], 2 * y + 1 < src.rows, c0, c1, win[2 * j + 3]);
       pyr_finish_shared(raw[2 * j + 4], 2 * y + 2 < src.rows, c0, c1, win[2 * j + 4]);
-      // (a per-row tap count shared by the outputs that hold the row saves 12 adds per output but costs 6 VGPRs: 7 -> 6 waves / SIMD, 0.34 -> 0.43 us per lane)
+      // (a per-row tap count shared by the outputs that hold the row saves 12 adds per output but costs 6 VGPRs: 7 -> 6 waves / SIMD, 0.34 -> 0.43 us
+      // per lane; forcing 8 waves / SIMD spills: 0.49)
       float sum1 = 0.f, sum2 = 0.f, count = 0.f;
 #pragma unroll
       for (int dy = 0; dy < 5; ++dy)
@@ -520,19 +439,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RGBID_PD_WA
 }
 void launch_pyr_down(hipStream_t s, int B, ImgB src, ImgB dst, LaneMask m) {
   int strips = div_up(dst.rows, PD_ROWS);
-#ifndef RGBID_PD_NO_DPP
   const int wpr = div_up(dst.cols, PD_WAVE_OUT);
   hipLaunchKernelGGL(k_pyr_down_dpp, dim3(div_up(strips * wpr, 4), B), dim3(256), 0, s, src, dst, pyr_weights(), strips, wpr, m);
-#else
-  hipLaunchKernelGGL(k_pyr_down_roll, dim3(div_up(dst.cols * strips, 256), B), dim3(256), 0, s, src, dst, pyr_weights(), strips, m);
-#endif
 }
 
 // ---- bilateralKernel (filters.cu:86-135), clipped 5x5 window -------------------------------------
-#ifndef RGBID_BIL_TILES
-#define RGBID_BIL_TILES 4
-#endif
-static constexpr int BR = 2, BIL_TILES = RGBID_BIL_TILES;
+static constexpr int BR = 2, BIL_TILES = 4;
 // the 24 off-centre taps of one pixel.  FAST: the per-tap division by sigma (a constant of the launch) as the 3-instruction exact sequence of
 // common.h div_const_fast; the caller recomputes the pixel with the IEEE division if any tap left its verified range.  The centre tap is the
 // pixel itself: its weight is expf(-0) = 1 exactly, so it enters the sums as (value, 1) without arithmetic -- at its place in the tap order.

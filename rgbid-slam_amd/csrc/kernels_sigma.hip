@@ -79,11 +79,7 @@ static const NuTable& nu_table() {
 // One workgroup per (lane, channel).  512 threads x <= 40 samples in registers: four workgroups fit a CU, so the 1 024 workgroups of a 512-lane
 // launch are resident in ONE round (1 024 threads x 24 samples needed two rounds of 512 and paid the ~10 block reductions of a pass sequence
 // twice: 81 us; 768 x 26: 57; 512 x 40: 54; 384 x 50: 64; 256 x 76: 59).
-#ifndef RGBID_SIG_T
-#define RGBID_SIG_T 512
-#define RGBID_SIG_MAXPT 40
-#endif
-static constexpr int SIG_T = RGBID_SIG_T, SIG_MAXPT = RGBID_SIG_MAXPT, SIG_W = SIG_T / 64;
+static constexpr int SIG_T = 512, SIG_MAXPT = 40, SIG_W = SIG_T / 64;
 static constexpr float TH_HUBER = 1.345f, TH_TUKEY = 4.685f, STUDENT_DOF = 5.f;
 
 // block-wide sum of 4 per-thread fp32 partials: DPP wave reduction in fp32, then the SIG_W wave totals are

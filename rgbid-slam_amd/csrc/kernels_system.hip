@@ -1,18 +1,25 @@
 // kernels_system.hip -- per-pixel photometric + inverse-depth residual/Jacobian rows and the 21+6 term
 // Gauss-Newton normal-equation reduction for gfx950 (the headline kernel).  Replaces
 // src/cuda/estimate_VO.cu: constraintsHandler (:95-441), FinalReductionKernel (:459-500) and the host
-// wrappers buildSystemGridStride (:505-645) / buildSystemStudentNuGridStride (:649-789).
+// wrappers buildSystemGridStride (:505-645) / buildSystemStudentNuGridStride (:649-789); in its FUSED forms also the two warps of
+// a Gauss-Newton iteration (src/cuda/warping_registration.cu:465-546).
 //
 // Reference geometry (NOT reproduced): 32x2-thread blocks, grid capped at 120 blocks (tuned for a 5-SM
 // GTX 850M), 27 sequential __syncthreads-bracketed shared-memory tree reductions, a second kernel and
 // two stream syncs + a 216-byte D2H per call.
 //
-// CDNA4 design: a pure 8-stream read (32 B/px, no reuse -> no LDS staging).  Each lane of a wave64 owns
-// 4 consecutive pixels and issues eight 16-byte loads (1 KiB per wave per map, fully coalesced); 27 fp32
-// accumulators live in VGPRs; the workgroup (4 waves) reduces with wave64 shuffles -> 4x27 floats of LDS
-// -> doubles, and writes ONE 27-double partial row per workgroup.  Partials are summed in a fixed order
-// by a second tiny kernel (or by the batched engine's solve kernel), so results are deterministic --
-// no floating-point atomics.  blockIdx is remapped so that the 8 XCDs each stream a contiguous slab.
+// CDNA4 design: one template, k_build_system<params source, 16-byte path, level tag, FUSED, weight variant>.
+//  * FUSED = 0 -- the normal equations on stored W1 / I1: a pure 8-stream read (32 B/px, no reuse -> no LDS staging), 0.83 of the HBM peak.
+//  * FUSED = 2 -- what the engine runs: W1 / I1 are formed in registers from the current frame (fast-numerics gathers), so an iteration
+//    moves 32 instead of 52 B/px and is one launch instead of two.  0.72-0.75 of the HBM peak at 761 VALU instructions per 4-pixel unit:
+//    memory (6.5 TB/s streaming ceiling), VALU issue (~2.4 ms of the 3.4 ms launch) and the L1 address path (~1.5 ms) all run at 45-90 %
+//    under 4 waves per SIMD -- what is left is their imperfect overlap (profiles/r03_experiments/).  FUSED = 1: the same with the
+//    exact-numerics warps (0.44).
+// Each lane of a wave64 owns 4 consecutive pixels (16-byte loads, 1 KiB per wave per map, fully coalesced); 27 fp32 accumulators live in
+// VGPRs; the workgroup (4 waves) reduces with DPP wave reductions -> 4x27 floats of LDS -> doubles, and writes ONE 27-double partial row
+// per workgroup.  Partials are summed in a fixed order by a second tiny kernel (or by the batched engine's solve kernel), so results are
+// deterministic -- no floating-point atomics.  blockIdx is remapped so that the 8 XCDs each stream a contiguous slab.
+#define RGBID_ROW_PTR_MUL64   // common.h row_ptr: this file forms row addresses with the 64-bit multiply (its scalar unit does them; the 24-bit VALU form costs VGPRs here)
 #include "kernels.h"
 #include <cstdlib>
 #include <type_traits>
@@ -22,14 +29,9 @@
 namespace rgbid {
 
 static constexpr int SYS_T = 256;
-#ifndef RGBID_FUSED_WAVES
-#define RGBID_FUSED_WAVES 4   // waves per SIMD the fused fast kernel's register allocation must allow (<= 128 VGPRs)
-#endif
-#ifndef RGBID_SYS_NO_FENCE
+static constexpr int FUSED_WAVES = 4;   // waves per SIMD the fused fast kernel's register allocation must allow (<= 128 VGPRs; a 96-VGPR schedule spills 25 registers)
+// a scheduling fence between the four pixels of a unit: each pixel's tap loads are waited for where its rows are built, not all at the top
 #define RGBID_SYS_PIXEL_FENCE __builtin_amdgcn_sched_barrier(0)
-#else
-#define RGBID_SYS_PIXEL_FENCE
-#endif
 static constexpr float TH_HUBER = 1.345f, TH_TUKEY = 4.685f, STUDENT_DOF = 5.f;
 
 struct SysConst {  // per-thread derived constants
@@ -50,8 +52,8 @@ __device__ __forceinline__ float m_weight(float e, int mest) {  // computeWeight
 }
 
 // One pixel: invDepthConstraint (:214-262) + intensityConstraint (:176-212) + the 27-term update (:408-418).
-// The kernel is VALU-bound (SQ counters: 95 % VALU-busy while streaming 80 % of the HBM peak), so the row algebra is arranged for the
-// fewest instructions, not for the reference's order of operations (the sums agree with the oracle to ~1e-6 relative; tolerance 2e-5):
+// VALU issue is a co-limiter of every variant (see the file header), so the row algebra is arranged for the fewest instructions, not for the
+// reference's order of operations (the sums agree with the oracle to ~1e-6 relative; tolerance 2e-5):
 //  * both rows are accumulated WITHOUT their 1/sigma factors: A = (1/sigma_d^2) sum[ w_d nfac Jd Jd' + (w_i rho2) Ji Ji' ] with
 //    rho2 = (sigma_d/sigma_i)^2 folded into the intensity weight's numerator; the common factor multiplies the 27 workgroup sums once
 //    (in double, block_reduce_store) -- 8 multiplies per pixel less;
@@ -162,12 +164,8 @@ __device__ __forceinline__ void block_reduce_store(float acc[SYS_TERMS], double*
 // 16-byte streaming load: every map is read exactly once per launch, so bypass-friendly (non-temporal) loads
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld_stream4(const float* p) {
-#ifdef RGBID_SYS_NT_LOADS
   f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
   return make_float4(v.x, v.y, v.z, v.w);
-#else
-  return *reinterpret_cast<const float4*>(p);
-#endif
 }
 
 // XCD-aware logical block id: hardware places block b on XCD b % 8; give every XCD a contiguous slab
@@ -199,7 +197,7 @@ static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 void set_system_kernel_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = start; g_ev_stop = stop; }
 
 template <class PS, bool VEC, int LEVEL, int FUSED, int WMK = 0>
-__global__ __launch_bounds__(SYS_T) __attribute__((amdgpu_waves_per_eu(FUSED == 2 ? RGBID_FUSED_WAVES : 1, 8))) void k_build_system(ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB W1, ImgB I1,
+__global__ __launch_bounds__(SYS_T) __attribute__((amdgpu_waves_per_eu(FUSED == 2 ? FUSED_WAVES : 1, 8))) void k_build_system(ImgB W0, ImgB I0, ImgB gWx, ImgB gWy, ImgB gIx, ImgB gIy, ImgB W1, ImgB I1,
                                                         PS ps, double* partials, int nblk, int upt, LaneMask m, FusedArgs fa, SysTiles tp) {
   int gb = xcd_slab_block(blockIdx.x, gridDim.x);
   int lane = gb / nblk, blk = gb - lane * nblk;
@@ -357,9 +355,6 @@ static SysTiles system_tiles(int rows, int cols) {
   const int upr = cols / 4;
   int L = 5;
   if (upr % 32 != 0) { if (upr % 16 == 0) L = 4; else if (upr % 8 == 0) L = 3; }
-#ifdef RGBID_SYS_FORCE_TWLOG2
-  if (upr % (1 << RGBID_SYS_FORCE_TWLOG2) == 0) L = RGBID_SYS_FORCE_TWLOG2;   // experiment hook (tools/ab_build.sh)
-#endif
   const int tw = 1 << L, th = SYS_T >> L;
   SysTiles t;
   t.tw_log2 = L;

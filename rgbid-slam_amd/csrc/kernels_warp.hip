@@ -297,10 +297,7 @@ void launch_integrate_warped(hipStream_t s, int B, ImgB warped, ImgB wweight, Im
 // 24 B/px are writes, read-modify-write of two maps in place.  One group per thread; and the FAST class does not carry the reference's
 // warped-weight buffer at all (20 B/px): that buffer only exists between the reference's two kernels, and the one case in which the fused
 // kernel reads it back -- a valid warped value whose weight was not positive, i.e. an infinite intermediate -- takes weight 0 there.
-#ifndef RGBID_FUSE_UNITS
-#define RGBID_FUSE_UNITS 1
-#endif
-static constexpr int FUSE_UNITS = RGBID_FUSE_UNITS;
+static constexpr int FUSE_UNITS = 1;
 template <class PS, bool FAST>
 __global__ __launch_bounds__(256) void k_fuse_frame4(ImgB src, ImgB kf, ImgB kfw, ImgB wweight, PS ps, int cols4, int units, LaneMask m) {
   int lane = blockIdx.y;

@@ -5,7 +5,7 @@
 # Summaries land in gpurun_out/profiles_${ROUND}/ ; copy what matters into profiles/.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-ROUND=${ROUND:-r02}
+ROUND=${ROUND:-r03}
 OUT=$ROOT/gpurun_out/profiles_$ROUND
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -5,11 +5,20 @@
 Only the library's own kernels are kept (the synthetic-scene generator's torch kernels are dropped); launches whose lanes
 were all predicated off finish in a few microseconds and are reported separately (`calls_active` counts launches lasting
 more than 10% of the kernel's median-of-the-top-half duration)."""
-import collections, csv, glob, os, sys
+import collections, csv, glob, os, re, sys
 import numpy as np
 
 d = sys.argv[1]
 keep = lambda n: ("rgbid" in n) or ("anonymous namespace" in n) or ("rocclr" in n)
+
+# rocprofv3's VGPR_Count column is HALF the allocation of a wave64 kernel on gfx950 (60 for the fused Gauss-Newton kernel's 118): the
+# register figures come from the compiler's own resource remarks (tools/kernel_resources.py -> profiles/*kernel_resources.csv) when present
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+norm = lambda n: re.sub(r"\(anonymous namespace\)::", "", n.split("(")[0].replace("void ", "")).strip()
+RES = {}
+for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*kernel_resources.csv"))):
+    for r in csv.DictReader(open(f)):
+        RES[r["name"]] = r
 
 for tr in glob.glob(os.path.join(d, "*kernel_trace.csv")):
     agg = collections.defaultdict(list)
@@ -22,14 +31,16 @@ for tr in glob.glob(os.path.join(d, "*kernel_trace.csv")):
     out = tr.replace("kernel_trace.csv", "kernels_rgbid.csv")
     with open(out, "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "CallsActive", "AverageActiveNs", "MinNs", "MaxNs", "VGPRs", "SGPRs", "LDS", "WG_X", "LastGrid"])
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "CallsActive", "AverageActiveNs", "MinNs", "MaxNs", "VGPRs", "SGPRs", "LDS", "WG_X", "LastGrid", "VGPRsFrom"])
         for n, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
             v = np.array(v, dtype=np.float64)
             top = np.sort(v)[len(v) // 2:]
             thr = 0.1 * np.median(top)
             act = v[v > thr]
             m = meta[n]
-            w.writerow([n, len(v), int(v.sum()), v.mean(), len(act), act.mean() if len(act) else 0.0, int(v.min()), int(v.max()), m[0], m[1], m[2], m[3], "x".join(m[4:])])
+            res = RES.get(norm(n))
+            vg, sg, src = (res["vgprs"], res["sgprs"], "compiler remarks") if res else (m[0], m[1], "rocprofv3 column (half the wave64 allocation on gfx950)")
+            w.writerow([n, len(v), int(v.sum()), v.mean(), len(act), act.mean() if len(act) else 0.0, int(v.min()), int(v.max()), vg, sg, m[2], m[3], "x".join(m[4:]), src])
     if "pmc" in os.path.basename(tr):
         os.remove(tr)
 
