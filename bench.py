@@ -305,6 +305,52 @@ def run_config(ctx, dev, work_stream, rows, cols, levels, iters, B, Kst, W, reps
     return res, keep
 
 
+def pcie_leg(ctx, dev, work, eng, depth, rgb, W, Kst, ref_rec=None):
+    """the timed steps again with the frames streamed from pinned host memory: frame k + 1 is uploaded on a copy stream while step k computes
+    (double-buffered, event-ordered against the engine's stream)"""
+    T = 1 + W + Kst
+    B = depth.shape[1]
+    depth_h, rgb_h = depth.cpu().pin_memory(), rgb.cpu().pin_memory()
+    bufs = [(torch.empty_like(depth[0]), torch.empty_like(rgb[0])) for _ in range(2)]
+    copy_stream = torch.cuda.Stream(dev)
+    ready = [torch.cuda.Event() for _ in range(2)]
+    free = [torch.cuda.Event() for _ in range(2)]
+
+    def upload(k, slot):
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(free[slot])
+            bufs[slot][0].copy_(depth_h[k], non_blocking=True)
+            bufs[slot][1].copy_(rgb_h[k], non_blocking=True)
+            ready[slot].record(copy_stream)
+
+    eng.reset()
+    for ev in free:
+        ev.record(work)
+    upload(0, 0)
+    t1 = None
+    for k in range(T):
+        slot = k % 2
+        if k + 1 < T:
+            upload(k + 1, 1 - slot)
+        if k == 1 + W:
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+        work.wait_event(ready[slot])
+        eng.step(bufs[slot][0], bufs[slot][1])
+        free[slot].record(work)
+    rec_h = eng.records(1 + W, Kst)
+    torch.cuda.synchronize(dev)
+    el_h = time.perf_counter() - t1
+    per_step = (depth_h[0].numel() * 2 + rgb_h[0].numel()) / 1e9
+    out = {"value": B * Kst / el_h, "unit": "frames/s", "lanes": B, "ms_per_step": el_h / Kst * 1e3, "h2d_gb_per_step": per_step,
+           "h2d_gbs_needed": per_step / (el_h / Kst),
+           "note": "frames streamed from pinned host memory on a copy stream, double-buffered, overlapped with the previous step"}
+    if ref_rec is not None:
+        out["records_identical_to_resident_run"] = bool(rec_h.tobytes() == ref_rec.tobytes())
+    del depth_h, rgb_h, bufs
+    return out
+
+
 def extra_config1(ctx, dev, K):
     """BASELINE config 1 on the GPU: the residual + 27-term normal equations (unit U1) of ONE 640x480 pair through the single-image C-ABI
     call (cache-resident: 9.8 MB of maps live in L2 / Infinity Cache), device time from the call's own hipEvent pair."""
@@ -557,45 +603,8 @@ def main():
 
     pcie = None
     if args.h2d:
-        # PCIe-inclusive leg: frames start in pinned host memory; frame k+1 is uploaded on a copy stream while step k computes
-        T = 1 + W + Kst
-        depth_h, rgb_h = depth.cpu().pin_memory(), rgb.cpu().pin_memory()
-        bufs = [(torch.empty_like(depth[0]), torch.empty_like(rgb[0])) for _ in range(2)]
-        copy_stream = torch.cuda.Stream(dev)
-        ready = [torch.cuda.Event() for _ in range(2)]
-        free = [torch.cuda.Event() for _ in range(2)]
-
-        def upload(k, slot):
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(free[slot])
-                bufs[slot][0].copy_(depth_h[k], non_blocking=True)
-                bufs[slot][1].copy_(rgb_h[k], non_blocking=True)
-                ready[slot].record(copy_stream)
-
-        eng.reset()
-        for ev in free:
-            ev.record(work)
-        upload(0, 0)
-        t1 = None
-        for k in range(T):
-            slot = k % 2
-            if k + 1 < T:
-                upload(k + 1, 1 - slot)
-            if k == 1 + W:
-                torch.cuda.synchronize(dev)
-                t1 = time.perf_counter()
-            work.wait_event(ready[slot])
-            eng.step(bufs[slot][0], bufs[slot][1])
-            free[slot].record(work)
-        rec_h = eng.records(1 + W, Kst)
-        torch.cuda.synchronize(dev)
-        el_h = time.perf_counter() - t1
-        same = bool(rec_h.tobytes() == rec.tobytes())
-        per_step = (depth_h[0].numel() * 2 + rgb_h[0].numel()) / 1e9
-        pcie = {"value": B * Kst / el_h, "unit": "frames/s", "ms_per_step": el_h / Kst * 1e3, "h2d_gb_per_step": per_step,
-                "h2d_gbs_needed": per_step / (el_h / Kst), "records_identical_to_resident_run": same,
-                "note": "frames streamed from pinned host memory on a copy stream, double-buffered, overlapped with the previous step"}
-        del depth_h, rgb_h, bufs
+        # PCIe-inclusive leg at the headline lane count (the driver-run line carries it at 512 lanes in extra_configs: pinning 35 GB of frames takes longer than the run)
+        pcie = pcie_leg(ctx, dev, work, eng, depth, rgb, W, Kst, rec)
     eng.close()
 
     result = None
@@ -669,6 +678,25 @@ def main():
                                "engine_bytes_per_frame": rx["engine_bytes_per_frame"], "parity": rx["parity"]})
             except Exception as e:
                 extras.append({"config": name, "error": f"{type(e).__name__}: {e}"})
+        # what smaller batches deliver (the headline needs 2 048 concurrent streams), and the PCIe-inclusive rate
+        for Bs in (64, 512):
+            if Bs >= B:
+                continue
+            try:
+                sub = (seqs, depth[:, :Bs], rgb[:, :Bs])
+                rs, keeps = run_config(ctx, dev, work, rows, cols, args.levels, iters, Bs, Kst, W, 3, args.streams, args.graph, args.fused, args.keyframes, K,
+                                       {"use_dist": False, "world": 1}, check_streams=0, fast_numerics=args.fast, inputs=sub)
+                entry = {"config": f"lanes-{Bs}: the headline workload with {Bs} concurrent streams per GPU ({keeps[3].bytes() / 1e9:.1f} GB of engine state)", "value": rs["value"], "unit": "frames/s",
+                         "ms_per_step": rs["ms_per_step"], "lanes": Bs, "steps": Kst, "warmup": W, "repetitions": 3, "u1_frac_of_hbm_peak": rs["u1"]["achieved"] / HBM_PEAK_GBS,
+                         "lanes_bit_identical": rs["parity"]["lanes_bit_identical"]}
+                if Bs == 512:
+                    pc = pcie_leg(ctx, dev, work, keeps[3], sub[1], sub[2], W, Kst, keeps[4])
+                    entry["pcie_inclusive"] = pc
+                keeps[3].close()
+                del keeps, sub
+                extras.append(entry)
+            except Exception as e:
+                extras.append({"config": f"lanes-{Bs}", "error": f"{type(e).__name__}: {e}"})
         del inputs
     if rank == 0 and world == 1 and not args.no_extras and headline_shape:
         del depth, rgb, keep, gathered
