@@ -224,11 +224,12 @@ __global__ __launch_bounds__(SYS_T) __attribute__((amdgpu_waves_per_eu(FUSED == 
     int sx = T0 / tp.tiles_y, ty = T0 - sx * tp.tiles_y;       // strip and tile-in-strip: one scalar division, then count-and-wrap
     int xu = (sx << L) + lx, y = ty * TH + ly;
     if (FUSED == 2) {
-      // A unit needs three dependent memory round trips (keyframe inverse depth -> point-sampled current inverse depth -> bilinear taps), and
-      // a wave that walks through them one after the other leaves the HBM stream idle most of its time.  Schedule: the unit's inverse depth
-      // w0 is loaded one unit AHEAD (4 VGPRs); its other five 16-byte streams are issued at the top of the iteration and travel together with
-      // the inverse-depth gathers (they are only needed by the row update at the end); the next w0 goes out behind the tap loads and lands
-      // during the 4 x ~150-instruction row update.  Two exposed waits per unit instead of three, the stream is in flight during both.
+      // A unit needs three dependent memory round trips (keyframe inverse depth -> point-sampled current inverse depth -> bilinear taps).  The
+      // unit's inverse depth w0 is loaded one unit AHEAD (4 VGPRs); hipcc issues the other five 16-byte streams behind the eight tap loads and the
+      // next w0 behind them (ISA of this build: 4 gathers, counted waits, 8 taps, 5 streams, next w0, then the row updates with vmcnt(12) / (11) /
+      // (2)).  Where the streams are issued does not matter -- forced to the top the in-order vmcnt makes the gather wait include them, and
+      // fetched a whole unit ahead through LDS by LDS-DMA the kernel gets 3.5 - 8 % slower (profiles/r03_experiments/gn_lds_dma_prefetch.md): it is
+      // not waiting for HBM round trips, it is co-limited by VALU issue, streaming bandwidth and the L1 address path (file header).
       // The six keyframe maps of a level share their geometry (checked by the launcher): ONE 32-bit byte offset per unit on six wave-uniform
       // lane bases (global_load ... saddr) instead of six 64-bit row pointers -- the kernel holds ~100 wave-uniform values (8 image
       // descriptors, intrinsics, scale constants, the warp) and whatever does not fit the 102 SGPRs lives in VGPRs and costs occupancy.
