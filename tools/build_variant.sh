@@ -6,7 +6,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 C=$ROOT/rgbid-slam_amd/csrc
 name=$1; file=$2; flags=$3
 base="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-result -Wno-unused-value"
-[ "$file" = kernels_system.hip ] && base="$base -fno-slp-vectorize -DRGBID_SYS_NT_LOADS -DRGBID_ROW_PTR_MUL64"
+[ "$file" = kernels_system.hip ] && base="$base -fno-slp-vectorize"
 make -C $C -j8 > /dev/null
 /opt/rocm/bin/hipcc $base $flags -c $C/$file -o /tmp/variant_$name.o
 objs=""
