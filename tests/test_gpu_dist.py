@@ -109,3 +109,10 @@ def test_bench_fails_loudly_when_the_cabi_communicator_fails():
     import json
     r = json.loads(p.stdout.strip().splitlines()[-1])
     assert "asked for with --gather torch" in r["multi_gpu"]["gather"] and r["multi_gpu"]["gather_equals_torch_all_gather"]
+    # and the product path itself on one rank: the C-ABI communicator comes up, gathers inside the timed region, the line says so per rank
+    p = _run_bench(args, {"RGBID_FORCE_DIST": "1"})
+    assert p.returncode == 0, p.stderr[-1500:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    mg = r["multi_gpu"]
+    assert mg["rccl_ranks"] == 1 and mg["rccl_ranks_per_rank"] == [1] and "rgbid_dist_gather_records" in mg["gather"] and mg["gather_equals_torch_all_gather"]
+    assert len(mg["gather_us_per_repetition_rank0"]) == 1 and len(mg["per_rank_frames_per_s"]) == 1 and mg["per_rank_frames_per_s"][0] >= r["value"] * 0.999
