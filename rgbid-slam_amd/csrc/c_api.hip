@@ -100,6 +100,7 @@ int rgbid_ctx_destroy(rgbid_ctx* c) {
   if (c->partials) hipFree(c->partials);
   if (c->lane_dev) hipFree(c->lane_dev);
   if (c->lane_host) hipHostFree(c->lane_host);
+  if (c->lane_ev) hipEventDestroy(c->lane_ev);
   if (c->small_dev) hipFree(c->small_dev);
   if (c->small_host) hipHostFree(c->small_host);
   if (c->ev0) hipEventDestroy(c->ev0);
@@ -118,6 +119,7 @@ int rgbid_ctx_set_stream(rgbid_ctx* c, void* stream) {
   return RGBID_OK;
 }
 int rgbid_ctx_set_async(rgbid_ctx* c, int on) { if (!c) return RGBID_E_INVALID; c->async = on ? 1 : 0; return RGBID_OK; }
+int rgbid_ctx_get_async(rgbid_ctx* c, int* on) { if (!c || !on) return RGBID_E_INVALID; *on = c->async; return RGBID_OK; }
 int rgbid_ctx_set_interp_mode(rgbid_ctx* c, int mode) {
   if (!c || (mode != RGBID_INTERP_EXACT && mode != RGBID_INTERP_TEX8)) return RGBID_E_INVALID;
   c->interp_mode = mode;
@@ -300,6 +302,8 @@ int rgbid::ctx_reserve_lane(rgbid_ctx* c, size_t bytes) {
   bytes = (bytes + 4095) & ~(size_t)4095;
   hipError_t e = hipMalloc(&c->lane_dev, bytes);
   if (e == hipSuccess) e = hipHostMalloc(&c->lane_host, bytes, hipHostMallocDefault);
+  if (e == hipSuccess && !c->lane_ev) e = hipEventCreateWithFlags(&c->lane_ev, hipEventDisableTiming);
+  c->lane_ev_pending = false;
   if (e != hipSuccess) {
     if (c->lane_dev) { hipFree(c->lane_dev); c->lane_dev = nullptr; }
     (void)hipGetLastError();

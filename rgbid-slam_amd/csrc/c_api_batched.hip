@@ -1,5 +1,6 @@
 // c_api_batched.hip -- the batched C-ABI of include/rgbid_batched.h: every kernel the engine (engine.hip) launches on its hot path as a
-// single call over `lanes` images.  Argument validation, per-lane parameters staged through the context's pinned scratch, the SAME launchers
+// single call over `lanes` images.  Argument validation, per-lane parameters staged through the context's pinned scratch (an event behind each
+// staging copy lets an asynchronous context issue the next call without overwriting parameters still in flight), the SAME launchers
 // (kernels.h) the engine calls -- nothing here has an implementation of its own, and nothing falls back to another numerics class or to a CPU.
 #include "../../include/rgbid_batched.h"
 #include "ctx.h"
@@ -55,24 +56,34 @@ struct Call {
 
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// per-lane warps host -> device at `off` of the lane scratch (the scratch must have been reserved).  The source is PAGEABLE memory on purpose:
-// the runtime stages such a copy before the call returns, so an asynchronous context may issue the next call (and its parameters) at once.
+// the pinned staging area may be rewritten once the previous call's H2D out of it has run (the kernels behind it need not have)
+int staging_free(rgbid_ctx* c) {
+  if (c->lane_ev_pending) { RGBID_HIPB(hipEventSynchronize(c->lane_ev)); c->lane_ev_pending = false; }
+  return RGBID_OK;
+}
+int staging_sent(rgbid_ctx* c) {
+  RGBID_HIPB(hipEventRecord(c->lane_ev, c->stream));
+  c->lane_ev_pending = true;
+  return RGBID_OK;
+}
+// per-lane warps host -> pinned staging -> device at `off` of the lane scratch (the scratch must have been reserved; call staging_free() first
+// and staging_sent() after the last stage_* of the call)
 int stage_warps(rgbid_ctx* c, int lanes, const float* R, const float* t, size_t off) {
-  std::vector<WarpParams> h(lanes);
+  WarpParams* h = reinterpret_cast<WarpParams*>((char*)c->lane_host + off);
   for (int l = 0; l < lanes; ++l) {
     for (int i = 0; i < 9; ++i) h[l].R[i] = R[(size_t)l * 9 + i];
     for (int i = 0; i < 3; ++i) h[l].t[i] = t[(size_t)l * 3 + i];
   }
-  RGBID_HIPB(hipMemcpyAsync((char*)c->lane_dev + off, h.data(), sizeof(WarpParams) * lanes, hipMemcpyHostToDevice, c->stream));
+  RGBID_HIPB(hipMemcpyAsync((char*)c->lane_dev + off, h, sizeof(WarpParams) * lanes, hipMemcpyHostToDevice, c->stream));
   return RGBID_OK;
 }
 
 int stage_sys(rgbid_ctx* c, int lanes, rgbid_intr k, const rgbid_sys_params* p, size_t off) {
-  std::vector<SysParams> h(lanes);
+  SysParams* h = reinterpret_cast<SysParams*>((char*)c->lane_host + off);
   for (int l = 0; l < lanes; ++l)
     h[l] = SysParams{k.fx, k.fy, k.cx, k.cy, p[l].sigma_depthinv, p[l].sigma_int, p[l].bias_depthinv, p[l].bias_int, p[l].nu_depthinv, p[l].nu_int,
                      p[l].mestimator, p[l].weighting, p[l].student_nu ? 1 : 0, p[l].nu_int_from_max ? 1 : 0};
-  RGBID_HIPB(hipMemcpyAsync((char*)c->lane_dev + off, h.data(), sizeof(SysParams) * lanes, hipMemcpyHostToDevice, c->stream));
+  RGBID_HIPB(hipMemcpyAsync((char*)c->lane_dev + off, h, sizeof(SysParams) * lanes, hipMemcpyHostToDevice, c->stream));
   return RGBID_OK;
 }
 
@@ -127,8 +138,10 @@ int rgbid_gn_fused_batched(rgbid_ctx* c, int lanes, const rgbid_imgb* W0, const 
   const int nb = system_blocks_per_lane(W0->rows, W0->cols, lanes);
   e = ctx_reserve_partials(c, (size_t)nb * SYS_TERMS * lanes);
   if (e) return e;
+  if ((e = staging_free(c))) return e;
   if ((e = stage_warps(c, lanes, R, t, off_wp))) return e;
   if ((e = stage_sys(c, lanes, intr, params, off_sp))) return e;
+  if ((e = staging_sent(c))) return e;
   double* sums_d = reinterpret_cast<double*>((char*)c->lane_dev + off_sums);
   Call call(c, ms);
   const int nblk = launch_gn_fused(c->stream, lanes, bW0, bI0, bgWx, bgWy, bgIx, bgIy, bWc, bIc, reinterpret_cast<const WarpParams*>((char*)c->lane_dev + off_wp),
@@ -155,7 +168,9 @@ int rgbid_build_system_batched(rgbid_ctx* c, int lanes, const rgbid_imgb* W0, co
   const int nb = system_blocks_per_lane(W0->rows, W0->cols, lanes);
   e = ctx_reserve_partials(c, (size_t)nb * SYS_TERMS * lanes);
   if (e) return e;
+  if ((e = staging_free(c))) return e;
   if ((e = stage_sys(c, lanes, intr, params, off_sp))) return e;
+  if ((e = staging_sent(c))) return e;
   double* sums_d = reinterpret_cast<double*>((char*)c->lane_dev + off_sums);
   Call call(c, ms);
   const int nblk = launch_build_system(c->stream, lanes, BB(W0, lanes), BB(I0, lanes), BB(gWx, lanes), BB(gWy, lanes), BB(gIx, lanes), BB(gIy, lanes), BB(W1, lanes),
@@ -177,7 +192,9 @@ int rgbid_warp_pair_batched(rgbid_ctx* c, int lanes, const rgbid_imgb* src_iD, c
   hipSetDevice(c->device);
   int e = ctx_reserve_lane(c, sizeof(WarpParams) * lanes);
   if (e) return e;
+  if ((e = staging_free(c))) return e;
   if ((e = stage_warps(c, lanes, R, t, 0))) return e;
+  if ((e = staging_sent(c))) return e;
   const WarpParams* wp = reinterpret_cast<const WarpParams*>(c->lane_dev);
   Call call(c, ms);
   if (fast) {
@@ -213,7 +230,9 @@ int rgbid_lattice_residuals_batched(rgbid_ctx* c, int lanes, const rgbid_imgb* W
   hipSetDevice(c->device);
   int e = ctx_reserve_lane(c, sizeof(WarpParams) * lanes);
   if (e) return e;
+  if ((e = staging_free(c))) return e;
   if ((e = stage_warps(c, lanes, R, t, 0))) return e;
+  if ((e = staging_sent(c))) return e;
   Call call(c, ms);
   launch_lattice_residuals_fused(c->stream, lanes, BB(Wcur, lanes), BB(W0, lanes), BB(Icur, lanes), BB(I0, lanes), reinterpret_cast<const WarpParams*>(c->lane_dev),
                                  c->interp_mode, min_nsamples, ALL, fast, res_dev, res_lane_stride, kf_lat_dev, kf_lat_dev ? kf_lat_lane_stride : 0);
@@ -245,7 +264,9 @@ int rgbid_fuse_frame_batched(rgbid_ctx* c, int lanes, const rgbid_imgb* cur, con
   hipSetDevice(c->device);
   int e = ctx_reserve_lane(c, sizeof(WarpParams) * lanes);
   if (e) return e;
+  if ((e = staging_free(c))) return e;
   if ((e = stage_warps(c, lanes, R, t, 0))) return e;
+  if ((e = staging_sent(c))) return e;
   Call call(c, ms);
   if (!launch_fuse_frame(c->stream, lanes, BB(cur, lanes), BB(kf, lanes), BB(kfw, lanes), BB(wweight, lanes), reinterpret_cast<const WarpParams*>(c->lane_dev), ALL,
                          numerics == RGBID_NUMERICS_FAST))
@@ -271,8 +292,10 @@ int rgbid_visibility_pair_batched(rgbid_ctx* c, int lanes, const rgbid_imgb* a, 
   const size_t off_ab = 0, off_ba = up256(sizeof(WarpParams) * lanes), off_cnt = off_ba + up256(sizeof(WarpParams) * lanes);
   int e = ctx_reserve_lane(c, off_cnt + sizeof(unsigned int) * 4 * lanes);
   if (e) return e;
+  if ((e = staging_free(c))) return e;
   if ((e = stage_warps(c, lanes, R_ab, t_ab, off_ab))) return e;
   if ((e = stage_warps(c, lanes, R_ba, t_ba, off_ba))) return e;
+  if ((e = staging_sent(c))) return e;
   unsigned int* cnt = reinterpret_cast<unsigned int*>((char*)c->lane_dev + off_cnt);   // [2][lanes][2]: a->b block, then b->a block
   RGBID_HIPB(hipMemsetAsync(cnt, 0, sizeof(unsigned int) * 4 * lanes, c->stream));
   Call call(c, ms);

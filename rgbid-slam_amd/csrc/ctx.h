@@ -20,6 +20,8 @@ struct rgbid_ctx {
   void* lane_dev = nullptr;    // per-lane parameter / result scratch of the batched C-ABI (rgbid_batched.h), grown on demand
   void* lane_host = nullptr;   // pinned mirror
   size_t lane_cap = 0;         // bytes
+  hipEvent_t lane_ev = nullptr; // recorded behind the last H2D out of lane_host: the next call waits for it before it rewrites the staging area
+  bool lane_ev_pending = false;
 };
 
 namespace rgbid {

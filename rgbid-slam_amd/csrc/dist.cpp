@@ -356,6 +356,11 @@ struct SeqScratch {   // everything the driver allocates, released on every exit
     for (void* p : {d_depth, d_rgb, d_local, d_all}) if (p) (void)hipFree(p);
   }
 };
+struct AsyncGuard {   // the driver enqueues asynchronously; the caller's context gets its own mode back on every exit path
+  rgbid_ctx* c; int was = 0;
+  explicit AsyncGuard(rgbid_ctx* c_) : c(c_) { rgbid_ctx_get_async(c, &was); rgbid_ctx_set_async(c, 1); }
+  ~AsyncGuard() { rgbid_ctx_sync(c); rgbid_ctx_set_async(c, was); }
+};
 inline double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
 }  // namespace
 
@@ -427,7 +432,7 @@ int rgbid_dist_track_sequence(rgbid_ctx* ctx, const rgbid_seq_config* cfg, const
     S.ev.resize(L, nullptr);
     for (int j = 0; j < L && he == hipSuccess; ++j) he = hipEventCreateWithFlags(&S.ev[j], hipEventDisableTiming);
     if (he != hipSuccess) { (void)hipGetLastError(); return he == hipErrorOutOfMemory ? RGBID_E_NOMEM : (int)he; }
-    rgbid_ctx_set_async(ctx, 1);
+    AsyncGuard async_guard(ctx);   // declared after S: the stream is drained before the engine / staging buffers go
     rgbid_ctx_sync(ctx);
     rep.setup_ms = ms_since(t_setup);
     if (S.comm && (r = rgbid_dist_barrier(S.comm))) return r;   // ranks start their clocks together
