@@ -84,3 +84,12 @@ def test_dist_library_exports_every_declared_symbol():
     assert not missing, missing
     # the 392-byte record of SURVEY 8e, as the Python harness mirrors it
     assert D.GATHER_DTYPE.itemsize == 392 and D.GATHER_DTYPE.fields["R"][1] == 8 and D.GATHER_DTYPE.fields["cov"][1] == 104
+
+
+def test_headers_are_valid_c(tmp_path):
+    """every C-ABI header compiles as C99 on its own (no C++-isms leaked into the boundary)"""
+    import subprocess
+    for h in ("rgbid.h", "rgbid_batched.h", "rgbid_engine.h", "rgbid_dist.h", "rgbid_host.h"):
+        src = tmp_path / (h + ".c")
+        src.write_text(f'#include "{h}"\nint main(void) {{ return 0; }}\n')
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), str(src)])

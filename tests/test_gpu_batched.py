@@ -468,3 +468,18 @@ def test_batched_stencils(bt, rows, cols, lanes):
             assert np.array_equal(np.isnan(g), np.isnan(ref))
             m = ~np.isnan(ref)
             assert (np.abs(g[m] - ref[m]) <= 2e-6 * np.abs(ref[m]) + 1e-30).all()
+
+
+def test_plain_c_consumer(tmp_path):
+    """tests/cpp/test_batched_c.c: rgbid_batched.h, rgbid_engine.h and rgbid_dist.h from plain C (gcc -std=c99): frame preparation -> Sobel -> fused
+    Gauss-Newton evaluation with the identity known answer in both numerics classes, the FAST refusal on odd geometry, two engine steps, the
+    partition helpers"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "rgbid-slam_amd", "lib")
+    exe = str(tmp_path / "test_batched_c")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "test_batched_c.c"),
+                           "-L" + lib, "-lrgbid_dist", "-lrgbid_hip", "-lm", "-Wl,-rpath," + lib, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "all ok" in r.stdout and "FAILED" not in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
