@@ -91,22 +91,33 @@ int main(void) {
   CHECK(rgbid_malloc(&dd, sizeof(depth))); CHECK(rgbid_malloc(&dc, sizeof(rgb)));
   CHECK(rgbid_memcpy_h2d(ctx, dd, depth, sizeof(depth))); CHECK(rgbid_memcpy_h2d(ctx, dc, rgb, sizeof(rgb)));
   CHECK(rgbid_engine_step(eng, dd, dc));
-  CHECK(rgbid_engine_step(eng, dd, dc));
+  /* the second frame: the same view with sensor noise (identical frames have zero residuals, and the estimated scale sigma = 0 makes the reference
+   * algorithm itself divide by zero) */
+  for (int l = 0; l < LANES; ++l)
+    for (int y = 0; y < ROWS; ++y)
+      for (int x = 0; x < COLS; ++x) {
+        if (depth[l][y][x]) depth[l][y][x] = (unsigned short)(depth[l][y][x] + ((x * 5 + y * 3 + l) % 5) - 2);
+        for (int c = 0; c < 3; ++c) { int v = rgb[l][y][x][c] + ((x * 3 + y * 7 + c) % 5) - 2; rgb[l][y][x][c] = (unsigned char)(v < 0 ? 0 : v > 255 ? 255 : v); }
+      }
+  void *dd2 = NULL, *dc2 = NULL;
+  CHECK(rgbid_malloc(&dd2, sizeof(depth))); CHECK(rgbid_malloc(&dc2, sizeof(rgb)));
+  CHECK(rgbid_memcpy_h2d(ctx, dd2, depth, sizeof(depth))); CHECK(rgbid_memcpy_h2d(ctx, dc2, rgb, sizeof(rgb)));
+  CHECK(rgbid_engine_step(eng, dd2, dc2));
   rgbid_pose_record rec[2 * LANES];
   CHECK(rgbid_engine_read_records(eng, 0, 2, rec));
   for (int l = 0; l < LANES; ++l) {
     const rgbid_pose_record* p = &rec[LANES + l];
     double tn = sqrt(p->t[0] * p->t[0] + p->t[1] * p->t[1] + p->t[2] * p->t[2]);
-    if (!(p->status & RGBID_ST_TRACKED) || tn > 1e-4 || fabs(p->R[0] - 1) > 1e-6) { printf("FAILED engine lane %d status %d |t| %g\n", l, p->status, tn); return 1; }
+    if (!(p->status & RGBID_ST_TRACKED) || tn > 2e-3 || fabs(p->R[0] - 1) > 1e-5) { printf("FAILED engine lane %d status %d |t| %g\n", l, p->status, tn); return 1; }
   }
-  printf("ok engine tracked the repeated frame at identity\n");
+  printf("ok engine tracked the noisy repeat of the frame at (near) identity\n");
   CHECK(rgbid_engine_destroy(eng));
   /* partition + composition helpers (host arithmetic) */
   int first[3], last[3], start, count;
   CHECK(rgbid_dist_chunk_ranges(10, 3, first, last));
   CHECK(rgbid_dist_rank_chunks(3, 2, 1, &start, &count));
   if (first[0] != 0 || last[2] != 9 || last[0] != first[1] || start != 2 || count != 1) { printf("FAILED partition\n"); return 1; }
-  rgbid_free(dd); rgbid_free(dc); rgbid_free(kd); rgbid_free(kc);
+  rgbid_free(dd); rgbid_free(dc); rgbid_free(dd2); rgbid_free(dc2); rgbid_free(kd); rgbid_free(kc);
   for (int i = 0; i < 9; ++i) rgbid_free(k[i]);
   CHECK(rgbid_ctx_destroy(ctx));
   printf("all ok\n");
