@@ -135,11 +135,11 @@ __global__ __launch_bounds__(256) void k_prep_frame4(ImgB depth, ImgB rgb, ImgB 
       float v = 0.2126f * R[i] + 0.7152f * G[i] + 0.0722f * Bl[i];
       l[i] = fmaxf(0.f, fminf(v, 255.f));
     }
-    *reinterpret_cast<float4*>(row_ptr<float>(iD, lane, y) + x) = make_float4(w[0], w[1], w[2], w[3]);
-    *reinterpret_cast<float4*>(row_ptr<float>(I, lane, y) + x) = make_float4(l[0], l[1], l[2], l[3]);
-    *reinterpret_cast<float4*>(row_ptr<float>(r, lane, y) + x) = make_float4(R[0], R[1], R[2], R[3]);
-    *reinterpret_cast<float4*>(row_ptr<float>(g, lane, y) + x) = make_float4(G[0], G[1], G[2], G[3]);
-    *reinterpret_cast<float4*>(row_ptr<float>(b, lane, y) + x) = make_float4(Bl[0], Bl[1], Bl[2], Bl[3]);
+    st16_stream(row_ptr<float>(iD, lane, y) + x, w[0], w[1], w[2], w[3]);
+    st16_stream(row_ptr<float>(I, lane, y) + x, l[0], l[1], l[2], l[3]);
+    st16_stream(row_ptr<float>(r, lane, y) + x, R[0], R[1], R[2], R[3]);
+    st16_stream(row_ptr<float>(g, lane, y) + x, G[0], G[1], G[2], G[3]);
+    st16_stream(row_ptr<float>(b, lane, y) + x, Bl[0], Bl[1], Bl[2], Bl[3]);
   }
 }
 void launch_prep_frame(hipStream_t s, int B, ImgB depth, ImgB rgb, ImgB iD, ImgB I, ImgB r, ImgB g, ImgB b, float factor_depth, LaneMask m) {
@@ -225,8 +225,8 @@ __global__ __launch_bounds__(256) void k_gradient4(ImgB src, ImgB gx, ImgB gy, i
         }
       h[i] = res_hor / 8.f; v[i] = res_vert / 8.f;
     }
-    *reinterpret_cast<float4*>(row_ptr<float>(gx, lane, y) + x) = make_float4(h[0], h[1], h[2], h[3]);
-    *reinterpret_cast<float4*>(row_ptr<float>(gy, lane, y) + x) = make_float4(v[0], v[1], v[2], v[3]);
+    st16_stream(row_ptr<float>(gx, lane, y) + x, h[0], h[1], h[2], h[3]);
+    st16_stream(row_ptr<float>(gy, lane, y) + x, v[0], v[1], v[2], v[3]);
 #pragma unroll
     for (int i = 0; i < 6; ++i) { a[i] = b[i]; b[i] = c[i]; }
   }
@@ -297,12 +297,12 @@ __global__ __launch_bounds__(256) void k_kf_maps4(ImgB src, ImgB vmap, ImgB nmap
       const bool keep = !(isnan(w) || isnan(gx) || isnan(gy)) && ((double)acos_vn > 0.1);
       N0[i] = keep ? nx : qnan(); N1[i] = keep ? ny : qnan(); N2[i] = keep ? nz : qnan();
     }
-    *reinterpret_cast<float4*>(row_ptr<float>(vmap, lane, y) + x) = make_float4(X[0], X[1], X[2], X[3]);
-    *reinterpret_cast<float4*>(row_ptr<float>(vmap, lane, y + rows) + x) = make_float4(Y[0], Y[1], Y[2], Y[3]);
-    *reinterpret_cast<float4*>(row_ptr<float>(vmap, lane, y + 2 * rows) + x) = make_float4(Z[0], Z[1], Z[2], Z[3]);
-    *reinterpret_cast<float4*>(row_ptr<float>(nmap, lane, y) + x) = make_float4(N0[0], N0[1], N0[2], N0[3]);
-    *reinterpret_cast<float4*>(row_ptr<float>(nmap, lane, y + rows) + x) = make_float4(N1[0], N1[1], N1[2], N1[3]);
-    *reinterpret_cast<float4*>(row_ptr<float>(nmap, lane, y + 2 * rows) + x) = make_float4(N2[0], N2[1], N2[2], N2[3]);
+    st16_stream(row_ptr<float>(vmap, lane, y) + x, X[0], X[1], X[2], X[3]);
+    st16_stream(row_ptr<float>(vmap, lane, y + rows) + x, Y[0], Y[1], Y[2], Y[3]);
+    st16_stream(row_ptr<float>(vmap, lane, y + 2 * rows) + x, Z[0], Z[1], Z[2], Z[3]);
+    st16_stream(row_ptr<float>(nmap, lane, y) + x, N0[0], N0[1], N0[2], N0[3]);
+    st16_stream(row_ptr<float>(nmap, lane, y + rows) + x, N1[0], N1[1], N1[2], N1[3]);
+    st16_stream(row_ptr<float>(nmap, lane, y + 2 * rows) + x, N2[0], N2[1], N2[2], N2[3]);
 #pragma unroll
     for (int i = 0; i < 6; ++i) { a[i] = b[i]; b[i] = c[i]; }
   }
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void k_copy_rows(ImgB src, ImgB dst, int row_b
     if (vec) {
       int n16 = row_bytes >> 4;
       for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x)
-        reinterpret_cast<float4*>(dp)[i] = reinterpret_cast<const float4*>(sp)[i];
+        { typedef float f4v __attribute__((ext_vector_type(4))); __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const f4v*>(sp) + i), reinterpret_cast<f4v*>(dp) + i); }   // one pass over both images
     } else {
       for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < row_bytes; i += gridDim.x * blockDim.x) dp[i] = sp[i];
     }

@@ -368,8 +368,8 @@ __global__ __launch_bounds__(256) void k_fuse_frame4(ImgB src, ImgB kf, ImgB kfw
         integrate_px(ws[g][i], qs, k[i], q[i]);
       }
     }
-    *reinterpret_cast<float4*>(row_ptr<float>(kf, lane, ys_[g]) + xs_[g]) = make_float4(k[0], k[1], k[2], k[3]);
-    *reinterpret_cast<float4*>(row_ptr<float>(kfw, lane, ys_[g]) + xs_[g]) = make_float4(q[0], q[1], q[2], q[3]);
+    st16_stream(row_ptr<float>(kf, lane, ys_[g]) + xs_[g], k[0], k[1], k[2], k[3]);
+    st16_stream(row_ptr<float>(kfw, lane, ys_[g]) + xs_[g], q[0], q[1], q[2], q[3]);
   }
 }
 bool launch_fuse_frame(hipStream_t s, int B, ImgB src, ImgB kf, ImgB kfw, ImgB wweight, const WarpParams* lp, LaneMask m, bool fast) {
