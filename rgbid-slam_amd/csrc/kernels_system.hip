@@ -21,7 +21,6 @@
 // deterministic -- no floating-point atomics.  blockIdx is remapped so that the 8 XCDs each stream a contiguous slab.
 #define RGBID_ROW_PTR_MUL64   // common.h row_ptr: this file forms row addresses with the 64-bit multiply (its scalar unit does them; the 24-bit VALU form costs VGPRs here)
 #include "kernels.h"
-#include <cstdlib>
 #include <type_traits>
 #include "warp_device.h"
 #include <hip/hip_ext.h>
@@ -365,16 +364,17 @@ static SysTiles system_tiles(int rows, int cols) {
 }
 
 // launch plan: steps per thread (upt; a step = one tile of SYS_T units on the 16-byte path, SYS_T single pixels otherwise) and workgroups per
-// lane.  The grid is sized to whole "rounds" of the chip's resident capacity (its compute units x the 4-wave workgroups one CU holds: 5 at
-// <= 102 VGPRs, 4 for the fused fast kernel's <= 128) so there is no partially filled tail round; a thread's fp32 partial sums run over at
-// most 16 units (64 px).  The plan depends on the geometry and the device only -- never on the kernel variant -- so that every variant sums
-// the same pixels in the same order (fused and unfused results are bit-identical); 5 workgroups per CU divides evenly into the 4-per-CU case
-// for the shipped geometries (10 240 workgroups = 8 rounds of 1 280 = 10 rounds of 1 024 on 256 CUs).
+// lane.  16-byte path: the grid is a whole multiple of 20 workgroups per compute unit -- whole rounds of the chip's resident capacity both for
+// the kernels that hold 5 four-wave workgroups per CU (<= 102 VGPRs) and for the fused fast kernel's 4 (<= 128), so there is no partially
+// filled tail round -- and as few workgroups as that allows with at most 60 tiles (240 px per thread in fp32 partial sums) each: the epilogue of a
+// workgroup (27-term DPP + LDS reduction, one row of partials) is not free -- 15 -> 60 tiles per workgroup at 2 048 lanes: -2.2 % per launch.
+// The plan depends on the geometry and the device only -- never on the kernel variant -- so that every variant sums the same pixels in the same
+// order (fused and unfused results are bit-identical).
 static void system_plan(int rows, int cols, int B, bool vec, int* upt, int* nblk) {
   long long steps = vec ? (long long)system_tiles(rows, cols).ntiles : ((long long)rows * cols + SYS_T - 1) / SYS_T;   // workgroup-steps per lane
   if (steps < 1) steps = 1;
-  const long long capacity = (long long)device_cus() * 5;    // resident workgroups
-  const long long max_upt = vec ? 16 : 64;
+  const long long capacity = (long long)device_cus() * (vec ? 20 : 5);
+  const long long max_upt = vec ? 60 : 64;
   long long rounds = (steps * B + capacity * max_upt - 1) / (capacity * max_upt);
   long long nb = (rounds * capacity) / B;                    // workgroups per lane
   if (nb < 1) nb = 1;

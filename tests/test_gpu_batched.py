@@ -201,6 +201,32 @@ def test_gn_fused_fast_equals_unfused_fast(bt, rows, cols, lanes):
     assert np.array_equal(A, A2) and np.array_equal(b, b2)
 
 
+@pytest.mark.parametrize("many", [256, 1024])
+def test_gn_fused_long_partial_sums(bt, many):
+    """the launch plan of the benchmarked batch sizes: with 256 / 1 024 lanes at 640x480 a workgroup walks 15 / 60 tiles (a thread's fp32 partial
+    sums run over 60 / 240 pixels before the workgroup reduction) -- 2 distinct lanes dealt onto `many`, every copy bit-identical, A and b of the
+    fused FAST kernel and of the normal equations on stored maps still within the plain 2e-5 of the oracle on the device's warp pair, and the two
+    kernels still bit-identical to each other"""
+    rows, cols = 480, 640
+    K, L = gn_case(rows, cols, 2, 34)
+    idx = torch.arange(many, device="cuda") % 2
+    dm = [t[idx].contiguous() for t in dev_maps(L, KF_NAMES + ("Wc", "Ic"))]
+    Rs, ts = [L[l % 2]["Rp"] for l in range(many)], [L[l % 2]["tp"] for l in range(many)]
+    okw = CONFIGS[0][1]
+    A, b = bt.gn_fused(*dm, Rs, ts, K, sp_from(many, okw), fast=True)
+    for l in range(2, many):
+        assert np.array_equal(A[l], A[l % 2]) and np.array_equal(b[l], b[l % 2]), l
+    W1f, I1f = torch.empty_like(dm[0]), torch.empty_like(dm[0])
+    bt.warp_pair(dm[6], dm[7], dm[0], W1f, I1f, Rs, ts, fast=True)
+    A2, b2 = bt.build_system(*dm[:6], W1f, I1f, K, sp_from(many, okw))
+    assert np.array_equal(A, A2) and np.array_equal(b, b2)
+    W1h, I1h = W1f[:2].cpu().numpy(), I1f[:2].cpu().numpy()
+    for l, d in enumerate(L):
+        oA, ob = O.build_system(*[d[n] for n in KF_NAMES], W1h[l], I1h[l], K, **okw)
+        ra, rb = check_system(A[l], b[l], oA, ob)
+        print(f"{many} lanes, lane {l}: dA {ra:.2e}, db {rb:.2e}")
+
+
 def test_gn_fused_nu_int_from_max(bt):
     """visodo.cpp:1186: nu_int = max(nu_int, nu_depthinv) applied inside the kernel when asked for"""
     rows, cols, lanes = 48, 64, 2
