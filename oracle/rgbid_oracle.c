@@ -779,21 +779,33 @@ static float estimate_nu(const float* err, int n, float bias, float sigma) {
   return nu;
 }
 
-void orc_sigma_nu_student(const float* err, int n, float* bias, float* sigma, float* nu, int mestimator) {
-  /* computeSigmaAndNuStudent sigmaFuncs.cu:858-1066 */
+void orc_sigma_nu_student_margin(const float* err, int n, float* bias, float* sigma, float* nu, int mestimator, float* stop_margin) {
+  /* computeSigmaAndNuStudent sigmaFuncs.cu:858-1066.  stop_margin (nullable; TEST DIAGNOSTIC, no counterpart in the reference): the smallest
+   * distance of the stopping test's ratio |sigma - sigma_prev| / sigma_prev from its threshold 0.1 over the iterations that evaluated it.  The
+   * iteration count -- and with it sigma, to a few 1e-3 -- is a discontinuous function of the residuals wherever that ratio sits on the threshold;
+   * two implementations whose residuals differ by 1e-6 may then stop one iteration apart. */
   float sh_sigma = *sigma, sh_bias = *bias, sh_nu = 5.f;
   int sh_mest = ORC_LSQ;
   float sigma_prev;
   const int max_iters = 10;
   const float rel_tol = 0.1f;
+  float margin = 1e30f;
   for (int i = 0; i < max_iters; i++) {
     moments4 m = pass_bias_sigma(err, n, sh_bias, sh_sigma, sh_nu, sh_mest, 1);
     final_bias_sigma(m, bias, sigma);
     sigma_prev = sh_sigma;
     sh_bias = *bias; sh_sigma = *sigma; sh_mest = mestimator;
-    if ((i > 0) && ((fabsf(*sigma - sigma_prev) / sigma_prev) < rel_tol)) break;
+    if (i > 0) {
+      const float ratio = fabsf(*sigma - sigma_prev) / sigma_prev;
+      if (fabsf(ratio - rel_tol) < margin) margin = fabsf(ratio - rel_tol);
+      if (ratio < rel_tol) break;
+    }
   }
+  if (stop_margin) *stop_margin = margin;
   *nu = estimate_nu(err, n, sh_bias, sh_sigma);
+}
+void orc_sigma_nu_student(const float* err, int n, float* bias, float* sigma, float* nu, int mestimator) {
+  orc_sigma_nu_student_margin(err, n, bias, sigma, nu, mestimator, NULL);
 }
 
 void orc_nu_student(const float* err, int n, float bias, float sigma, float* nu) {

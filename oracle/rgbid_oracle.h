@@ -109,7 +109,9 @@ void orc_register_depthinv(const float* src, int rows, int cols, int irows, int 
 int  orc_error_lattice(const float* im1, const float* im0, int rows, int cols, int min_nsamples,
                        float* err, int* out_rows, int* out_cols, int* out_stride);
 void orc_sigma_nu_student(const float* err, int n, float* bias, float* sigma, float* nu,
-                          int mestimator);                                                        /* :858-1066 */
+                          int mestimator);
+/* the same, also reporting how close the stopping test of the sigma iteration came to its threshold (test diagnostic, see the .c) */
+void orc_sigma_nu_student_margin(const float* err, int n, float* bias, float* sigma, float* nu, int mestimator, float* stop_margin);                                                        /* :858-1066 */
 void orc_nu_student(const float* err, int n, float bias, float sigma, float* nu);                 /* :1068-1222 */
 void orc_sigma_pdf(const float* err, int n, float* bias, float* sigma, int mestimator);           /* :773-854 */
 void orc_chi_square(const float* err_int, const float* err_depth, int n, float sigma_int,
@@ -192,6 +194,8 @@ typedef struct {
   float sigma_int, sigma_depthinv, nu_int, nu_depthinv, bias_int, bias_depthinv; /* last GN iteration */
   double delta_R[9], delta_t[3], delta_cov[36];  /* KF-relative pose + covariance after the frame */
   int odo_kf_natural, integr_kf_natural;         /* what the two covisibility tests decided on their own (see the hook below) */
+  float sigma_stop_margin_int, sigma_stop_margin_depthinv; /* last GN iteration: distance of the sigma iteration's stopping ratio from its threshold */
+  float sigma_stop_margin_frame;                           /* the smallest such distance over ALL Gauss-Newton iterations of the frame, both channels */
 } orc_frame_info;
 void orc_tracker_last_info(const orc_tracker* t, orc_frame_info* info);
 /* TEST HOOK (no counterpart in the reference): impose the two keyframe decisions of the NEXT tracked frame (-1 = decide naturally,

@@ -649,8 +649,10 @@ static int estimate_visual_odometry(orc_tracker* t, double R_io[9], double t_io[
       if (c->sigma_estimator == ORC_SIGMA_PDF) {
         int nI = orc_error_lattice(t->wI[level], t->I_kf[level], r, cc, c->nsamples, t->res_I, NULL, NULL, NULL);
         int nD = orc_error_lattice(t->wiD[level], t->iD_kf[level], r, cc, c->nsamples, t->res_D, NULL, NULL, NULL);
-        orc_sigma_nu_student(t->res_I, nI, &bias_int, &sigma_int, &nu_int, c->mestimator);
-        orc_sigma_nu_student(t->res_D, nD, &bias_depthinv, &sigma_depthinv, &nu_depthinv, c->mestimator);
+        orc_sigma_nu_student_margin(t->res_I, nI, &bias_int, &sigma_int, &nu_int, c->mestimator, &t->info.sigma_stop_margin_int);
+        orc_sigma_nu_student_margin(t->res_D, nD, &bias_depthinv, &sigma_depthinv, &nu_depthinv, c->mestimator, &t->info.sigma_stop_margin_depthinv);
+        if (t->info.sigma_stop_margin_int < t->info.sigma_stop_margin_frame) t->info.sigma_stop_margin_frame = t->info.sigma_stop_margin_int;
+        if (t->info.sigma_stop_margin_depthinv < t->info.sigma_stop_margin_frame) t->info.sigma_stop_margin_frame = t->info.sigma_stop_margin_depthinv;
         nu_int = fmaxf(nu_int, nu_depthinv); /* :1186 */
       } else if (c->sigma_estimator == ORC_SIGMA_CONS) {
         sigma_int = (float)exp(log((double)sigma_int_ref)); sigma_depthinv = (float)exp(log((double)sigma_depthinv_ref));
@@ -725,6 +727,7 @@ static int tracker_track(orc_tracker* t, const uint16_t* depth, const uint8_t* r
   const orc_tracker_config* c = &t->c;
   t->delta_t = c->delta_t; /* computeInterframeTime :1929-1964 with compute_deltat_flag_ off */
   memset(&t->info, 0, sizeof(t->info));
+  t->info.sigma_stop_margin_frame = 1e30f;
   const int force_odo = t->force_odo, force_integr = t->force_integr;   /* one-shot */
   t->force_odo = t->force_integr = -1;
   prepare_images(t, depth, rgb);

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import oracle as O
-from rgbid import synth
+from rgbid import device, synth
 from rgbid import engine as E
 
 pytestmark = pytest.mark.gpu
@@ -39,6 +39,8 @@ def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, m
     worst_r = worst_t = 0.0
     imposed = 0
     th_o, th_i = cfg_kw.get("visratio_odo", 0.9), cfg_kw.get("visratio_integr", 0.7)
+    fin = cfg_kw.get("finest_level", 0)
+    n_lattice = device.error_lattice_size(rows >> fin, cols >> fin, cfg_kw.get("nsamples", 10000))[0]
     for l in range(n_lanes):
         trk = O.Tracker(O.default_config(**okw))
         d = depth[:, l].cpu().numpy().view(np.uint16)
@@ -67,8 +69,17 @@ def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, m
                 assert abs(info.visratio_integr - th_i) < 5e-4, (l, k, st, info.visratio_integr)
                 imposed += 1
             assert rec[k, l]["nu_depthinv"] == info.nu_depthinv and rec[k, l]["nu_int"] == info.nu_int, (l, k)
-            # sigma is the scale of the residuals AT the current pose estimate, which itself agrees to ~1e-5: 1e-3 relative
-            assert abs(rec[k, l]["sigma_int"] - info.sigma_int) < sigma_tol * info.sigma_int, (l, k, rec[k, l]["sigma_int"], info.sigma_int)
+            # sigma is the scale of the residuals AT the current pose estimate, which itself agrees to ~1e-5: 1e-3 relative on a full-size lattice.
+            # Two discontinuities of the reference algorithm widen that: (1) a pose difference of 1e-7 can move a point-sampled or range-checked
+            # pixel across a pixel boundary; a Student-t sample's weighted square is bounded by (nu + 1) sigma^2, so ONE flipped sample moves sigma by
+            # up to ~5.5 / n_samples relative -- on the 5 000-sample lattice of a 62x84 image that is 1e-3 per sample (seen at seed 14 of a fuzz
+            # campaign: 2.3e-3, exact and fast engine alike): allow three; (2) the sigma iteration stops when its relative change drops below 0.1:
+            # with the ratio ON that threshold (the oracle reports the distance, rgbid_oracle.h sigma_stop_margin_frame) the two may stop one iteration
+            # apart, which moves sigma by a few 1e-3.
+            ds = abs(rec[k, l]["sigma_int"] - info.sigma_int)
+            if not ds < max(sigma_tol, 15.0 / n_lattice) * info.sigma_int:
+                assert info.sigma_stop_margin_frame < 1e-4 and ds < 2e-2 * info.sigma_int, (l, k, rec[k, l]["sigma_int"], info.sigma_int, info.sigma_stop_margin_frame, n_lattice)
+                print(f"lane {l} frame {k}: sigma iteration on its stopping threshold (margin {info.sigma_stop_margin_frame:.1e}): sigma_int {rec[k, l]['sigma_int']} vs {info.sigma_int}")
         Rs, ts = trk.poses()
         oR, ot, ocov = trk.odometry()
         for k in range(1, n_frames):

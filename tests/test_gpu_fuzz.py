@@ -105,7 +105,7 @@ def test_fuzz_stencils_and_fusion(ctx, seed):
 def test_fuzz_bilateral_fast_numerics(ctx, seed):
     """the engine's FAST bilateral filter (k_bilateral<2>: invalid taps as a finite sentinel) on odd sizes with +-inf, +-3e38, the sentinel value
     itself (1e19), 1e10, values either side of its validity bound 1e9, zeros, denormals and dense NaN.  Its stated domain: the oracle's result
-    (filters.cu:86-135) on the map with |v| >= 1e9 and +-inf replaced by NaN -- same NaN pattern, 2e-6 relative."""
+    (filters.cu:86-135) on the map with |v| >= 1e9 and +-inf replaced by NaN -- same NaN pattern, 2e-6 relative (+ 1e-12 of the data's magnitude)."""
     r = util.rng(2500 + seed)
     rows, cols = int(r.integers(5, 90)), int(r.integers(5, 130))
     sigma = (2 * 0.0025, 3.0)[seed % 2]
@@ -128,7 +128,11 @@ def test_fuzz_bilateral_fast_numerics(ctx, seed):
     assert np.array_equal(np.isnan(got), np.isnan(ref)), (int(np.count_nonzero(np.isnan(got) != np.isnan(ref))), rows, cols)
     m = ~np.isnan(ref)
     assert np.isfinite(got[m]).all()
-    err = np.abs(got[m].astype(np.float64) - ref[m]) - (2e-6 * np.abs(ref[m].astype(np.float64)) + 1e-36)
+    # 2e-6 relative -- plus 1e-12 of the map's largest valid magnitude: where the centre value is (near) zero the result is a sum of taps with
+    # VANISHING weights (exp(-60) ...), and v_exp_f32 of a large negative argument is good to ~4e-6 relative, not 2e-6; such results are 1e-17 and
+    # smaller on data of order 1 - 255 (seen at seeds >= 51 of a 600-seed campaign; the default seeds do not reach it)
+    floor = 1e-12 * float(np.nanmax(np.abs(dom))) if np.isfinite(dom).any() else 0.0
+    err = np.abs(got[m].astype(np.float64) - ref[m]) - (2e-6 * np.abs(ref[m].astype(np.float64)) + floor + 1e-36)
     assert (err <= 0).all(), float(err.max())
 
 
