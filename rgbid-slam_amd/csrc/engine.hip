@@ -597,23 +597,31 @@ void enqueue_save_odo_kf(rgbid_engine* e, hipStream_t s) {
   const int B = e->B, L = e->L;
   LaneMask m = M(e->flags.sw_odo);
   {
-    // algorithmic bytes of a keyframe switch (bucket 1): 2 copies per level (4 B read + 4 B written per pixel), the lattice pack, two
+    // algorithmic bytes of a keyframe switch (bucket 1): 2 copies per level (4 B read + 4 B written per pixel; folded into the Sobel pass where possible), the lattice pack, two
     // bilateral filters (8 B/px), the pyramid of the filtered maps, Sobel (12 B/px) of the filtered and of the unfiltered maps
     double b = 0.0;
     for (int i = 0; i < L; ++i) {
       const double n = npx(e->iD_kf[i]);
-      b += 2 * 8 * n;
+      const bool keep = e->cfg.image_filtering != RGBID_FILTER_GRADS && e->iD_kf[i].cols % 4 == 0;   // Sobel pair + copy in one pass (16 B/px)
+      if (!keep) b += 2 * 8 * n;
       if (e->lat_res) b += 16.0 * lattice_samples(e->iD_kf[i].rows, e->iD_kf[i].cols, e->cfg.nsamples);
       b += 2 * 12 * n;                                                            // gradients of the filtered maps
       if (i) b += 2 * (4 * npx(e->iD_kf_f[i - 1]) + 4 * n);                       // pyrDown of the filtered maps
-      b += (e->cfg.image_filtering == RGBID_FILTER_GRADS) ? 4 * 8 * n : 2 * 12 * n;
+      b += (e->cfg.image_filtering == RGBID_FILTER_GRADS) ? 4 * 8 * n : keep ? 2 * 16 * n : 2 * 12 * n;
     }
     b += 2 * 8 * npx(e->iD_kf[0]);
     e->step_bytes[1] = b;
   }
+  // the current frame's pyramids become the keyframe's.  Where the Sobel pair of the unfiltered maps is taken anyway it writes the copy as well (one
+  // read of the map instead of two, one launch instead of two per map and level); the gradients of those levels are done then, not at the end
+  bool kept[MAXL] = {};
   for (int i = 0; i < L; ++i) {
-    launch_copy_bytes(s, B, e->iD_curr[i], e->iD_kf[i], 4, m);
-    launch_copy_bytes(s, B, e->I_curr[i], e->I_kf[i], 4, m);
+    if (e->cfg.image_filtering != RGBID_FILTER_GRADS)
+      kept[i] = launch_gradient_keep(s, B, e->I_curr[i], e->gxI[i], e->gyI[i], e->I_kf[i], m) && launch_gradient_keep(s, B, e->iD_curr[i], e->gxD[i], e->gyD[i], e->iD_kf[i], m);
+    if (!kept[i]) {
+      launch_copy_bytes(s, B, e->iD_curr[i], e->iD_kf[i], 4, m);
+      launch_copy_bytes(s, B, e->I_curr[i], e->I_kf[i], 4, m);
+    }
     e->launches += 2;
   }
   if (e->lat_res)
@@ -635,7 +643,7 @@ void enqueue_save_odo_kf(rgbid_engine* e, hipStream_t s) {
       launch_copy_bytes(s, B, e->gxI_c[i], e->gxI[i], 4, m); launch_copy_bytes(s, B, e->gyI_c[i], e->gyI[i], 4, m);
       launch_copy_bytes(s, B, e->gxD_c[i], e->gxD[i], 4, m); launch_copy_bytes(s, B, e->gyD_c[i], e->gyD[i], 4, m);
       e->launches += 4;
-    } else {
+    } else if (!kept[i]) {
       launch_gradient(s, B, e->I_kf[i], e->gxI[i], e->gyI[i], m);
       launch_gradient(s, B, e->iD_kf[i], e->gxD[i], e->gyD[i], m);
       e->launches += 2;

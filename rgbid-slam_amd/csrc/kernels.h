@@ -42,6 +42,7 @@ void launch_nmap_cross(hipStream_t s, int B, ImgB vmap, ImgB nmap, LaneMask m);
 void launch_integrate_warped_rgb(hipStream_t s, int B, ImgB warped, ImgB r, ImgB g, ImgB b, ImgB wweight, ImgB kf, ImgB colors, ImgB kfw, LaneMask m);
 void launch_decompose_rgb(hipStream_t s, int B, ImgB rgb, ImgB r, ImgB g, ImgB b, LaneMask m);
 void launch_gradient(hipStream_t s, int B, ImgB src, ImgB gx, ImgB gy, LaneMask m);
+bool launch_gradient_keep(hipStream_t s, int B, ImgB src, ImgB gx, ImgB gy, ImgB keep, LaneMask m);   // Sobel pair + copy of src into keep; false: not launched
 // depth->iD + rgb->luma + rgb->r,g,b planes in one pass (engine); falls back to the three kernels when not 16-byte aligned
 void launch_prep_frame(hipStream_t s, int B, ImgB depth_u16, ImgB rgb, ImgB iD, ImgB I, ImgB r, ImgB g, ImgB b, float factor_depth, LaneMask m);
 void launch_copy_bytes(hipStream_t s, int B, ImgB src, ImgB dst, int elem_size, LaneMask m);  // row-wise D2D copy kernel

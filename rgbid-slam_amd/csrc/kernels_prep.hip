@@ -198,7 +198,9 @@ __device__ __forceinline__ void sobel_load_row(const ImgB& src, int lane, int y,
   float4 v = *reinterpret_cast<const float4*>(rp + x);
   r[0] = rp[xl]; r[1] = v.x; r[2] = v.y; r[3] = v.z; r[4] = v.w; r[5] = rp[xr];
 }
-__global__ __launch_bounds__(256) void k_gradient4(ImgB src, ImgB gx, ImgB gy, int cols4, int strips, LaneMask m) {
+// COPY: the source row is also written to `keep` (the keyframe's own copy of a current-frame map: the copy kernel's 4 B/px read and one launch saved)
+template <bool COPY>
+__global__ __launch_bounds__(256) void k_gradient4(ImgB src, ImgB gx, ImgB gy, ImgB keep, int cols4, int strips, LaneMask m) {
   int lane = blockIdx.y;
   if (!m.on(lane)) return;
   int u = blockIdx.x * 256 + threadIdx.x;
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(256) void k_gradient4(ImgB src, ImgB gx, ImgB gy, i
     }
     st16_stream(row_ptr<float>(gx, lane, y) + x, h[0], h[1], h[2], h[3]);
     st16_stream(row_ptr<float>(gy, lane, y) + x, v[0], v[1], v[2], v[3]);
+    if (COPY) st16_stream(row_ptr<float>(keep, lane, y) + x, b[1], b[2], b[3], b[4]);
 #pragma unroll
     for (int i = 0; i < 6; ++i) { a[i] = b[i]; b[i] = c[i]; }
   }
@@ -234,10 +237,18 @@ __global__ __launch_bounds__(256) void k_gradient4(ImgB src, ImgB gx, ImgB gy, i
 void launch_gradient(hipStream_t s, int B, ImgB src, ImgB gx, ImgB gy, LaneMask m) {
   if ((src.cols % 4 == 0) && vec4_ok(src, 4) && vec4_ok(gx, 4) && vec4_ok(gy, 4)) {
     int cols4 = src.cols / 4, strips = div_up(src.rows, GR_ROWS);
-    hipLaunchKernelGGL(k_gradient4, dim3(div_up(cols4 * strips, 256), B), dim3(256), 0, s, src, gx, gy, cols4, strips, m);
+    hipLaunchKernelGGL(k_gradient4<false>, dim3(div_up(cols4 * strips, 256), B), dim3(256), 0, s, src, gx, gy, src, cols4, strips, m);
     return;
   }
   hipLaunchKernelGGL(k_gradient, grid2d(src.cols, src.rows, B), dim3(TX, TY), 0, s, src, gx, gy, m);
+}
+// Sobel pair of `src` + a copy of `src` into `keep` in one pass (keyframe switch: the current-frame map becomes the keyframe's); false: the
+// geometry is not the 16-byte path's, nothing launched (the caller copies, then takes the gradient)
+bool launch_gradient_keep(hipStream_t s, int B, ImgB src, ImgB gx, ImgB gy, ImgB keep, LaneMask m) {
+  if (!((src.cols % 4 == 0) && vec4_ok(src, 4) && vec4_ok(gx, 4) && vec4_ok(gy, 4) && vec4_ok(keep, 4) && keep.rows == src.rows && keep.cols == src.cols)) return false;
+  int cols4 = src.cols / 4, strips = div_up(src.rows, GR_ROWS);
+  hipLaunchKernelGGL(k_gradient4<true>, dim3(div_up(cols4 * strips, 256), B), dim3(256), 0, s, src, gx, gy, keep, cols4, strips, m);
+  return true;
 }
 
 // ---- engine: vertex map + Sobel + normal map of the fused keyframe in ONE pass --------------------------------------------------
