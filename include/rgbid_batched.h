@@ -120,6 +120,11 @@ int rgbid_pyr_down_batched(rgbid_ctx*, int lanes, const rgbid_imgb* src, const r
 /* computeGradientIntensity / computeGradientDepth (misc.cu:400-441) */
 int rgbid_compute_gradient_batched(rgbid_ctx*, int lanes, const rgbid_imgb* src, const rgbid_imgb* dst_hor, const rgbid_imgb* dst_vert,
                                    float* ms);
+/* the same Sobel pair + a copy of src into `keep` in ONE pass: what the engine runs at a keyframe switch, where copyImages (visodo.cpp:837-841) is followed
+ * by computeGradient* of the copied map (:862-877).  Takes the 16-byte path only: returns RGBID_E_INVALID for a geometry it does not cover (cols % 4 != 0,
+ * rows / lanes not 16-byte aligned) -- the engine then copies and takes the gradient as two calls */
+int rgbid_gradient_keep_batched(rgbid_ctx*, int lanes, const rgbid_imgb* src, const rgbid_imgb* dst_hor, const rgbid_imgb* dst_vert,
+                                const rgbid_imgb* keep, float* ms);
 /* bilateralFilter (filters.cu:139-162); numerics FAST = the engine's v_exp_f32 kernel */
 int rgbid_bilateral_filter_batched(rgbid_ctx*, int lanes, const rgbid_imgb* src, const rgbid_imgb* dst, float sigma_floatmap,
                                    int numerics, float* ms);

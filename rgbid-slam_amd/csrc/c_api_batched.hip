@@ -339,6 +339,17 @@ int rgbid_compute_gradient_batched(rgbid_ctx* c, int lanes, const rgbid_imgb* sr
   return call.finish();
 }
 
+int rgbid_gradient_keep_batched(rgbid_ctx* c, int lanes, const rgbid_imgb* src, const rgbid_imgb* gx, const rgbid_imgb* gy, const rgbid_imgb* keep, float* ms) {
+  if (!c || lanes < 1 || !ok_b(src, lanes) || !ok_b(gx, lanes) || !ok_b(gy, lanes) || !ok_b(keep, lanes) || !same_b(src, gx) || !same_b(src, gy) || !same_b(src, keep) ||
+      src->data == keep->data)
+    return RGBID_E_INVALID;
+  hipSetDevice(c->device);
+  Call call(c, ms);
+  const bool launched = launch_gradient_keep(c->stream, lanes, BB(src, lanes), BB(gx, lanes), BB(gy, lanes), BB(keep, lanes), ALL);
+  const int r = call.finish();
+  return launched ? r : RGBID_E_INVALID;
+}
+
 int rgbid_bilateral_filter_batched(rgbid_ctx* c, int lanes, const rgbid_imgb* src, const rgbid_imgb* dst, float sigma_floatmap, int numerics, float* ms) {
   if (!c || lanes < 1 || !ok_b(src, lanes) || !ok_b(dst, lanes) || !same_b(src, dst) || src->data == dst->data || !numerics_ok(numerics) ||
       !(sigma_floatmap > 0.f))

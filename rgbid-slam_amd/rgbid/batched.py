@@ -19,7 +19,7 @@ BATCHED_EXPORTS = [
     "rgbid_gn_fused_batched", "rgbid_build_system_batched", "rgbid_warp_pair_batched", "rgbid_lattice_pack_batched",
     "rgbid_lattice_residuals_batched", "rgbid_sigma_pair_batched", "rgbid_fuse_frame_batched", "rgbid_kf_maps_batched",
     "rgbid_visibility_pair_batched", "rgbid_prep_frame_batched", "rgbid_pyr_down_batched", "rgbid_compute_gradient_batched",
-    "rgbid_bilateral_filter_batched",
+    "rgbid_bilateral_filter_batched", "rgbid_gradient_keep_batched",
 ]
 
 
@@ -168,6 +168,11 @@ class Batched:
     def gradient(self, src, gx, gy):
         ms = C.c_float()
         check(self.L.rgbid_compute_gradient_batched(self._h, src.shape[0], C.byref(imgb(src)), C.byref(imgb(gx)), C.byref(imgb(gy)), C.byref(ms)))
+        return ms.value
+
+    def gradient_keep(self, src, gx, gy, keep):
+        ms = C.c_float()
+        check(self.L.rgbid_gradient_keep_batched(self._h, src.shape[0], C.byref(imgb(src)), C.byref(imgb(gx)), C.byref(imgb(gy)), C.byref(imgb(keep)), C.byref(ms)))
         return ms.value
 
     def bilateral(self, src, dst, sigma_floatmap, fast=False):

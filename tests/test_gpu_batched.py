@@ -467,6 +467,26 @@ def test_prep_frame(bt, rows, cols, lanes, factor):
             assert_bits(got[l].cpu().numpy(), ref, 0, "channel")
 
 
+@pytest.mark.parametrize("rows,cols,lanes", [GEOMS[0], GEOMS[2], GEOMS[4]])
+def test_gradient_keep(bt, rows, cols, lanes):
+    """k_gradient4<true>, the engine's keyframe-switch pass: Sobel pair of a map + a copy of the map in one launch -- gradients bit-exact against the
+    oracle (NaN pattern included), the copy bit-identical to the source (NaN payloads included), padded rows left alone; a geometry off the 16-byte
+    path is refused"""
+    srcs = [util.rand_invdepth(util.rng(9300 + l), rows, cols, nan_frac=0.1) for l in range(lanes)]
+    s = stack(srcs, pad=4)
+    full = [torch.full((lanes, rows, cols + 4), 7.0, device="cuda") for _ in range(3)]
+    gx, gy, keep = [t[:, :, :cols] for t in full]
+    bt.gradient_keep(s, gx, gy, keep)
+    for l in range(lanes):
+        ogx, ogy = O.gradient(srcs[l])
+        assert_bits(gx[l].cpu().numpy(), ogx, 0, "gx"); assert_bits(gy[l].cpu().numpy(), ogy, 0, "gy")
+        assert np.array_equal(keep[l].cpu().numpy().view(np.uint32), srcs[l].view(np.uint32))
+    assert all(bool((t[:, :, cols:] == 7.0).all()) for t in full)
+    odd = torch.zeros((1, 9, 83), device="cuda")
+    with pytest.raises(Exception):
+        bt.gradient_keep(odd, torch.zeros_like(odd), torch.zeros_like(odd), torch.zeros_like(odd))
+
+
 @pytest.mark.parametrize("rows,cols,lanes", [GEOMS[0], GEOMS[1], GEOMS[4]])
 def test_batched_stencils(bt, rows, cols, lanes):
     """natively batched pyrDown / Sobel / bilateral (EXACT and the engine's FAST class) per lane against the oracle"""
