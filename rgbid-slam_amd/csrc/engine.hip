@@ -12,6 +12,7 @@
 #include "kernels.h"
 #include "../../include/rgbid/se3.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -438,6 +439,50 @@ __global__ void k_decide(LaneState* st, Flags f, const unsigned int* counts, War
   ++s.global_time;
 }
 
+// ---- saveCurrentImagesAsIntegrationKeyframes (visodo.cpp:880-893) + the overlap-mask reset of a first frame (:2021) in ONE launch ---------------
+// lanes that switch integration keyframe: current inverse depth -> keyframe inverse depth and its raw copy (one read, two writes), current colours ->
+// keyframe colours, keyframe weight = 1; lanes on their first frame: overlap mask = 0.  (Five row-copy / fill launches before, each dispatching its grid
+// for the 98 % of lanes that do nothing in a step.)
+__device__ __forceinline__ bool rows16(const ImgB& a, int row_bytes) { return (row_bytes & 15) == 0 && (a.pitch & 15) == 0 && (a.lane_stride & 15) == 0 && (((uintptr_t)a.base) & 15) == 0; }
+__global__ __launch_bounds__(256) void k_save_integr_kf(ImgB iD_cur, ImgB rgb_cur, ImgB iD_kf, ImgB iD_raw, ImgB colors, ImgB weight, ImgB mask, const int* sw_int, const int* first) {
+  const int lane = blockIdx.y;
+  const bool sw = sw_int[lane] == 1, fr = first[lane] == 1;
+  if (!sw && !fr) return;
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const int rows = iD_cur.rows, cols = iD_cur.cols;
+  const bool v4 = rows16(iD_cur, 4 * cols) && rows16(iD_kf, 4 * cols) && rows16(iD_raw, 4 * cols) && rows16(weight, 4 * cols);
+  const bool v3 = rows16(rgb_cur, 3 * cols) && rows16(colors, 3 * cols);
+  const bool v1 = rows16(mask, cols);
+  for (int y = blockIdx.x; y < rows; y += gridDim.x) {
+    if (sw) {
+      const float* s = row_ptr<float>(iD_cur, lane, y);
+      float *d0 = row_ptr<float>(iD_kf, lane, y), *d1 = row_ptr<float>(iD_raw, lane, y), *w = row_ptr<float>(weight, lane, y);
+      if (v4) {
+        for (int i = threadIdx.x; i < cols / 4; i += 256) {
+          const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(s) + i);
+          __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(d0) + i);
+          __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(d1) + i);
+          __builtin_nontemporal_store(f4v{1.f, 1.f, 1.f, 1.f}, reinterpret_cast<f4v*>(w) + i);
+        }
+      } else {
+        for (int i = threadIdx.x; i < cols; i += 256) { const float v = s[i]; d0[i] = v; d1[i] = v; w[i] = 1.f; }
+      }
+      const uint8_t* cs = row_ptr<uint8_t>(rgb_cur, lane, y);
+      uint8_t* cd = row_ptr<uint8_t>(colors, lane, y);
+      if (v3) {
+        for (int i = threadIdx.x; i < 3 * cols / 16; i += 256) reinterpret_cast<uint4*>(cd)[i] = reinterpret_cast<const uint4*>(cs)[i];
+      } else {
+        for (int i = threadIdx.x; i < 3 * cols; i += 256) cd[i] = cs[i];
+      }
+    }
+    if (fr) {
+      uint8_t* mk = row_ptr<uint8_t>(mask, lane, y);
+      if (v1) { for (int i = threadIdx.x; i < cols / 16; i += 256) reinterpret_cast<uint4*>(mk)[i] = make_uint4(0, 0, 0, 0); }
+      else { for (int i = threadIdx.x; i < cols; i += 256) mk[i] = 0; }
+    }
+  }
+}
+
 // the four downloads of resetIntegrationKeyframe (:1638-1641) as one device-side packed copy into the lane's ring slot:
 // section 0 overlap mask, 1 colours, 2 inverse depth, 3 normals (3*rows rows).  blockIdx = (row chunk, section, lane).
 struct KfSrc { ImgB im[4]; int row_bytes[4]; size_t off[4]; };
@@ -819,13 +864,10 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
     if (hipError_t he = hipMemsetAsync(e->counts, 0, sizeof(unsigned int) * 2 * B, s); he != hipSuccess) return (int)he;
     launch_visibility(s, B, e->iD_curr[0], e->iD_integr_raw, e->overlap_mask, nullptr, e->ivis_ab, e->counts, M(f.overlap));
   }
-  launch_copy_bytes(s, B, e->iD_curr[0], e->iD_integr, 4, M(f.sw_int));
-  launch_copy_bytes(s, B, e->iD_curr[0], e->iD_integr_raw, 4, M(f.sw_int));
-  launch_copy_bytes(s, B, e->cur_rgb, e->colors_integr, 3, M(f.sw_int));
-  launch_fill(s, B, e->w_integr, 4, 0x3f800000u, M(f.sw_int));
-  launch_fill(s, B, e->overlap_mask, 1, 0u, M(f.first));  // initialiseDeviceMemory2D(overlap_mask, 0) :2021
-  e->launches += 7;
-  sb[2] += (9 + 8 + 8 + 6 + 4) * N0;                                              // overlap mask pass, three copies, weight fill
+  hipLaunchKernelGGL(k_save_integr_kf, dim3(std::min(c.rows, 32), B), dim3(256), 0, s, e->iD_curr[0], e->cur_rgb, e->iD_integr, e->iD_integr_raw, e->colors_integr, e->w_integr,
+                     e->overlap_mask, f.sw_int, f.first);   // three copies + weight fill; initialiseDeviceMemory2D(overlap_mask, 0) :2021
+  e->launches += 3;
+  sb[2] += (9 + 12 + 6 + 4) * N0;                                                 // overlap mask pass; inverse depth read once and written twice, colours, weight fill
   // ... or integrateImagesIntoKeyframes (:1674-1764)
   if (!first) {
     if (launch_fuse_frame(s, B, e->iD_curr[0], e->iD_integr, e->w_integr, e->warped_w, e->fuse_wp, M(f.fuse), c.fast_numerics != 0)) {
