@@ -1,4 +1,20 @@
-// settings.cpp -- INI parser with the reference's semantics (src/settings.cpp:25-170): see include/rgbid/settings.h.
+// settings.cpp -- loader for the tracker's INI files (the class interface of include/rgbid/settings.h is what
+// VisodoTracker::loadSettings / loadCalibration consume; the reference's counterpart is include/settings.h + src/settings.cpp).
+//
+// Written from the file GRAMMAR, as a line tokenizer feeding a small state machine:
+//
+//   file     := { line '\n' }
+//   line     := ws* ( blank | comment | header | assign | cont ) ws*
+//   comment  := ('#' | ';') any*
+//   header   := '[' name [ ']' any* ]              -- a missing ']' takes the rest of the line as the name
+//   assign   := key '=' value                      -- split at the FIRST '='; key and value are stripped of blanks
+//   cont     := any+ without '='                   -- continues the value of the last `assign` line
+//
+// Semantics the shipped configuration files rely on, and that tests/test_cpu_host.py pins against the reference's own parser built into
+// oracle/_ref: keys assigned before any header live in the section named ""; a repeated header re-opens the existing section; the FIRST
+// assignment of a key wins; an assignment with an empty key is dropped and also closes the open value (continuation lines after it go
+// nowhere); a continuation line extends the value of the last assignment with '\n' + the stripped line -- and stores it under that key even
+// when the assignment itself lost against an earlier one (the running value of the LAST assignment replaces the stored one).
 #include "../../include/rgbid/settings.h"
 
 #include <iostream>
@@ -6,81 +22,115 @@
 namespace RGBID_SLAM {
 
 std::string trim(std::string src, char const* delims) {
-  // include/settings.h:32-46
-  std::string res(src);
-  std::string::size_type index = res.find_last_not_of(delims);
-  if (index != std::string::npos) res.erase(++index);
-  index = res.find_first_not_of(delims);
-  if (index != std::string::npos) res.erase(0, index);
-  else res.erase();
-  return res;
+  const std::string::size_type first = src.find_first_not_of(delims);
+  if (first == std::string::npos) return std::string();
+  const std::string::size_type last = src.find_last_not_of(delims);
+  return src.substr(first, last - first + 1);
 }
 
-void Section::addEntry(Entry& new_entry) {
-  if (entries_.find(new_entry.getName()) != entries_.end()) {
-    std::cout << "Warning: entry " << new_entry.getName() << " is already loaded." << std::endl;
-    return;  // the first value wins
+namespace {
+
+enum class LineKind { Blank, Comment, Header, Assignment, Continuation };
+
+struct LineToken {
+  LineKind kind = LineKind::Blank;
+  std::string head;  // Header: section name; Assignment: key; Continuation: the stripped text
+  std::string tail;  // Assignment: value
+};
+
+// one physical line -> one token; no state
+LineToken tokenize(const std::string& physical_line) {
+  LineToken tok;
+  const std::string text = trim(physical_line);
+  if (text.empty()) return tok;
+  const char lead = text.front();
+  if (lead == '#' || lead == ';') {
+    tok.kind = LineKind::Comment;
+    return tok;
   }
-  entries_[new_entry.getName()] = new_entry;
+  if (lead == '[') {
+    tok.kind = LineKind::Header;
+    std::string::size_type close = 1;
+    while (close < text.size() && text[close] != ']') ++close;
+    tok.head = trim(text.substr(1, close - 1));
+    return tok;
+  }
+  std::string::size_type eq = 0;
+  while (eq < text.size() && text[eq] != '=') ++eq;
+  if (eq == text.size()) {
+    tok.kind = LineKind::Continuation;
+    tok.head = text;
+    return tok;
+  }
+  tok.kind = LineKind::Assignment;
+  tok.head = trim(text.substr(0, eq));
+  tok.tail = trim(text.substr(eq + 1));
+  return tok;
+}
+
+}  // namespace
+
+void Section::addEntry(Entry& new_entry) {
+  const bool inserted = entries_.insert(std::make_pair(new_entry.getName(), new_entry)).second;
+  if (!inserted) std::cout << "[settings] key '" << new_entry.getName() << "' assigned twice in [" << name_ << "]: the first value is kept" << std::endl;
 }
 
 bool Section::getEntry(const std::string& entry_name, Entry& entry) const {
-  std::map<std::string, Entry>::const_iterator it = entries_.find(entry_name);
-  if (it == entries_.end()) return false;
-  entry = it->second;
-  return true;
+  const auto hit = entries_.find(entry_name);
+  if (hit != entries_.end()) entry = hit->second;
+  return hit != entries_.end();
 }
 
 Settings::Settings(std::ifstream& filestream, bool verbose) : verbose_(verbose) { load(filestream); }
 
 void Settings::load(std::ifstream& filestream) {
-  std::string entry_name, entry_value, section_name, line;
-  while (std::getline(filestream, line)) {
-    line = trim(line);
-    if (!line.length()) continue;
-    if (line[0] == '#' || line[0] == ';') continue;
-    if (line[0] == '[') {
-      section_name = trim(line.substr(1, line.find(']') - 1));
-      Section new_section(section_name);
-      addSection(new_section);
-      continue;
-    }
-    std::string::size_type pos_equal = line.find('=');
-    if (pos_equal != std::string::npos) {
-      entry_name = trim(line.substr(0, pos_equal));
-      entry_value = trim(line.substr(pos_equal + 1));
-      if (!entry_name.empty()) {
-        Entry new_entry(entry_name, entry_value);
-        sections_[section_name].addEntry(new_entry);
+  // parser state: the section assignments go to, and the value a continuation line would extend (key empty = nothing open)
+  std::string open_section, open_key, open_value;
+  for (std::string physical_line; std::getline(filestream, physical_line);) {
+    const LineToken tok = tokenize(physical_line);
+    switch (tok.kind) {
+      case LineKind::Blank:
+      case LineKind::Comment:
+        break;
+      case LineKind::Header: {
+        open_section = tok.head;
+        Section opened(open_section);
+        addSection(opened);
+        break;
       }
-    } else if (!entry_name.empty()) {
-      // continuation line: appended to the running value and stored (src/settings.cpp:117-124)
-      entry_value += '\n';
-      entry_value += trim(line);
-      sections_[section_name].entries_[entry_name].setValue(entry_value);
+      case LineKind::Assignment: {
+        open_key = tok.head;
+        open_value = tok.tail;
+        if (open_key.empty()) break;   // "= value": dropped, and nothing stays open
+        Entry assigned(open_key, open_value);
+        sections_[open_section].addEntry(assigned);
+        break;
+      }
+      case LineKind::Continuation: {
+        if (open_key.empty()) break;
+        open_value.push_back('\n');
+        open_value.append(tok.head);
+        sections_[open_section].entries_[open_key].setValue(open_value);
+        break;
+      }
     }
   }
-  if (verbose_)
-    for (std::map<std::string, Section>::iterator it = sections_.begin(); it != sections_.end(); ++it) {
-      std::cout << it->second.getName() << std::endl;
-      for (std::map<std::string, Entry>::iterator e = it->second.entries_.begin(); e != it->second.entries_.end(); ++e)
-        std::cout << "    " << e->second.getName() << ": " << e->second.getValue() << std::endl;
-    }
+  if (!verbose_) return;
+  for (const auto& sec : sections_) {
+    std::cout << sec.second.getName() << std::endl;
+    for (const auto& ent : sec.second.entries_) std::cout << "    " << ent.second.getName() << ": " << ent.second.getValue() << std::endl;
+  }
 }
 
 void Settings::addSection(Section& new_section) {
-  if (sections_.find(new_section.getName()) != sections_.end()) {
-    std::cout << "Warning: section " << new_section.getName() << " is already loaded." << std::endl;
-    return;
-  }
-  sections_[new_section.getName()] = new_section;
+  const bool inserted = sections_.insert(std::make_pair(new_section.getName(), new_section)).second;
+  if (!inserted) std::cout << "[settings] section [" << new_section.getName() << "] opened again: later keys join the existing section" << std::endl;
 }
 
 bool Settings::getSection(const std::string& section_name, Section& section) const {
-  std::map<std::string, Section>::const_iterator it = sections_.find(section_name);
-  if (it == sections_.end()) return false;
-  section = it->second;
-  return true;
+  const auto hit = sections_.find(section_name);
+  if (hit != sections_.end()) section = hit->second;
+  return hit != sections_.end();
 }
 
 }  // namespace RGBID_SLAM

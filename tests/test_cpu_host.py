@@ -119,3 +119,41 @@ def test_settings_match_reference_parser_on_shipped_config_files():
                 assert host.settings_get(f, sec, key) == want, (f, sec, key, want)
                 n_keys += want is not None
     assert n_keys > 60
+
+
+def test_settings_match_reference_parser_on_random_grammar(tmp_path):
+    """The product's INI loader is written from the file grammar (host/settings.cpp), not from the reference's source: hold it to the
+    reference's own parser (oracle/_ref) on randomly generated files that mix every production -- headers with and without ']', repeated
+    headers, keys before any header, repeated keys, empty keys, empty values, continuation lines after accepted, refused and dropped
+    assignments, comments, blank and blank-padded lines."""
+    so = os.path.join(ROOT, "oracle", "_ref", "libref_settings.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    ref = ctypes.CDLL(so)
+    rs = np.random.default_rng(20260929)
+    secs, keys = ["A", "B", "", "A B"], ["k", "x", "kd", "long key", ""]
+    pad = lambda: " " * int(rs.integers(0, 3)) + "\t" * int(rs.integers(0, 2))
+    n_hits = 0
+    for case in range(40):
+        lines = []
+        for _ in range(int(rs.integers(5, 40))):
+            kind = int(rs.integers(0, 9))
+            s, k = secs[int(rs.integers(0, len(secs)))], keys[int(rs.integers(0, len(keys)))]
+            v = " ".join(str(int(q)) for q in rs.integers(0, 99, int(rs.integers(0, 4))))
+            if kind == 0: body = ""
+            elif kind == 1: body = ("#" if rs.random() < 0.5 else ";") + " note = 1"
+            elif kind == 2: body = "[" + pad() + s + pad() + ("]" if rs.random() < 0.8 else "") + (" trailing" if rs.random() < 0.2 else "")
+            elif kind in (3, 4, 5): body = k + pad() + "=" + pad() + v + ("= 7" if rs.random() < 0.1 else "")
+            elif kind == 6: body = "=" + v
+            else: body = v if v else "word"
+            lines.append(pad() + body + pad() + ("\r" if rs.random() < 0.1 else ""))
+        path = tmp_path / f"case{case}.ini"
+        path.write_text("\n".join(lines) + ("\n" if rs.random() < 0.5 else ""))
+        for s in secs + ["missing"]:
+            for k in keys + ["missing"]:
+                buf = ctypes.create_string_buffer(8192)
+                n = ref.ref_settings_get(str(path).encode(), s.encode(), k.encode(), buf, 8192)
+                want = None if n < 0 else buf.value.decode()
+                assert host.settings_get(str(path), s, k) == want, (case, s, k, want, lines)
+                n_hits += want is not None
+    assert n_hits > 100
