@@ -412,11 +412,11 @@ struct FusedLatticeGetter {
     int y = ly * stride, x = lx * stride;
     float w1, i1;
     if (fast) {
-      // the ray exactly as the normal-equation kernel forms it for this pixel: evaluated at the start of its 4-pixel group, stepped along x
-      fastnum::Ray r = fastnum::ray(P, (float)(x & ~3), (float)y);
-      for (int i = 0; i < (x & 3); ++i) r = fastnum::ray_step(r, P.R[0], P.R[3], P.R[6]);
-      w1 = fastnum::warp_invdepth_px(FMap(cur_iD, lane), r, w0, P);
-      i1 = fastnum::warp_intensity_px(FMap(cur_I, lane), r, w1, P, interp_mode);
+      // the same functions of the pixel as the normal-equation kernel that follows: identical W1 / I1, identical selection
+      const fastnum::Guard G = fastnum::lane_guard(P, cur_iD.cols, cur_iD.rows);
+      const fastnum::Ray r = fastnum::ray(P, (float)x, (float)y);
+      w1 = fastnum::warp_invdepth_px(FMap(cur_iD, lane), r, x, y, w0, P, G);
+      i1 = fastnum::warp_intensity_px(FMap(cur_I, lane), r, x, y, w1, P, G, interp_mode);
     } else {
       w1 = warp_invdepth_px(FMap(cur_iD, lane), x, y, w0, P);
       i1 = warp_intensity_px(FMap(cur_I, lane), x, y, w1, P, interp_mode);

@@ -241,6 +241,8 @@ __global__ __launch_bounds__(SYS_T) __attribute__((amdgpu_waves_per_eu(FUSED == 
       const unsigned pitch_b = (unsigned)W0.pitch;
       auto unit_off = [&](int yy, int xx) { return __umul24((unsigned)yy, pitch_b) + ((unsigned)xx << 2); };
       const int im = WM == 1 ? 1 : fa.interp_mode;   // variant 1 also fixes the 1.8 fixed-point bilinear weights (launcher)
+      const fastnum::Guard G = fastnum::lane_guard(WP, Wc.cols, Wc.rows);
+      const fastnum::BorderBand BB = fastnum::border_band(G, Ic.cols, Ic.rows);
       bool live = nt > 0 && xu < upr && y < rows;               // ragged right / bottom tiles
       float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (live) w0 = ld_stream4(reinterpret_cast<const float*>(bW0 + unit_off(y, xu << 2)));
@@ -257,26 +259,65 @@ __global__ __launch_bounds__(SYS_T) __attribute__((amdgpu_waves_per_eu(FUSED == 
         const float4 i0 = ld_stream4(reinterpret_cast<const float*>(bI0 + off)), a = ld_stream4(reinterpret_cast<const float*>(bA + off)),
                      b = ld_stream4(reinterpret_cast<const float*>(bB + off)), c = ld_stream4(reinterpret_cast<const float*>(bC + off)),
                      d = ld_stream4(reinterpret_cast<const float*>(bD + off));
-        const fastnum::Ray r0 = fastnum::ray(WP, (float)x, (float)y);
-        const fastnum::Ray r1 = fastnum::ray_step(r0, WP.R[0], WP.R[3], WP.R[6]), r2 = fastnum::ray_step(r1, WP.R[0], WP.R[3], WP.R[6]),
-                           r3 = fastnum::ray_step(r2, WP.R[0], WP.R[3], WP.R[6]);
+        // fast values, the oracle's selection (warp_device.h fastnum, guard_band.h): the four projections, then -- for the few pixels per thousand
+        // whose coordinates lie inside the guard band -- the oracle's coordinates under a wave-level branch, then the four gathers
+        const fastnum::RowRay rr = fastnum::row_ray(WP, (float)y);
+        const float xf = (float)x;
+        const fastnum::Ray r0 = fastnum::ray_at(WP, rr, xf), r1 = fastnum::ray_at(WP, rr, xf + 1.f), r2 = fastnum::ray_at(WP, rr, xf + 2.f),
+                           r3 = fastnum::ray_at(WP, rr, xf + 3.f);
+        // per pixel: projection -> [the oracle's coordinates if inside the guard band] -> gather issued; the flags die with the pixel (SGPR pairs)
+        bool fc, f0, f1, f2, f3;
+        fastnum::IdProj p0 = fastnum::id_project(r0, w0.x, WP, G, Wc.cols, Wc.rows, fc);
+        if (__builtin_expect(fc, 0)) fastnum::id_fix_coords(p0, x, y, WP, Wc.cols, Wc.rows);
+        const float s0 = Wc.at(p0.iy, p0.ix);   // unclamped (warp_device.h)
+        fastnum::IdProj p1 = fastnum::id_project(r1, w0.y, WP, G, Wc.cols, Wc.rows, fc);
+        if (__builtin_expect(fc, 0)) fastnum::id_fix_coords(p1, x + 1, y, WP, Wc.cols, Wc.rows);
+        const float s1 = Wc.at(p1.iy, p1.ix);
+        fastnum::IdProj p2 = fastnum::id_project(r2, w0.z, WP, G, Wc.cols, Wc.rows, fc);
+        if (__builtin_expect(fc, 0)) fastnum::id_fix_coords(p2, x + 2, y, WP, Wc.cols, Wc.rows);
+        const float s2 = Wc.at(p2.iy, p2.ix);
+        fastnum::IdProj p3 = fastnum::id_project(r3, w0.w, WP, G, Wc.cols, Wc.rows, fc);
+        if (__builtin_expect(fc, 0)) fastnum::id_fix_coords(p3, x + 3, y, WP, Wc.cols, Wc.rows);
+        const float s3 = Wc.at(p3.iy, p3.ix);
         float4 w1;
-        w1.x = fastnum::warp_invdepth_px(Wc, r0, w0.x, WP); w1.y = fastnum::warp_invdepth_px(Wc, r1, w0.y, WP);
-        w1.z = fastnum::warp_invdepth_px(Wc, r2, w0.z, WP); w1.w = fastnum::warp_invdepth_px(Wc, r3, w0.w, WP);
-        const fastnum::IntensityTaps t0 = fastnum::intensity_taps(Ic, r0, w1.x, WP, im), t1 = fastnum::intensity_taps(Ic, r1, w1.y, WP, im),
-                                     t2 = fastnum::intensity_taps(Ic, r2, w1.z, WP, im), t3 = fastnum::intensity_taps(Ic, r3, w1.w, WP, im);
+        w1.x = fastnum::id_finish(p0, s0, WP, G, f0); w1.y = fastnum::id_finish(p1, s1, WP, G, f1);
+        w1.z = fastnum::id_finish(p2, s2, WP, G, f2); w1.w = fastnum::id_finish(p3, s3, WP, G, f3);
+        if (__builtin_expect(f0 | f1 | f2 | f3, 0)) {   // the sign of the oracle's value is not implied by the fast one (never on data of the stated domain and sane motion)
+          if (f0) w1.x = warp_invdepth_px(Wc, x, y, w0.x, WP);
+          if (f1) w1.y = warp_invdepth_px(Wc, x + 1, y, w0.y, WP);
+          if (f2) w1.z = warp_invdepth_px(Wc, x + 2, y, w0.z, WP);
+          if (f3) w1.w = warp_invdepth_px(Wc, x + 3, y, w0.w, WP);
+        }
+        bool bd;
+        fastnum::IntensityTaps t0 = fastnum::intensity_taps(Ic, r0, w1.x, WP, BB, im, bd);
+        if (__builtin_expect(bd, 0)) t0.ok = fastnum::intensity_fix_border(Ic, r0, x, y, w1.x, WP, G);   // not safely inside the image: surely outside, or the oracle's predicate
+        fastnum::IntensityTaps t1 = fastnum::intensity_taps(Ic, r1, w1.y, WP, BB, im, bd);
+        if (__builtin_expect(bd, 0)) t1.ok = fastnum::intensity_fix_border(Ic, r1, x + 1, y, w1.y, WP, G);
+        fastnum::IntensityTaps t2 = fastnum::intensity_taps(Ic, r2, w1.z, WP, BB, im, bd);
+        if (__builtin_expect(bd, 0)) t2.ok = fastnum::intensity_fix_border(Ic, r2, x + 2, y, w1.z, WP, G);
+        fastnum::IntensityTaps t3 = fastnum::intensity_taps(Ic, r3, w1.w, WP, BB, im, bd);
+        if (__builtin_expect(bd, 0)) t3.ok = fastnum::intensity_fix_border(Ic, r3, x + 3, y, w1.w, WP, G);
         if (live_n) w0n = ld_stream4(reinterpret_cast<const float*>(bW0 + unit_off(yn, xn << 2)));
         float py_ = ((float)y - C.cy_f) * C.inv_fy, pp_y = fmaf(py_, py_, 1.f);
         float px0 = ((float)x - C.cx_f) * C.inv_fx;
         // each pixel's taps are waited for where its rows are built (RGBID_SYS_PIXEL_FENCE keeps the scheduler from hoisting all four
         // waits to the top of the unit when the per-pixel code is branch-free): the later gathers land under the earlier pixels' updates
-        accumulate_pixel<WM>(acc, px0, py_, pp_y, w0.x, i0.x, a.x, b.x, c.x, d.x, w1.x, fastnum::intensity_finish(t0), P, C);
+        bool nt;
+        float i1v = fastnum::intensity_finish(t0, nt);
+        if (__builtin_expect(nt, 0)) i1v = warp_intensity_px(Ic, x, y, w1.x, WP, im);   // a NaN tap (corner pixels of levels >= 1): the oracle's texel pair decides
+        accumulate_pixel<WM>(acc, px0, py_, pp_y, w0.x, i0.x, a.x, b.x, c.x, d.x, w1.x, i1v, P, C);
         RGBID_SYS_PIXEL_FENCE;
-        accumulate_pixel<WM>(acc, px0 + C.inv_fx, py_, pp_y, w0.y, i0.y, a.y, b.y, c.y, d.y, w1.y, fastnum::intensity_finish(t1), P, C);
+        i1v = fastnum::intensity_finish(t1, nt);
+        if (__builtin_expect(nt, 0)) i1v = warp_intensity_px(Ic, x + 1, y, w1.y, WP, im);
+        accumulate_pixel<WM>(acc, px0 + C.inv_fx, py_, pp_y, w0.y, i0.y, a.y, b.y, c.y, d.y, w1.y, i1v, P, C);
         RGBID_SYS_PIXEL_FENCE;
-        accumulate_pixel<WM>(acc, fmaf(2.f, C.inv_fx, px0), py_, pp_y, w0.z, i0.z, a.z, b.z, c.z, d.z, w1.z, fastnum::intensity_finish(t2), P, C);
+        i1v = fastnum::intensity_finish(t2, nt);
+        if (__builtin_expect(nt, 0)) i1v = warp_intensity_px(Ic, x + 2, y, w1.z, WP, im);
+        accumulate_pixel<WM>(acc, fmaf(2.f, C.inv_fx, px0), py_, pp_y, w0.z, i0.z, a.z, b.z, c.z, d.z, w1.z, i1v, P, C);
         RGBID_SYS_PIXEL_FENCE;
-        accumulate_pixel<WM>(acc, fmaf(3.f, C.inv_fx, px0), py_, pp_y, w0.w, i0.w, a.w, b.w, c.w, d.w, w1.w, fastnum::intensity_finish(t3), P, C);
+        i1v = fastnum::intensity_finish(t3, nt);
+        if (__builtin_expect(nt, 0)) i1v = warp_intensity_px(Ic, x + 3, y, w1.w, WP, im);
+        accumulate_pixel<WM>(acc, fmaf(3.f, C.inv_fx, px0), py_, pp_y, w0.w, i0.w, a.w, b.w, c.w, d.w, w1.w, i1v, P, C);
         } else if (live_n) w0n = ld_stream4(reinterpret_cast<const float*>(bW0 + unit_off(yn, xn << 2)));
         w0 = w0n; live = live_n; y = yn; xu = xn; ty = tyn; sx = sxn;
       }
@@ -322,7 +363,11 @@ __global__ __launch_bounds__(SYS_T) __attribute__((amdgpu_waves_per_eu(FUSED == 
       if (u < units) {
         int y = u / cols, x = u - y * cols;
         float w0 = px<float>(W0, lane, y, x), w1, i1;
-        if (FUSED == 2) { const fastnum::Ray r = fastnum::ray(WP, (float)x, (float)y); w1 = fastnum::warp_invdepth_px(Wc, r, w0, WP); i1 = fastnum::warp_intensity_px(Ic, r, w1, WP, fa.interp_mode); }
+        if (FUSED == 2) {
+          const fastnum::Guard G = fastnum::lane_guard(WP, Wc.cols, Wc.rows);
+          const fastnum::Ray r = fastnum::ray(WP, (float)x, (float)y);
+          w1 = fastnum::warp_invdepth_px(Wc, r, x, y, w0, WP, G); i1 = fastnum::warp_intensity_px(Ic, r, x, y, w1, WP, G, fa.interp_mode);
+        }
         else if (FUSED) { w1 = warp_invdepth_px(Wc, x, y, w0, WP); i1 = warp_intensity_px(Ic, x, y, w1, WP, fa.interp_mode); }
         else { w1 = px<float>(W1, lane, y, x); i1 = px<float>(I1, lane, y, x); }
         float py_ = ((float)y - C.cy_f) * C.inv_fy, pp_y = fmaf(py_, py_, 1.f);

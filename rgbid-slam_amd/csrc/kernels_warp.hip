@@ -148,14 +148,44 @@ __global__ __launch_bounds__(256) void k_warp_pair_fast(ImgB src_iD, ImgB src_I,
   float wv[RPB], w1[RPB], i1[RPB];
 #pragma unroll
   for (int i = 0; i < RPB; ++i) { int y = yb + i * TY; wv[i] = (y < dst_iD.rows) ? G.at(y, x) : qnan(); }
-  // the ray of a pixel is DEFINED as: evaluated at the first pixel of its 4-pixel group, stepped along x (so that this kernel, the fused
-  // normal-equation kernel -- which owns whole groups -- and the sigma / nu lattice agree bit for bit)
+  // the ray of a pixel is a function of the pixel alone (warp_device.h ray_at), so this kernel, the fused normal-equation kernel and the
+  // sigma / nu lattice agree bit for bit
+  const fastnum::Guard GB = fastnum::lane_guard(P, dst_iD.cols, dst_iD.rows);
+  const fastnum::BorderBand BB = fastnum::border_band(GB, SI.cols, SI.rows);
+  // phases over the thread's RPB pixels (a branch between a gather and its use would serialise their chains): projections (+ the oracle's
+  // coordinates inside the guard band) -> point-sample gathers -> warped inverse depths -> tap loads (+ the oracle's in-image predicate) -> blends
+  fastnum::Ray q[RPB];
+  fastnum::IdProj pr[RPB];
+  float s2[RPB];
+  bool fr[RPB];
 #pragma unroll
   for (int i = 0; i < RPB; ++i) {
-    fastnum::Ray q = fastnum::ray(P, (float)(x & ~3), (float)(yb + i * TY));
-    for (int k = 0; k < (x & 3); ++k) q = fastnum::ray_step(q, P.R[0], P.R[3], P.R[6]);
-    w1[i] = fastnum::warp_invdepth_px(SD, q, wv[i], P);
-    i1[i] = fastnum::warp_intensity_px(SI, q, w1[i], P, interp_mode);
+    const int y = yb + i * TY;
+    q[i] = fastnum::ray(P, (float)x, (float)y);
+    bool fc;
+    pr[i] = fastnum::id_project(q[i], wv[i], P, GB, SD.cols, SD.rows, fc);
+    if (__builtin_expect(fc, 0)) fastnum::id_fix_coords(pr[i], x, y, P, SD.cols, SD.rows);
+  }
+#pragma unroll
+  for (int i = 0; i < RPB; ++i) s2[i] = SD.at(pr[i].iy, pr[i].ix);   // unclamped (warp_device.h)
+#pragma unroll
+  for (int i = 0; i < RPB; ++i) w1[i] = fastnum::id_finish(pr[i], s2[i], P, GB, fr[i]);
+  if (__builtin_expect(fr[0] | fr[1] | fr[2] | fr[3], 0)) {
+#pragma unroll
+    for (int i = 0; i < RPB; ++i) if (fr[i]) w1[i] = warp_invdepth_px(SD, x, yb + i * TY, wv[i], P);
+  }
+  fastnum::IntensityTaps tp[RPB];
+#pragma unroll
+  for (int i = 0; i < RPB; ++i) {
+    bool bd;
+    tp[i] = fastnum::intensity_taps(SI, q[i], w1[i], P, BB, interp_mode, bd);
+    if (__builtin_expect(bd, 0)) tp[i].ok = fastnum::intensity_fix_border(SI, q[i], x, yb + i * TY, w1[i], P, GB);
+  }
+#pragma unroll
+  for (int i = 0; i < RPB; ++i) {
+    bool nan_tap;
+    i1[i] = fastnum::intensity_finish(tp[i], nan_tap);
+    if (__builtin_expect(nan_tap, 0)) i1[i] = warp_intensity_px(SI, x, yb + i * TY, w1[i], P, interp_mode);   // a NaN tap: the oracle's texel pair decides
   }
 #pragma unroll
   for (int i = 0; i < RPB; ++i) {
@@ -321,17 +351,33 @@ __global__ __launch_bounds__(256) void k_fuse_frame4(ImgB src, ImgB kf, ImgB kfw
       k4[g] = make_float4(a_.x, a_.y, a_.z, a_.w); q4[g] = make_float4(b_.x, b_.y, b_.z, b_.w);
     }
   }
-  float ws[FUSE_UNITS][4], wt[FUSE_UNITS][4];
+  float ws[FUSE_UNITS][4], wt[FUSE_UNITS][4], eps[FUSE_UNITS][4];
   bool st[FUSE_UNITS][4];
-  if (FAST) {   // reference-build-class numerics (warp_device.h fastnum): the ray of the group's first pixel stepped along x
+  if (FAST) {   // fast values, the oracle's selection (warp_device.h fastnum)
+    const fastnum::Guard G = fastnum::lane_guard(P, kf.cols, kf.rows);
 #pragma unroll
     for (int g = 0; g < FUSE_UNITS; ++g) {
       const float k[4] = {k4[g].x, k4[g].y, k4[g].z, k4[g].w};
-      fastnum::Ray r = fastnum::ray(P, (float)xs_[g], (float)ys_[g]);
+      const fastnum::RowRay rr = fastnum::row_ray(P, (float)ys_[g]);
+      // the four projections (+ the oracle's coordinates inside the guard band), then the four gathers, then the four values
+      fastnum::IdProj pr[4];
+      float w2[4];
+      bool fr[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        ws[g][i] = fastnum::warp_invdepth_weighted_px(S, r, k[i], P, wt[g][i], st[g][i]);
-        r = fastnum::ray_step(r, P.R[0], P.R[3], P.R[6]);
+        bool fc;
+        pr[i] = fastnum::id_project(fastnum::ray_at(P, rr, (float)(xs_[g] + i)), k[i], P, G, S.cols, S.rows, fc);
+        if (__builtin_expect(fc, 0)) fastnum::id_fix_coords(pr[i], xs_[g] + i, ys_[g], P, S.cols, S.rows);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w2[i] = S.at(pr[i].iy, pr[i].ix);   // unclamped (warp_device.h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ws[g][i] = fastnum::id_finish_weighted(pr[i], w2[i], P, G, wt[g][i], st[g][i], eps[g][i], fr[i]);
+      if (__builtin_expect(fr[0] | fr[1] | fr[2] | fr[3], 0)) {   // the sign of the oracle's value is not implied (guard_band.h (4)): the oracle's pixel
+        RcpIeee ieee;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (fr[i]) { ws[g][i] = warp_invdepth_weighted_px_t(S, xs_[g] + i, ys_[g], k[i], P, ieee, wt[g][i], st[g][i]); eps[g][i] = 0.f; }
       }
     }
   } else {
@@ -358,7 +404,19 @@ __global__ __launch_bounds__(256) void k_fuse_frame4(ImgB src, ImgB kf, ImgB kfw
     float k[4] = {k4[g].x, k4[g].y, k4[g].z, k4[g].w}, q[4] = {q4[g].x, q4[g].y, q4[g].z, q4[g].w};
     if (FAST) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) integrate_px(ws[g][i], st[g][i] ? wt[g][i] : 0.f, k[i], q[i]);
+      for (int i = 0; i < 4; ++i) {
+        float wsi = ws[g][i], qsi = st[g][i] ? wt[g][i] : 0.f;
+        // the fusion gate |w_s - w_KF| < 3 * 0.0075 (:653) is open when the fast value lies within its error bound of the threshold
+        // (guard_band.h (5)): that pixel is warped again with the oracle's instruction sequence and fuses ITS value and weight
+        const float gap = fabsf(fabsf(wsi - k[i]) - 3 * 0.0075f);
+        if (__builtin_expect(gap <= __builtin_fmaf(fabsf(wsi), eps[g][i], 4.f * 0x1p-24f * 0.0225f), 0)) {
+          RcpIeee ieee;
+          float wte; bool ste;
+          wsi = warp_invdepth_weighted_px_t(S, xs_[g] + i, ys_[g], k[i], P, ieee, wte, ste);
+          qsi = ste ? wte : 0.f;
+        }
+        integrate_px(wsi, qsi, k[i], q[i]);
+      }
     } else {
       float* wp = row_ptr<float>(wweight, lane, ys_[g]) + xs_[g];
       const bool all_st = st[g][0] & st[g][1] & st[g][2] & st[g][3];
@@ -469,13 +527,6 @@ __global__ __launch_bounds__(256) void k_visibility(ImgB src, ImgB dst, ImgB mas
 // the pair: each thread loads its pixel of A and of B (coalesced) and runs the two projection -> gather -> gate chains side by side --
 // the single-direction kernel is latency-bound (SQ counters: waves parked 75 % of their cycles), so the second independent chain is
 // nearly free, and two of the four launches per frame disappear.  Counters: counts_ab / counts_ba as in k_visibility.
-__device__ __forceinline__ bool visible_px(const FMap& D, int cols, int rows, int x, int y, float w, bool valid, const WarpParams& P) {
-  float xd, yd;
-  float w_dst = register_pixel(xd, yd, x, y, valid ? w : 1.f, P);
-  bool inside_img = (xd > 0) && (xd < (float)(cols - 1)) && (yd > 0) && (yd < (float)(rows - 1));
-  int xi = clampi(__float2int_rn(xd), cols - 1), yi = clampi(__float2int_rn(yd), rows - 1);
-  return valid && inside_img && (fabsf(w_dst - D.at(yi, xi)) < 0.020f);
-}
 template <bool FAST>
 __global__ __launch_bounds__(256) void k_visibility_pair(ImgB A, ImgB Bm, const WarpParams* p_ab, const WarpParams* p_ba, unsigned int* counts_ab,
                                                          unsigned int* counts_ba, LaneMask m) {
@@ -485,6 +536,7 @@ __global__ __launch_bounds__(256) void k_visibility_pair(ImgB A, ImgB Bm, const 
   const WarpParams Pab = p_ab[lane], Pba = p_ba[lane];
   const FMap FA(A, lane), FB(Bm, lane);
   const int cols = A.cols, rows = A.rows;
+  const fastnum::Guard Gab = FAST ? fastnum::lane_guard(Pab, cols, rows) : fastnum::Guard{}, Gba = FAST ? fastnum::lane_guard(Pba, cols, rows) : fastnum::Guard{};
   const int x = blockIdx.x * TX + threadIdx.x;
   const bool xin = x < cols;
   unsigned int n[4] = {0, 0, 0, 0};  // visible a->b, valid a, visible b->a, valid b
@@ -498,20 +550,35 @@ __global__ __launch_bounds__(256) void k_visibility_pair(ImgB A, ImgB Bm, const 
       wa[i] = in ? FA.at(y, x) : qnan();
       wb[i] = in ? FB.at(y, x) : qnan();
     }
+    if (FAST) {
+      // all four projections (+ the oracle's coordinates where the guard band asks for them), then the four gathers, then the four gates
+      fastnum::VisProj pa[2], pb[2];
+      float da[2], db[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int y = yb + i * TY;
-      const bool va = !isnan(wa[i]), vb = !isnan(wb[i]);
-      bool sa, sb;
-      if (FAST) {
-        sa = fastnum::visible_px(FB, cols, rows, fastnum::ray(Pab, (float)x, (float)y), wa[i], va, Pab);
-        sb = fastnum::visible_px(FA, cols, rows, fastnum::ray(Pba, (float)x, (float)y), wb[i], vb, Pba);
-      } else {
-        sa = visible_px(FB, cols, rows, x, y, wa[i], va, Pab);
-        sb = visible_px(FA, cols, rows, x, y, wb[i], vb, Pba);
+      for (int i = 0; i < 2; ++i) {
+        const int y = yb + i * TY;
+        pa[i] = fastnum::vis_project(cols, rows, fastnum::ray(Pab, (float)x, (float)y), x, y, wa[i], Pab, Gab);
+        pb[i] = fastnum::vis_project(cols, rows, fastnum::ray(Pba, (float)x, (float)y), x, y, wb[i], Pba, Gba);
       }
-      n[0] += (unsigned int)__popcll(__ballot(sa)); n[1] += (unsigned int)__popcll(__ballot(va));
-      n[2] += (unsigned int)__popcll(__ballot(sb)); n[3] += (unsigned int)__popcll(__ballot(vb));
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { da[i] = FB.at(pa[i].yi, pa[i].xi); db[i] = FA.at(pb[i].yi, pb[i].xi); }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int y = yb + i * TY;
+        const bool va = !isnan(wa[i]), vb = !isnan(wb[i]);
+        const bool sa = va & fastnum::vis_gate(pa[i], da[i], x, y, Pab, Gab), sb = vb & fastnum::vis_gate(pb[i], db[i], x, y, Pba, Gba);
+        n[0] += (unsigned int)__popcll(__ballot(sa)); n[1] += (unsigned int)__popcll(__ballot(va));
+        n[2] += (unsigned int)__popcll(__ballot(sb)); n[3] += (unsigned int)__popcll(__ballot(vb));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int y = yb + i * TY;
+        const bool va = !isnan(wa[i]), vb = !isnan(wb[i]);
+        const bool sa = visible_px_exact(FB, cols, rows, x, y, wa[i], va, Pab), sb = visible_px_exact(FA, cols, rows, x, y, wb[i], vb, Pba);
+        n[0] += (unsigned int)__popcll(__ballot(sa)); n[1] += (unsigned int)__popcll(__ballot(va));
+        n[2] += (unsigned int)__popcll(__ballot(sb)); n[3] += (unsigned int)__popcll(__ballot(vb));
+      }
     }
   }
   if (threadIdx.x == 0) { for (int k = 0; k < 4; ++k) sm[k][threadIdx.y] = n[k]; }  // one wave per threadIdx.y (TX == 64)

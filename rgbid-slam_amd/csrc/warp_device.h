@@ -10,6 +10,7 @@
 // __float2int_rd/_rn semantics that registerPixel's callers rely on -- so the conversions need no range checks.
 #pragma once
 #include "common.h"
+#include "guard_band.h"
 
 namespace rgbid {
 
@@ -164,19 +165,36 @@ __device__ __forceinline__ float warp_intensity_px(const FMap& src, int x, int y
   return res;
 }
 
+// one direction of computeCovisibility's gate (partialVisibilityKernel :297-360), the oracle's evaluation
+__device__ __forceinline__ bool visible_px_exact(const FMap& D, int cols, int rows, int x, int y, float w, bool valid, const WarpParams& P) {
+#pragma clang fp contract(off)
+  float xd, yd;
+  float w_dst = register_pixel(xd, yd, x, y, valid ? w : 1.f, P);
+  bool inside_img = (xd > 0) && (xd < (float)(cols - 1)) && (yd > 0) && (yd < (float)(rows - 1));
+  int xi = clampi(__float2int_rn(xd), cols - 1), yi = clampi(__float2int_rn(yd), rows - 1);
+  return valid && inside_img && (fabsf(w_dst - D.at(yi, xi)) < 0.020f);
+}
+
 // =====================================================================================================================================
-// "Reference-build-class" numerics for the ENGINE's gather kernels (rgbid_engine_config.fast_numerics, default on).
+// FAST numerics class of the ENGINE's gather kernels (rgbid_engine_config.fast_numerics, default on): cheap VALUES, the oracle's SELECTION.
 //
 // The reference compiles its kernels with --prec-div=false --prec-sqrt=false --ftz=true (CMakeLists.txt:105) and nvcc's default FMA
-// contraction: its own pixel selection is that of approximate reciprocals and fused multiply-adds, not of IEEE arithmetic.  The functions
-// above reproduce the IEEE evaluation of the scalar oracle bit for bit (the compat bridge always uses them); the functions below evaluate
-// the same formulas in the reference build's class of arithmetic -- v_rcp_f32 (1 ulp) for every division, explicit FMAs, the ray
-// q = R (x, y, 1) formed once per pixel and shared by every projection from that pixel (registerPixel, warping_registration.cu:129-146,
-// re-associated: R (x z, y z, z) + t = z q + t, and projected from the scaled point w X = q + w t so that no reciprocal of the inverse depth
-// is taken), 1 / (1 / X.z) taken as X.z -- which removes ~45 % of the instructions of kernels that
-// are VALU-bound.  What changes: a coordinate that lands within an ulp of a pixel boundary may select the neighbouring pixel.  Measured
-// against the exact kernels (tests/test_gpu_engine.py::test_engine_fast_numerics_vs_exact): a few boundary pixels per map, poses
-// within 1e-6; the oracle's model of the reference's nvcc flags moves poses by the same order (tests/test_oracle_cuda_numerics.py).
+// contraction: its own arithmetic is approximate reciprocals and fused multiply-adds, not IEEE.  The functions above reproduce the IEEE
+// evaluation of the scalar oracle bit for bit (the compat bridge always uses them); the functions below evaluate the same formulas in
+// the reference build's class of arithmetic -- v_rcp_f32 (1 ulp) for every division, explicit FMAs, the ray q = R (x, y, 1) formed once per
+// pixel and shared by every projection from that pixel (registerPixel, warping_registration.cu:129-146, re-associated:
+// R (x z, y z, z) + t = z q + t, and projected from the scaled point w X = q + w t so that no reciprocal of the inverse depth is taken),
+// 1 / (1 / X.z) taken as X.z -- which removes ~45 % of the instructions of kernels that are VALU-bound.
+//
+// Round 4: every DISCRETE decision -- which source pixel is point-sampled, whether a projection lies inside the image, the sign test of the
+// warped value, the covisibility lattice point, the covisibility / fusion gates, the texel pair of a bilinear sample that meets a NaN texel -- is
+// the ORACLE's, bit for bit.  A cheap coordinate can only flip such a decision when it lies within a proven error bound (guard_band.h) of the
+// decision's threshold; those pixels (a few per thousand) are recomputed with the exact instruction sequence under a wave-level branch,
+// everything else keeps the fast arithmetic.  What still differs from the oracle are float values in their last bits, and the 1.8 fixed-point
+// bilinear weight where a coordinate sits within the bound of a 1/256 step (a value step of 1/256 of the local contrast, no selection).
+// Structure rule for the kernels: a branch between a gather and its use makes the wave wait for that gather there, which serialises the
+// independent chains of a thread's pixels -- so kernels run the projections (+ coordinate fixes) of ALL their pixels, then the gathers, then the
+// finishing steps (measured: the covisibility pair 2.0 x slower, the fusion 13 % slower with per-pixel branch -> gather -> branch chains).
 namespace fastnum {
 
 // Rejected pixels (coordinates outside the image, invalid inverse depth) are not clamped to a legal address first, as the exact functions do:
@@ -186,56 +204,111 @@ __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x);
 // floor + saturating convert in one instruction (NaN -> 0); verified against v_floor_f32 + v_cvt_i32_f32 by rgbid_selftest_cvt_flr
 __device__ __forceinline__ int cvt_flr(float x) { int r; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
 
-struct Ray { float q0, q1, q2; };   // K R^-1 K^-1 (x, y, 1)
-__device__ __forceinline__ Ray ray(const WarpParams& P, float xf, float yf) {
-  Ray r;
-  r.q0 = __builtin_fmaf(P.R[0], xf, __builtin_fmaf(P.R[1], yf, P.R[2]));
-  r.q1 = __builtin_fmaf(P.R[3], xf, __builtin_fmaf(P.R[4], yf, P.R[5]));
-  r.q2 = __builtin_fmaf(P.R[6], xf, __builtin_fmaf(P.R[7], yf, P.R[8]));
-  return r;
+// the guard constants of a lane as wave-uniform scalars (guard_band.h make_guard on uniform inputs; readfirstlane pins them to SGPRs)
+__device__ __forceinline__ float uniform_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ Guard lane_guard(const WarpParams& P, int cols, int rows) {
+  Guard g = make_guard(P.R, P.t, cols, rows);
+  g.d1 = uniform_f(g.d1); g.c2 = uniform_f(g.c2); g.d2 = uniform_f(g.d2); g.q0 = uniform_f(g.q0); g.q1 = uniform_f(g.q1); g.db = uniform_f(g.db);
+  g.g0 = uniform_f(g.g0); g.g1 = uniform_f(g.g1); g.e0 = uniform_f(g.e0); g.e1 = uniform_f(g.e1);
+  g.zsafe = __builtin_amdgcn_readfirstlane(g.zsafe);
+#ifdef RGBID_EXPERIMENT_GUARD_NEVER_FIRES   // timing experiment only (tools/build_variant.sh): the checks run, no pixel is ever recomputed
+  g.d1 = uniform_f(0.f); g.c2 = uniform_f(10.f); g.db = uniform_f(-1e9f); g.d2 = uniform_f(0.f);
+#endif
+  return g;
 }
-__device__ __forceinline__ Ray ray_step(const Ray& r, float d0, float d1, float d2) { return Ray{r.q0 + d0, r.q1 + d1, r.q2 + d2}; }
+
+// the part of the ray q = K R^-1 K^-1 (x, y, 1) that a pixel row shares, and the ray of one pixel of the row: q_r = fl(R[3r] x + fl(R[3r+1] y + R[3r+2]))
+// (two FMAs: the evaluation the bound (F) of guard_band.h is proven for; a function of the pixel alone, whatever kernel asks)
+struct RowRay { float c0, c1, c2; };
+struct Ray { float q0, q1, q2; };
+__device__ __forceinline__ RowRay row_ray(const WarpParams& P, float yf) {
+  return RowRay{__builtin_fmaf(P.R[1], yf, P.R[2]), __builtin_fmaf(P.R[4], yf, P.R[5]), __builtin_fmaf(P.R[7], yf, P.R[8])};
+}
+__device__ __forceinline__ Ray ray_at(const WarpParams& P, const RowRay& c, float xf) {
+  return Ray{__builtin_fmaf(P.R[0], xf, c.c0), __builtin_fmaf(P.R[3], xf, c.c1), __builtin_fmaf(P.R[6], xf, c.c2)};
+}
+__device__ __forceinline__ Ray ray(const WarpParams& P, float xf, float yf) { return ray_at(P, row_ray(P, yf), xf); }
 // The back-projected, transformed point X = q / w + t of a pixel with inverse depth w, scaled by w: Y = w X = q + w t.  Y projects to the same
 // pixel as X (Y.x / Y.z = X.x / X.z) and needs no reciprocal of w; the depth along the keyframe ray comes out as (X.z - t_z) w = q_z.
 struct Scaled { float y0, y1, y2; };
 __device__ __forceinline__ Scaled scaled_point(const Ray& q, float w, const WarpParams& P) {
   return Scaled{__builtin_fmaf(P.t[0], w, q.q0), __builtin_fmaf(P.t[1], w, q.q1), __builtin_fmaf(P.t[2], w, q.q2)};
 }
-
-// trafo3DKernelInvDepthGridStride (:505-546), one pixel
-__device__ __forceinline__ float warp_invdepth_px(const FMap& src, const Ray& q, float w, const WarpParams& P) {
-  const bool valid = w > 0.f;   // an inverse depth of 0 (a point at infinity) is rejected like NaN, as the exact path ends up doing
-  const float ws = valid ? w : 1.f;
-  const Scaled Y = scaled_point(q, ws, P);
-  const float wc = rcp(Y.y2);
-  const float xs = __builtin_fmaf(Y.y0, wc, 0.5f), ys = __builtin_fmaf(Y.y1, wc, 0.5f);
-  const int ix = cvt_flr(xs), iy = cvt_flr(ys);
-  const bool inb = inside(ix, iy, src.cols, src.rows);
-  const float w2 = src.at(iy, ix);   // unclamped: see the note on rejected pixels above
-  const float res = (q.q2 * rcp(__builtin_fmaf(-w2, P.t[2], 1.f))) * w2;   // v1_z = (X.z - t_z) w = q_z
-  return (valid & inb & (res > 0.f)) ? res : qnan();
+// a grid inverse depth of the FAST domain [W_LO, W_HI], or the stand-in for an invalid one (NaN, <= 0, out of the domain): one v_med3_f32 (NaN
+// operands make it a min3, which skips them) + one compare -- the cost of the `w > 0` + select it replaces
+__device__ __forceinline__ float sanitised(float w, bool& valid) {
+  const float ws = __builtin_amdgcn_fmed3f(w, W_LO, W_HI);
+  valid = ws == w;
+  return ws;
 }
 
-// the weighted variant (:549-594): warped inverse depth + weight (1 - w2 tz)^4 / v^2
-__device__ __forceinline__ float warp_invdepth_weighted_px(const FMap& src, const Ray& q, float w, const WarpParams& P, float& weight_res, bool& store_weight) {
-  const bool valid = w > 0.f;   // an inverse depth of 0 (a point at infinity) is rejected like NaN, as the exact path ends up doing
-  const float ws = valid ? w : 1.f;
-  const Scaled Y = scaled_point(q, ws, P);
+// ---- trafo3DKernelInvDepthGridStride (:505-546), one pixel, in steps so that a kernel can run the steps of several pixels side by side:
+// id_project (coordinates + guard verdict) -> [id_fix_coords for flagged pixels] -> gather -> id_finish -> [exact pixel where the sign is open]
+struct IdProj {
+  float ws, q2;       // sanitised inverse depth; depth along the keyframe ray times w (= the oracle's v1_z)
+  int ix, iy;         // source pixel of the point sample
+  bool ok;            // inverse depth valid and source pixel inside the image
+};
+// `fixc`: the coordinates lie inside the guard band -- the caller replaces them by the oracle's (id_fix_coords) before it gathers
+__device__ __forceinline__ IdProj id_project(const Ray& q, float w, const WarpParams& P, const Guard& G, int cols, int rows, bool& fixc) {
+  IdProj r;
+  bool valid;
+  r.ws = sanitised(w, valid);
+  r.q2 = q.q2;
+  const Scaled Y = scaled_point(q, r.ws, P);
   const float wc = rcp(Y.y2);
   const float xs = __builtin_fmaf(Y.y0, wc, 0.5f), ys = __builtin_fmaf(Y.y1, wc, 0.5f);
-  const int ix = cvt_flr(xs), iy = cvt_flr(ys);
-  const bool inb = inside(ix, iy, src.cols, src.rows);
-  const float w2 = src.at(iy, ix);   // unclamped: see the note on rejected pixels above
-  const float v1_z = q.q2;
+  r.ix = cvt_flr(xs); r.iy = cvt_flr(ys);
+  r.ok = valid & inside(r.ix, r.iy, cols, rows);
+  const float ex = __builtin_amdgcn_fractf(xs) - 0.5f, ey = __builtin_amdgcn_fractf(ys) - 0.5f;
+  // guard_band.h (3); NaN / inf anywhere: not safe.  A lane whose sign analysis (4) does not hold has d1 = inf: none of its pixels is safe
+  const bool safe_xy = fmaxf(fabsf(ex), fabsf(ey)) <= __builtin_fmaf(-fabsf(wc), G.d1, G.c2);
+  fixc = valid & !safe_xy;
+  return r;
+}
+// cold path: the oracle's coordinates (register_pixel: no contraction, IEEE reciprocals) of a valid pixel
+__device__ __forceinline__ void id_fix_coords(IdProj& r, int x, int y, const WarpParams& P, int cols, int rows) {
+#pragma clang fp contract(off)
+  float xe, ye;
+  register_pixel(xe, ye, x, y, r.ws, P);
+  xe += 0.5f; ye += 0.5f;
+  r.ix = cvt_rd(xe); r.iy = cvt_rd(ye);
+  r.ok = inside(r.ix, r.iy, cols, rows);
+}
+// after the gather of w2 = src(iy, ix): the warped value; `fixr`: the sign of the oracle's result is not implied (recompute the pixel exactly)
+__device__ __forceinline__ float id_finish(const IdProj& r, float w2, const WarpParams& P, const Guard& G, bool& fixr) {
+  const float rwf = rcp(__builtin_fmaf(-w2, P.t[2], 1.f));
+  const float res = (r.q2 * rwf) * w2;   // v1_z = (X.z - t_z) w = q_z
+  fixr = r.ok & ((G.zsafe == 0) | (fabsf(rwf) > 0x1p19f));   // guard_band.h (4): per lane (wave-uniform), and per pixel
+  return (r.ok & (res > 0.f)) ? res : qnan();
+}
+// the whole pixel for kernels with one pixel per thread (lattice pre-pass, scalar path of the normal equations)
+__device__ __forceinline__ float warp_invdepth_px(const FMap& src, const Ray& q, int x, int y, float w, const WarpParams& P, const Guard& G) {
+  bool fixc, fixr;
+  IdProj r = id_project(q, w, P, G, src.cols, src.rows, fixc);
+  if (__builtin_expect(fixc, 0)) id_fix_coords(r, x, y, P, src.cols, src.rows);
+  float res = id_finish(r, src.at(r.iy, r.ix), P, G, fixr);   // unclamped: see the note on rejected pixels above
+  if (__builtin_expect(fixr, 0)) res = rgbid::warp_invdepth_px(src, x, y, w, P);
+  return res;
+}
+
+// the weighted variant (:549-594) after the gather: warped inverse depth + weight (1 - w2 tz)^4 / v^2.  eps_res: bound of the relative distance between
+// this value and the oracle's (guard_band.h (5)), for the gate of the fusion that follows.  `fixr` as id_finish.
+__device__ __forceinline__ float id_finish_weighted(const IdProj& r, float w2, const WarpParams& P, const Guard& G, float& weight_res, bool& store_weight,
+                                                    float& eps_res, bool& fixr) {
+  const float v1_z = r.q2;
   const float w_factor = __builtin_fmaf(-w2, P.t[2], 1.f);
+  const float rwf = rcp(w_factor);
   const float rv = rcp(v1_z), wf2 = w_factor * w_factor;
   weight_res = (wf2 * wf2) * (rv * rv);
-  const float res = (v1_z * rcp(w_factor)) * w2;
-  store_weight = valid & inb & (weight_res > 0.f);
-  return (valid & inb & (res > 0.f)) ? res : qnan();
+  const float res = (v1_z * rwf) * w2;
+  store_weight = r.ok & (weight_res > 0.f);
+  eps_res = __builtin_fmaf(fabsf(rwf), G.e1, G.e0);
+  fixr = r.ok & ((G.zsafe == 0) | (fabsf(rwf) > 0x1p19f));
+  return (r.ok & (res > 0.f)) ? res : qnan();
 }
 
-// the same intensity warp in two halves, so that a caller can put other memory traffic between the tap loads and their use:
+// the intensity warp in two halves, so that a caller can put other memory traffic between the tap loads and their use:
 // intensity_taps() projects, forms the 1.8 fixed-point weights and ISSUES the two 8-byte tap loads; intensity_finish() blends.
 struct IntensityTaps { float2 p0, p1; float a, b; bool ok; };
 // Clamp addressing without integer clamps or per-tap selects: the sample coordinate itself is clamped to [0, n - 1) (one v_med3_f32 per
@@ -245,14 +318,24 @@ struct IntensityTaps { float2 p0, p1; float a, b; bool ok; };
 // the weight of the last texel is 1 - ulp(n - 1) (1 - 2^-14 at 640 columns) -- exactly 1 after the 1.8 fixed-point rounding of
 // RGBID_INTERP_TEX8, the engine's mode; with RGBID_INTERP_EXACT the last texel is blended with its neighbour by that 2^-14 (at most 0.016 grey
 // levels), a bound of the FAST class only (the exact functions above clamp the texel indices instead).
-__device__ __forceinline__ IntensityTaps intensity_taps(const FMap& src, const Ray& q, float w, const WarpParams& P, int interp_mode) {
+// The bilinear VALUE is continuous across texel boundaries (a tap pair one texel off carries weight 0 / 1 there), so the discrete decisions of
+// this warp are the in-image predicate (:486-487) -- taken as "inside" / "outside" when the coordinate is farther than the guard band from the
+// image border, and from the oracle's coordinates otherwise (`border`: the caller runs intensity_fix_border for those pixels) -- and the texel
+// pair of a sample that meets a NaN texel (intensity_finish).
+struct BorderBand { float x0, x1, y0, y1; };   // safe-inside interval of the coordinate (wave-uniform)
+__device__ __forceinline__ BorderBand border_band(const Guard& G, int cols, int rows) {
+  return BorderBand{uniform_f(-0.5f + G.db), uniform_f((float)cols - 0.5f - G.db), uniform_f(-0.5f + G.db), uniform_f((float)rows - 0.5f - G.db)};
+}
+__device__ __forceinline__ IntensityTaps intensity_taps(const FMap& src, const Ray& q, float w, const WarpParams& P, const BorderBand& B, int interp_mode, bool& border) {
   IntensityTaps t;
-  const bool valid = w > 0.f;   // an inverse depth of 0 (a point at infinity) is rejected like NaN, as the exact path ends up doing
-  const float ws = valid ? w : 1.f;
+  bool valid;
+  const float ws = sanitised(w, valid);
   const Scaled Y = scaled_point(q, ws, P);
   const float wc = rcp(Y.y2);
   const float xB = Y.y0 * wc, yB = Y.y1 * wc;
-  t.ok = valid & (xB >= -0.5f) & (xB < (float)src.cols - 0.5f) & (yB >= -0.5f) & (yB < (float)src.rows - 0.5f);
+  const bool safe_in = (xB >= B.x0) & (xB < B.x1) & (yB >= B.y0) & (yB < B.y1) & (fabsf(wc) <= RHO_BORDER);
+  t.ok = valid & safe_in;
+  border = valid & !safe_in;
   const float hx = __builtin_bit_cast(float, __builtin_bit_cast(int, (float)(src.cols - 1)) - 1);   // wave-uniform
   const float hy = __builtin_bit_cast(float, __builtin_bit_cast(int, (float)(src.rows - 1)) - 1);
   const float xc = __builtin_amdgcn_fmed3f(xB, 0.f, hx), yc = __builtin_amdgcn_fmed3f(yB, 0.f, hy);
@@ -265,27 +348,84 @@ __device__ __forceinline__ IntensityTaps intensity_taps(const FMap& src, const R
   t.p0 = src.at2_raw(off, 0u); t.p1 = src.at2_raw(off, src.pitch_b);
   return t;
 }
-__device__ __forceinline__ float intensity_finish(const IntensityTaps& t) {
+// cold path of a pixel whose projection is not safely inside: surely outside (farther than the band beyond the border), or the oracle's predicate
+__device__ __forceinline__ bool intensity_fix_border(const FMap& src, const Ray& q, int x, int y, float w, const WarpParams& P, const Guard& G) {
+#pragma clang fp contract(off)
+  const Scaled Y = scaled_point(q, w, P);
+  const float wc = rcp(Y.y2);
+  const float xB = Y.y0 * wc, yB = Y.y1 * wc;
+  const bool surely_out = (fabsf(wc) <= RHO_BORDER) & ((xB < -0.5f - G.db) | (xB >= (float)src.cols - 0.5f + G.db) | (yB < -0.5f - G.db) | (yB >= (float)src.rows - 0.5f + G.db));
+  if (surely_out) return false;
+  float xe, ye;
+  register_pixel(xe, ye, x, y, w, P);
+  xe += 0.5f; ye += 0.5f;
+  return inside(cvt_rd(xe), cvt_rd(ye), src.cols, src.rows);
+}
+// `nan_tap`: a tap is NaN (or the blend is: inf - inf) -- the one case in which the texel PAIR matters: a pair one texel off carries weight 0 / 1 at
+// the boundary, but 0 * NaN is NaN -- so the caller takes the oracle's pixel (rgbid::warp_intensity_px) for it.  Intensity maps hold NaN only at
+// the three corner pixels of pyramid levels >= 1.
+__device__ __forceinline__ float intensity_finish(const IntensityTaps& t, bool& nan_tap) {
   const float top = __builtin_fmaf(t.a, t.p0.y - t.p0.x, t.p0.x), bot = __builtin_fmaf(t.a, t.p1.y - t.p1.x, t.p1.x);
   float res = __builtin_fmaf(t.b, bot - top, top);
+  nan_tap = t.ok & (res != res);
   res = fmaxf(0.f, fminf(res, 255.f));
   return t.ok ? res : qnan();
 }
 
 // trafo3DKernelIntensityWithInvDepthGridStride (:465-501), one pixel; bilinear tap in the lerp form
-__device__ __forceinline__ float warp_intensity_px(const FMap& src, const Ray& q, float w, const WarpParams& P, int interp_mode) {
-  return intensity_finish(intensity_taps(src, q, w, P, interp_mode));
+__device__ __forceinline__ float warp_intensity_px(const FMap& src, const Ray& q, int x, int y, float w, const WarpParams& P, const Guard& G, int interp_mode) {
+  bool border, nan_tap;
+  IntensityTaps t = intensity_taps(src, q, w, P, border_band(G, src.cols, src.rows), interp_mode, border);
+  if (__builtin_expect(border, 0)) t.ok = intensity_fix_border(src, q, x, y, w, P, G);
+  float res = intensity_finish(t, nan_tap);
+  if (__builtin_expect(nan_tap, 0)) res = rgbid::warp_intensity_px(src, x, y, w, P, interp_mode);
+  return res;
 }
 
-// one direction of computeCovisibility's gate (partialVisibilityKernel :297-360)
-__device__ __forceinline__ bool visible_px(const FMap& D, int cols, int rows, const Ray& q, float w, bool valid, const WarpParams& P) {
-  const float ws = valid ? w : 1.f;
-  const Scaled Y = scaled_point(q, ws, P);
-  const float ry = rcp(Y.y2), wc = ws * ry;                 // inverse depth of the point in the other frame: 1 / X.z = w / Y.z
-  const float xd = Y.y0 * ry, yd = Y.y1 * ry;
-  const bool inside_img = (xd > 0) & (xd < (float)(cols - 1)) & (yd > 0) & (yd < (float)(rows - 1));
-  const int xi = __float2int_rn(xd), yi = __float2int_rn(yd);   // inside_img: both already in the image
-  return valid & inside_img & (fabsf(wc - D.at(yi, xi)) < 0.020f);
+// one direction of computeCovisibility's gate (partialVisibilityKernel :297-360), in two steps around the gather of the other frame's inverse depth.
+// Discrete decisions: the lattice point rint(xd), rint(yd) (open within delta of a half-integer), the comparisons with the image border (open within
+// delta of 0 / cols - 1 / rows - 1), the gate |w' - D| < 0.020 (open within eps_w |w'|).  An open coordinate is replaced by the oracle's BEFORE the
+// gather; an open gate re-evaluates w' the oracle's way on the same texel.
+struct VisProj { float ws, wc, ry; int xi, yi; bool ok, exact; };   // ok: inverse depth of the domain and projection strictly inside the image
+__device__ __forceinline__ VisProj vis_project(int cols, int rows, const Ray& q, int x, int y, float w, const WarpParams& P, const Guard& G) {
+#pragma clang fp contract(off)
+  VisProj v;
+  bool in_domain;
+  v.ws = sanitised(w, in_domain);
+  const Scaled Y = scaled_point(q, v.ws, P);
+  v.ry = rcp(Y.y2);
+  v.wc = v.ws * v.ry;                                       // inverse depth of the point in the other frame: 1 / X.z = w / Y.z
+  float xd = Y.y0 * v.ry, yd = Y.y1 * v.ry;
+  const float xm = (float)(cols - 1), ym = (float)(rows - 1);
+  const float hx = 0.5f * xm, hy = 0.5f * ym;               // exact: the image centre and half extent
+  // signed distance to the image border along each axis (negative inside); m < 0 <=> 0 < xd < cols - 1 and 0 < yd < rows - 1 whenever |m| > delta
+  const float m = fmaxf(fabsf(xd - hx) - hx, fabsf(yd - hy) - hy);
+  float rx = rintf(xd), ryy = rintf(yd);
+  const float delta = __builtin_fmaf(fabsf(v.ry), G.d1, G.d2);
+  // open: within delta of a half-integer (the lattice point) or of the image border.  NaN / inf anywhere: open
+  v.exact = in_domain & !((fmaxf(fabsf(xd - rx), fabsf(yd - ryy)) + delta < 0.5f) & (fabsf(m) > delta));
+  bool inside_img = m < 0.f;
+  if (__builtin_expect(v.exact, 0)) {
+    v.wc = register_pixel(xd, yd, x, y, v.ws, P);
+    inside_img = (xd > 0) & (xd < xm) & (yd > 0) & (yd < ym);
+    rx = rintf(xd); ryy = rintf(yd);
+  }
+  v.xi = __float2int_rz(rx); v.yi = __float2int_rz(ryy);   // integral values; inside_img: both already in the image (NaN -> 0, saturating)
+  v.ok = in_domain & inside_img;
+  return v;
+}
+__device__ __forceinline__ bool vis_gate(const VisProj& v, float d, int x, int y, const WarpParams& P, const Guard& G) {
+#pragma clang fp contract(off)
+  float dgap = fabsf(v.wc - d);
+  // the gate is open within eps_w |w'| of the threshold (guard_band.h (5)); screened by a fixed band first
+  if (__builtin_expect(v.ok & !v.exact & (fabsf(dgap - 0.020f) <= 0x1p-10f), 0)) {
+    const float band = __builtin_fmaf(fabsf(v.wc), __builtin_fmaf(fabsf(v.ry), G.g1, G.g0), 4.f * 0x1p-24f * 0.020f);
+    if (!(fabsf(dgap - 0.020f) > band) | !(band < 0x1p-10f)) {
+      float xe, ye;
+      dgap = fabsf(register_pixel(xe, ye, x, y, v.ws, P) - d);
+    }
+  }
+  return v.ok & (dgap < 0.020f);
 }
 
 }  // namespace fastnum

@@ -209,3 +209,94 @@ def test_fuzz_cpp_tracker_configurations(seed):
     # per-pixel arithmetic, so those combinations are held to 1e-3 instead of the 1e-4 of the robust (shipped) estimators
     lsq = kw["mestimator"] == O.LSQ
     run(120, 160, SMALL_K, 4, kw, SLOW, pose_tol=1e-3 if lsq else 1e-4, map_outliers=1.0 if lsq else 5e-3)
+
+
+# ---- FAST numerics: fast values, the oracle's SELECTION (round 4, csrc/guard_band.h) -------------------------------------------------------------
+W_LO, W_HI = 2.0 ** -14, 2.0 ** 14   # csrc/guard_band.h: grid inverse depths outside are invalid in the FAST class
+
+
+def _fast_case(seed):
+    """as _case, with special values of the FAST class's stated DOMAIN (include/rgbid_batched.h): the grid map carries anything -- values outside
+    [2^-14, 2^14] (zero, negative, infinite, denormal, 3e38, 1e-5) count as invalid, so the oracle sees them replaced by NaN; the sampled map carries
+    NaN, 0 and magnitudes in [2^-60, 2^60] of either sign"""
+    r = util.rng(5000 + seed)
+    rows, cols = int(r.integers(6, 90)), int(r.integers(6, 130))
+    K = (float(r.uniform(20, 200)), float(r.uniform(20, 200)), float(r.uniform(0, cols)), float(r.uniform(0, rows)))
+    grid = util.rand_invdepth(r, rows, cols, nan_frac=float(r.uniform(0, 0.5)), smooth=bool(r.integers(0, 2)))
+    src = util.rand_invdepth(r, rows, cols, nan_frac=float(r.uniform(0, 0.5)), smooth=bool(r.integers(0, 2)))
+    inten = util.rand_intensity(r, rows, cols, nan_frac=float(r.uniform(0, 0.1)))
+    g_specials = np.array([0.0, -0.0, 1e-45, 1e-39, 3e38, 1e30, -1.0, np.inf, -np.inf, 1e-5, 7e-5, 5e-4, 1e4, 2e4], np.float32)
+    s_specials = np.array([0.0, -0.0, -1.0, 1e-15, 1e15, -1e12, 5e-4, 1e4], np.float32)
+    for m, sp in ((grid, g_specials), (src, s_specials)):
+        idx = r.integers(0, m.size, size=max(1, m.size // 40))
+        m.reshape(-1)[idx] = sp[r.integers(0, sp.size, size=idx.size)]
+    mode = seed % 3
+    if mode == 0:      # gentle motion: the guard band's regular regime
+        R, t = util.small_motion(r, K, float(r.uniform(0, 0.05)), float(r.uniform(0, 2)))
+    elif mode == 1:    # violent: up to 170 degrees, metres of translation (the per-lane sign analysis fails: every pixel takes the exact path)
+        R, t = util.small_motion(r, K, float(r.uniform(0, 3)), float(r.uniform(20, 170)))
+    else:              # translation that puts X.z near / exactly at zero for part of the image
+        R, t = util.small_motion(r, K, 0.0, float(r.uniform(0, 1)))
+        t = np.array([0.0, 0.0, -float(1.0 / np.nanmedian(np.abs(grid[np.isfinite(grid)]) + 1e-6))])
+    Rp, tp = util.project(K, *util.inv_pose(R, t))
+    with np.errstate(invalid="ignore"):
+        grid_dom = np.where((grid >= W_LO) & (grid <= W_HI), grid, np.float32(np.nan)).astype(np.float32)
+    return rows, cols, K, grid, grid_dom, src, inten, Rp, tp
+
+
+def _same_selection(got, ref, what, rtol=1e-3):
+    assert np.array_equal(np.isnan(got), np.isnan(ref)), (what, int(np.count_nonzero(np.isnan(got) != np.isnan(ref))))
+    both = ~np.isnan(ref)
+    with np.errstate(all="ignore"):
+        bad = np.abs(got[both] - ref[both]) > rtol * np.abs(ref[both])
+        bad &= ~(np.isinf(ref[both]) & (got[both] == ref[both]))
+    assert not bad.any(), (what, int(bad.sum()), got[both][bad][:4], ref[both][bad][:4])
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RGBID_FUZZ_N", "36"))))
+def test_fuzz_fast_numerics_select_like_the_oracle(ctx, seed):
+    """FAST warp pair / one-pass fusion / two-direction covisibility on random odd geometries, gentle and violent motions and the special values of
+    the class's domain: validity patterns and integer counts IDENTICAL to the oracle's on the domain-sanitised maps, every point sample from the
+    oracle's source pixel (a neighbouring pixel of these random maps differs by orders of magnitude more than the 1e-3 allowed)."""
+    from rgbid import batched as BT
+    rows, cols, K, grid, grid_dom, src, inten, Rp, tp = _fast_case(seed)
+    new = lambda: torch.full((rows, cols), float("nan"), device="cuda")
+    W1, I1 = new(), new()
+    ctx.warpPair(dev(src), dev(inten), dev(grid), W1, I1, Rp, tp, fast=True)
+    with np.errstate(all="ignore"):
+        oW1 = O.warp_invdepth(src, grid_dom, Rp, tp)
+    gW1 = W1.cpu().numpy()
+    _same_selection(gW1, oW1, "warp iD")
+    # the intensity warp is sampled at the WARPED inverse depth (visodo.cpp:1098-1100); the class's domain rule applies to that grid as well
+    with np.errstate(invalid="ignore"):
+        w1_dom = np.where((gW1 >= W_LO) & (gW1 <= W_HI), gW1, np.float32(np.nan)).astype(np.float32)
+        oI1 = O.warp_intensity(inten, w1_dom, Rp, tp, O.INTERP_TEX8)
+    gI1 = I1.cpu().numpy()
+    assert np.array_equal(np.isnan(gI1), np.isnan(oI1)), int(np.count_nonzero(np.isnan(gI1) != np.isnan(oI1)))
+    ok = ~np.isnan(oI1)
+    assert (np.abs(gI1[ok] - oI1[ok]) <= 2.0 * 255.0 / 256.0 + 1e-3 + 1e-3 * np.abs(oI1[ok])).all()      # bilinear values: continuous, 1/256 weight steps
+    if cols % 4:
+        return
+    bt = BT.Batched(ctx)
+    # covisibility, both directions, on two unrelated maps: the four integer counts
+    with np.errstate(all="ignore"):
+        _, v1, n1, _ = O.visibility_ratio(grid_dom, src, Rp, tp)
+        src_dom = np.where((src >= W_LO) & (src <= W_HI), src, np.float32(np.nan)).astype(np.float32)
+        _, v2, n2, _ = O.visibility_ratio(src_dom, grid, Rp, tp)
+    c = bt.visibility_pair(dev(grid)[None], dev(src)[None], [Rp], [tp], [Rp], [tp], fast=True)[0]
+    n_valid_a, n_valid_b = int(np.count_nonzero(~np.isnan(grid))), int(np.count_nonzero(~np.isnan(src)))     # the oracle's VALID count is !isnan
+    assert (int(c[0]), int(c[1]), int(c[2]), int(c[3])) == (int(v1), n_valid_a, int(v2), n_valid_b), (c, v1, n1, v2, n2)
+    # keyframe fusion: the grid is the keyframe map itself
+    r = util.rng(9000 + seed)
+    kfw = r.uniform(0.5, 4.0, grid.shape).astype(np.float32)
+    ww = np.zeros_like(grid)
+    with np.errstate(all="ignore"):
+        od, ow = O.warp_invdepth_weighted(src, grid_dom, Rp, tp, weight_init=ww)
+        ow = np.where(np.isnan(od) | ~(ow > 0), np.float32(0), ow)      # the FAST class fuses a valid value whose weight was not stored with weight 0
+        okf, okfw = O.integrate_warped(od, ow, grid_dom, kfw)
+    kf_d, kfw_d, ww_d = dev(grid.copy())[None], dev(kfw.copy())[None], dev(ww.copy())[None]
+    bt.fuse_frame(dev(src)[None], kf_d, kfw_d, ww_d, [Rp], [tp], fast=True)
+    g = kf_d[0].cpu().numpy()
+    dom = ~np.isnan(grid_dom) | np.isnan(grid)          # pixels whose keyframe value is inside the domain (or NaN): the statement covers these
+    with np.errstate(all="ignore"):
+        _same_selection(np.where(dom, g, 0), np.where(dom, okf, 0), "fused iD", rtol=2e-3)
