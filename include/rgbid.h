@@ -88,8 +88,17 @@ int rgbid_ctx_set_interp_mode(rgbid_ctx* ctx, int mode);     /* default RGBID_IN
 int rgbid_ctx_sync(rgbid_ctx* ctx);                          /* internal.h:456-457 sync() */
 /* Arithmetic class of the bridge calls that have two implementations (today: rgbid_bilateral_filter; rgbid_warp_pair takes it per call):
  * RGBID_NUMERICS_EXACT (default) = the IEEE evaluation of the oracle, bit for bit; RGBID_NUMERICS_FAST = the reference BUILD's class of
- * arithmetic (hardware reciprocal / exp2, FMA contraction -- what nvcc --prec-div=false, default fmad and __expf give the reference's own
- * kernels, CMakeLists.txt:105, filters.cu:124).  The batched engine selects it with rgbid_engine_config.fast_numerics. */
+ * arithmetic for the float VALUES (hardware reciprocal / exp2, FMA contraction -- what nvcc --prec-div=false, default fmad and __expf give
+ * the reference's own kernels, CMakeLists.txt:105, filters.cu:124) with the oracle's SELECTION: which source pixel a warp point-samples,
+ * whether a projection is inside the image, the sign test of a warped value, the covisibility lattice point and the covisibility / fusion
+ * gates are decided exactly as the IEEE evaluation decides them (a pixel whose cheap coordinate lies within a proven error bound of a
+ * decision threshold is recomputed with the exact instruction sequence: csrc/guard_band.h).  The batched engine selects the class with
+ * rgbid_engine_config.fast_numerics.
+ * DOMAIN of the FAST class: non-NaN inverse depths of a PROJECTED map (the `grid` / keyframe map of a warp, both maps of a covisibility pair)
+ * inside [2^-14, 2^14] m^-1 -- a value outside (zero, negative, infinite, denormal) is treated as invalid, like NaN, where the oracle would
+ * project it; non-NaN values of a SAMPLED map 0 or of magnitude in [2^-60, 2^60]; transforms with finite entries below 2^20.  A lane whose
+ * motion defeats the sign analysis of the bound (rotations towards 90 degrees, translations of the order of 2^14 scene depths) is not an error:
+ * all its pixels take the exact path.  Maps this library builds from 16-bit depth are inside the domain by construction. */
 int rgbid_ctx_set_numerics(rgbid_ctx* ctx, int numerics);
 /* orders the context's stream after a hipEvent_t recorded on another stream (interop with the caller's framework streams) */
 int rgbid_ctx_wait_event(rgbid_ctx* ctx, void* hip_event);
@@ -104,6 +113,15 @@ int rgbid_selftest_div_const(rgbid_ctx* ctx, float divisor, unsigned long long* 
  * v_cvt_i32_f32 over every `stride`-th of the 2^32 float bit patterns (stride 1 = exhaustive; NaN excluded: the two differ there and
  * every index is clamped before it addresses memory); *mismatches must come back 0 */
 int rgbid_selftest_cvt_flr(rgbid_ctx* ctx, unsigned stride, unsigned long long* mismatches);
+/* The three hardware facts the FAST class's guard band (csrc/guard_band.h) rests on, over all 2^32 float bit patterns: v_rcp_f32 within 1 ulp of
+ * 1 / x for every normal x with a normal reciprocal (a denormal x reads as zero); v_med3_f32(x, lo, hi) == x exactly for lo <= x <= hi and a
+ * value of [lo, hi] otherwise, NaN included (the sanitising clamp of the domain rule above); v_fract_f32(x) == min(x - floor(x), 1 - 2^-24) for
+ * |x| < 2^23.  *mismatches must come back 0. */
+int rgbid_selftest_fast_primitives(rgbid_ctx* ctx, unsigned long long* mismatches);
+/* the guard-band constants of one projection (host-side evaluation of csrc/guard_band.h make_guard; no device needed; ctx may be NULL):
+ * out[0..9] = d1, c2, d2, q0, q1, db, g0, g1, e0, e1; *zsafe = the per-lane verdict of the sign analysis.  For tests and for hosts that want
+ * to know in advance whether a transform runs in the guard band's regular regime. */
+int rgbid_fast_guard(const float R_proj[9], const float t_proj[3], int cols, int rows, float out[10], int* zsafe);
 /* the context's hipStream_t */
 int rgbid_ctx_get_stream(rgbid_ctx* ctx, void** hip_stream);
 /* showGPUMemoryUsage(), src/cuda/misc.cu:526-540 */
@@ -170,8 +188,8 @@ int rgbid_warp_intensity(rgbid_ctx*, const rgbid_img* src, const rgbid_img* dst,
 /* Both warps of one Gauss-Newton iteration in one launch (the pair the tracker issues back to back, src/visodo.cpp:1094-1100): dst_iD =
  * warpInvDepthWithTrafo3D(src_iD, grid), dst_I = warpIntensityWithTrafo3DInvDepth(src_I, dst_iD) with the warped inverse depth consumed from
  * registers.  numerics EXACT: bit-identical to the two calls above (IEEE evaluation of the oracle); FAST: the reference BUILD's class of
- * arithmetic -- hardware reciprocal + FMA contraction, what nvcc --prec-div=false and default fmad give the reference's own kernels
- * (CMakeLists.txt:105) -- in which a coordinate within an ulp of a pixel boundary may select the neighbouring pixel (what the batched
+ * arithmetic for the values -- hardware reciprocal + FMA contraction, what nvcc --prec-div=false and default fmad give the reference's own
+ * kernels (CMakeLists.txt:105) -- with the oracle's pixel selection and validity at every pixel (rgbid_ctx_set_numerics above; what the batched
  * engine runs by default, rgbid_engine_config.fast_numerics). */
 int rgbid_warp_pair(rgbid_ctx*, const rgbid_img* src_iD, const rgbid_img* src_I, const rgbid_img* grid_iD, const rgbid_img* dst_iD, const rgbid_img* dst_I,
                     const float R_proj[9], const float t_proj[3], int numerics, float* ms);

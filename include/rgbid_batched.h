@@ -14,10 +14,11 @@
  *  - rgbid_imgb = `lanes` images of identical geometry in ONE allocation, lane l at data + l * lane_stride bytes (the engine's
  *    structure-of-lanes layout); lane_stride is ignored when lanes == 1.
  *  - per-lane parameters (transforms, noise scales) are HOST arrays of `lanes` entries; results (A, b, counts, scales) are HOST arrays.
- *  - numerics: RGBID_NUMERICS_EXACT = the IEEE evaluation of the oracle (bit-exact pixel selection); RGBID_NUMERICS_FAST = the reference
- *    build's class of arithmetic (rgbid.h rgbid_ctx_set_numerics), which needs rows of whole 4-pixel groups, 16-byte aligned rows
- *    and lanes, and one pitch for the six keyframe-side maps: a FAST call on any other geometry returns RGBID_E_INVALID (it never
- *    silently runs the other class).
+ *  - numerics: RGBID_NUMERICS_EXACT = the IEEE evaluation of the oracle (bit-exact values and selection); RGBID_NUMERICS_FAST = the
+ *    reference build's class of arithmetic for the values with the oracle's pixel SELECTION, validity and gates (rgbid.h
+ *    rgbid_ctx_set_numerics, which also states the class's DOMAIN: projected inverse depths in [2^-14, 2^14] or invalid).  FAST needs rows of
+ *    whole 4-pixel groups, 16-byte aligned rows and lanes, and one pitch for the six keyframe-side maps: a FAST call on any other geometry
+ *    returns RGBID_E_INVALID (it never silently runs the other class).
  *  - the one-pass kernels marked "16-byte geometry" need cols % 4 == 0 and 16-byte aligned data / step / lane_stride and return
  *    RGBID_E_INVALID otherwise; a caller with odd geometry uses the kernel sequence of rgbid.h, as the engine does.
  *  - synchronous on return unless the context is asynchronous (rgbid_ctx_set_async: the `_async` form of every call below; results

@@ -6,6 +6,7 @@
 #include "../../include/rgbid.h"
 #include "ctx.h"
 #include "kernels.h"
+#include "guard_band.h"
 
 #include <cstdio>
 #include <cstring>
@@ -173,6 +174,50 @@ int rgbid_selftest_cvt_flr(rgbid_ctx* c, unsigned stride, unsigned long long* mi
   RGBID_HIP(hipGetLastError());
   RGBID_HIP(hipMemcpyAsync(mismatches, d, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   RGBID_HIP(hipStreamSynchronize(c->stream));
+  return RGBID_OK;
+}
+namespace {
+// v_rcp_f32 within 1 ulp; v_med3_f32 of a NaN first operand returns the smaller bound; v_fract_f32(x) == x - floor(x) in [0, 1)
+__global__ __launch_bounds__(256) void k_selftest_fast_primitives(unsigned long long* mismatches) {
+  const uint32_t hi = blockIdx.x;
+  unsigned int bad = 0;
+  for (uint32_t lo = threadIdx.x; lo < 65536u; lo += blockDim.x) {
+    const float x = __uint_as_float((hi << 16) | lo);
+    const float r = __builtin_amdgcn_rcpf(x);
+    const double e = 1.0 / (double)x;
+    if (__builtin_amdgcn_classf(x, 0x108) && __builtin_amdgcn_classf((float)e, 0x108)) {   // x and its reciprocal normal numbers (a denormal x reads as 0: inf, which the guard treats as "recompute")
+      const float rn = (float)e;                                       // correctly rounded
+      const int d = (int)__float_as_uint(r) - (int)__float_as_uint(rn);
+      bad += (d < -1 || d > 1) ? 1u : 0u;
+    }
+    const float m = __builtin_amdgcn_fmed3f(x, rgbid::fastnum::W_LO, rgbid::fastnum::W_HI);
+    const bool in = x >= rgbid::fastnum::W_LO && x <= rgbid::fastnum::W_HI;
+    bad += ((m == x) != in) ? 1u : 0u;                                 // NaN, out-of-range values: med3 != x
+    bad += !(m >= rgbid::fastnum::W_LO && m <= rgbid::fastnum::W_HI) ? 1u : 0u;   // and always a finite value of the domain
+    if (fabsf(x) < 8388608.f) {
+      const float f = __builtin_amdgcn_fractf(x);
+      bad += !(f >= 0.f && f < 1.f && f == fminf(x - floorf(x), 0x1.fffffep-1f)) ? 1u : 0u;   // tiny negative x: x - floor(x) rounds to 1, v_fract stays below
+    }
+  }
+  if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+}  // namespace
+int rgbid_selftest_fast_primitives(rgbid_ctx* c, unsigned long long* mismatches) {
+  if (!c || !mismatches) return RGBID_E_INVALID;
+  unsigned long long* d = static_cast<unsigned long long*>(c->small_dev);
+  RGBID_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(k_selftest_fast_primitives, dim3(65536), dim3(256), 0, c->stream, d);
+  RGBID_HIP(hipGetLastError());
+  RGBID_HIP(hipMemcpyAsync(mismatches, d, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  RGBID_HIP(hipStreamSynchronize(c->stream));
+  return RGBID_OK;
+}
+int rgbid_fast_guard(const float R_proj[9], const float t_proj[3], int cols, int rows, float out[10], int* zsafe) {
+  if (!R_proj || !t_proj || !out || cols < 1 || rows < 1) return RGBID_E_INVALID;
+  const rgbid::fastnum::Guard g = rgbid::fastnum::make_guard(R_proj, t_proj, cols, rows);
+  const float v[10] = {g.d1, g.c2, g.d2, g.q0, g.q1, g.db, g.g0, g.g1, g.e0, g.e1};
+  for (int i = 0; i < 10; ++i) out[i] = v[i];
+  if (zsafe) *zsafe = g.zsafe;
   return RGBID_OK;
 }
 int rgbid_ctx_wait_event(rgbid_ctx* c, void* ev) {

@@ -106,6 +106,12 @@ class Context:
         check(self.L.rgbid_selftest_cvt_flr(self._h, C.c_uint(int(stride)), C.byref(n)))
         return n.value
 
+    def selftest_fast_primitives(self):
+        """v_rcp_f32 within 1 ulp, v_med3_f32 as the domain clamp, v_fract_f32 == x - floor(x): the hardware facts under csrc/guard_band.h (must be 0)"""
+        n = C.c_ulonglong(1)
+        check(self.L.rgbid_selftest_fast_primitives(self._h, C.byref(n)))
+        return n.value
+
     def selftest_div_const(self, divisor):
         """(mismatches of the bilateral filter's short division by `divisor` vs IEEE over all 2^32 dividends, whether the filter uses it)"""
         n, used = C.c_ulonglong(1), C.c_int(0)
@@ -317,3 +323,14 @@ def error_lattice_size(rows, cols, min_nsamples):
     n, lr, lc, st = C.c_int(), C.c_int(), C.c_int(), C.c_int()
     check(_lib.lib().rgbid_error_lattice_size(int(rows), int(cols), int(min_nsamples), C.byref(n), C.byref(lr), C.byref(lc), C.byref(st)))
     return n.value, lr.value, lc.value, st.value
+
+
+def fast_guard(R_proj, t_proj, cols, rows):
+    """guard-band constants of one projection (csrc/guard_band.h, host evaluation; no GPU): dict d1, c2, d2, q0, q1, db, g0, g1, e0, e1, zsafe"""
+    from ._lib import lib
+    out = (C.c_float * 10)()
+    z = C.c_int()
+    check(lib().rgbid_fast_guard(_fa(R_proj, 9), _fa(t_proj, 3), int(cols), int(rows), out, C.byref(z)))
+    d = dict(zip(("d1", "c2", "d2", "q0", "q1", "db", "g0", "g1", "e0", "e1"), [float(v) for v in out]))
+    d["zsafe"] = int(z.value)
+    return d

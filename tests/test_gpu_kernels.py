@@ -171,6 +171,12 @@ def test_selftest_cvt_flr_exhaustive(ctx):
     assert ctx.selftest_cvt_flr(1) == 0
 
 
+def test_selftest_fast_primitives_exhaustive(ctx):
+    """the hardware facts under the guard band (csrc/guard_band.h) over all 2^32 floats: v_rcp_f32 within 1 ulp, v_med3_f32 as the domain clamp (NaN ->
+    the lower bound), v_fract_f32(x) == x - floor(x)"""
+    assert ctx.selftest_fast_primitives() == 0
+
+
 @pytest.mark.parametrize("rows,cols", SIZES)
 @pytest.mark.parametrize("seed", [6, 21])
 def test_warp_pair_fast_selects_the_oracles_pixels(ctx, rows, cols, seed):
