@@ -287,8 +287,8 @@ def run_config(ctx, dev, work_stream, rows, cols, levels, iters, B, Kst, W, reps
     sbytes = eng.step_bytes()
     st_all = rec["status"]
     n_tr = max(1, int(np.count_nonzero(st_all & E.ST_TRACKED)))
-    p_odo = float(np.count_nonzero((st_all & E.ST_TRACKED) & ((st_all & E.ST_ODO_KF) != 0))) / n_tr
-    p_int = float(np.count_nonzero((st_all & E.ST_TRACKED) & ((st_all & E.ST_INTEGR_KF) != 0))) / n_tr
+    p_odo = float(np.count_nonzero(((st_all & E.ST_TRACKED) != 0) & ((st_all & E.ST_ODO_KF) != 0))) / n_tr
+    p_int = float(np.count_nonzero(((st_all & E.ST_TRACKED) != 0) & ((st_all & E.ST_INTEGR_KF) != 0))) / n_tr
     engine_bytes_per_frame = sbytes[0] + p_odo * sbytes[1] + p_int * sbytes[2] + (1.0 - p_int) * sbytes[3]
     res = {
         "value": B * Kst * world / el, "ms_per_step": el / Kst * 1e3,

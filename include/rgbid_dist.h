@@ -92,6 +92,7 @@ typedef struct rgbid_seq_config {
   int exchange;                 /* RGBID_EXCHANGE_RCCL: ncclAllGather on the context's stream; RGBID_EXCHANGE_TCP: the test transport above */
   const char* master_addr;      /* rank 0's address for the rendezvous (world > 1) */
   int master_port;
+  int inject_chunk_len;         /* with `inject`: records per chunk in that buffer; must equal the chunk length the partition implies (else RGBID_E_INVALID) */
 } rgbid_seq_config;
 typedef struct rgbid_seq_report {
   int lanes, chunk_len, n_chunks, world, rccl_ranks;
@@ -103,8 +104,9 @@ typedef struct rgbid_seq_report {
   unsigned long long staged_bytes, engine_bytes;
 } rgbid_seq_report;
 /* depth_host [n_frames][rows][cols] u16 millimetres, rgb_host [n_frames][rows][cols][3] (host memory; pinned memory uploads asynchronously).
- * inject (nullable): [n_chunks][chunk_len] records to use INSTEAD of running the engine (chunk_len = the longest chunk) -- exercises
- * partition / exchange / composition without a GPU; needs world == 1 or RGBID_EXCHANGE_TCP, ctx may then be NULL.
+ * inject (nullable): [n_chunks][cfg->inject_chunk_len] records to use INSTEAD of running the engine -- exercises partition / exchange / composition
+ * without a GPU; needs world == 1 or RGBID_EXCHANGE_TCP, ctx may then be NULL.  inject_chunk_len must be the longest chunk of the partition of
+ * n_frames into n_chunks (max over rgbid_dist_chunk_ranges of last - first + 1): a buffer laid out for another length is refused, not mis-strided.
  * Outputs as rgbid_dist_compose_trajectory: R [n_frames][9], t [n_frames][3], status / cov nullable.  Every rank receives the trajectory. */
 int rgbid_dist_track_sequence(rgbid_ctx* ctx, const rgbid_seq_config* cfg, const uint16_t* depth_host, const uint8_t* rgb_host, int n_frames,
                               const rgbid_gather_record* inject, double* R, double* t, int* status, double* cov, rgbid_seq_report* report);

@@ -21,10 +21,15 @@ namespace {
 
 const LaneMask ALL{nullptr, 0};
 
-// rows and the row pitch enter the kernels' 24-bit row-offset multiply (common.h row_ptr): both stay below 2^24 and a lane's image below 4 GB
-inline bool ok_b(const rgbid_imgb* i, int lanes) {
-  return i && i->data && i->rows > 0 && i->cols > 0 && i->step > 0 && i->rows < (1 << 24) && i->step < ((size_t)1 << 24) &&
-         (unsigned long long)i->rows * i->step < (1ull << 32) && (lanes == 1 || i->lane_stride >= (size_t)i->rows * i->step);
+// rows and the row pitch enter the kernels' 24-bit row-offset multiply (common.h row_ptr): both stay below 2^24 and a lane's image below 4 GB.
+// elem: bytes per pixel of the map (4: the fp32 maps; 2 / 3: the 16-bit depth and packed rgb inputs of frame preparation) -- a row must hold its
+// `cols` pixels (a caller-described step < cols * elem would make kernels write past rows and lanes) and rows / lanes must start on element
+// boundaries; lanes is a grid dimension of the kernels (<= 65535).
+inline bool ok_b(const rgbid_imgb* i, int lanes, size_t elem = 4) {
+  const size_t align = elem == 3 ? 1 : elem;
+  return i && i->data && lanes >= 1 && lanes <= 65535 && i->rows > 0 && i->cols > 0 && i->step >= (size_t)i->cols * elem && i->step % align == 0 &&
+         ((uintptr_t)i->data) % align == 0 && i->rows < (1 << 24) && i->step < ((size_t)1 << 24) && (unsigned long long)i->rows * i->step < (1ull << 32) &&
+         (lanes == 1 || (i->lane_stride >= (size_t)i->rows * i->step && i->lane_stride % align == 0));
 }
 inline bool same_b(const rgbid_imgb* a, const rgbid_imgb* b) { return a->rows == b->rows && a->cols == b->cols; }
 inline ImgB BB(const rgbid_imgb* i, int lanes) { return ImgB{i->data, i->step, lanes == 1 ? 0 : i->lane_stride, i->rows, i->cols}; }
@@ -315,8 +320,7 @@ int rgbid_prep_frame_batched(rgbid_ctx* c, int lanes, const rgbid_imgb* depth, c
                              const rgbid_imgb* g, const rgbid_imgb* b, float factor_depth, float* ms) {
   const rgbid_imgb* all[7] = {depth, rgb, iD, I, r, g, b};
   if (!c || lanes < 1 || !(factor_depth == factor_depth) || factor_depth == 0.f) return RGBID_E_INVALID;
-  for (int i = 0; i < 7; ++i) if (!ok_b(all[i], lanes) || !same_b(all[i], iD)) return RGBID_E_INVALID;
-  if (depth->step < (size_t)depth->cols * 2 || rgb->step < (size_t)rgb->cols * 3) return RGBID_E_INVALID;
+  for (int i = 0; i < 7; ++i) if (!ok_b(all[i], lanes, i == 0 ? 2 : i == 1 ? 3 : 4) || !same_b(all[i], iD)) return RGBID_E_INVALID;
   hipSetDevice(c->device);
   Call call(c, ms);
   launch_prep_frame(c->stream, lanes, BB(depth, lanes), BB(rgb, lanes), BB(iD, lanes), BB(I, lanes), BB(r, lanes), BB(g, lanes), BB(b, lanes), factor_depth, ALL);

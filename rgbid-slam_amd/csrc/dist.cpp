@@ -19,6 +19,8 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <map>
+#include <mutex>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -60,11 +62,16 @@ bool recv_all(int fd, void* p, size_t n) {
 }
 
 // ---- TCP rendezvous ------------------------------------------------------------------------------------------------------------------
-// One listening socket on rank 0, one short connection per other rank.  hello = {magic, nonce, rank}; anything else that connects (a port
-// scanner, a stale process of another job, a rank that has been served already) is dropped and rank 0 keeps accepting until every rank
-// 1..world-1 has been served once or the deadline passes.
-constexpr uint32_t HELLO_MAGIC = 0x52474244u;   // "RGBD"
-struct Hello { uint32_t magic; int32_t rank; uint64_t nonce; };
+// One listening socket on rank 0, one short connection per other rank and exchange.  hello = {magic, rank, nonce, kind, seq, bytes}: the job
+// (nonce), WHICH exchange this is (kind: broadcast / gather; seq: the number of exchanges this process has taken part in -- every rank calls the
+// same sequence of exchanges, so the counters agree) and its payload size.  Rank 0 answers every hello with one byte: ACK -- the hello names
+// the exchange rank 0 is serving and this rank has not been served in it -- or NAK.  A client that is refused (NAK), that finds nobody
+// listening, or whose connection breaks before its payload went through, closes, waits and tries again until the deadline: a rank that
+// finishes exchange k early and reaches rank 0's listener while it still serves exchange k (back-to-back exchanges on one port, world >= 3)
+// is told "not yet" instead of failing the job.  Anything else that connects (a port scanner, a stale process of another job) is dropped.
+constexpr uint32_t HELLO_MAGIC = 0x52474245u;   // "RGBE" (the hello of round 3, without kind / seq, was "RGBD")
+struct Hello { uint32_t magic; int32_t rank; uint64_t nonce; uint32_t kind, seq; uint64_t bytes; };
+constexpr unsigned char ACK = 1, NAK = 0;
 
 uint64_t job_nonce() {
   if (const char* e = getenv("RGBID_DIST_NONCE")) return strtoull(e, nullptr, 0);
@@ -86,6 +93,14 @@ void set_io_timeout(int fd, int seconds) {
   setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
   setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
 }
+// exchanges entered so far, per (port, rank): every rank calls the same sequence of exchanges on a port, so the counters agree across the ranks of
+// a job whether they are processes (the product) or threads of one test process
+uint32_t next_exchange_seq(int port, int rank) {
+  static std::mutex mu;
+  static std::map<std::pair<int, int>, uint32_t> seq;
+  std::lock_guard<std::mutex> lock(mu);
+  return seq[std::make_pair(port, rank)]++;
+}
 
 // rank 0: blob -> every rank (gather == false), or every rank's n bytes -> all[world][n] on every rank (gather == true)
 int tcp_exchange(const char* addr, int port, int world, int rank, void* blob, size_t n, void* all, bool gather) {
@@ -97,16 +112,21 @@ int tcp_exchange(const char* addr, int port, int world, int rank, void* blob, si
   const std::string ports = std::to_string(port);
   if (getaddrinfo(addr, ports.c_str(), &hints, &res) != 0 || !res) return RGBID_E_NET;
   const uint64_t nonce = job_nonce();
+  const uint32_t seq = next_exchange_seq(port, rank), kind = gather ? 1u : 0u;
   const auto deadline = Clock::now() + std::chrono::seconds(timeout_s());
   int rc = RGBID_E_NET;
   if (rank == 0) {
     int ls = -1;
-    for (addrinfo* a = res; a && ls < 0; a = a->ai_next) {
-      ls = ::socket(a->ai_family, a->ai_socktype, a->ai_protocol);
-      if (ls < 0) continue;
-      int one = 1;
-      setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
-      if (::bind(ls, a->ai_addr, a->ai_addrlen) != 0 || ::listen(ls, world + 8) != 0) { ::close(ls); ls = -1; }
+    // the previous exchange's listener on this port may still be in TIME_WAIT teardown on some stacks: retry the bind briefly
+    while (ls < 0 && ms_left(deadline) > 0) {
+      for (addrinfo* a = res; a && ls < 0; a = a->ai_next) {
+        ls = ::socket(a->ai_family, a->ai_socktype, a->ai_protocol);
+        if (ls < 0) continue;
+        int one = 1;
+        setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+        if (::bind(ls, a->ai_addr, a->ai_addrlen) != 0 || ::listen(ls, world + 8) != 0) { ::close(ls); ls = -1; }
+      }
+      if (ls < 0) usleep(50 * 1000);
     }
     freeaddrinfo(res);
     if (ls < 0) return RGBID_E_NET;
@@ -124,15 +144,17 @@ int tcp_exchange(const char* addr, int port, int world, int rank, void* blob, si
       if (pr == 0) { rc = RGBID_E_NET; break; }
       int fd = ::accept(ls, nullptr, nullptr);
       if (fd < 0) { if (errno == EINTR || errno == EAGAIN || errno == ECONNABORTED) continue; rc = RGBID_E_NET; break; }
-      set_io_timeout(fd, 5);                // a peer that connects and says nothing costs 5 s, not the job
+      set_io_timeout(fd, 2);                // a peer that connects and says nothing costs 2 s, not the job
       Hello h{};
-      const bool hello_ok = recv_all(fd, &h, sizeof(h)) && h.magic == HELLO_MAGIC && h.nonce == nonce && h.rank > 0 && h.rank < world && !served[h.rank];
-      if (!hello_ok) { ::close(fd); continue; }           // not one of ours (or a duplicate): drop it, keep listening
+      if (!recv_all(fd, &h, sizeof(h)) || h.magic != HELLO_MAGIC || h.nonce != nonce) { ::close(fd); continue; }   // not one of ours: no answer
+      const bool mine = h.rank > 0 && h.rank < world && h.kind == kind && h.seq == seq && h.bytes == (uint64_t)n && !served[h.rank];
+      const unsigned char answer = mine ? ACK : NAK;   // NAK: one of ours, but for another exchange (or served already): it will come back
+      if (!send_all(fd, &answer, 1) || !mine) { ::close(fd); continue; }
       set_io_timeout(fd, timeout_s());
       bool ok;
       if (gather) ok = recv_all(fd, (char*)all + (size_t)h.rank * n, n);
       else ok = send_all(fd, blob, n);
-      if (!ok) { ::close(fd); continue; }                  // the rank may reconnect until the deadline
+      if (!ok) { ::close(fd); continue; }                  // the rank reconnects until the deadline
       served[h.rank] = 1; ++n_served;
       if (gather) fds[h.rank] = fd; else ::close(fd);
     }
@@ -146,24 +168,29 @@ int tcp_exchange(const char* addr, int port, int world, int rank, void* blob, si
     ::close(ls);
     return rc;
   }
-  // ranks > 0: rank 0 may not be listening yet -- retry until the deadline
+  // ranks > 0: rank 0 may not be listening yet, may still be serving the previous exchange (NAK), or the connection may break before the payload
+  // went through -- close, wait, try again until the deadline
+  const Hello hello{HELLO_MAGIC, rank, nonce, kind, seq, (uint64_t)n};
   while (ms_left(deadline) > 0) {
     for (addrinfo* a = res; a; a = a->ai_next) {
       int fd = ::socket(a->ai_family, a->ai_socktype, a->ai_protocol);
       if (fd < 0) continue;
       if (::connect(fd, a->ai_addr, a->ai_addrlen) == 0) {
-        set_io_timeout(fd, timeout_s());
-        Hello h{HELLO_MAGIC, rank, nonce};
-        bool ok = send_all(fd, &h, sizeof(h));
-        if (ok && gather) ok = send_all(fd, blob, n) && recv_all(fd, all, (size_t)world * n);
-        else if (ok) ok = recv_all(fd, blob, n);
+        set_io_timeout(fd, 5);
+        unsigned char answer = NAK;
+        bool ok = send_all(fd, &hello, sizeof(hello)) && recv_all(fd, &answer, 1) && answer == ACK;
+        if (ok) {
+          set_io_timeout(fd, timeout_s());
+          if (gather) ok = send_all(fd, blob, n) && recv_all(fd, all, (size_t)world * n);
+          else ok = recv_all(fd, blob, n);
+        }
         ::close(fd);
-        freeaddrinfo(res);
-        return ok ? RGBID_OK : RGBID_E_NET;
+        if (ok) { freeaddrinfo(res); return RGBID_OK; }
+        break;                                             // refused or broken: back off, then start over
       }
       ::close(fd);
     }
-    usleep(100 * 1000);
+    usleep(50 * 1000);
   }
   freeaddrinfo(res);
   return RGBID_E_NET;
@@ -393,6 +420,7 @@ int rgbid_dist_track_sequence(rgbid_ctx* ctx, const rgbid_seq_config* cfg, const
   double track_ms = 0.0, gather_ms = 0.0;
 
   if (inject) {
+    if (cfg->inject_chunk_len != L) return RGBID_E_INVALID;   // the caller's buffer is laid out for another chunk length
     rep.setup_ms = ms_since(t_setup);
     const auto t0 = Clock::now();
     std::vector<rgbid_gather_record> local(n_local);

@@ -21,6 +21,7 @@
 // deterministic -- no floating-point atomics.  blockIdx is remapped so that the 8 XCDs each stream a contiguous slab.
 #define RGBID_ROW_PTR_MUL64   // common.h row_ptr: this file forms row addresses with the 64-bit multiply (its scalar unit does them; the 24-bit VALU form costs VGPRs here)
 #include "kernels.h"
+#include <atomic>
 #include <type_traits>
 #include "warp_device.h"
 #include <hip/hip_ext.h>
@@ -383,16 +384,19 @@ __global__ __launch_bounds__(SYS_T) __attribute__((amdgpu_waves_per_eu(FUSED == 
 
 static inline bool vec_ok(const ImgB& a) { return ((a.pitch & 15) == 0) && ((a.lane_stride & 15) == 0) && ((((uintptr_t)a.base) & 15) == 0); }
 
-// compute units of the current device (hipDeviceProp_t::multiProcessorCount), cached per device id
+// compute units of the current device (hipDeviceProp_t::multiProcessorCount), cached per device id.  The library is re-entrant (two host threads
+// may plan launches at once): the cache entries are atomics, and two threads that both miss store the same value
 static int device_cus() {
-  static int cus[64] = {0};
+  static std::atomic<int> cus[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  if (!cus[dev]) {
+  int v = cus[dev].load(std::memory_order_relaxed);
+  if (!v) {
     int n = 0;
-    cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    v = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    cus[dev].store(v, std::memory_order_relaxed);
   }
-  return cus[dev];
+  return v;
 }
 
 // tile shape of the 16-byte path (SysTiles): the widest of 32 / 16 / 8 units that divides the row, else 32 with a ragged last strip

@@ -147,7 +147,7 @@ def track_sequence(ctx, engine_cfg, depth_host, rgb_host, n_chunks, world=1, ran
 
     class SeqConfig(C.Structure):
         _fields_ = [("engine", EngineConfig), ("n_chunks", C.c_int), ("world", C.c_int), ("rank", C.c_int), ("exchange", C.c_int),
-                    ("master_addr", C.c_char_p), ("master_port", C.c_int)]
+                    ("master_addr", C.c_char_p), ("master_port", C.c_int), ("inject_chunk_len", C.c_int)]
 
     def ptr(a):
         if a is None:
@@ -163,6 +163,7 @@ def track_sequence(ctx, engine_cfg, depth_host, rgb_host, n_chunks, world=1, ran
     if inject is not None:
         inject = np.ascontiguousarray(inject)
         assert inject.dtype == GATHER_DTYPE and inject.ndim == 2 and inject.shape[0] == n_chunks
+        cfg.inject_chunk_len = int(inject.shape[1])
         inj = _ip(inject)
     R = np.zeros((T, 3, 3)); t = np.zeros((T, 3)); st = np.zeros(T, np.int32); cov = np.zeros((T, 6, 6))
     rep = SeqReport()

@@ -101,6 +101,7 @@ int main(int argc, char* argv[]) {
   cfg.master_addr = addr.c_str(); cfg.master_port = port;
 
   std::vector<rgbid_gather_record> inject;
+  int inject_chunk_len = 0;
   if (!inject_file.empty()) {
     std::ifstream f(inject_file.c_str(), std::ios::binary);
     if (!f) { std::cerr << "cannot open " << inject_file << std::endl; return 1; }
@@ -108,7 +109,9 @@ int main(int argc, char* argv[]) {
     if (bytes == 0 || bytes % (sizeof(rgbid_gather_record) * chunks) != 0) { std::cerr << inject_file << ": not [chunks][chunk_len] records\n"; return 1; }
     inject.resize(bytes / sizeof(rgbid_gather_record));
     f.read((char*)inject.data(), (std::streamsize)bytes);
+    inject_chunk_len = (int)(inject.size() / (size_t)chunks);   // the driver refuses it unless it is the chunk length -frames / -chunks imply
   }
+  cfg.inject_chunk_len = inject_chunk_len;
   rgbid_ctx* ctx = nullptr;
   if (inject.empty()) {
     int e = rgbid_ctx_create(&ctx, gpu, nullptr);

@@ -127,6 +127,20 @@ def test_cpp_sequence_driver_partition_exchange_compose(world, chunks, tmp_path)
     assert not any(o.exists() for o in outs[1:])          # rank 0 writes
 
 
+def test_sequence_driver_refuses_injected_records_of_another_chunk_length():
+    """rgbid_dist_track_sequence reads inject[chunk * chunk_len ...]: a buffer laid out for another chunk length (a records file made for another
+    -frames) must be refused, not read out of bounds or mis-strided"""
+    from rgbid import engine as E
+    from rgbid._lib import RgbidError
+    F, chunks = 25, 4
+    good, _, _, _, L = _chain_records(F, chunks)
+    D.track_sequence(None, E.default_config(rows=48, cols=64, lanes=1), None, None, chunks, inject=good, n_frames=F)
+    for bad_len in (L - 1, L + 1, 2 * L):
+        bad = np.zeros((chunks, bad_len), D.GATHER_DTYPE)
+        with pytest.raises(RgbidError):
+            D.track_sequence(None, E.default_config(rows=48, cols=64, lanes=1), None, None, chunks, inject=bad, n_frames=F)
+
+
 def test_tcp_rendezvous_ignores_strangers_and_duplicates():
     """rank 0 keeps accepting when something that is not a rank of this job connects (a port scanner, a stale process with another nonce, a
     rank that was served already); host names resolve (getaddrinfo)"""
@@ -146,7 +160,8 @@ def test_tcp_rendezvous_ignores_strangers_and_duplicates():
             out["rc0"] = L.rgbid_dist_broadcast_bytes(b"localhost", port, 2, 0, blob, C.c_size_t(16))
         th = threading.Thread(target=rank0); th.start()
         time.sleep(0.3)
-        for hello in (b"GET / HTTP/1.0\r\n\r\n", struct.pack("<IiQ", 0x52474244, 1, 999), struct.pack("<IiQ", 0x52474244, 7, 777), b""):
+        H = lambda rank, nonce, kind=0, seq=0, n=16: struct.pack("<IiQIIQ", 0x52474245, rank, nonce, kind, seq, n)
+        for hello in (b"GET / HTTP/1.0\r\n\r\n", H(1, 999), H(7, 777), H(1, 777, kind=1), H(1, 777, seq=5), H(1, 777, n=17), struct.pack("<IiQ", 0x52474244, 1, 777), b""):
             s = socket.create_connection(("127.0.0.1", port)); s.sendall(hello); time.sleep(0.05); s.close()
         blob = (C.c_char * 16)()
         rc1 = L.rgbid_dist_broadcast_bytes(b"localhost", port, 2, 1, blob, C.c_size_t(16))
@@ -163,6 +178,22 @@ def test_tcp_rendezvous_ignores_strangers_and_duplicates():
         ths = [threading.Thread(target=rk, args=(r,)) for r in (2, 1, 0)]
         [t_.start() for t_ in ths]; [t_.join(60) for t_ in ths]
         assert rcs == [0, 0, 0] and all(np.array_equal(a, np.repeat([1, 2, 3], 8)) for a in allb)
+        # two exchanges back to back on ONE port, 3 ranks (what rgbid_dist_exchange_id followed by the TCP all-gather does): rank 1 finishes the
+        # broadcast at once and reaches rank 0's listener while it still waits for the late rank 2 -- it is told "not yet" and comes back
+        port3 = D.free_port()
+        got = [None] * 3
+
+        def both(r):
+            if r == 2:
+                time.sleep(1.0)
+            blob = (C.c_char * 8)(*(b"ABCDEFGH" if r == 0 else b"\0" * 8))
+            rc_a = L.rgbid_dist_broadcast_bytes(b"127.0.0.1", port3, 3, r, blob, C.c_size_t(8))
+            mine = np.full(4, 10 + r, np.uint8); allv = np.zeros(12, np.uint8)
+            rc_b = L.rgbid_dist_allgather_bytes_tcp(b"127.0.0.1", port3, 3, r, mine.ctypes.data_as(C.c_void_p), C.c_size_t(4), allv.ctypes.data_as(C.c_void_p))
+            got[r] = (rc_a, bytes(blob), rc_b, allv.tolist())
+        ths = [threading.Thread(target=both, args=(r,)) for r in (1, 2, 0)]
+        [t_.start() for t_ in ths]; [t_.join(90) for t_ in ths]
+        assert all(g == (0, b"ABCDEFGH", 0, [10] * 4 + [11] * 4 + [12] * 4) for g in got), got
     finally:
         os.environ.pop("RGBID_DIST_NONCE"); os.environ.pop("RGBID_DIST_TIMEOUT_S")
 

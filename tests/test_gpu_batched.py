@@ -274,6 +274,20 @@ def test_gn_fused_argument_errors(bt):
         bt.kf_maps(K, dm[0], torch.zeros((lanes, 3 * rows, cols), device="cuda"), torch.zeros((lanes, 3 * rows, cols), device="cuda"))
 
 
+def test_batched_calls_refuse_images_that_do_not_hold_their_rows(bt):
+    """a caller-described image whose step is smaller than a row (or not a multiple of the element size), whose lanes overlap, or a lane count beyond
+    the kernels' grid dimension, is refused before anything is launched (the kernels would write past rows and lanes)"""
+    import ctypes as C
+    src = torch.zeros((2, 16, 32), device="cuda"); dst = torch.zeros((2, 8, 16), device="cuda")
+    ms = C.c_float()
+    good_s, good_d = BT.imgb(src), BT.imgb(dst)
+    assert bt.L.rgbid_pyr_down_batched(bt._h, 2, C.byref(good_s), C.byref(good_d), C.byref(ms)) == 0
+    for field, value in (("step", 4 * 16 - 4), ("step", 4 * 16 + 2), ("lane_stride", 4 * 16 * 4), ("lane_stride", 4 * 16 * 8 + 2)):
+        bad = BT.imgb(dst); setattr(bad, field, value)
+        assert bt.L.rgbid_pyr_down_batched(bt._h, 2, C.byref(good_s), C.byref(bad), C.byref(ms)) == -1, (field, value)
+    assert bt.L.rgbid_pyr_down_batched(bt._h, 70000, C.byref(good_s), C.byref(good_d), C.byref(ms)) == -1
+
+
 @pytest.mark.parametrize("rows,cols,lanes,ns", [(48, 64, 3, 500), (61, 83, 2, 1000), (480, 640, 2, 10000), (240, 320, 2, 10000), (960, 1280, 1, 10000)])
 @pytest.mark.parametrize("packed", [False, True])
 def test_lattice_residuals_and_sigma_pair(bt, rows, cols, lanes, ns, packed):

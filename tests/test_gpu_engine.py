@@ -38,6 +38,7 @@ def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, m
     okw.update(rows=rows, cols=cols, fx=K[0], fy=K[1], cx=K[2], cy=K[3])
     worst_r = worst_t = 0.0
     imposed = 0
+    frames_checked = widened_flip = widened_stop = 0
     th_o, th_i = cfg_kw.get("visratio_odo", 0.9), cfg_kw.get("visratio_integr", 0.7)
     fin = cfg_kw.get("finest_level", 0)
     n_lattice = device.error_lattice_size(rows >> fin, cols >> fin, cfg_kw.get("nsamples", 10000))[0]
@@ -76,10 +77,17 @@ def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, m
             # campaign: 2.3e-3, exact and fast engine alike): allow three; (2) the sigma iteration stops when its relative change drops below 0.1:
             # with the ratio ON that threshold (the oracle reports the distance, rgbid_oracle.h sigma_stop_margin_frame) the two may stop one iteration
             # apart, which moves sigma by a few 1e-3.
+            # The TIGHT tolerance is the default; a frame may use one of the two widened bounds only under its stated condition, and the frames that
+            # did are counted and reported (the gate must not loosen silently).
             ds = abs(rec[k, l]["sigma_int"] - info.sigma_int)
-            if not ds < max(sigma_tol, 15.0 / n_lattice) * info.sigma_int:
-                assert info.sigma_stop_margin_frame < 1e-4 and ds < 2e-2 * info.sigma_int, (l, k, rec[k, l]["sigma_int"], info.sigma_int, info.sigma_stop_margin_frame, n_lattice)
-                print(f"lane {l} frame {k}: sigma iteration on its stopping threshold (margin {info.sigma_stop_margin_frame:.1e}): sigma_int {rec[k, l]['sigma_int']} vs {info.sigma_int}")
+            frames_checked += 1
+            if not ds < sigma_tol * info.sigma_int:
+                if ds < 15.0 / n_lattice * info.sigma_int:
+                    widened_flip += 1
+                else:
+                    assert info.sigma_stop_margin_frame < 1e-4 and ds < 2e-2 * info.sigma_int, (l, k, rec[k, l]["sigma_int"], info.sigma_int, info.sigma_stop_margin_frame, n_lattice)
+                    widened_stop += 1
+                    print(f"lane {l} frame {k}: sigma iteration on its stopping threshold (margin {info.sigma_stop_margin_frame:.1e}): sigma_int {rec[k, l]['sigma_int']} vs {info.sigma_int}")
         Rs, ts = trk.poses()
         oR, ot, ocov = trk.odometry()
         for k in range(1, n_frames):
@@ -110,6 +118,9 @@ def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, m
     eng.close()
     if imposed:
         print(f"keyframe decisions on the threshold, imposed on the oracle: {imposed}")
+    if widened_flip or widened_stop:
+        print(f"sigma: {widened_flip} of {frames_checked} frames used the flipped-sample bound (15 / n_lattice), {widened_stop} the stopping-threshold bound")
+    assert widened_flip + widened_stop <= max(2, 0.15 * frames_checked), (widened_flip, widened_stop, frames_checked)
     return worst_r, worst_t
 
 
