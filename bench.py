@@ -521,7 +521,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip extra_configs (BASELINE configs 1 and 5)")
     ap.add_argument("--gather", default="rccl-cabi", choices=["rccl-cabi", "torch"], help="transport of the record all-gather at N > 1: the product's C-ABI helper over RCCL "
                     "(a failure of it ENDS the run with a non-zero exit code), or torch.distributed when asked for explicitly")
-    ap.add_argument("--h2d", type=int, default=0, help="also time the same steps with the frames streamed from pinned host memory (PCIe-inclusive rate; never `value`)")
+    ap.add_argument("--h2d", type=int, default=-1, help="also time the same steps with the frames streamed from pinned host memory (PCIe-inclusive rate at the headline lane count; never `value`); "
+                                                          "default: on for the single-GPU run (costs ~13 s: 31 GB of frames are copied to pinned host memory)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -602,8 +603,8 @@ def main():
         rccl_ranks_all = [int(v) for v in rr.cpu()]
 
     pcie = None
-    if args.h2d:
-        # PCIe-inclusive leg at the headline lane count (the driver-run line carries it at 512 lanes in extra_configs: pinning 35 GB of frames takes longer than the run)
+    if args.h2d > 0 or (args.h2d < 0 and world == 1 and not args.no_extras):
+        # PCIe-inclusive leg at the headline lane count: the same timed steps with every frame uploaded from pinned host memory
         pcie = pcie_leg(ctx, dev, work, eng, depth, rgb, W, Kst, rec)
     eng.close()
 
@@ -689,9 +690,6 @@ def main():
                 entry = {"config": f"lanes-{Bs}: the headline workload with {Bs} concurrent streams per GPU ({keeps[3].bytes() / 1e9:.1f} GB of engine state)", "value": rs["value"], "unit": "frames/s",
                          "ms_per_step": rs["ms_per_step"], "lanes": Bs, "steps": Kst, "warmup": W, "repetitions": 3, "u1_frac_of_hbm_peak": rs["u1"]["achieved"] / HBM_PEAK_GBS,
                          "lanes_bit_identical": rs["parity"]["lanes_bit_identical"]}
-                if Bs == 512:
-                    pc = pcie_leg(ctx, dev, work, keeps[3], sub[1], sub[2], W, Kst, keeps[4])
-                    entry["pcie_inclusive"] = pc
                 keeps[3].close()
                 del keeps, sub
                 extras.append(entry)

@@ -161,6 +161,12 @@ __device__ __forceinline__ TileId xcd_slab_tile() {
   return t;
 }
 
+// the same renumbering for a 1-D grid: hardware id -> logical id such that XCD k owns the contiguous range [k n / 8, (k + 1) n / 8)
+__device__ __forceinline__ unsigned xcd_slab_index(unsigned id, unsigned n) {
+  const unsigned per = n >> 3;
+  return (id < (per << 3)) ? (id & 7u) * per + (id >> 3) : id;   // tail ids keep their place
+}
+
 __device__ __forceinline__ bool in_bounds_rd(float xs, float ys, int cols, int rows) {
   int ix = f2i_rd(xs), iy = f2i_rd(ys);
   return !(ix < 0 || iy < 0 || ix >= cols || iy >= rows);

@@ -404,10 +404,14 @@ __device__ __forceinline__ void pyr_finish_shared(float2 p, bool row_in, bool c0
   r.v[4] = dpp_shift<0x130>(v0); r.m[4] = dpp_shift<0x130>(m0);
 }
 static constexpr int PD_WAVE_OUT = 62;   // outputs per wave (lanes 1 .. 62)
-__global__ __launch_bounds__(256) void k_pyr_down_dpp(ImgB src, ImgB dst, PyrWeights W, int strips, int wpr, LaneMask m) {
-  const int lane = blockIdx.y;
+__global__ __launch_bounds__(256) void k_pyr_down_dpp(ImgB src, ImgB dst, PyrWeights W, int strips, int wpr, int wgs_per_lane, LaneMask m) {
+  // 1-D grid in XCD-contiguous order (common.h): the workgroups of vertically adjacent strips -- which share 3 of their 19 source rows -- run on ONE
+  // XCD one after the other and find the shared rows in its L2 (with the natural order they sit on different XCDs and each fetches them from HBM:
+  // round 3 counted 1.48 x the algorithmic reads)
+  const unsigned V = xcd_slab_index(blockIdx.x, gridDim.x);
+  const int lane = (int)(V / (unsigned)wgs_per_lane), wg = (int)(V - (unsigned)lane * (unsigned)wgs_per_lane);
   if (!m.on(lane)) return;
-  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lid = threadIdx.x & 63;
+  const int wave = (wg * 256 + threadIdx.x) >> 6, lid = threadIdx.x & 63;
   if (wave >= strips * wpr) return;                       // whole waves only: every lane of a live wave takes part in the shifts
   const int strip = wave / wpr, wx = wave - strip * wpr;
   const int x = wx * PD_WAVE_OUT + lid - 1;                // -1 and >= dst.cols: halo / idle lanes (they still provide their column pair)
@@ -451,7 +455,8 @@ __global__ __launch_bounds__(256) void k_pyr_down_dpp(ImgB src, ImgB dst, PyrWei
 void launch_pyr_down(hipStream_t s, int B, ImgB src, ImgB dst, LaneMask m) {
   int strips = div_up(dst.rows, PD_ROWS);
   const int wpr = div_up(dst.cols, PD_WAVE_OUT);
-  hipLaunchKernelGGL(k_pyr_down_dpp, dim3(div_up(strips * wpr, 4), B), dim3(256), 0, s, src, dst, pyr_weights(), strips, wpr, m);
+  const int wgs = div_up(strips * wpr, 4);
+  hipLaunchKernelGGL(k_pyr_down_dpp, dim3((unsigned)wgs * (unsigned)B), dim3(256), 0, s, src, dst, pyr_weights(), strips, wpr, wgs, m);
 }
 
 // ---- bilateralKernel (filters.cu:86-135), clipped 5x5 window -------------------------------------
