@@ -404,6 +404,11 @@ def extra_config4(ctx, dev, K, world, rank, n_frames, chunks_per_gpu, fused, fas
     torch.cuda.empty_cache()
     render_s = time.perf_counter() - t0
     cfg = E.default_config(rows=rows, cols=cols, K=K, fused_gn=fused, fast_numerics=fast)
+    if chunks_per_gpu <= 0:
+        # measured on one GPU (tools/shard_sweep.py, profiles/r04_shard_sweep.json): throughput peaks at 128 lanes per GPU, and chunks
+        # shorter than ~10 frames cost accuracy (every chunk head starts without a velocity prior on a fresh keyframe: ATE 6.3 mm unsharded, 7.0 at 128
+        # chunks of 20 frames, 8.6 at 256 x 10, 9.4 at 512 x 5) and spend a growing share of the steps on chunk heads (1.08 / 1.13 / 1.23 x)
+        chunks_per_gpu = max(1, min(128, (n_frames // 10) // world))
     chunks = chunks_per_gpu * world
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1"); port = int(os.environ.get("MASTER_PORT", "29541")) + 2
     runs = []
@@ -435,6 +440,19 @@ def extra_config4(ctx, dev, K, world, rank, n_frames, chunks_per_gpu, fused, fas
                "trajectory_vs_unsharded": {"max_rot_rad": max(_rot_angle(R[k], Rs[k]) for k in range(n_frames)), "max_trans_m": float(np.abs(t - ts).max())},
                "ate_rmse_m": {"sharded": _ate_rmse(t, tg), "unsharded": _ate_rmse(ts, tg), "vs": "synthetic ground truth (exact camera path)"},
                "render_s": render_s}
+        if world == 1:
+            # what other chunk counts would have given on this GPU (the full sweep: tools/shard_sweep.py -> profiles/r04_shard_sweep.json)
+            sweep = []
+            for c in (8, 64, 256, 512):
+                if c == chunks or n_frames < c + 1:
+                    continue
+                Rc, tc, stc, _, repc = None, None, None, None, None
+                for _ in range(2):
+                    Rc, tc, stc, _, repc = D.track_sequence(ctx, cfg, depth_h, rgb_h, c)
+                sweep.append({"chunks": c, "frames_per_s": 1e3 * n_frames / repc["total_ms"], "chunk_len": repc["chunk_len"], "ms_per_step": repc["track_ms"] / repc["chunk_len"],
+                              "lane_steps_per_transition": c * repc["chunk_len"] / (n_frames - 1), "traj_max_trans_m_vs_unsharded": float(np.abs(tc - ts).max()),
+                              "ate_rmse_m": _ate_rmse(tc, tg), "frames_lost": int(np.count_nonzero(stc & E.ST_LOST))})
+            out["chunk_count_sweep_1gpu"] = sweep
     del depth_h, rgb_h
     return out
 
@@ -509,7 +527,8 @@ def main():
     ap.add_argument("--streams", type=int, default=32, help="distinct synthetic input streams dealt onto the lanes")
     ap.add_argument("--check-streams", type=int, default=32, help="lanes (one per distinct stream) held to the CPU oracle over all timed steps, after the timed regions (default: every distinct stream)")
     ap.add_argument("--seq-frames", type=int, default=2500, help="frames of the ONE long sequence of extra config 4 (BASELINE config 4: fr3/long_office has ~2 500)")
-    ap.add_argument("--seq-chunks-per-gpu", type=int, default=64, help="chunks (= engine lanes) per GPU of extra config 4")
+    ap.add_argument("--seq-chunks-per-gpu", type=int, default=0, help="chunks (= engine lanes) per GPU of extra config 4; 0 = the rule of DESIGN section 6 / tools/shard_sweep.py: "
+                                                                       "chunks of >= 10 frames (ATE within ~35 %% of the unsharded run), at most 128 lanes per GPU")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--levels", type=int, default=3)

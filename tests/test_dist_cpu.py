@@ -60,14 +60,14 @@ def test_compose_single_rank_matches_reference_composition():
     D.compose_trajectory(lost, 1, n_chunks, ranges)
 
 
-@pytest.mark.parametrize("world,chunks", [(2, 8), (2, 7), (3, 7)])
-def test_record_gather_and_composition_multi_rank(world, chunks):
+@pytest.mark.parametrize("world,chunks,frames", [(2, 8, 41), (2, 7, 41), (3, 7, 41), (8, 248, 2500)])   # the last: the shape bench.py --gpus 8 runs config 4 in
+def test_record_gather_and_composition_multi_rank(world, chunks, frames):
     """N ranks through the bench launcher; uneven chunk ownership (7 chunks on 2 or 3 ranks) pads with lanes nobody reads"""
-    p = D.spawn_local(world, [os.path.join(ROOT, "tools", "dist_selftest.py"), "--backend", "gloo", "--frames", "41", "--chunks", str(chunks),
+    p = D.spawn_local(world, [os.path.join(ROOT, "tools", "dist_selftest.py"), "--backend", "gloo", "--frames", str(frames), "--chunks", str(chunks),
                               "--expect-world", str(world)], timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     res = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-    assert res["world"] == world and res["compose_err"] < 1e-12 and res["cov_ok"] and res["status_ok"] and res["tcp_rendezvous_ok"], res
+    assert res["world"] == world and res["compose_err"] < 1e-13 * frames and res["cov_ok"] and res["status_ok"] and res["tcp_rendezvous_ok"], res
 
 
 def _chain_records(F, n_chunks, seed=11):
@@ -92,14 +92,13 @@ def _chain_records(F, n_chunks, seed=11):
     return rec, Rg, tg, ranges, L
 
 
-@pytest.mark.parametrize("world,chunks", [(1, 5), (2, 8), (2, 7), (3, 7)])
-def test_cpp_sequence_driver_partition_exchange_compose(world, chunks, tmp_path):
+@pytest.mark.parametrize("world,chunks,F", [(1, 5, 41), (2, 8, 41), (2, 7, 41), (3, 7, 41), (8, 248, 2500)])   # the last: the shape of bench.py --gpus 8 (31 chunks of 11 frames per GPU)
+def test_cpp_sequence_driver_partition_exchange_compose(world, chunks, F, tmp_path):
     """The C++ sharded-sequence driver (tools/rgbid_track_sequence.cpp -> rgbid_dist_track_sequence) as `world` PROCESSES with the per-chunk records
     injected (no GPU here): its partition (uneven ownership, padded lanes), its exchange (the library's TCP rendezvous: hello / nonce, all-gather)
     and its composition give the trajectory file rgbid/dist.py + rgbid/tum.py give for the same records, byte for byte.  RCCL itself needs one
     GPU per rank and stays unmeasured here (tests/test_gpu_dist.py covers world 1; tools/dist_selftest.py --backend nccl a multi-GPU node)."""
     from rgbid import tum
-    F = 41
     rec, Rg, tg, ranges, L = _chain_records(F, chunks)
     inj = tmp_path / "records.bin"
     rec.tofile(str(inj))
@@ -120,7 +119,7 @@ def test_cpp_sequence_driver_partition_exchange_compose(world, chunks, tmp_path)
         for i, c in enumerate(D.rank_chunks(chunks, world, r)):
             allrec[r, i] = rec[c]
     R, t, st, cov = D.compose_trajectory(allrec, world, chunks, ranges)
-    assert np.abs(R - Rg).max() < 1e-12 and np.abs(t - tg).max() < 1e-12
+    assert np.abs(R - Rg).max() < 1e-13 * F and np.abs(t - tg).max() < 1e-13 * F      # the composed chain against the generating chain: rounding of F products
     ref = tmp_path / "ref.txt"
     tum.write_trajectory(str(ref), [k / 30.0 for k in range(F)], R, t)
     assert outs[0].read_bytes() == ref.read_bytes()
