@@ -13,6 +13,13 @@
 #define RGBID_HD inline
 #endif
 
+// Device compilations evaluate these functions WITHOUT fused multiply-add contraction (hipcc's default would fuse a * b + c wherever its optimiser
+// sees one, differently in different kernels): every translation unit that inlines them -- the engine's per-lane kernels, the persistent
+// Gauss-Newton level kernel -- then computes bit-identical poses, and the device agrees with the host build (g++ does not contract on x86-64).
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
 namespace rgbid {
 namespace se3 {
 
@@ -242,3 +249,7 @@ RGBID_HD bool has_nan(const double* R, const double* t) {
 
 }  // namespace se3
 }  // namespace rgbid
+
+#if defined(__clang__) && defined(__HIPCC__)
+#pragma clang fp contract(fast)   // hipcc's default again for whatever the including translation unit defines next
+#endif

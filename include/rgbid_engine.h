@@ -47,8 +47,9 @@ typedef struct rgbid_engine_config {
   int fast_numerics;         /* gather kernels (warp pair, covisibility, keyframe fusion) in the reference BUILD's class of arithmetic --
                               * hardware reciprocal + FMA contraction, what nvcc --prec-div=false + default fmad give the reference
                               * (CMakeLists.txt:105) -- instead of the IEEE evaluation of the oracle (default 1; 0 = the bit-exact
-                              * kernels of the compat bridge).  A coordinate within an ulp of a pixel boundary may then select the
-                              * neighbouring pixel: a few pixels per map, poses within 1e-6 (csrc/warp_device.h) */
+                              * kernels of the compat bridge).  The float VALUES are then the cheap ones; every discrete decision (point-sampled
+                              * source pixel, validity, covisibility counts, fusion gate) is the oracle's (rgbid.h rgbid_ctx_set_numerics,
+                              * csrc/guard_band.h) */
 } rgbid_engine_config;
 
 #define RGBID_ST_TRACKED    1   /* trackNewFrame returned true */

@@ -11,6 +11,7 @@
 #include "ctx.h"
 #include "kernels.h"
 #include "../../include/rgbid/se3.h"
+#include "engine_device.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -18,58 +19,14 @@
 #include <new>
 #include <vector>
 
-using namespace rgbid;
+#pragma clang fp contract(off)   // the per-lane scalar kernels below (double-precision tracker logic): no FMA contraction, as se3.h / engine_device.h
 
-namespace {
+using namespace rgbid;
+using namespace rgbid::eng;
 
 constexpr int MAXL = 8;
 
-// ---- per-lane tracker state (the scalar members of VisodoTracker, include/visodo.h:280-390) -----------------
-struct LaneState {
-  double delta_R[9], delta_t[3], delta_cov[36];          // delta_rotation_/translation_/covariance_
-  double dprev_R[9], dprev_t[3], dprev_cov[36];          // their values at the start of trackNewFrame
-  double prev_R[9], prev_t[3];                           // previous_rotation/translation of estimateVisualOdometry
-  double cur_R[9], cur_t[3];                             // current_rotation/translation (GN working pose)
-  double odoKF_R[9], odoKF_t[3];                         // last_odoKF_global_*
-  double integrKF_R[9], integrKF_t[3];                   // last_integrKF_global_*
-  double last_est_R[9], last_est_t[3];                   // last_estimated_*
-  double o2i_last_R[9], o2i_last_t[3], o2i_last_cov[36]; // delta_*_odo2integr_last_
-  double o2i_next_R[9], o2i_next_t[3], o2i_next_cov[36]; // delta_*_odo2integr_next_
-  double dI_R[9], dI_t[3];                               // delta_integr_rotation/translation of this frame
-  double velocity[3], omega[3];
-  int global_time, lost, odoKF_count, integrKF_count, last_odoKF_index, last_integrKF_index;
-  int gn_failed;
-  int kf_exported;  // keyframes this lane has handed to the export ring
-  int status;       // RGBID_ST_* bits of the current step
-  float vis_odo, vis_int;
-  float rec_sigma_i, rec_sigma_d, rec_nu_i, rec_nu_d;  // scale estimates of the last GN iteration (diagnostics)
-};
-
-struct Flags {  // int[B] each; consumed through LaneMask
-  int *track, *first, *gn, *vis, *sw_odo, *sw_int, *overlap, *fuse, *maps;
-  int* kf_slot;  // ring slot the lane exports its outgoing integration keyframe into this step, or -1 (not a LaneMask flag)
-};
-
-struct StepCfg {  // by-value kernel argument with what the scalar kernels need
-  float fx, fy, cx, cy;
-  int levels, finest_level, motion_model, max_odoKF_count, max_integrKF_count;
-  float visratio_odo, visratio_integr, delta_t;
-  int mestimator, weighting;
-  int start_warp_level;  // pyramid level whose intrinsics project the first warp of a frame
-  rgbid_keyframe_header* kf_hdr;  // export ring headers [B][kf_cap] (nullptr: no export)
-  int kf_cap;
-  const int* active;     // per-lane 0/1: lanes without a new frame this step sit it out (nullptr: every lane is fed)
-};
-
-__device__ void set_warp_from_pose(const StepCfg& c, int level, const double* R, const double* t, WarpParams& wp) {
-  // inverse pose, projected with the level's K (visodo.cpp:1066-1067,1108-1114)
-  double Ri[9], ti[3];
-  se3::m3_inv(R, Ri);
-  se3::m3_mulv(Ri, t, ti);
-  ti[0] = -ti[0]; ti[1] = -ti[1]; ti[2] = -ti[2];
-  int div = 1 << level;
-  se3::project_trafo(c.fx / div, c.fy / div, c.cx / div, c.cy / div, Ri, ti, wp.R, wp.t);
-}
+namespace {
 
 __device__ void reset_odometry_keyframe(LaneState& s) {
   // resetOdometryKeyframe visodo.cpp:1541-1575
@@ -189,23 +146,7 @@ __global__ void k_step_begin(LaneState* st, Flags f, WarpParams* wp, SysParams* 
 __global__ void k_set_sys(SysParams* sp, LaneState* st, const int* track, StepCfg c, int level, int cov_pass, int B) {
   int lane = blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= B) return;
-  int div = 1 << level;
-  SysParams& p = sp[lane];
-  if (cov_pass && track[lane]) {
-    st[lane].rec_sigma_i = p.sigma_i; st[lane].rec_sigma_d = p.sigma_d;
-    st[lane].rec_nu_i = fmaxf(p.nu_i, p.nu_d); st[lane].rec_nu_d = p.nu_d;  // nu_int = max(nu_int, nu_depthinv), visodo.cpp:1186
-  }
-  p.fx = c.fx / div; p.fy = c.fy / div; p.cx = c.cx / div; p.cy = c.cy / div;
-  p.weighting = c.weighting;
-  if (cov_pass) {
-    // visodo.cpp:1349-1365: STUDENT with the fixed reference sigmas, zero bias
-    p.mestimator = RGBID_STUDENT; p.student_nu = 0; p.nu_i_max = 0;
-    p.sigma_i = (float)exp(log((double)5.f)); p.sigma_d = (float)exp(log((double)0.0025f));
-    p.bias_i = 0.f; p.bias_d = 0.f; p.nu_i = 5.f; p.nu_d = 5.f;
-  } else {
-    p.mestimator = c.mestimator; p.student_nu = 1; p.nu_i_max = 1;
-    p.sigma_i = 5.f; p.sigma_d = 0.0025f; p.bias_i = 0.f; p.bias_d = 0.f; p.nu_i = 5.f; p.nu_d = 5.f;  // visodo.cpp:1168-1173
-  }
+  set_sys_lane(sp, st, track, c, level, cov_pass, lane);
 }
 
 // ---- one GN update: reduce partials, LLT solve, exp-map, pose update, next warp (visodo.cpp:1242-1274) -------
@@ -215,44 +156,7 @@ __global__ __launch_bounds__(256) void k_solve_update(const double* partials, in
   if (!f.gn[lane]) return;
   __shared__ double sm[8][32];
   __shared__ double sums[SYS_TERMS];
-  int k = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  double t = 0.0;
-  if (k < SYS_TERMS) {
-    const double* p = partials + (size_t)lane * nblk * SYS_TERMS + k;
-    for (int b = sl; b < nblk; b += 8) t += p[(size_t)b * SYS_TERMS];
-  }
-  sm[sl][k] = t;
-  __syncthreads();
-  if (threadIdx.x < SYS_TERMS) {
-    double r = 0.0;
-    for (int i = 0; i < 8; ++i) r += sm[i][threadIdx.x];
-    sums[threadIdx.x] = r;
-  }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  LaneState& s = st[lane];
-  double A[36], b[6], x[6];
-  int shift = 0;  // estimate_VO.cu:774-786
-  for (int i = 0; i < 6; ++i)
-    for (int j = i; j < 7; ++j) {
-      double v = sums[shift++];
-      if (j == 6) b[i] = v; else A[j * 6 + i] = A[i * 6 + j] = v;
-    }
-  se3::llt_solve6(A, b, x);
-  double inc_inv[9], inc[9], tinc[3], tmp[3];
-  se3::expmap_rot(x + 3, inc_inv);
-  se3::m3_inv(inc_inv, inc);
-  se3::m3_mulv(inc, x, tinc);
-  tinc[0] = -tinc[0]; tinc[1] = -tinc[1]; tinc[2] = -tinc[2];
-  se3::m3_mulv(inc, s.cur_t, tmp);
-  for (int i = 0; i < 3; ++i) s.cur_t[i] = tmp[i] + tinc[i];
-  se3::m3_mul(inc, s.cur_R, s.cur_R);
-  if (se3::has_nan(s.cur_R, s.cur_t)) {  // :1265-1274
-    s.gn_failed = 1;
-    f.gn[lane] = 0;
-    return;
-  }
-  set_warp_from_pose(c, next_level, s.cur_R, s.cur_t, wp[lane]);
+  solve_update_block(partials, nblk, st, f, wp, c, next_level, lane, (int)threadIdx.x, sm, sums);
 }
 
 // ---- end of estimateVisualOdometry + pose bookkeeping of trackNewFrame (visodo.cpp:1367-1468, 2051-2170) -----

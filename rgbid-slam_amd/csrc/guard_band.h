@@ -59,9 +59,9 @@
 #include <math.h>
 
 #if defined(__HIPCC__)
-#define RGBID_HD __host__ __device__
+#define RGBID_GB_HD __host__ __device__
 #else
-#define RGBID_HD
+#define RGBID_GB_HD
 #endif
 
 namespace rgbid {
@@ -80,7 +80,7 @@ struct Guard {
   float e0, e1;     //        eps_res = e0 + e1 |rcp(1 - w2 t_z)| (relative distance of the warped inverse depth)
 };
 
-RGBID_HD inline Guard make_guard(const float R[9], const float t[3], int cols, int rows) {
+RGBID_GB_HD inline Guard make_guard(const float R[9], const float t[3], int cols, int rows) {
   const float u1 = 0x1p-24f * (1.f + 0x1p-10f);
   const float xm = (float)(cols - 1), ym = (float)(rows - 1);
   const float a0 = fabsf(R[0]), a1 = fabsf(R[1]), a2 = fabsf(R[2]), a3 = fabsf(R[3]), a4 = fabsf(R[4]), a5 = fabsf(R[5]), a6 = fabsf(R[6]), a7 = fabsf(R[7]),

@@ -19,6 +19,7 @@ struct IntrK { float fx, fy, cx, cy, k1, k2, k3, k4, k5; };                     
 struct DepthDistP { float c1, c0, q0[9], q1[9]; int xshift, yshift; };          // DepthDist, src/internal.h:142-161
 
 enum { SYS_TERMS = 27 };
+static constexpr float TH_HUBER = 1.345f, TH_TUKEY = 4.685f, STUDENT_DOF = 5.f;   // computeWeight estimate_VO.cu:141-167, sigmaFuncs.cu:179-255
 
 // ---- custom-calibration front-end (kernels_calib.hip) -------------------------------------------
 void launch_undistort(hipStream_t s, int B, ImgB src, ImgB dst, IntrK k, bool linear, int interp_mode, LaneMask m);
