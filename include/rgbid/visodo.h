@@ -22,6 +22,8 @@
 #include "internal.h"
 #include "settings.h"
 
+struct rgbid_engine;   // include/rgbid_engine.h (the engine-backed mode of the tracker)
+
 namespace RGBID_SLAM {
 
 struct PixelRGB { unsigned char r, g, b; };  // include/types.h:88-91
@@ -137,6 +139,17 @@ class VisodoTracker {
   // trackNewFrame ignores the milliseconds its device calls return, so by default it runs them through a ScopedAsyncBridge
   // (include/rgbid/containers.hpp): no per-call timing events / synchronisation, results identical.  Off = the reference's fully synchronous calls.
   void setAsyncBridge(bool on) { async_bridge_ = on; }
+  // Opt-in: trackNewFrame drives a ONE-LANE device-resident engine (include/rgbid_engine.h, exact numerics class) instead of
+  // issuing ~800 bridge calls per frame from the host -- the whole frame is one launch sequence without host round trips (2.8 -> ~1 ms per
+  // 640x480 frame).  Same public surface, same streams to the back-end, poses / covariances / keyframes equal to the host-driven path to double
+  // rounding (tests/test_gpu_tracker_cpp.py runs the tracker tests in both modes).  Returns false (and stays host-driven) for what only the
+  // host-driven path implements: CHI_SQUARED termination, custom calibration / registration, a non-identity initial pose; must be chosen before
+  // the first frame (or after reset()).
+  bool setEngineBacked(bool on);
+  bool engineBacked() const { return engine_backed_; }
+  // fused inverse depth + weight of the integration keyframe / the current frame's level-0 maps, wherever they live (tracker buffers or the engine)
+  void downloadKeyframeMaps(float* depthinv_host, float* weight_host) const;
+  void downloadCurrentMaps(float* depthinv_host, float* intensity_host) const;
   const std::vector<Matrix3ft>& odoRotations() const { return odo_rmats_; }
   const std::vector<Vector3ft>& odoTranslations() const { return odo_tvecs_; }
   const std::vector<Matrix6d>& odoCovariances() const { return odo_covmats_; }
@@ -169,6 +182,8 @@ class VisodoTracker {
   bool scene_view_has_changed_;
 
  private:
+  bool trackNewFrameEngine();
+  bool createEngine();
   float computeInterframeTime();
   void allocateBuffers(int rows_arg, int cols_arg);
   void prepareImages(const DepthMap& depth_raw, const View& colors_raw);
@@ -233,6 +248,9 @@ class VisodoTracker {
   float kf_time_accum_;
   bool preview_, verbose_;
   bool async_bridge_ = true;
+  int interp_mode_ = RGBID_INTERP_TEX8;
+  bool engine_backed_ = false;
+  ::rgbid_engine* engine_ = nullptr;
   LastFrameInfo last_info_;
   TrackerSink null_sink_;
 };

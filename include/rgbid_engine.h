@@ -90,6 +90,15 @@ int rgbid_engine_set_active(rgbid_engine* e, const int* active);
  * buffers IN PLACE (no staging copy): keep them valid and unmodified until the step has executed; with use_graph = 1 they are copied into
  * the engine's own staging buffers first (a captured graph needs fixed addresses) and may be reused once that copy has run. */
 int rgbid_engine_step(rgbid_engine* e, const void* depth_dev, const void* rgb_dev);
+/* the same for PITCHED inputs (cudaMallocPitch-style containers: rgb24_ / depth_ of the compat VisodoTracker): row steps and lane strides in bytes
+ * (lane strides ignored with one lane) */
+int rgbid_engine_step_strided(rgbid_engine* e, const void* depth_dev, size_t depth_step, size_t depth_lane_stride, const void* rgb_dev, size_t rgb_step,
+                              size_t rgb_lane_stride);
+/* the inter-frame time of the constant-velocity model for the steps that follow (computeInterframeTime, visodo.cpp:1902-1965, when the caller
+ * measures it per frame); needs use_graph = 0 (a captured graph has the value baked in: RGBID_E_INVALID) */
+int rgbid_engine_set_delta_t(rgbid_engine* e, float delta_t);
+/* device views of a lane's current-frame level-0 maps (inverse depth, intensity) */
+int rgbid_engine_current_maps(rgbid_engine* e, int lane, rgbid_img* depthinv, rgbid_img* intensity);
 /* number of steps taken since reset */
 int rgbid_engine_steps(const rgbid_engine* e);
 /* copies records of steps [first_step, first_step+n_steps) for all lanes to host: out[n_steps][lanes]. Synchronises. */

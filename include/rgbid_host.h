@@ -51,6 +51,12 @@ int rgbid_tracker_destroy(rgbid_tracker* t);
 /* 1 (default): trackNewFrame enqueues its device calls without per-call timing events / synchronisation (it ignores the returned milliseconds);
  * 0: every bridge call synchronous and timed, as in the reference.  Results are identical. */
 int rgbid_tracker_set_async_bridge(rgbid_tracker* t, int on);
+/* 1: trackNewFrame runs the frame as ONE step of a one-lane device-resident engine (rgbid_engine.h: the same kernels in the bit-exact numerics
+ * class, ~116 launches and no host round trip per Gauss-Newton iteration) instead of ~330 synchronous bridge calls; the tracker's
+ * observable state (poses, odometry constraints, keyframe stream, lastInfo) is maintained from the step's pose record.  Opt-in (default 0);
+ * only before the first frame or after reset().  RGBID_E_INVALID for what only the host-driven loop offers: CHI_SQUARED termination,
+ * custom_registration = 1, a non-identity initial pose.  VisodoTracker::setEngineBacked. */
+int rgbid_tracker_set_engine_backed(rgbid_tracker* t, int on);
 int rgbid_tracker_load_settings(rgbid_tracker* t, const char* ini_path);      /* VisodoTracker::loadSettings */
 int rgbid_tracker_load_calibration(rgbid_tracker* t, const char* ini_path);   /* VisodoTracker::loadCalibration */
 /* uploads depth (u16 mm, rows x cols) and rgb (u8 r,g,b) from HOST memory and runs trackNewFrame */

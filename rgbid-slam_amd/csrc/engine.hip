@@ -951,23 +951,46 @@ int rgbid_engine_reset_lane(rgbid_engine* e, int lane) {
 }
 
 int rgbid_engine_step(rgbid_engine* e, const void* depth_dev, const void* rgb_dev) {
+  if (!e) return RGBID_E_INVALID;
+  const rgbid_engine_config& c = e->cfg;
+  return rgbid_engine_step_strided(e, depth_dev, (size_t)c.cols * 2, (size_t)c.rows * c.cols * 2, rgb_dev, (size_t)c.cols * 3, (size_t)c.rows * c.cols * 3);
+}
+
+int rgbid_engine_set_delta_t(rgbid_engine* e, float delta_t) {
+  if (!e || e->cfg.use_graph || !(delta_t == delta_t)) return RGBID_E_INVALID;
+  e->cfg.delta_t = delta_t;
+  return RGBID_OK;
+}
+
+int rgbid_engine_step_strided(rgbid_engine* e, const void* depth_dev, size_t depth_step, size_t depth_lane_stride, const void* rgb_dev, size_t rgb_step,
+                              size_t rgb_lane_stride) {
   if (!e || !depth_dev || !rgb_dev) return RGBID_E_INVALID;
   hipStream_t s = e->ctx->stream;
   const rgbid_engine_config& c = e->cfg;
+  if (depth_step < (size_t)c.cols * 2 || rgb_step < (size_t)c.cols * 3 || (depth_step & 1) || depth_step >= ((size_t)1 << 24) || rgb_step >= ((size_t)1 << 24) ||
+      (e->B > 1 && (depth_lane_stride < depth_step * c.rows || rgb_lane_stride < rgb_step * c.rows || (depth_lane_stride & 1))))
+    return RGBID_E_INVALID;
   hipSetDevice(e->ctx->device);
-  // A captured graph bakes its kernel arguments in, so graph replay reads fixed staging buffers (dense [lanes][rows][cols] -> pitched
-  // lanes); eager steps read the caller's dense buffers in place (they must stay valid until the step has run, as documented).
+  // A captured graph bakes its kernel arguments in, so graph replay reads fixed staging buffers (-> pitched lanes); eager steps read the
+  // caller's buffers in place (they must stay valid until the step has run, as documented).
   hipError_t he = hipSuccess;
   if (c.use_graph) {   // also while profiling (which only skips the replay): the buffer-lifetime rule of graph mode does not change
-    he = hipMemcpy2DAsync(e->in_depth.base, e->in_depth.pitch, depth_dev, (size_t)c.cols * 2, (size_t)c.cols * 2, (size_t)c.rows * e->B,
-                          hipMemcpyDeviceToDevice, s);
-    if (he != hipSuccess) return (int)he;
-    he = hipMemcpy2DAsync(e->in_rgb.base, e->in_rgb.pitch, rgb_dev, (size_t)c.cols * 3, (size_t)c.cols * 3, (size_t)c.rows * e->B, hipMemcpyDeviceToDevice, s);
+    // the staging lanes are contiguous (lane stride = pitch x rows): a source with contiguous lanes is ONE 2-D copy per map, otherwise one per lane
+    const bool packed = e->B == 1 || (depth_lane_stride == depth_step * c.rows && rgb_lane_stride == rgb_step * c.rows);
+    const int copies = packed ? 1 : e->B;
+    const size_t nrows = packed ? (size_t)c.rows * e->B : (size_t)c.rows;
+    for (int l = 0; l < copies && he == hipSuccess; ++l) {
+      he = hipMemcpy2DAsync((char*)e->in_depth.base + (size_t)l * e->in_depth.lane_stride, e->in_depth.pitch, (const char*)depth_dev + (size_t)l * depth_lane_stride, depth_step,
+                            (size_t)c.cols * 2, nrows, hipMemcpyDeviceToDevice, s);
+      if (he == hipSuccess)
+        he = hipMemcpy2DAsync((char*)e->in_rgb.base + (size_t)l * e->in_rgb.lane_stride, e->in_rgb.pitch, (const char*)rgb_dev + (size_t)l * rgb_lane_stride, rgb_step,
+                              (size_t)c.cols * 3, nrows, hipMemcpyDeviceToDevice, s);
+    }
     if (he != hipSuccess) return (int)he;
     e->cur_depth = e->in_depth; e->cur_rgb = e->in_rgb;
   } else {
-    e->cur_depth = ImgB{const_cast<void*>(depth_dev), (size_t)c.cols * 2, (size_t)c.rows * c.cols * 2, c.rows, c.cols};
-    e->cur_rgb = ImgB{const_cast<void*>(rgb_dev), (size_t)c.cols * 3, (size_t)c.rows * c.cols * 3, c.rows, c.cols};
+    e->cur_depth = ImgB{const_cast<void*>(depth_dev), depth_step, depth_lane_stride, c.rows, c.cols};
+    e->cur_rgb = ImgB{const_cast<void*>(rgb_dev), rgb_step, rgb_lane_stride, c.rows, c.cols};
   }
   int r = RGBID_OK;
   const bool first = (e->steps == 0);
@@ -1102,6 +1125,13 @@ int rgbid_engine_keyframe_maps(rgbid_engine* e, int lane, rgbid_img* depthinv, r
   if (vmap) *vmap = lane_img(e->vmap, lane);
   if (nmap) *nmap = lane_img(e->nmap, lane);
   if (overlap_mask) *overlap_mask = lane_img(e->overlap_mask, lane);
+  return RGBID_OK;
+}
+
+int rgbid_engine_current_maps(rgbid_engine* e, int lane, rgbid_img* depthinv, rgbid_img* intensity) {
+  if (!e || lane < 0 || lane >= e->B) return RGBID_E_INVALID;
+  if (depthinv) *depthinv = lane_img(e->iD_curr[0], lane);
+  if (intensity) *intensity = lane_img(e->I_curr[0], lane);
   return RGBID_OK;
 }
 

@@ -97,6 +97,10 @@ int rgbid_tracker_create(rgbid_tracker** out, const rgbid_tracker_config* c, int
 
 int rgbid_tracker_destroy(rgbid_tracker* h) { if (h) { delete h->t; delete h->sink; delete h; } return RGBID_OK; }
 int rgbid_tracker_set_async_bridge(rgbid_tracker* h, int on) { if (!h) return RGBID_E_INVALID; h->t->setAsyncBridge(on != 0); return RGBID_OK; }
+int rgbid_tracker_set_engine_backed(rgbid_tracker* h, int on) {
+  if (!h) return RGBID_E_INVALID;
+  return h->t->setEngineBacked(on != 0) ? RGBID_OK : RGBID_E_INVALID;
+}
 int rgbid_tracker_load_settings(rgbid_tracker* h, const char* ini_path) {
   if (!h || !ini_path) return RGBID_E_INVALID;
   std::ifstream f(ini_path);
@@ -145,18 +149,13 @@ int rgbid_tracker_last_info(const rgbid_tracker* h, rgbid_tracker_info* info) {
 }
 int rgbid_tracker_keyframe_maps(rgbid_tracker* h, float* depthinv_host, float* weight_host) {
   if (!h) return RGBID_E_INVALID;
-  VisodoTracker& t = *h->t;
-  if (depthinv_host) t.integrationKeyframeDepthinv().download(depthinv_host, (size_t)t.cols() * 4);
-  if (weight_host) t.integrationKeyframeWeight().download(weight_host, (size_t)t.cols() * 4);
+  h->t->downloadKeyframeMaps(depthinv_host, weight_host);
   return RGBID_OK;
 }
 
 int rgbid_tracker_current_maps(const rgbid_tracker* h, float* depthinv, float* intensity) {
   if (!h) return RGBID_E_INVALID;
-  const VisodoTracker& t = *h->t;
-  int cols = const_cast<VisodoTracker&>(t).cols();
-  if (depthinv) t.currentDepthinv(0).download(depthinv, (size_t)cols * 4);
-  if (intensity) t.currentIntensity(0).download(intensity, (size_t)cols * 4);
+  h->t->downloadCurrentMaps(depthinv, intensity);
   return RGBID_OK;
 }
 

@@ -6,6 +6,7 @@
 #include "../../include/rgbid/visodo.h"
 
 #include <chrono>
+#include <cstring>
 #include <cmath>
 #include <cstdlib>
 #include <fstream>
@@ -13,6 +14,7 @@
 #include <sstream>
 
 #include "../../include/rgbid/se3.h"
+#include "../../include/rgbid_engine.h"
 
 using namespace RGBID_SLAM::device;
 namespace se3 = rgbid::se3;
@@ -73,6 +75,7 @@ VisodoTracker::VisodoTracker(int optim_dim, int Mestimator, int motion_model, in
 }
 
 VisodoTracker::~VisodoTracker() {
+  if (engine_) { rgbid_engine_destroy(engine_); engine_ = nullptr; }
   if (visodo_thread_ && visodo_thread_->joinable()) {
     { std::unique_lock<std::mutex> lock(mutex_); exit_ = true; }
     new_frame_cond_.notify_one();
@@ -81,7 +84,7 @@ VisodoTracker::~VisodoTracker() {
 }
 
 void VisodoTracker::setIterations(const int* iters, int n) { for (int i = 0; i < n && i < 8; ++i) visodo_iterations_[i] = iters[i]; }
-void VisodoTracker::setInterpMode(int mode) { rgbidSafeCall(rgbid_ctx_set_interp_mode(default_ctx(), mode)); }
+void VisodoTracker::setInterpMode(int mode) { rgbidSafeCall(rgbid_ctx_set_interp_mode(default_ctx(), mode)); interp_mode_ = mode; }
 
 void VisodoTracker::loadCalibration(std::string const& calib_file) {
   // src/visodo.cpp:99-181 ([CALIBRATION] / [RGB_CALIBRATION]: fx fy cx cy kd factor_depth)
@@ -675,8 +678,199 @@ float VisodoTracker::computeInterframeTime() {
   return dt;
 }
 
+// ---- engine-backed mode: the same trackNewFrame, driven through a one-lane device-resident engine (include/rgbid_engine.h) ---------------------------
+bool VisodoTracker::setEngineBacked(bool on) {
+  if (!on) { engine_backed_ = false; return true; }
+  if (global_time_ != 0) return false;                                  // before the first frame (or after reset())
+  const bool identity_start = std::memcmp(init_Rcam_.m, Matrix3ft::Identity().m, sizeof(init_Rcam_.m)) == 0 && init_tcam_[0] == 0.0 && init_tcam_[1] == 0.0 && init_tcam_[2] == 0.0;
+  if (termination_ == device::CHI_SQUARED || custom_registration_ || !identity_start || levels_ > 8) return false;   // host-driven only
+  engine_backed_ = true;
+  return true;
+}
+
+bool VisodoTracker::createEngine() {
+  if (engine_) { rgbid_engine_destroy(engine_); engine_ = nullptr; }
+  rgbid_engine_config c;
+  rgbid_engine_default_config(&c);
+  c.rows = rows_; c.cols = cols_; c.levels = levels_; c.lanes = 1;
+  for (int i = 0; i < 8; ++i) c.iters[i] = i < levels_ ? visodo_iterations_[i] : 0;
+  c.mestimator = Mestimator_; c.motion_model = motion_model_; c.sigma_estimator = sigma_estimator_; c.weighting = weighting_;
+  c.max_odoKF_count = max_odoKF_count_; c.finest_level = finest_level_; c.image_filtering = image_filtering_;
+  c.visratio_odo = visibility_ratio_odo_threshold_; c.visratio_integr = visibility_ratio_integr_threshold_;
+  c.max_integrKF_count = max_integrKF_count_; c.nsamples = Nsamples_;
+  c.fx = fx_; c.fy = fy_; c.cx = cx_; c.cy = cy_; c.factor_depth = factor_depth_;
+  c.interp_mode = interp_mode_;
+  c.delta_t = 0.03333f;
+  c.use_graph = 0;            // the inter-frame time may change from frame to frame (rgbid_engine_set_delta_t)
+  c.fused_gn = 1;
+  c.fast_numerics = 0;        // the compat tracker's numerics class: the IEEE evaluation of the oracle, bit for bit
+  c.chi_square_stats = 0;
+  c.preview = preview_ ? 1 : 0;
+  c.record_capacity = 2;
+  c.warping = warping_ == device::WARP_FIRST ? RGBID_WARP_FIRST : RGBID_PYR_FIRST;
+  c.keyframe_capacity = 2;    // what resetIntegrationKeyframe hands to the back-end is read out right after the step that exported it
+  return rgbid_engine_create(&engine_, default_ctx(), &c) == RGBID_OK;
+}
+
+void VisodoTracker::downloadKeyframeMaps(float* depthinv_host, float* weight_host) const {
+  if (engine_backed_ && engine_) {
+    rgbid_img d, w;
+    rgbidSafeCall(rgbid_engine_keyframe_maps(engine_, 0, &d, &w, nullptr, nullptr, nullptr));
+    rgbidSafeCall(rgbid_ctx_sync(default_ctx()));
+    if (depthinv_host) rgbidSafeCall(rgbid_memcpy2d_d2h(default_ctx(), depthinv_host, (size_t)cols_ * 4, d.data, d.step, (size_t)cols_ * 4, rows_));
+    if (weight_host) rgbidSafeCall(rgbid_memcpy2d_d2h(default_ctx(), weight_host, (size_t)cols_ * 4, w.data, w.step, (size_t)cols_ * 4, rows_));
+    return;
+  }
+  if (depthinv_host) depthinv_integrKF_.download(depthinv_host, (size_t)cols_ * 4);
+  if (weight_host) weight_integrKF_.download(weight_host, (size_t)cols_ * 4);
+}
+
+void VisodoTracker::downloadCurrentMaps(float* depthinv_host, float* intensity_host) const {
+  if (engine_backed_ && engine_) {
+    rgbid_img d, i;
+    rgbidSafeCall(rgbid_engine_current_maps(engine_, 0, &d, &i));
+    rgbidSafeCall(rgbid_ctx_sync(default_ctx()));
+    if (depthinv_host) rgbidSafeCall(rgbid_memcpy2d_d2h(default_ctx(), depthinv_host, (size_t)cols_ * 4, d.data, d.step, (size_t)cols_ * 4, rows_));
+    if (intensity_host) rgbidSafeCall(rgbid_memcpy2d_d2h(default_ctx(), intensity_host, (size_t)cols_ * 4, i.data, i.step, (size_t)cols_ * 4, rows_));
+    return;
+  }
+  if (depthinv_host) depthinvs_curr_[0].download(depthinv_host, (size_t)cols_ * 4);
+  if (intensity_host) intensities_curr_[0].download(intensity_host, (size_t)cols_ * 4);
+}
+
+bool VisodoTracker::trackNewFrameEngine() {
+  // src/visodo.cpp:1967-2247 with the device work of the frame done by ONE engine step; the host keeps the bookkeeping the application and the
+  // back-end see (rmats_ / tvecs_, odo_*, Pose / PoseConstraint / Keyframe pushes, shared pose, timing)
+  delta_t_ = computeInterframeTime();
+  kf_time_accum_ += delta_t_;
+  const double t1 = now_ms();
+  last_info_ = LastFrameInfo();
+  TrackerSink* sink = keyframe_manager_ptr_ ? keyframe_manager_ptr_ : &null_sink_;
+  keyframe_manager_ptr_ = sink;
+  if (!engine_ || global_time_ == 0) {
+    if (!createEngine()) { std::cerr << "VisodoTracker: the engine-backed mode could not create its engine" << std::endl; std::exit(0); }   // as pcl::gpu::error()
+  }
+  rgbidSafeCall(rgbid_engine_set_delta_t(engine_, delta_t_));
+  rgbidSafeCall(rgbid_engine_step_strided(engine_, depth_.ptr(), depth_.step(), 0, rgb24_.ptr(), rgb24_.step(), 0));
+  rgbid_pose_record rec;
+  rgbidSafeCall(rgbid_engine_read_records(engine_, rgbid_engine_steps(engine_) - 1, 1, &rec));   // synchronises
+  auto M3 = [](const double* p) { Matrix3ft m; std::memcpy(m.m, p, sizeof(m.m)); return m; };
+  auto V3 = [](const double* p) { Vector3ft v; std::memcpy(v.v, p, sizeof(v.v)); return v; };
+  auto M6 = [](const double* p) { Matrix6d m; std::memcpy(m.data(), p, sizeof(double) * 36); return m; };
+  // what resetIntegrationKeyframe hands over (:1631-1652), exported by the engine inside the step
+  auto push_exported_keyframe = [&]() {
+    int count = 0;
+    rgbidSafeCall(rgbid_engine_keyframe_counts(engine_, &count));
+    rgbid_keyframe_header h;
+    std::shared_ptr<KeyframeRecord> kf(new KeyframeRecord());
+    kf->overlap_mask_.resize((size_t)rows_ * cols_); kf->colors_.resize((size_t)rows_ * cols_); kf->depthinv_.resize((size_t)rows_ * cols_);
+    kf->normals_.resize((size_t)3 * rows_ * cols_);
+    rgbidSafeCall(rgbid_engine_read_keyframe(engine_, 0, count - 1, &h, kf->overlap_mask_.data(), reinterpret_cast<unsigned char*>(kf->colors_.data()), kf->depthinv_.data(),
+                                             kf->normals_.data()));
+    rmatsKF_.push_back(M3(h.R)); tvecsKF_.push_back(V3(h.t));
+    kf->K = getCalibMatrix(0);
+    kf->kd[0] = k1_; kf->kd[1] = k2_; kf->kd[2] = k3_; kf->kd[3] = k4_; kf->kd[4] = k5_;
+    kf->rotation = M3(h.R); kf->translation = V3(h.t);
+    kf->rotation_rel = M3(h.R_rel); kf->translation_rel = V3(h.t_rel);
+    kf->id = h.id; kf->cols = cols_; kf->rows = rows_;
+    if (sink->tryPushKeyframe(kf)) {
+      PoseConstraint kc;
+      kc.ini_id_ = h.id; kc.end_id_ = h.end_id; kc.type_ = PoseConstraint::SEQ_KF;
+      kc.rotation_ = kf->rotation_rel; kc.translation_ = kf->translation_rel; kc.scale_ = 1.f; kc.covariance_ = M6(h.cov_rel);
+      sink->pushConstraint(kc);
+    }
+    kf_times_.push_back(1000.f * kf_time_accum_);
+    kf_time_accum_ = 0.f;
+    last_integrKF_index_ = h.end_id;
+  };
+  if (rec.status & RGBID_ST_FIRST) {   // :1994-2045
+    ++global_time_;
+    odo_rmats_.push_back(Matrix3ft::Identity()); odo_tvecs_.push_back(Vector3ft::Zero()); odo_covmats_.push_back(zero6());
+    delta_rotation_ = Matrix3ft::Identity(); delta_translation_ = Vector3ft::Zero(); delta_covariance_ = zero6();
+    kf_time_accum_ = 0.f;
+    last_integrKF_index_ = 0;
+    Pose pose_new; pose_new.id_ = 0; pose_new.rotation_ = Matrix3ft::Identity(); pose_new.translation_ = Vector3ft::Zero(); pose_new.scale_ = 1.f;
+    sink->pushPose(pose_new);
+    sink_back_pose_ = pose_new;
+    setSharedCameraPose(pose_new.getAffine());
+    last_info_.odo_kf_switched = last_info_.integr_kf_switched = true;
+    lost_ = false;
+    return false;
+  }
+  const bool was_lost = lost_;
+  const bool tracked = (rec.status & RGBID_ST_TRACKED) != 0;
+  odometry_success_ = tracked;
+  if (!tracked) {
+    if (was_lost) return false;                                     // still lost: keyframes re-seeded from this frame, nothing recorded (:2110-2116)
+    last_info_.odo_kf_switched = last_info_.integr_kf_switched = true;
+    // this frame lost tracking (:2066-2085)
+    lost_ = true;
+    delta_rotation_ = M3(rec.kf_R); delta_translation_ = V3(rec.kf_t); delta_covariance_ = M6(rec.kf_cov);
+    last_estimated_rotation_ = M3(rec.R); last_estimated_translation_ = V3(rec.t);
+    rmats_.push_back(last_estimated_rotation_); tvecs_.push_back(last_estimated_translation_);
+    PoseConstraint dummy; dummy.ini_id_ = global_time_ - 1; dummy.end_id_ = global_time_; dummy.type_ = PoseConstraint::SEQ_ODO;
+    dummy.rotation_ = Matrix3ft::Identity(); dummy.translation_ = Vector3ft::Zero(); dummy.scale_ = 1.f; dummy.covariance_ = zero6();
+    for (int i = 0; i < 6; ++i) dummy.covariance_[i * 7] = 100.0;
+    sink->pushConstraint(dummy);
+    sink->backPose(sink_back_pose_);
+    Pose p = sink_back_pose_; p.id_ = global_time_; p.scale_ = 1.f;
+    sink->pushPose(p);
+    sink_back_pose_ = p;
+    if (rec.status & RGBID_ST_KF_EXPORTED) push_exported_keyframe();
+    ++global_time_;
+    if (verbose_) std::cout << "I am LOST!!!" << std::endl;
+    return false;
+  }
+  lost_ = false;
+  last_info_.sigma_int = rec.sigma_int; last_info_.sigma_depthinv = rec.sigma_depthinv; last_info_.nu_int = rec.nu_int; last_info_.nu_depthinv = rec.nu_depthinv;
+  delta_rotation_ = M3(rec.kf_R); delta_translation_ = V3(rec.kf_t); delta_covariance_ = M6(rec.kf_cov);
+  last_estimated_rotation_ = M3(rec.R); last_estimated_translation_ = V3(rec.t);
+  rmats_.push_back(last_estimated_rotation_); tvecs_.push_back(last_estimated_translation_);
+  {
+    // sequential constraint + pose :2128-2165
+    const Matrix3ft Rseq = M3(rec.odo_R); const Vector3ft tseq = V3(rec.odo_t); const Matrix6d cseq = M6(rec.odo_cov);
+    odo_rmats_.push_back(Rseq); odo_tvecs_.push_back(tseq); odo_covmats_.push_back(cseq);
+    PoseConstraint c; c.ini_id_ = global_time_ - 1; c.end_id_ = global_time_; c.type_ = PoseConstraint::SEQ_ODO;
+    c.rotation_ = Rseq; c.translation_ = tseq; c.scale_ = 1.f; c.covariance_ = cseq;
+    sink->pushConstraint(c);
+    sink->backPose(sink_back_pose_);
+    Pose p; p.id_ = global_time_; p.scale_ = 1.f;
+    se3::m3_mul(sink_back_pose_.rotation_.m, Rseq.m, p.rotation_.m);
+    double tb[3];
+    se3::m3_mulv(sink_back_pose_.rotation_.m, tseq.v, tb);
+    for (int i = 0; i < 3; ++i) p.translation_[i] = sink_back_pose_.translation_[i] + tb[i];
+    sink->pushPose(p);
+    sink_back_pose_ = p;
+    setSharedCameraPose(p.getAffine());
+  }
+  last_info_.visratio_odo = rec.vis_odo; last_info_.visratio_integr = rec.vis_integr;
+  if (rec.status & RGBID_ST_ODO_KF) {   // resetOdometryKeyframe :1541-1575
+    last_info_.odo_kf_switched = true;
+    delta_rotation_ = Matrix3ft::Identity(); delta_translation_ = Vector3ft::Zero(); delta_covariance_ = zero6();
+  }
+  if (rec.status & RGBID_ST_INTEGR_KF) {
+    if (rec.status & RGBID_ST_KF_EXPORTED) push_exported_keyframe();
+    newKF_ = true;
+    last_info_.integr_kf_switched = true;
+  }
+  vis_odo_times_.push_back((float)(now_ms() - t1));
+  if (preview_) {
+    std::lock_guard<std::mutex> lock(mutex_scene_view_);
+    rgbid_img pv;
+    scene_view_.resize((size_t)rows_ * cols_); intensity_view_.resize((size_t)rows_ * cols_); depthinv_view_.resize((size_t)rows_ * cols_);
+    rgbidSafeCall(rgbid_engine_preview(engine_, 0, &pv, nullptr));
+    rgbidSafeCall(rgbid_memcpy2d_d2h(default_ctx(), scene_view_.data(), (size_t)cols_ * 3, pv.data, pv.step, (size_t)cols_ * 3, rows_));
+    downloadCurrentMaps(nullptr, intensity_view_.data());     // getImage :559-580: the current intensity next to the keyframe's inverse depth
+    downloadKeyframeMaps(depthinv_view_.data(), nullptr);
+    scene_view_has_changed_ = true;
+  }
+  ++global_time_;
+  return true;
+}
+
 bool VisodoTracker::trackNewFrame() {
   // src/visodo.cpp:1967-2247
+  if (engine_backed_) return trackNewFrameEngine();
   pcl::gpu::ScopedAsyncBridge bridge_scope(async_bridge_);
   delta_t_ = computeInterframeTime();
   kf_time_accum_ += delta_t_;

@@ -14,11 +14,16 @@ def rot_angle(Ra, Rb):
     return float(np.arccos(np.clip((np.trace(Ra.T @ Rb) - 1) / 2, -1, 1)))
 
 
-def run(rows, cols, K, n_frames, cfg_kw, seq_kw, pose_tol=1e-4, map_outliers=5e-3):
+# the compat tracker in its two modes: host-driven through the bridge (the reference's call sequence), and backed by the one-lane engine
+# (VisodoTracker::setEngineBacked, opt-in)
+both_modes = pytest.mark.parametrize("engine_backed", [False, True], ids=["host", "engine"])
+
+
+def run(rows, cols, K, n_frames, cfg_kw, seq_kw, pose_tol=1e-4, map_outliers=5e-3, engine_backed=False):
     seq = synth.make_sequence(n_frames, K=K, rows=rows, cols=cols, device="cuda", **seq_kw)
     d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
     kw = dict(rows=rows, cols=cols, fx=K[0], fy=K[1], cx=K[2], cy=K[3], **cfg_kw)
-    trk = host.Tracker(host.default_config(**kw))
+    trk = host.Tracker(host.default_config(**kw), engine_backed=engine_backed)
     orc = O.Tracker(O.default_config(**kw))
     th_odo, th_int = cfg_kw.get("visratio_odo", 0.9), cfg_kw.get("visratio_integr", 0.7)
     imposed = 0
@@ -63,20 +68,24 @@ SMALL_K = (131.25, 131.25, 79.5, 59.5)
 SLOW = dict(trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8))
 
 
-def test_cpp_tracker_shipped_config():
-    run(120, 160, SMALL_K, 6, dict(), SLOW)
+@both_modes
+def test_cpp_tracker_shipped_config(engine_backed):
+    run(120, 160, SMALL_K, 6, dict(), SLOW, engine_backed=engine_backed)
 
 
-def test_cpp_tracker_warp_first():
-    run(120, 160, SMALL_K, 4, dict(warping=O.WARP_FIRST), SLOW)
+@both_modes
+def test_cpp_tracker_warp_first(engine_backed):
+    run(120, 160, SMALL_K, 4, dict(warping=O.WARP_FIRST), SLOW, engine_backed=engine_backed)
 
 
-def test_cpp_tracker_filter_grads_and_min_weight():
-    run(120, 160, SMALL_K, 4, dict(image_filtering=O.FILTER_GRADS, weighting=O.MIN_WEIGHT), SLOW)
+@both_modes
+def test_cpp_tracker_filter_grads_and_min_weight(engine_backed):
+    run(120, 160, SMALL_K, 4, dict(image_filtering=O.FILTER_GRADS, weighting=O.MIN_WEIGHT), SLOW, engine_backed=engine_backed)
 
 
-def test_cpp_tracker_sigma_const_no_motion_model():
-    run(120, 160, SMALL_K, 4, dict(sigma_estimator=O.SIGMA_CONS, motion_model=O.NO_MM), SLOW)
+@both_modes
+def test_cpp_tracker_sigma_const_no_motion_model(engine_backed):
+    run(120, 160, SMALL_K, 4, dict(sigma_estimator=O.SIGMA_CONS, motion_model=O.NO_MM), SLOW, engine_backed=engine_backed)
 
 
 def test_cpp_tracker_chi_squared_termination():
@@ -96,18 +105,21 @@ def test_cpp_tracker_chi_squared_termination():
     assert np.abs(out[0] - out[1]).max() > 1e-7
 
 
-def test_cpp_tracker_keyframe_switches():
-    run(120, 160, SMALL_K, 8, dict(visratio_odo=0.985, visratio_integr=0.97), dict(trans_step=(0.01, 0.02), rot_step_deg=(0.5, 1.0)))
+@both_modes
+def test_cpp_tracker_keyframe_switches(engine_backed):
+    run(120, 160, SMALL_K, 8, dict(visratio_odo=0.985, visratio_integr=0.97), dict(trans_step=(0.01, 0.02), rot_step_deg=(0.5, 1.0)), engine_backed=engine_backed)
 
 
-def test_cpp_tracker_full_res():
-    run(480, 640, synth.TUM_K, 4, dict(), dict())
+@both_modes
+def test_cpp_tracker_full_res(engine_backed):
+    run(480, 640, synth.TUM_K, 4, dict(), dict(), engine_backed=engine_backed)
 
 
-def test_cpp_tracker_four_levels_1280x960():
+@both_modes
+def test_cpp_tracker_four_levels_1280x960(engine_backed):
     """BASELINE config 5: 1280x960 upsampled synthetic stream, 4-level pyramid."""
     K = (1050.0, 1050.0, 639.5, 479.5)
-    run(960, 1280, K, 3, dict(levels=4, iters=[10, 5, 3, 3]), dict())
+    run(960, 1280, K, 3, dict(levels=4, iters=[10, 5, 3, 3]), dict(), engine_backed=engine_backed)
 
 
 def test_keyframe_align_vs_oracle():
@@ -223,13 +235,14 @@ def _blackout_sequence(n, black):
     return d, c
 
 
-def test_cpp_tracker_lost_and_recovery():
+@both_modes
+def test_cpp_tracker_lost_and_recovery(engine_backed):
     """visodo.cpp:2056-2113: a frame without valid depth makes the solve fail; the tracker declares itself lost, re-keys on the
     incoming frames (pushing no pose while it stays lost) and resumes odometry once a frame aligns again."""
     n = 8
     d, c = _blackout_sequence(n, black=(3,))
     kw = dict(rows=120, cols=160, fx=SMALL_K[0], fy=SMALL_K[1], cx=SMALL_K[2], cy=SMALL_K[3])
-    trk = host.Tracker(host.default_config(**kw))
+    trk = host.Tracker(host.default_config(**kw), engine_backed=engine_backed)
     orc = O.Tracker(O.default_config(**kw))
     rets = []
     for k in range(n):
@@ -410,7 +423,8 @@ def _cmp_backend_streams(trk, orc, rows, cols, K=None, pose_tol=1e-4):
     return len(cb), orc.num_keyframes()
 
 
-def test_backend_streams_keyframe_switches():
+@both_modes
+def test_backend_streams_keyframe_switches(engine_backed):
     """what trackNewFrame hands to the back-end (visodo.cpp:1612-1652, 2033-2038, 2155-2164) -- one Pose per frame, one
     SEQ_ODO PoseConstraint per tracked frame, and at each integration-keyframe switch the exported keyframe (global + relative pose,
     overlap mask, colours, fused inverse depth, normals) plus its SEQ_KF constraint -- equals the oracle's on a sequence that switches."""
@@ -418,7 +432,7 @@ def test_backend_streams_keyframe_switches():
     seq = synth.make_sequence(n, K=SMALL_K, rows=rows, cols=cols, device="cuda", trans_step=(0.01, 0.02), rot_step_deg=(0.5, 1.0))
     d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
     kw = dict(rows=rows, cols=cols, fx=SMALL_K[0], fy=SMALL_K[1], cx=SMALL_K[2], cy=SMALL_K[3], visratio_odo=0.985, visratio_integr=0.97)
-    trk = host.Tracker(host.default_config(**kw)); trk.collect()
+    trk = host.Tracker(host.default_config(**kw), engine_backed=engine_backed); trk.collect()
     orc = O.Tracker(O.default_config(**kw))
     for k in range(n):
         assert trk.track(d[k], c[k]) == orc.track(d[k], c[k])
@@ -435,15 +449,16 @@ def test_backend_streams_keyframe_switches():
     trk.close(); orc.close()
 
 
-def test_backend_streams_lost_frame_and_full_buffer():
+@both_modes
+def test_backend_streams_lost_frame_and_full_buffer(engine_backed):
     """visodo.cpp:2066-2085: the frame that loses tracking pushes a dummy SEQ_ODO constraint (identity, covariance 100 I), a pose that repeats
     the back-end's last one, and -- through resetIntegrationKeyframe -- the keyframe before the failure with its SEQ_KF constraint.
     With a full keyframe buffer (try_push fails, :1644) the keyframe AND its constraint are dropped."""
     n = 8
     d, c = _blackout_sequence(n, black=(3,))
     kw = dict(rows=120, cols=160, fx=SMALL_K[0], fy=SMALL_K[1], cx=SMALL_K[2], cy=SMALL_K[3])
-    trk = host.Tracker(host.default_config(**kw)); trk.collect()
-    full = host.Tracker(host.default_config(**kw)); full.collect(keyframe_capacity=1)
+    trk = host.Tracker(host.default_config(**kw), engine_backed=engine_backed); trk.collect()
+    full = host.Tracker(host.default_config(**kw), engine_backed=engine_backed); full.collect(keyframe_capacity=1)
     orc = O.Tracker(O.default_config(**kw))
     for k in range(n):
         r = orc.track(d[k], c[k])
@@ -463,14 +478,15 @@ def test_backend_streams_lost_frame_and_full_buffer():
     trk.close(); full.close(); orc.close()
 
 
-def test_backend_pose_moved_by_optimiser_is_continued():
+@both_modes
+def test_backend_pose_moved_by_optimiser_is_continued(engine_backed):
     """visodo.cpp:2161-2162: the pose pushed for frame k continues poses_.back() AS THE BACK-END HOLDS IT (a pose-graph optimisation may
     have moved it), composed with the sequential odometry -- not the tracker's own global estimate."""
     n = 5
     seq = synth.make_sequence(n, K=SMALL_K, rows=120, cols=160, device="cuda", **SLOW)
     d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
     kw = dict(rows=120, cols=160, fx=SMALL_K[0], fy=SMALL_K[1], cx=SMALL_K[2], cy=SMALL_K[3])
-    trk = host.Tracker(host.default_config(**kw)); trk.collect()
+    trk = host.Tracker(host.default_config(**kw), engine_backed=engine_backed); trk.collect()
     for k in range(3):
         trk.track(d[k], c[k])
     Rm = host.expmap_rot([0.02, -0.01, 0.03]); tm = np.array([0.5, -0.25, 1.0])
@@ -505,3 +521,57 @@ def test_async_bridge_changes_nothing_but_the_time():
         trk.close()
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+def test_engine_backed_tracker_equals_host_driven_tracker():
+    """VisodoTracker::setEngineBacked(true): the frame runs as one step of a one-lane engine in the bit-exact numerics class.  Both modes run the
+    same kernels on the same data in the same order, so everything the application and the back-end see -- return values, poses, odometry
+    constraints and covariances, keyframe decisions, exported keyframes, fused maps, lastInfo -- must be IDENTICAL, bit for bit, on a sequence
+    that switches keyframes, loses tracking and recovers."""
+    n = 12
+    seq = synth.make_sequence(n, K=SMALL_K, rows=120, cols=160, device="cuda", trans_step=(0.01, 0.02), rot_step_deg=(0.5, 1.0))
+    d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+    d[7][:] = 0
+    kw = dict(rows=120, cols=160, fx=SMALL_K[0], fy=SMALL_K[1], cx=SMALL_K[2], cy=SMALL_K[3], visratio_odo=0.985, visratio_integr=0.97)
+    out = []
+    for eb in (False, True):
+        trk = host.Tracker(host.default_config(**kw), engine_backed=eb); trk.collect()
+        rets, infos = [], []
+        for k in range(n):
+            rets.append(trk.track(d[k], c[k]))
+            i = trk.last_info()
+            infos.append((i.lost, i.odo_kf_switched, i.integr_kf_switched, i.visratio_odo, i.visratio_integr, i.sigma_int, i.sigma_depthinv, i.nu_int, i.nu_depthinv))
+        R, t = trk.poses(); oR, ot, ocov = trk.odometry(); kd, kw_ = trk.keyframe_maps(); cd, ci = trk.current_maps()
+        ids, sR, st = trk.sink_poses()
+        cons = [(q["ini"], q["end"], q["type"], q["R"], q["t"], q["cov"]) for q in trk.constraints()]
+        kfs = []
+        for i in range(trk.num_keyframes()):
+            q = trk.peek_keyframe(i)
+            nrm = q["normals"]; nrm[:, np.isnan(nrm[0])] = np.nan
+            kfs.append((q["id"], q["R"], q["t"], q["R_rel"], q["t_rel"], q["K"], q["kd"], q["overlap_mask"], q["colors"], q["depthinv"], nrm))
+        out.append(dict(rets=rets, infos=np.array(infos, dtype=np.float64), R=R, t=t, oR=oR, ot=ot, ocov=ocov, kd=kd, kw=kw_, cd=cd, ci=ci, ids=ids, sR=sR, st=st, cons=cons, kfs=kfs))
+        trk.close()
+    a, b = out
+    assert a["rets"] == b["rets"] and not a["rets"][7] and sum(a["rets"]) >= 8
+    assert len(a["kfs"]) == len(b["kfs"]) >= 2 and len(a["cons"]) == len(b["cons"])
+    for key in ("infos", "R", "t", "oR", "ot", "ocov", "kd", "kw", "cd", "ci", "ids", "sR", "st"):
+        assert np.array_equal(np.asarray(a[key]), np.asarray(b[key]), equal_nan=True), key
+    for qa, qb in zip(a["cons"], b["cons"]):
+        assert qa[:3] == qb[:3] and all(np.array_equal(x, y) for x, y in zip(qa[3:], qb[3:])), qa[:3]
+    for qa, qb in zip(a["kfs"], b["kfs"]):
+        assert qa[0] == qb[0] and all(np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True) for x, y in zip(qa[1:], qb[1:])), qa[0]
+
+
+def test_engine_backed_mode_refuses_what_only_the_host_loop_offers():
+    kw = dict(rows=120, cols=160, fx=SMALL_K[0], fy=SMALL_K[1], cx=SMALL_K[2], cy=SMALL_K[3])
+    trk = host.Tracker(host.default_config(termination=O.CHI_SQUARED, **kw))
+    with pytest.raises(Exception):
+        trk.set_engine_backed(True)
+    trk.close()
+    seq = synth.make_sequence(2, K=SMALL_K, rows=120, cols=160, device="cuda", **SLOW)
+    d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+    trk = host.Tracker(host.default_config(**kw))
+    trk.track(d[0], c[0])
+    with pytest.raises(Exception):
+        trk.set_engine_backed(True)            # only before the first frame
+    trk.close()
