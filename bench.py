@@ -699,7 +699,7 @@ def main():
             except Exception as e:
                 extras.append({"config": name, "error": f"{type(e).__name__}: {e}"})
         # what smaller batches deliver (the headline needs 2 048 concurrent streams), and the PCIe-inclusive rate
-        for Bs in (64, 512):
+        for Bs in (1, 8, 64, 512):     # 1 lane: ms_per_step is the latency of one stream's frame (what an 8-GPU strong-scaling run approaches)
             if Bs >= B:
                 continue
             try:
@@ -710,7 +710,14 @@ def main():
                          "ms_per_step": rs["ms_per_step"], "lanes": Bs, "steps": Kst, "warmup": W, "repetitions": 3, "u1_frac_of_hbm_peak": rs["u1"]["achieved"] / HBM_PEAK_GBS,
                          "lanes_bit_identical": rs["parity"]["lanes_bit_identical"]}
                 keeps[3].close()
-                del keeps, sub
+                del keeps
+                if Bs <= 64 and not args.graph:   # the few-lane regime is launch-bound: the same steps replayed as one hipGraph each
+                    rg, keepg = run_config(ctx, dev, work, rows, cols, args.levels, iters, Bs, Kst, W, 3, args.streams, 1, args.fused, args.keyframes, K,
+                                           {"use_dist": False, "world": 1}, check_streams=0, fast_numerics=args.fast, inputs=sub)
+                    entry["hipgraph"] = {"value": rg["value"], "ms_per_step": rg["ms_per_step"], "lanes_bit_identical": rg["parity"]["lanes_bit_identical"]}
+                    keepg[3].close()
+                    del keepg
+                del sub
                 extras.append(entry)
             except Exception as e:
                 extras.append({"config": f"lanes-{Bs}", "error": f"{type(e).__name__}: {e}"})

@@ -95,10 +95,13 @@ __device__ void reset_integration_keyframe(LaneState& s, const StepCfg& c, const
 }
 
 // ---- step begin: first-frame initialisation or GN start (visodo.cpp:1994-2045, 1012-1035) ------------------
-__global__ void k_step_begin(LaneState* st, Flags f, WarpParams* wp, SysParams* sp, StepCfg c, int B) {
+// Also what two tiny launches used to do: the lane's eight covisibility counters are zeroed (was a memset node), and the SysParams of the first
+// Gauss-Newton stage are set (was the first k_set_sys; the later stages' are set by the k_solve_update that ends the stage before them).
+__global__ void k_step_begin(LaneState* st, Flags f, WarpParams* wp, SysParams* sp, StepCfg c, int B, unsigned int* counts, int sys_level, int sys_cov) {
   int lane = blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= B) return;
   LaneState& s = st[lane];
+  for (int which = 0; which < 4; ++which) { counts[(which * B + lane) * 2 + 0] = 0u; counts[(which * B + lane) * 2 + 1] = 0u; }
   f.vis[lane] = 0; f.overlap[lane] = 0; f.fuse[lane] = 0; f.kf_slot[lane] = -1;   // per-step launch predicates, not tracker state
   if (c.active && !c.active[lane]) {
     // no frame for this lane: nothing of its tracker state moves (only the per-step status word reads 0), every kernel of the step is
@@ -139,20 +142,16 @@ __global__ void k_step_begin(LaneState* st, Flags f, WarpParams* wp, SysParams* 
     for (int i = 0; i < 3; ++i) s.cur_t[i] = s.prev_t[i];
   }
   set_warp_from_pose(c, c.start_warp_level, s.cur_R, s.cur_t, wp[lane]);
-  (void)sp;
-}
-
-// sets the per-level constants of the lane's SysParams before a level's iterations / the covariance pass
-__global__ void k_set_sys(SysParams* sp, LaneState* st, const int* track, StepCfg c, int level, int cov_pass, int B) {
-  int lane = blockIdx.x * blockDim.x + threadIdx.x;
-  if (lane >= B) return;
-  set_sys_lane(sp, st, track, c, level, cov_pass, lane);
+  if (sys_level >= 0) set_sys_lane(sp, st, f.track, c, sys_level, sys_cov, lane);
 }
 
 // ---- one GN update: reduce partials, LLT solve, exp-map, pose update, next warp (visodo.cpp:1242-1274) -------
+// sys_level >= 0: this is the last update of a stage -- the per-level constants of the lane's SysParams for the stage that follows (the next level's
+// iterations, or the covariance pass: sys_cov) are set here (every lane, as the separate k_set_sys launch did; nothing of the solve reads them)
 __global__ __launch_bounds__(256) void k_solve_update(const double* partials, int nblk, LaneState* st, Flags f, WarpParams* wp,
-                                                      StepCfg c, int next_level) {
+                                                      StepCfg c, int next_level, SysParams* sp, int sys_level, int sys_cov) {
   int lane = blockIdx.x;
+  if (sys_level >= 0 && threadIdx.x == 64) set_sys_lane(sp, st, f.track, c, sys_level, sys_cov, lane);
   if (!f.gn[lane]) return;
   __shared__ double sm[8][32];
   __shared__ double sums[SYS_TERMS];
@@ -306,12 +305,16 @@ __global__ __launch_bounds__(256) void k_frame_finish(const double* partials, in
 }
 
 // counts: [4][B][2] = {odo B->A, odo A->B, integr B->A, integr A->B} x {visible, valid}
-__global__ void k_decide(LaneState* st, Flags f, const unsigned int* counts, WarpParams* fuse_wp, StepCfg c, int B) {
+// The lane's first counter pair is handed back zeroed: computeOverlapping counts into it next (was a memset node).
+__global__ void k_decide(LaneState* st, Flags f, unsigned int* counts, WarpParams* fuse_wp, StepCfg c, int B) {
   int lane = blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= B || !f.vis[lane]) return;
   LaneState& s = st[lane];
+  float cnt[4][2];
+  for (int which = 0; which < 4; ++which) { cnt[which][0] = (float)counts[(which * B + lane) * 2 + 0]; cnt[which][1] = (float)counts[(which * B + lane) * 2 + 1]; }
+  counts[lane * 2 + 0] = 0u; counts[lane * 2 + 1] = 0u;
   auto ratio = [&](int which) {
-    float vis = (float)counts[(which * B + lane) * 2 + 0], val = (float)counts[(which * B + lane) * 2 + 1];
+    float vis = cnt[which][0], val = cnt[which][1];
     return (val < 1.f) ? 0.f : vis / val;  // warping_registration.cu:862-865
   };
   // odometry keyframe :2172-2180.  NOTE: evaluated with the pre-switch delta pose, exactly as the reference.
@@ -566,26 +569,25 @@ void enqueue_save_odo_kf(rgbid_engine* e, hipStream_t s) {
   bool kept[MAXL] = {};
   for (int i = 0; i < L; ++i) {
     if (e->cfg.image_filtering != RGBID_FILTER_GRADS)
-      kept[i] = launch_gradient_keep(s, B, e->I_curr[i], e->gxI[i], e->gyI[i], e->I_kf[i], m) && launch_gradient_keep(s, B, e->iD_curr[i], e->gxD[i], e->gyD[i], e->iD_kf[i], m);
-    if (!kept[i]) {
+      kept[i] = launch_gradient_keep2(s, B, e->I_curr[i], e->gxI[i], e->gyI[i], e->I_kf[i], e->iD_curr[i], e->gxD[i], e->gyD[i], e->iD_kf[i], m);
+    if (kept[i]) e->launches += 1;
+    else {
       launch_copy_bytes(s, B, e->iD_curr[i], e->iD_kf[i], 4, m);
       launch_copy_bytes(s, B, e->I_curr[i], e->I_kf[i], 4, m);
+      e->launches += 2;
     }
-    e->launches += 2;
   }
-  if (e->lat_res)
-    for (int i = 0; i < L; ++i) { launch_lattice_pack(s, B, e->iD_kf[i], e->I_kf[i], e->cfg.nsamples, e->lat_kf[i], 2 * e->lat_cap, m); e->launches++; }
-  launch_bilateral(s, B, e->iD_kf[0], e->iD_kf_f[0], 2.f * 0.0025f, m, e->cfg.fast_numerics != 0);
-  launch_bilateral(s, B, e->I_kf[0], e->I_kf_f[0], 3.f, m, e->cfg.fast_numerics != 0);
-  launch_gradient(s, B, e->I_kf_f[0], e->gxI_c[0], e->gyI_c[0], m);
-  launch_gradient(s, B, e->iD_kf_f[0], e->gxD_c[0], e->gyD_c[0], m);
-  e->launches += 4;
+  if (e->lat_res) {
+    launch_lattice_pack_levels(s, B, L, e->iD_kf, e->I_kf, e->cfg.nsamples, e->lat_kf, 2 * e->lat_cap, m);
+    e->launches += (L + 3) / 4;
+  }
+  launch_bilateral2(s, B, e->iD_kf[0], e->iD_kf_f[0], 2.f * 0.0025f, e->I_kf[0], e->I_kf_f[0], 3.f, m, e->cfg.fast_numerics != 0);
+  launch_gradient2(s, B, e->I_kf_f[0], e->gxI_c[0], e->gyI_c[0], e->iD_kf_f[0], e->gxD_c[0], e->gyD_c[0], m);
+  e->launches += 2;
   for (int i = 1; i < L; ++i) {
-    launch_pyr_down(s, B, e->iD_kf_f[i - 1], e->iD_kf_f[i], m);
-    launch_pyr_down(s, B, e->I_kf_f[i - 1], e->I_kf_f[i], m);
-    launch_gradient(s, B, e->I_kf_f[i], e->gxI_c[i], e->gyI_c[i], m);
-    launch_gradient(s, B, e->iD_kf_f[i], e->gxD_c[i], e->gyD_c[i], m);
-    e->launches += 4;
+    launch_pyr_down2(s, B, e->iD_kf_f[i - 1], e->iD_kf_f[i], e->I_kf_f[i - 1], e->I_kf_f[i], m);
+    launch_gradient2(s, B, e->I_kf_f[i], e->gxI_c[i], e->gyI_c[i], e->iD_kf_f[i], e->gxD_c[i], e->gyD_c[i], m);
+    e->launches += 2;
   }
   for (int i = 0; i < L; ++i) {
     if (e->cfg.image_filtering == RGBID_FILTER_GRADS) {
@@ -593,9 +595,8 @@ void enqueue_save_odo_kf(rgbid_engine* e, hipStream_t s) {
       launch_copy_bytes(s, B, e->gxD_c[i], e->gxD[i], 4, m); launch_copy_bytes(s, B, e->gyD_c[i], e->gyD[i], 4, m);
       e->launches += 4;
     } else if (!kept[i]) {
-      launch_gradient(s, B, e->I_kf[i], e->gxI[i], e->gyI[i], m);
-      launch_gradient(s, B, e->iD_kf[i], e->gxD[i], e->gyD[i], m);
-      e->launches += 2;
+      launch_gradient2(s, B, e->I_kf[i], e->gxI[i], e->gyI[i], e->iD_kf[i], e->gxD[i], e->gyD[i], m);
+      e->launches += 1;
     }
   }
 }
@@ -627,20 +628,24 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   e->launches += 1;
   sb[0] += 25 * N0;                                                               // 2 + 3 B/px read, five fp32 planes written
   for (int i = 1; i < L; ++i) {
-    launch_pyr_down(s, B, e->I_curr[i - 1], e->I_curr[i], fed);
-    launch_pyr_down(s, B, e->iD_curr[i - 1], e->iD_curr[i], fed);
-    e->launches += 2;
+    launch_pyr_down2(s, B, e->I_curr[i - 1], e->I_curr[i], e->iD_curr[i - 1], e->iD_curr[i], fed);
+    e->launches += 1;
     sb[0] += 2 * (4 * npx(e->I_curr[i - 1]) + 4 * npx(e->I_curr[i]));
   }
-  hipLaunchKernelGGL(k_step_begin, dim3(gb), dim3(tb), 0, s, e->state, f, e->wp, e->sp, sc, B);
+  // the Gauss-Newton stages of the step: the levels that iterate, coarse to fine, then the covariance pass
+  int stage_level[MAXL + 1], n_stages = 0;
+  for (int level = L - 1; level >= c.finest_level; --level) if (c.iters[level] > 0) stage_level[n_stages++] = level;
+  const int n_gn_stages = n_stages;
+  stage_level[n_stages++] = c.finest_level;   // covariance pass
+  hipLaunchKernelGGL(k_step_begin, dim3(gb), dim3(tb), 0, s, e->state, f, e->wp, e->sp, sc, B, e->counts, stage_level[0], n_gn_stages == 0 ? 1 : 0);
   e->launches++;
+  int stage = 0;
   // The first step after reset() is host-known to be every lane's first frame (visodo.cpp:1994-2045): only the
   // keyframe-creation part of the sequence below is enqueued (k_step_begin has set first / sw_odo / sw_int / maps).
   // ---- estimateVisualOdometry (visodo.cpp:1041-1281), PYR_FIRST
   for (int level = L - 1; !first && level >= c.finest_level; --level) {
-    hipLaunchKernelGGL(k_set_sys, dim3(gb), dim3(tb), 0, s, e->sp, e->state, f.track, sc, level, 0, B);
-    e->launches++;
     int iters = c.iters[level];
+    if (iters > 0) ++stage;     // stage_level[stage]: what follows this level
     for (int it = 0; it < iters; ++it) {
       bool last_of_level = (it == iters - 1);
       // level whose intrinsics project the NEXT warp: same level, the next lower level that iterates, or (after the very last
@@ -700,14 +705,14 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
         nblk = launch_build_system(s, B, e->iD_kf[level], e->I_kf[level], e->gxD[level], e->gyD[level], e->gxI[level], e->gyI[level],
                                    e->wiD[level], e->wI[level], nullptr, e->sp, e->partials, M(f.gn), level < 2 ? level : 2);
       }
-      hipLaunchKernelGGL(k_solve_update, dim3(B), dim3(256), 0, s, e->partials, nblk, e->state, f, e->wp, sc, next_level);
+      hipLaunchKernelGGL(k_solve_update, dim3(B), dim3(256), 0, s, e->partials, nblk, e->state, f, e->wp, sc, next_level, e->sp,
+                         last_of_level ? stage_level[stage] : -1, (last_of_level && stage == n_gn_stages) ? 1 : 0);
       e->launches += 2;
     }
   }
   // ---- covariance pass (visodo.cpp:1283-1409)
   if (!first) {
     int fl = c.finest_level;
-    hipLaunchKernelGGL(k_set_sys, dim3(gb), dim3(tb), 0, s, e->sp, e->state, f.track, sc, fl, 1, B);
     bool prof = e->prof_on && fl == 0 && e->prof_used + 2 <= (int)e->prof_ev.size();
     bool fuse_cov = c.fused_gn && !c.chi_square_stats;  // the chi-square statistics need W1 / I1 in memory
     sb[0] += (fuse_cov ? 32 : 52) * npx(e->iD_kf[fl]);
@@ -718,14 +723,14 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
                              e->iD_curr[fl], e->I_curr[fl], e->wp, c.interp_mode, e->sp, e->partials, M(f.gn), fl < 2 ? fl : 2, fast_at(fl),
                              c.weighting == RGBID_MIN_WEIGHT ? 0 : 2);   // k_set_sys: the covariance pass is fixed-nu STUDENT
       if (nblk < 0) return RGBID_E_INVALID;
-      e->launches += 2;
+      e->launches += 1;
     } else {
       if (!(fast_at(fl) && launch_warp_pair_fast(s, B, e->iD_curr[fl], e->I_curr[fl], e->iD_kf[fl], e->wiD[fl], e->wI[fl], nullptr, e->wp, c.interp_mode, M(f.gn))))
         launch_warp_pair(s, B, e->iD_curr[fl], e->I_curr[fl], e->iD_kf[fl], e->wiD[fl], e->wI[fl], e->wp, c.interp_mode, M(f.gn));
       if (prof) { set_system_kernel_events(e->prof_ev[e->prof_used], e->prof_ev[e->prof_used + 1]); e->prof_used += 2; }
       nblk = launch_build_system(s, B, e->iD_kf[fl], e->I_kf[fl], e->gxD_c[fl], e->gyD_c[fl], e->gxI_c[fl], e->gyI_c[fl],
                                  e->wiD[fl], e->wI[fl], nullptr, e->sp, e->partials, M(f.gn), fl < 2 ? fl : 2);
-      e->launches += 3;
+      e->launches += 2;
     }
     if (c.chi_square_stats) {  // :1411-1415 (results unused by the reference)
       int n, lr, lc, st;
@@ -741,11 +746,10 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   }
   // ---- covisibility with both keyframes (visodo.cpp:2172-2188), 4 ratio evaluations
   if (!first) {
-    if (hipError_t he = hipMemsetAsync(e->counts, 0, sizeof(unsigned int) * 8 * B, s); he != hipSuccess) return (int)he;
-    launch_visibility_pair(s, B, e->iD_curr[0], e->iD_kf[0], e->vis_ab, e->vis_ba, e->counts + 0 * 2 * B, e->counts + 1 * 2 * B, M(f.vis), c.fast_numerics != 0);
-    launch_visibility_pair(s, B, e->iD_curr[0], e->iD_integr_raw, e->ivis_ab, e->ivis_ba, e->counts + 2 * 2 * B, e->counts + 3 * 2 * B, M(f.vis), c.fast_numerics != 0);
+    launch_visibility_pair2(s, B, e->iD_curr[0], e->iD_kf[0], e->vis_ab, e->vis_ba, e->counts + 0 * 2 * B, e->counts + 1 * 2 * B,
+                            e->iD_integr_raw, e->ivis_ab, e->ivis_ba, e->counts + 2 * 2 * B, e->counts + 3 * 2 * B, M(f.vis), c.fast_numerics != 0);
     hipLaunchKernelGGL(k_decide, dim3(gb), dim3(tb), 0, s, e->state, f, e->counts, e->fuse_wp, sc, B);
-    e->launches += 4;
+    e->launches += 2;
     sb[0] += 2 * 16 * N0;                                                         // two covisibility pairs: both maps read + both gathered
   }
   // ---- odometry keyframe switch
@@ -765,12 +769,12 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   }
   // ---- integration keyframe: computeOverlapping (:1517-1539) + saveCurrentImagesAsIntegrationKeyframes (:880-893) ...
   if (!first) {
-    if (hipError_t he = hipMemsetAsync(e->counts, 0, sizeof(unsigned int) * 2 * B, s); he != hipSuccess) return (int)he;
     launch_visibility(s, B, e->iD_curr[0], e->iD_integr_raw, e->overlap_mask, nullptr, e->ivis_ab, e->counts, M(f.overlap));
+    e->launches++;
   }
   hipLaunchKernelGGL(k_save_integr_kf, dim3(std::min(c.rows, 32), B), dim3(256), 0, s, e->iD_curr[0], e->cur_rgb, e->iD_integr, e->iD_integr_raw, e->colors_integr, e->w_integr,
                      e->overlap_mask, f.sw_int, f.first);   // three copies + weight fill; initialiseDeviceMemory2D(overlap_mask, 0) :2021
-  e->launches += 3;
+  e->launches += 1;
   sb[2] += (9 + 12 + 6 + 4) * N0;                                                 // overlap mask pass; inverse depth read once and written twice, colours, weight fill
   // ... or integrateImagesIntoKeyframes (:1674-1764)
   if (!first) {

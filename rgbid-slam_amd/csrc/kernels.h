@@ -49,6 +49,15 @@ void launch_prep_frame(hipStream_t s, int B, ImgB depth_u16, ImgB rgb, ImgB iD, 
 void launch_copy_bytes(hipStream_t s, int B, ImgB src, ImgB dst, int elem_size, LaneMask m);  // row-wise D2D copy kernel
 void launch_fill(hipStream_t s, int B, ImgB dst, int elem_size, uint32_t bits, LaneMask m);
 void launch_pyr_down(hipStream_t s, int B, ImgB src, ImgB dst, LaneMask m);
+// Two maps of the same geometry in ONE launch (the intensity / inverse-depth pair of a pyramid level; the two covisibility checks of a frame; every
+// level's lattice pack): below ~100 lanes a step is bound by its number of dependent launches.  Same kernels, same per-map results.
+void launch_pyr_down2(hipStream_t s, int B, ImgB src0, ImgB dst0, ImgB src1, ImgB dst1, LaneMask m);
+void launch_gradient2(hipStream_t s, int B, ImgB src0, ImgB gx0, ImgB gy0, ImgB src1, ImgB gx1, ImgB gy1, LaneMask m);
+bool launch_gradient_keep2(hipStream_t s, int B, ImgB src0, ImgB gx0, ImgB gy0, ImgB keep0, ImgB src1, ImgB gx1, ImgB gy1, ImgB keep1, LaneMask m);
+void launch_bilateral2(hipStream_t s, int B, ImgB src0, ImgB dst0, float sigma0, ImgB src1, ImgB dst1, float sigma1, LaneMask m, bool fast = false);
+void launch_lattice_pack_levels(hipStream_t s, int B, int n_levels, const ImgB* W0, const ImgB* I0, int min_nsamples, float* const* out, size_t out_lane_stride, LaneMask m);
+void launch_visibility_pair2(hipStream_t s, int B, ImgB a, ImgB b0, const WarpParams* p_ab0, const WarpParams* p_ba0, unsigned int* counts_ab0, unsigned int* counts_ba0,
+                             ImgB b1, const WarpParams* p_ab1, const WarpParams* p_ba1, unsigned int* counts_ab1, unsigned int* counts_ba1, LaneMask m, bool fast);
 void launch_bilateral(hipStream_t s, int B, ImgB src, ImgB dst, float sigma_floatmap, LaneMask m, bool fast = false);
 bool div_const_verified(float c);   // constants for which the bilateral filter uses the short exact division
 void launch_selftest_div_const(hipStream_t s, float c, unsigned long long* mismatches_dev);

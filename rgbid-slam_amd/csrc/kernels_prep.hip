@@ -112,6 +112,7 @@ void launch_decompose_rgb(hipStream_t s, int B, ImgB rgb, ImgB r, ImgB g, ImgB b
 // ---- engine frame preparation: the three converters above in ONE pass, 4 pixels per thread -------------------
 // reads the u16 depth (8 B) and the packed rgb (12 B) of a 4-pixel group once, writes five 16-byte vectors
 // (iD, luma, r, g, b planes).  Same per-pixel arithmetic as k_depth_to_invdepth / k_intensity / k_decompose.
+static inline bool same_geometry(const ImgB& a, const ImgB& b) { return a.rows == b.rows && a.cols == b.cols; }
 static inline bool vec4_ok(const ImgB& a, int elem) {
   return ((a.pitch & 15) == 0) && ((a.lane_stride & 15) == 0) && ((((uintptr_t)a.base) & 15) == 0) && (((size_t)a.cols * elem) % (4 * elem) == 0);
 }
@@ -199,10 +200,14 @@ __device__ __forceinline__ void sobel_load_row(const ImgB& src, int lane, int y,
   r[0] = rp[xl]; r[1] = v.x; r[2] = v.y; r[3] = v.z; r[4] = v.w; r[5] = rp[xr];
 }
 // COPY: the source row is also written to `keep` (the keyframe's own copy of a current-frame map: the copy kernel's 4 B/px read and one launch saved)
+struct GradSet { ImgB src, gx, gy, keep; };
+// blockIdx.z: which of (up to) two maps of the same geometry (intensity and inverse depth of a pyramid level: one launch instead of two)
 template <bool COPY>
-__global__ __launch_bounds__(256) void k_gradient4(ImgB src, ImgB gx, ImgB gy, ImgB keep, int cols4, int strips, LaneMask m) {
+__global__ __launch_bounds__(256) void k_gradient4(GradSet s0, GradSet s1, int cols4, int strips, LaneMask m) {
   int lane = blockIdx.y;
   if (!m.on(lane)) return;
+  const GradSet& S = blockIdx.z ? s1 : s0;
+  const ImgB& src = S.src; const ImgB& gx = S.gx; const ImgB& gy = S.gy; const ImgB& keep = S.keep;
   int u = blockIdx.x * 256 + threadIdx.x;
   if (u >= cols4 * strips) return;
   int strip = u / cols4, x = (u - strip * cols4) * 4;
@@ -237,17 +242,35 @@ __global__ __launch_bounds__(256) void k_gradient4(ImgB src, ImgB gx, ImgB gy, I
 void launch_gradient(hipStream_t s, int B, ImgB src, ImgB gx, ImgB gy, LaneMask m) {
   if ((src.cols % 4 == 0) && vec4_ok(src, 4) && vec4_ok(gx, 4) && vec4_ok(gy, 4)) {
     int cols4 = src.cols / 4, strips = div_up(src.rows, GR_ROWS);
-    hipLaunchKernelGGL(k_gradient4<false>, dim3(div_up(cols4 * strips, 256), B), dim3(256), 0, s, src, gx, gy, src, cols4, strips, m);
+    const GradSet g{src, gx, gy, src};
+    hipLaunchKernelGGL(k_gradient4<false>, dim3(div_up(cols4 * strips, 256), B), dim3(256), 0, s, g, g, cols4, strips, m);
     return;
   }
   hipLaunchKernelGGL(k_gradient, grid2d(src.cols, src.rows, B), dim3(TX, TY), 0, s, src, gx, gy, m);
+}
+void launch_gradient2(hipStream_t s, int B, ImgB src0, ImgB gx0, ImgB gy0, ImgB src1, ImgB gx1, ImgB gy1, LaneMask m) {
+  const bool v = (src0.cols % 4 == 0) && same_geometry(src0, src1) && vec4_ok(src0, 4) && vec4_ok(gx0, 4) && vec4_ok(gy0, 4) && vec4_ok(src1, 4) && vec4_ok(gx1, 4) && vec4_ok(gy1, 4);
+  if (!v) { launch_gradient(s, B, src0, gx0, gy0, m); launch_gradient(s, B, src1, gx1, gy1, m); return; }
+  int cols4 = src0.cols / 4, strips = div_up(src0.rows, GR_ROWS);
+  hipLaunchKernelGGL(k_gradient4<false>, dim3(div_up(cols4 * strips, 256), B, 2), dim3(256), 0, s, GradSet{src0, gx0, gy0, src0}, GradSet{src1, gx1, gy1, src1}, cols4, strips, m);
 }
 // Sobel pair of `src` + a copy of `src` into `keep` in one pass (keyframe switch: the current-frame map becomes the keyframe's); false: the
 // geometry is not the 16-byte path's, nothing launched (the caller copies, then takes the gradient)
 bool launch_gradient_keep(hipStream_t s, int B, ImgB src, ImgB gx, ImgB gy, ImgB keep, LaneMask m) {
   if (!((src.cols % 4 == 0) && vec4_ok(src, 4) && vec4_ok(gx, 4) && vec4_ok(gy, 4) && vec4_ok(keep, 4) && keep.rows == src.rows && keep.cols == src.cols)) return false;
   int cols4 = src.cols / 4, strips = div_up(src.rows, GR_ROWS);
-  hipLaunchKernelGGL(k_gradient4<true>, dim3(div_up(cols4 * strips, 256), B), dim3(256), 0, s, src, gx, gy, keep, cols4, strips, m);
+  const GradSet g{src, gx, gy, keep};
+  hipLaunchKernelGGL(k_gradient4<true>, dim3(div_up(cols4 * strips, 256), B), dim3(256), 0, s, g, g, cols4, strips, m);
+  return true;
+}
+static bool gradient_keep_ok(const ImgB& src, const ImgB& gx, const ImgB& gy, const ImgB& keep) {
+  return (src.cols % 4 == 0) && vec4_ok(src, 4) && vec4_ok(gx, 4) && vec4_ok(gy, 4) && vec4_ok(keep, 4) && keep.rows == src.rows && keep.cols == src.cols;
+}
+// both maps of a level in one launch; false: nothing launched (the caller takes the one-map path for each)
+bool launch_gradient_keep2(hipStream_t s, int B, ImgB src0, ImgB gx0, ImgB gy0, ImgB keep0, ImgB src1, ImgB gx1, ImgB gy1, ImgB keep1, LaneMask m) {
+  if (!(gradient_keep_ok(src0, gx0, gy0, keep0) && gradient_keep_ok(src1, gx1, gy1, keep1) && same_geometry(src0, src1))) return false;
+  int cols4 = src0.cols / 4, strips = div_up(src0.rows, GR_ROWS);
+  hipLaunchKernelGGL(k_gradient4<true>, dim3(div_up(cols4 * strips, 256), B, 2), dim3(256), 0, s, GradSet{src0, gx0, gy0, keep0}, GradSet{src1, gx1, gy1, keep1}, cols4, strips, m);
   return true;
 }
 
@@ -404,11 +427,17 @@ __device__ __forceinline__ void pyr_finish_shared(float2 p, bool row_in, bool c0
   r.v[4] = dpp_shift<0x130>(v0); r.m[4] = dpp_shift<0x130>(m0);
 }
 static constexpr int PD_WAVE_OUT = 62;   // outputs per wave (lanes 1 .. 62)
-__global__ __launch_bounds__(256) void k_pyr_down_dpp(ImgB src, ImgB dst, PyrWeights W, int strips, int wpr, int wgs_per_lane, LaneMask m) {
+// src1 / dst1: a second map of the SAME geometry reduced by the same launch (the intensity and inverse-depth pyramids of a frame: one launch per
+// level instead of two -- below ~100 lanes a step is bound by its number of dependent launches); its workgroups are the second half of the grid
+__global__ __launch_bounds__(256) void k_pyr_down_dpp(ImgB src0, ImgB dst0, ImgB src1, ImgB dst1, PyrWeights W, int strips, int wpr, int wgs_per_lane, int wgs_per_map, LaneMask m) {
   // 1-D grid in XCD-contiguous order (common.h): the workgroups of vertically adjacent strips -- which share 3 of their 19 source rows -- run on ONE
   // XCD one after the other and find the shared rows in its L2 (with the natural order they sit on different XCDs and each fetches them from HBM:
   // round 3 counted 1.48 x the algorithmic reads)
-  const unsigned V = xcd_slab_index(blockIdx.x, gridDim.x);
+  unsigned V = xcd_slab_index(blockIdx.x, gridDim.x);
+  const bool second = V >= (unsigned)wgs_per_map;   // wave-uniform
+  if (second) V -= (unsigned)wgs_per_map;
+  const ImgB& src = second ? src1 : src0;
+  const ImgB& dst = second ? dst1 : dst0;
   const int lane = (int)(V / (unsigned)wgs_per_lane), wg = (int)(V - (unsigned)lane * (unsigned)wgs_per_lane);
   if (!m.on(lane)) return;
   const int wave = (wg * 256 + threadIdx.x) >> 6, lid = threadIdx.x & 63;
@@ -456,7 +485,14 @@ void launch_pyr_down(hipStream_t s, int B, ImgB src, ImgB dst, LaneMask m) {
   int strips = div_up(dst.rows, PD_ROWS);
   const int wpr = div_up(dst.cols, PD_WAVE_OUT);
   const int wgs = div_up(strips * wpr, 4);
-  hipLaunchKernelGGL(k_pyr_down_dpp, dim3((unsigned)wgs * (unsigned)B), dim3(256), 0, s, src, dst, pyr_weights(), strips, wpr, wgs, m);
+  hipLaunchKernelGGL(k_pyr_down_dpp, dim3((unsigned)wgs * (unsigned)B), dim3(256), 0, s, src, dst, src, dst, pyr_weights(), strips, wpr, wgs, wgs * B, m);
+}
+void launch_pyr_down2(hipStream_t s, int B, ImgB src0, ImgB dst0, ImgB src1, ImgB dst1, LaneMask m) {
+  if (!(same_geometry(src0, src1) && same_geometry(dst0, dst1))) { launch_pyr_down(s, B, src0, dst0, m); launch_pyr_down(s, B, src1, dst1, m); return; }
+  int strips = div_up(dst0.rows, PD_ROWS);
+  const int wpr = div_up(dst0.cols, PD_WAVE_OUT);
+  const int wgs = div_up(strips * wpr, 4);
+  hipLaunchKernelGGL(k_pyr_down_dpp, dim3(2u * (unsigned)wgs * (unsigned)B), dim3(256), 0, s, src0, dst0, src1, dst1, pyr_weights(), strips, wpr, wgs, wgs * B, m);
 }
 
 // ---- bilateralKernel (filters.cu:86-135), clipped 5x5 window -------------------------------------
@@ -514,18 +550,27 @@ __device__ __forceinline__ float bilateral_px_fast(const float (*tile)[TX + 2 * 
     }
   return sum1 * __builtin_amdgcn_rcpf(sum2);
 }
+struct BilSet { ImgB src, dst; float sigma; DivConst dc; };
+// ny: tile rows of one map; blockIdx.y >= ny: the second map of the launch (same geometry, its own range sigma -- the keyframe's inverse depth and
+// intensity: one launch instead of two)
 template <int MODE>   // 0: IEEE division per tap, 1: the verified 3-instruction exact division, 2: reference-build-class numerics
-__global__ __launch_bounds__(256) void k_bilateral(ImgB src, ImgB dst, float sigma_floatmap, DivConst dc, LaneMask m) {
+__global__ __launch_bounds__(256) void k_bilateral(BilSet b0, BilSet b1, int ny, LaneMask m) {
   constexpr bool FAST = MODE == 1;
   int lane = blockIdx.z;
   if (!m.on(lane)) return;
+  const bool second = (int)blockIdx.y >= ny;
+  const BilSet& S = second ? b1 : b0;
+  const ImgB& src = S.src; const ImgB& dst = S.dst;
+  const float sigma_floatmap = S.sigma;
+  const DivConst dc = S.dc;
+  const int tile_y = (int)blockIdx.y - (second ? ny : 0);
   // one halo tile of BIL_TILES x TY rows per workgroup (16 + 4 rows x 68 columns: 1.33 loads per output, ONE barrier and ONE exposed memory round
   // trip per four outputs of a thread; four separate 4-row tiles cost 2.1 loads per output and four round trips)
   __shared__ float tile[TY * BIL_TILES + 2 * BR][TX + 2 * BR + 1];
   const int x0 = blockIdx.x * TX;
   const float sigma_space = 5.f;
   const float s2ih = (float)(0.5 / (double)(sigma_space * sigma_space));
-  const int y0 = blockIdx.y * (TY * BIL_TILES);
+  const int y0 = tile_y * (TY * BIL_TILES);
   for (int ty = threadIdx.y; ty < TY * BIL_TILES + 2 * BR; ty += TY) {
     const int cy = y0 + ty - BR;
     const bool row_in = cy >= 0 && cy < src.rows;
@@ -565,11 +610,25 @@ __global__ __launch_bounds__(256) void k_bilateral(ImgB src, ImgB dst, float sig
 // range sigmas, 2 * 0.0025 (inverse depth) and 3 (intensity), visodo.cpp:843-844
 bool div_const_verified(float c) { return c == 2.f * 0.0025f || c == 3.f; }
 void launch_bilateral(hipStream_t s, int B, ImgB src, ImgB dst, float sigma_floatmap, LaneMask m, bool fast) {
-  const DivConst dc{sigma_floatmap, 1.0f / sigma_floatmap};
-  const dim3 g(div_up(src.cols, TX), div_up(src.rows, TY * BIL_TILES), B), b(TX, TY);
-  if (fast) hipLaunchKernelGGL(k_bilateral<2>, g, b, 0, s, src, dst, sigma_floatmap, dc, m);
-  else if (div_const_verified(sigma_floatmap)) hipLaunchKernelGGL(k_bilateral<1>, g, b, 0, s, src, dst, sigma_floatmap, dc, m);
-  else hipLaunchKernelGGL(k_bilateral<0>, g, b, 0, s, src, dst, sigma_floatmap, dc, m);
+  const BilSet bs{src, dst, sigma_floatmap, DivConst{sigma_floatmap, 1.0f / sigma_floatmap}};
+  const int ny = div_up(src.rows, TY * BIL_TILES);
+  const dim3 g(div_up(src.cols, TX), ny, B), b(TX, TY);
+  if (fast) hipLaunchKernelGGL(k_bilateral<2>, g, b, 0, s, bs, bs, ny, m);
+  else if (div_const_verified(sigma_floatmap)) hipLaunchKernelGGL(k_bilateral<1>, g, b, 0, s, bs, bs, ny, m);
+  else hipLaunchKernelGGL(k_bilateral<0>, g, b, 0, s, bs, bs, ny, m);
+}
+void launch_bilateral2(hipStream_t s, int B, ImgB src0, ImgB dst0, float sigma0, ImgB src1, ImgB dst1, float sigma1, LaneMask m, bool fast) {
+  const bool both_verified = div_const_verified(sigma0) && div_const_verified(sigma1);
+  if (!same_geometry(src0, src1) || (!fast && !both_verified && (div_const_verified(sigma0) || div_const_verified(sigma1)))) {   // the two maps need different kernels
+    launch_bilateral(s, B, src0, dst0, sigma0, m, fast); launch_bilateral(s, B, src1, dst1, sigma1, m, fast);
+    return;
+  }
+  const BilSet b0{src0, dst0, sigma0, DivConst{sigma0, 1.0f / sigma0}}, b1{src1, dst1, sigma1, DivConst{sigma1, 1.0f / sigma1}};
+  const int ny = div_up(src0.rows, TY * BIL_TILES);
+  const dim3 g(div_up(src0.cols, TX), 2 * ny, B), b(TX, TY);
+  if (fast) hipLaunchKernelGGL(k_bilateral<2>, g, b, 0, s, b0, b1, ny, m);
+  else if (both_verified) hipLaunchKernelGGL(k_bilateral<1>, g, b, 0, s, b0, b1, ny, m);
+  else hipLaunchKernelGGL(k_bilateral<0>, g, b, 0, s, b0, b1, ny, m);
 }
 // exhaustive check of div_const_fast for one constant: every x whose fast result is flagged ok must equal x / c bit for bit (a zero result
 // only up to its sign); returns the number of violations over all 2^32 bit patterns of x

@@ -166,20 +166,36 @@ __global__ __launch_bounds__(256) void k_lattice_residuals_fused(ImgB Wcur, ImgB
   float* r = res + (size_t)lane * res_lane_stride;
   r[i] = rd; r[n + i] = ri;
 }
-__global__ __launch_bounds__(256) void k_lattice_pack(ImgB W0, ImgB I0, int n, int lcols, int stride, float* out, size_t out_lane_stride, LaneMask m) {
+struct LatPackLevel { ImgB W0, I0; int n, lcols, stride; float* out; };
+struct LatPackLevels { LatPackLevel l[4]; };
+// blockIdx.z: pyramid level (the keyframe side of every level's lattice in ONE launch at a keyframe switch)
+__global__ __launch_bounds__(256) void k_lattice_pack(LatPackLevels L, size_t out_lane_stride, LaneMask m) {
   const int lane = blockIdx.y;
   if (!m.on(lane)) return;
+  const LatPackLevel& P = L.l[blockIdx.z];
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int ly = i / lcols, lx = i - ly * lcols;
-  float* o = out + (size_t)lane * out_lane_stride;
-  o[i] = px<float>(W0, lane, ly * stride, lx * stride);
-  o[n + i] = px<float>(I0, lane, ly * stride, lx * stride);
+  if (i >= P.n) return;
+  const int ly = i / P.lcols, lx = i - ly * P.lcols;
+  float* o = P.out + (size_t)lane * out_lane_stride;
+  o[i] = px<float>(P.W0, lane, ly * P.stride, lx * P.stride);
+  o[P.n + i] = px<float>(P.I0, lane, ly * P.stride, lx * P.stride);
+}
+void launch_lattice_pack_levels(hipStream_t s, int B, int n_levels, const ImgB* W0, const ImgB* I0, int min_nsamples, float* const* out, size_t out_lane_stride, LaneMask m) {
+  for (int first = 0; first < n_levels; first += 4) {
+    LatPackLevels L{};
+    const int cnt = n_levels - first < 4 ? n_levels - first : 4;
+    int nmax = 0;
+    for (int k = 0; k < cnt; ++k) {
+      int n, lr, lc, st;
+      lattice_geometry(W0[first + k].rows, W0[first + k].cols, min_nsamples, &n, &lr, &lc, &st);
+      L.l[k] = LatPackLevel{W0[first + k], I0[first + k], n, lc, st, out[first + k]};
+      nmax = n > nmax ? n : nmax;
+    }
+    hipLaunchKernelGGL(k_lattice_pack, dim3(div_up(nmax, 256), B, cnt), dim3(256), 0, s, L, out_lane_stride, m);
+  }
 }
 void launch_lattice_pack(hipStream_t s, int B, ImgB W0, ImgB I0, int min_nsamples, float* out, size_t out_lane_stride, LaneMask m) {
-  int n, lr, lc, st;
-  lattice_geometry(W0.rows, W0.cols, min_nsamples, &n, &lr, &lc, &st);
-  hipLaunchKernelGGL(k_lattice_pack, dim3(div_up(n, 256), B), dim3(256), 0, s, W0, I0, n, lc, st, out, out_lane_stride, m);
+  launch_lattice_pack_levels(s, B, 1, &W0, &I0, min_nsamples, &out, out_lane_stride, m);
 }
 template <bool REG>
 __global__ __launch_bounds__(SIG_T) void k_sigma_pair_arrays(NuTable T, const float* res, size_t res_lane_stride, int n, SysParams* sp, int mestimator, LaneMask m) {

@@ -529,12 +529,20 @@ __global__ __launch_bounds__(256) void k_visibility(ImgB src, ImgB dst, ImgB mas
 // the pair: each thread loads its pixel of A and of B (coalesced) and runs the two projection -> gather -> gate chains side by side --
 // the single-direction kernel is latency-bound (SQ counters: waves parked 75 % of their cycles), so the second independent chain is
 // nearly free, and two of the four launches per frame disappear.  Counters: counts_ab / counts_ba as in k_visibility.
+struct VisOther { ImgB Bm; const WarpParams *p_ab, *p_ba; unsigned int *counts_ab, *counts_ba; };
+// o1: a second "other" map the same frame A is compared with in the same launch (trackNewFrame's two covisibility checks, against the odometry and the
+// integration keyframe: one launch instead of two); its workgroups are the second half of the grid (wgs_per_other each)
 template <bool FAST>
-__global__ __launch_bounds__(256) void k_visibility_pair(ImgB A, ImgB Bm, const WarpParams* p_ab, const WarpParams* p_ba, unsigned int* counts_ab,
-                                                         unsigned int* counts_ba, int nbx, int nby, LaneMask m) {
+__global__ __launch_bounds__(256) void k_visibility_pair(ImgB A, VisOther o0, VisOther o1, int nbx, int nby, unsigned wgs_per_other, LaneMask m) {
   // 1-D grid in XCD-contiguous order (common.h xcd_slab_index): a lane's 64-pixel-wide strips run on one XCD, so the gather footprints neighbouring
   // strips share in the other map are fetched once (round 3: 1.15 x the algorithmic traffic with the natural order)
-  const unsigned V = xcd_slab_index(blockIdx.x, gridDim.x);
+  unsigned V = xcd_slab_index(blockIdx.x, gridDim.x);
+  const bool second = V >= wgs_per_other;
+  if (second) V -= wgs_per_other;
+  const VisOther& O = second ? o1 : o0;
+  const ImgB& Bm = O.Bm;
+  const WarpParams* const p_ab = O.p_ab; const WarpParams* const p_ba = O.p_ba;
+  unsigned int* const counts_ab = O.counts_ab; unsigned int* const counts_ba = O.counts_ba;
   const unsigned per_lane = (unsigned)nbx * (unsigned)nby;
   const int lane = (int)(V / per_lane);
   const unsigned tl = V - (unsigned)lane * per_lane;
@@ -601,9 +609,21 @@ __global__ __launch_bounds__(256) void k_visibility_pair(ImgB A, ImgB Bm, const 
 void launch_visibility_pair(hipStream_t s, int B, ImgB a, ImgB b, const WarpParams* p_ab, const WarpParams* p_ba, unsigned int* counts_ab,
                             unsigned int* counts_ba, LaneMask m, bool fast) {
   const int nbx = div_up(a.cols, TX), nby = div_up(a.rows, VIS_ROWS);
-  dim3 g((unsigned)nbx * (unsigned)nby * (unsigned)B), blk(TX, TY);
-  if (fast) hipLaunchKernelGGL(k_visibility_pair<true>, g, blk, 0, s, a, b, p_ab, p_ba, counts_ab, counts_ba, nbx, nby, m);
-  else hipLaunchKernelGGL(k_visibility_pair<false>, g, blk, 0, s, a, b, p_ab, p_ba, counts_ab, counts_ba, nbx, nby, m);
+  const unsigned wgs = (unsigned)nbx * (unsigned)nby * (unsigned)B;
+  dim3 g(wgs), blk(TX, TY);
+  const VisOther o{b, p_ab, p_ba, counts_ab, counts_ba};
+  if (fast) hipLaunchKernelGGL(k_visibility_pair<true>, g, blk, 0, s, a, o, o, nbx, nby, wgs, m);
+  else hipLaunchKernelGGL(k_visibility_pair<false>, g, blk, 0, s, a, o, o, nbx, nby, wgs, m);
+}
+// frame `a` against two other maps of the same geometry in one launch
+void launch_visibility_pair2(hipStream_t s, int B, ImgB a, ImgB b0, const WarpParams* p_ab0, const WarpParams* p_ba0, unsigned int* counts_ab0, unsigned int* counts_ba0,
+                             ImgB b1, const WarpParams* p_ab1, const WarpParams* p_ba1, unsigned int* counts_ab1, unsigned int* counts_ba1, LaneMask m, bool fast) {
+  const int nbx = div_up(a.cols, TX), nby = div_up(a.rows, VIS_ROWS);
+  const unsigned wgs = (unsigned)nbx * (unsigned)nby * (unsigned)B;
+  dim3 g(2u * wgs), blk(TX, TY);
+  const VisOther o0{b0, p_ab0, p_ba0, counts_ab0, counts_ba0}, o1{b1, p_ab1, p_ba1, counts_ab1, counts_ba1};
+  if (fast) hipLaunchKernelGGL(k_visibility_pair<true>, g, blk, 0, s, a, o0, o1, nbx, nby, wgs, m);
+  else hipLaunchKernelGGL(k_visibility_pair<false>, g, blk, 0, s, a, o0, o1, nbx, nby, wgs, m);
 }
 
 void launch_visibility(hipStream_t s, int B, ImgB src, ImgB dst, ImgB mask, const WarpParams* hp, const WarpParams* lp, unsigned int* counts, LaneMask m) {

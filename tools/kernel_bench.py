@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--skew", type=int, default=0, help="experiment: byte offset added per map allocation (i * skew), to move the maps' relative HBM channel alignment")
     ap.add_argument("--json", default="")
+    ap.add_argument("--identity-pose", action="store_true", help="experiment: every lane warps with the identity (gathers land on the sampling pixel's own row)")
     args = ap.parse_args()
     from rgbid import batched as BT, device, synth
     B, rows, cols = args.lanes, args.rows, args.cols
@@ -55,6 +56,8 @@ def main():
         Km = np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]])
         Rp.append((Km @ Ri @ np.linalg.inv(Km)).astype(np.float32).reshape(9)); tp.append((Km @ ti).astype(np.float32))
     Rs = [Rp[l % n] for l in range(B)]; ts = [tp[l % n] for l in range(B)]
+    if args.identity_pose:
+        Rs = [np.eye(3, dtype=np.float32).reshape(9) for _ in range(B)]; ts = [np.zeros(3, dtype=np.float32) for _ in range(B)]
     nalloc = [0]
 
     def f32(*shape):

@@ -5,7 +5,7 @@
 # Summaries land in gpurun_out/profiles_${ROUND}/ ; copy what matters into profiles/.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 OUT=$ROOT/gpurun_out/profiles_$ROUND
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -19,6 +19,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trac
 rm -f $OUT/*agent_info.csv
 python $ROOT/tools/summarize_prof.py $OUT
 python $ROOT/tools/make_pmc_traffic.py $OUT $OUT/pmc_traffic.json ${LANES:-2048} || true
+python $ROOT/tools/make_pmc_traffic_all.py $OUT $OUT/pmc_traffic_all.json ${LANES:-2048} || true
 python $ROOT/tools/sq_table.py $OUT > $OUT/sq_table.md || true
 find $OUT -name "*kernel_trace.csv" -size +4M -delete
 ls -la $OUT

@@ -46,10 +46,18 @@ for tr in glob.glob(os.path.join(d, "*kernel_trace.csv")):
 
 for cc in glob.glob(os.path.join(d, "*counter_collection.csv")):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    bygrid = collections.defaultdict(list)     # (kernel, grid, counter) -> values: a kernel that runs at several pyramid levels, one row per level
     for r in csv.DictReader(open(cc)):
         n = r["Kernel_Name"]
         if keep(n):
             agg[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            grid = "x".join(str(r.get(k, "")) for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z")) if "Grid_Size_X" in r else r.get("Grid_Size", "")
+            bygrid[(n, grid, r["Counter_Name"])].append(float(r["Counter_Value"]))
+    with open(cc.replace("counter_collection.csv", "pmc_bygrid_rgbid.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Grid", "Counter", "Dispatches", "Mean", "Max"])
+        for (n, g, c), v in sorted(bygrid.items()):
+            w.writerow([n, g, c, len(v), float(np.mean(v)), float(np.max(v))])
     out = cc.replace("counter_collection.csv", "pmc_rgbid.csv")
     with open(out, "w", newline="") as f:
         w = csv.writer(f)
