@@ -32,13 +32,13 @@ TABLE = [
     ("k_lattice_residuals_fused", 36.0 * ns, "per lattice sample: packed keyframe pair 8 B, gathered current iD 4 B + 4 intensity texels 16 B, two residuals written 8 B"),
     ("k_sigma_pair_arrays", 8.0 * ns, "two residual arrays read once"),
     ("k_kf_maps4", 28.0 * px, "iD read 4 B, vertex + normal maps written 24 B"),
-    ("k_bilateral<2>", 8.0 * px, "map read + filtered map written"),
-    ("k_visibility_pair", 16.0 * px, "two inverse-depth maps, each read as grid and as gather source"),
+    ("k_bilateral<2>", 2 * 8.0 * px, "two maps per launch (keyframe inverse depth + intensity): map read + filtered map written each"),
+    ("k_visibility_pair", 2 * 16.0 * px, "two covisibility checks per launch (frame vs odometry and vs integration keyframe): per check two inverse-depth maps, each read as grid and as gather source (the frame's map is common to both checks: 8 of the 32 B/px can come from L2)"),
     ("k_prep_frame4", 25.0 * px, "u16 depth 2 B + rgb 3 B read; iD, luma, r, g, b planes written 20 B"),
-    ("k_pyr_down_dpp", 5.0 * px, "L0 -> L1: source read 4 B/px, quarter-size destination written"),
+    ("k_pyr_down_dpp", 2 * 5.0 * px, "two maps per launch (intensity + inverse depth), L0 -> L1: source read 4 B/px, quarter-size destination written"),
     ("k_fuse_frame4", 20.0 * px, "keyframe iD + weight read and written (16 B), current iD gathered (4 B)"),
-    ("k_gradient4<true>", 16.0 * px, "map read, two gradients + the keyframe copy written"),
-    ("k_gradient4<false>", 12.0 * px, "map read, two gradients written"),
+    ("k_gradient4<true>", 2 * 16.0 * px, "two maps per launch: map read, two gradients + the keyframe copy written"),
+    ("k_gradient4<false>", 2 * 12.0 * px, "two maps per launch: map read, two gradients written"),
 ]
 
 
