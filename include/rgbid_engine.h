@@ -95,7 +95,7 @@ int rgbid_engine_step(rgbid_engine* e, const void* depth_dev, const void* rgb_de
 int rgbid_engine_step_strided(rgbid_engine* e, const void* depth_dev, size_t depth_step, size_t depth_lane_stride, const void* rgb_dev, size_t rgb_step,
                               size_t rgb_lane_stride);
 /* the inter-frame time of the constant-velocity model for the steps that follow (computeInterframeTime, visodo.cpp:1902-1965, when the caller
- * measures it per frame); needs use_graph = 0 (a captured graph has the value baked in: RGBID_E_INVALID) */
+ * measures it per frame).  Ordered on the context's stream; the kernels read it through a device pointer, so it also works with use_graph = 1 */
 int rgbid_engine_set_delta_t(rgbid_engine* e, float delta_t);
 /* device views of a lane's current-frame level-0 maps (inverse depth, intensity) */
 int rgbid_engine_current_maps(rgbid_engine* e, int lane, rgbid_img* depthinv, rgbid_img* intensity);

@@ -132,7 +132,8 @@ __global__ void k_step_begin(LaneState* st, Flags f, WarpParams* wp, SysParams* 
   for (int i = 0; i < 3; ++i) s.prev_t[i] = s.delta_t[i];
   if ((s.global_time > 1) && (c.motion_model == RGBID_CONSTANT_VELOCITY) && (!s.lost)) {
     double vt[3], wt[3], dR[9], dt[3], tmp[3];
-    for (int i = 0; i < 3; ++i) { vt[i] = s.velocity[i] * c.delta_t; wt[i] = s.omega[i] * c.delta_t; }
+    const float dt_frame = *c.delta_t;
+    for (int i = 0; i < 3; ++i) { vt[i] = s.velocity[i] * dt_frame; wt[i] = s.omega[i] * dt_frame; }
     se3::expmap(wt, vt, dR, dt);
     se3::m3_mulv(s.prev_R, dt, tmp);
     for (int i = 0; i < 3; ++i) s.cur_t[i] = tmp[i] + s.prev_t[i];
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void k_frame_finish(const double* partials, in
     for (int i = 0; i < 3; ++i) d[i] = s.cur_t[i] - s.prev_t[i];
     se3::m3_mulv(pT, d, dt);
     se3::logmap(dR, dt, twist);
-    float inv_dt = 1.f / c.delta_t;
+    float inv_dt = 1.f / *c.delta_t;
     for (int i = 0; i < 3; ++i) { s.velocity[i] = twist[i] * (double)inv_dt; s.omega[i] = twist[3 + i] * (double)inv_dt; }
   } else {
     // resulting = previous, covariance = 100 I :1267-1269
@@ -478,6 +479,7 @@ struct rgbid_engine {
   SysParams* sp = nullptr;
   LightP* light = nullptr;
   unsigned int* counts = nullptr;
+  float* delta_t_dev = nullptr;   // StepCfg::delta_t
   rgbid_pose_record* records = nullptr;  // [capacity][B]
   rgbid_pose_record* rec_cur = nullptr;  // [B] staging written by the step, copied into the ring
   int* active_dev = nullptr;                // [B] lanes fed by the next steps (rgbid_engine_set_active)
@@ -532,7 +534,7 @@ StepCfg step_cfg(const rgbid_engine_config& c) {
   s.fx = c.fx; s.fy = c.fy; s.cx = c.cx; s.cy = c.cy;
   s.levels = c.levels; s.finest_level = c.finest_level; s.motion_model = c.motion_model;
   s.max_odoKF_count = c.max_odoKF_count; s.max_integrKF_count = c.max_integrKF_count;
-  s.visratio_odo = c.visratio_odo; s.visratio_integr = c.visratio_integr; s.delta_t = c.delta_t;
+  s.visratio_odo = c.visratio_odo; s.visratio_integr = c.visratio_integr; s.delta_t = nullptr;   // set by enqueue_step (engine's device copy)
   s.mestimator = c.mestimator; s.weighting = c.weighting;
   // first level (coarse to fine) that runs at least one iteration; the covariance pass warps at the finest level
   s.start_warp_level = c.finest_level;
@@ -607,6 +609,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   const int B = e->B, L = e->L;
   StepCfg sc_ = step_cfg(c);
   sc_.kf_hdr = e->kf_hdr; sc_.kf_cap = c.keyframe_capacity;
+  sc_.delta_t = e->delta_t_dev;
   sc_.active = e->active_dev;   // always passed (all ones by default): the captured graphs stay valid when the mask changes
   const StepCfg sc = sc_;
   const IntrP K0{c.fx, c.fy, c.cx, c.cy};
@@ -889,6 +892,8 @@ int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_c
   if (!r) r = alloc_dev(e, (void**)&e->rec_cur, sizeof(rgbid_pose_record) * B);
   if (!r) r = alloc_dev(e, (void**)&e->flags.kf_slot, sizeof(int) * B);
   if (!r) r = alloc_dev(e, (void**)&e->active_dev, sizeof(int) * B);
+  if (!r) r = alloc_dev(e, (void**)&e->delta_t_dev, sizeof(float));
+  if (!r && hipMemsetD32Async((hipDeviceptr_t)e->delta_t_dev, __builtin_bit_cast(int, cfg->delta_t), 1, ctx->stream) != hipSuccess) r = RGBID_E_NOMEM;
   if (!r) { std::vector<int> ones(B, 1); if (hipMemcpyAsync(e->active_dev, ones.data(), sizeof(int) * B, hipMemcpyHostToDevice, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) r = RGBID_E_NOMEM; }
   if (!r && cfg->keyframe_capacity > 0) {
     e->kf_block_bytes = 20 * (size_t)rows * cols;   // u8 mask + 3 u8 colours + f32 inverse depth + 3 f32 normals per pixel
@@ -961,7 +966,10 @@ int rgbid_engine_step(rgbid_engine* e, const void* depth_dev, const void* rgb_de
 }
 
 int rgbid_engine_set_delta_t(rgbid_engine* e, float delta_t) {
-  if (!e || e->cfg.use_graph || !(delta_t == delta_t)) return RGBID_E_INVALID;
+  if (!e || !(delta_t == delta_t)) return RGBID_E_INVALID;
+  hipSetDevice(e->ctx->device);
+  // the kernels read the value through a device pointer (StepCfg::delta_t): captured graphs stay valid; ordered on the context's stream
+  if (hipError_t he = hipMemsetD32Async((hipDeviceptr_t)e->delta_t_dev, __builtin_bit_cast(int, delta_t), 1, e->ctx->stream); he != hipSuccess) return (int)he;
   e->cfg.delta_t = delta_t;
   return RGBID_OK;
 }

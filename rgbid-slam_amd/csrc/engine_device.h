@@ -40,7 +40,8 @@ struct Flags {  // int[B] each; consumed through LaneMask
 struct StepCfg {  // by-value kernel argument with what the scalar kernels need
   float fx, fy, cx, cy;
   int levels, finest_level, motion_model, max_odoKF_count, max_integrKF_count;
-  float visratio_odo, visratio_integr, delta_t;
+  float visratio_odo, visratio_integr;
+  const float* delta_t;  // device: inter-frame time of the constant-velocity model (a pointer, so that captured graphs follow rgbid_engine_set_delta_t)
   int mestimator, weighting;
   int start_warp_level;  // pyramid level whose intrinsics project the first warp of a frame
   rgbid_keyframe_header* kf_hdr;  // export ring headers [B][kf_cap] (nullptr: no export)

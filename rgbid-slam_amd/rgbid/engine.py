@@ -118,6 +118,11 @@ class Engine:
             self._inflight.clear()
         check(self.L.rgbid_engine_step(self._h, C.c_void_p(depth.data_ptr()), C.c_void_p(rgb.data_ptr())))
 
+    def set_delta_t(self, delta_t):
+        """inter-frame time of the constant-velocity model for the following steps (also with use_graph = 1: the kernels read it through a device pointer)"""
+        self.L.rgbid_engine_set_delta_t.argtypes = [C.c_void_p, C.c_float]
+        check(self.L.rgbid_engine_set_delta_t(self._h, C.c_float(delta_t)))
+
     def steps(self):
         return self.L.rgbid_engine_steps(self._h)
 

@@ -656,3 +656,25 @@ def test_engine_inactive_lanes_sit_steps_out(ctx, use_graph):
     for t in trk:
         t.close()
     eng.close()
+
+
+def test_delta_t_per_frame_reaches_captured_graphs(ctx):
+    """rgbid_engine_set_delta_t (the per-frame computeInterframeTime of the compat tracker, visodo.cpp:1902-1965): the kernels read the value through a device
+    pointer, so a step replayed as a captured hipGraph follows it.  Records with a different inter-frame time every frame are bit-identical between eager
+    launches and graph replay, and differ from the run with the constant default (the constant-velocity prediction really uses it)."""
+    K = (131.25, 131.25, 79.5, 59.5)
+    n, B = 7, 2
+    seqs = [synth.make_sequence(n, seed=synth.SEED + 5 * l, K=K, rows=120, cols=160, device="cuda", trans_step=(0.01, 0.02), rot_step_deg=(0.5, 1.0)) for l in range(B)]
+    depth = torch.stack([s["depth"] for s in seqs], 1).to(torch.int16).contiguous(); rgb = torch.stack([s["rgb"] for s in seqs], 1).contiguous()
+    dts = [0.0333, 0.05, 0.02, 0.0333, 0.1, 0.04, 0.03]
+    out = []
+    for use_graph, vary in ((0, True), (1, True), (1, False)):
+        eng = E.Engine(ctx, E.default_config(rows=120, cols=160, lanes=B, K=K, use_graph=use_graph, record_capacity=n))
+        for k in range(n):
+            if vary:
+                eng.set_delta_t(dts[k])
+            eng.step(depth[k], rgb[k])
+        out.append(eng.records().copy())
+        eng.close()
+    assert out[0].tobytes() == out[1].tobytes()
+    assert not np.array_equal(out[1]["R"], out[2]["R"])
