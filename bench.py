@@ -154,6 +154,59 @@ def pmc_traffic(lanes, rows, cols, fused):
     return None, None
 
 
+def selection_check(ctx, dev, depth, rgb, rec_step, step, n_lanes, rows, cols, K):
+    """Size-independent property of the headline numerics class, on the benchmark's own frames: the FAST gather kernels (cheap float arithmetic) must take
+    the same DISCRETE decisions as the EXACT kernels (bit-identical to the oracle, tests/) -- validity of every pixel, the point-sampled source pixel
+    (a neighbouring pixel moves the value by far more than rounding), the four covisibility counts, the fusion gate.  Frames step - 1 -> step of the first
+    n_lanes lanes, warped with the engine's own frame-to-frame odometry of that step (rec_step: the pose records of frame `step`).  Runs after the timed regions; device kernels only."""
+    from rgbid import batched as BT
+    bt = BT.Batched(ctx)
+    L = n_lanes
+    f32 = lambda: torch.empty((L, rows, cols), device=dev)
+    W, I = [f32(), f32()], [f32(), f32()]
+    ch = [f32() for _ in range(3)]
+    for j, k in enumerate((step - 1, step)):
+        bt.prep_frame(depth[k][:L].contiguous(), rgb[k][:L].contiguous(), W[j], I[j], *ch, 1.0)
+    Km = np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]], np.float64)
+    Ki = np.linalg.inv(Km)
+    Rab, tab, Rba, tba = [], [], [], []
+    for l in range(L):
+        R = np.asarray(rec_step[l]["odo_R"], np.float64).reshape(3, 3); t = np.asarray(rec_step[l]["odo_t"], np.float64)
+        Ri = R.T; ti = -Ri @ t
+        Rab.append((Km @ Ri @ Ki).astype(np.float32).reshape(9)); tab.append((Km @ ti).astype(np.float32))
+        Rba.append((Km @ R @ Ki).astype(np.float32).reshape(9)); tba.append((Km @ t).astype(np.float32))
+    out = {"lanes": L, "pixels": int(L * rows * cols), "frames": [int(step - 1), int(step)]}
+    # warp pair: frame `step` sampled on the grid of frame `step - 1`
+    res = {}
+    for fast in (False, True):
+        d1, d2 = f32(), f32()
+        bt.warp_pair(W[1], I[1], W[0], d1, d2, Rab, tab, fast=fast)
+        res[fast] = (d1.cpu().numpy(), d2.cpu().numpy())
+    (e1, e2), (g1, g2) = res[False], res[True]
+    both = ~np.isnan(e1) & ~np.isnan(g1)
+    out["warp_validity_mismatches"] = int(np.count_nonzero(np.isnan(e1) != np.isnan(g1)) + np.count_nonzero(np.isnan(e2) != np.isnan(g2)))
+    out["warp_other_source_pixel"] = int(np.count_nonzero(np.abs(g1[both] - e1[both]) > 1e-5 * np.abs(e1[both])))
+    out["warp_valid_pixels"] = int(both.sum())
+    # covisibility counts, both directions
+    ce = bt.visibility_pair(W[1], W[0], Rab, tab, Rba, tba, fast=False); cf = bt.visibility_pair(W[1], W[0], Rab, tab, Rba, tba, fast=True)
+    out["covisibility_counts_equal"] = bool(np.array_equal(ce, cf))
+    out["covisibility_counted"] = int(ce.sum())
+    # one-pass fusion of frame `step` into frame `step - 1` as keyframe
+    fe = {}
+    for fast in (False, True):
+        kf, kw, ww = W[0].clone(), torch.ones((L, rows, cols), device=dev), torch.zeros((L, rows, cols), device=dev)
+        bt.fuse_frame(W[1], kf, kw, ww, Rab, tab, fast=fast)
+        fe[fast] = (kf.cpu().numpy(), kw.cpu().numpy())
+    (ke, we), (kg, wg) = fe[False], fe[True]
+    both = ~np.isnan(ke) & ~np.isnan(kg)
+    out["fusion_validity_mismatches"] = int(np.count_nonzero(np.isnan(ke) != np.isnan(kg)))
+    out["fusion_other_decision"] = int(np.count_nonzero(np.abs(kg[both] - ke[both]) > 1e-5 * np.abs(ke[both])) + np.count_nonzero(np.abs(wg[both] - we[both]) > 1e-4 * np.abs(we[both])))
+    out["selection_identical"] = bool(out["warp_validity_mismatches"] == 0 and out["warp_other_source_pixel"] == 0 and out["covisibility_counts_equal"]
+                                      and out["fusion_validity_mismatches"] == 0 and out["fusion_other_decision"] == 0)
+    out["note"] = "FAST vs EXACT device kernels on the benchmark's own frames (the EXACT kernels are bit-identical to the oracle in tests/): discrete decisions only; float values differ by rounding"
+    return out
+
+
 def oracle_check(depth, rgb, lanes_to_check, rows, cols, K, levels, iters, rec, first_step, n_steps):
     # rec: the engine's records of ALL steps [T, B] (status bits of every frame are imposed on the oracle where a ratio sits on its threshold)
     """Parity of the surface that was just benchmarked: for each lane in `lanes_to_check` run the CPU oracle tracker over the SAME frames
@@ -625,6 +678,12 @@ def main():
     if args.h2d > 0 or (args.h2d < 0 and world == 1 and not args.no_extras):
         # PCIe-inclusive leg at the headline lane count: the same timed steps with every frame uploaded from pinned host memory
         pcie = pcie_leg(ctx, dev, work, eng, depth, rgb, W, Kst, rec)
+    selection = None
+    if rank == 0 and world == 1 and args.fast and args.check_streams > 0 and Kst >= 2:
+        try:
+            selection = selection_check(ctx, dev, depth, rgb, rec[1], 1 + W + 1, min(8, B, res["n_unique_streams"]), rows, cols, K)
+        except Exception as e_:
+            selection = {"error": f"{type(e_).__name__}: {e_}"}
     eng.close()
 
     result = None
@@ -670,6 +729,8 @@ def main():
             "parity": res["parity"],
             "lanes_bit_identical": res["parity"]["lanes_bit_identical"],
         }
+        if selection is not None:
+            result["parity"]["fast_class_selection_vs_exact_kernels"] = selection
         if use_dist:
             med_i = int(np.argsort(res["repetitions"]["frames_per_s"])[::-1][len(res["repetitions"]["frames_per_s"]) // 2])
             result["multi_gpu"] = {"rccl_ranks": rccl_ranks, "rccl_ranks_per_rank": rccl_ranks_all, "gather": gather_how, "record_bytes": 392,
