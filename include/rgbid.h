@@ -98,7 +98,10 @@ int rgbid_ctx_sync(rgbid_ctx* ctx);                          /* internal.h:456-4
  * inside [2^-14, 2^14] m^-1 -- a value outside (zero, negative, infinite, denormal) is treated as invalid, like NaN, where the oracle would
  * project it; non-NaN values of a SAMPLED map 0 or of magnitude in [2^-60, 2^60]; transforms with finite entries below 2^20.  A lane whose
  * motion defeats the sign analysis of the bound (rotations towards 90 degrees, translations of the order of 2^14 scene depths) is not an error:
- * all its pixels take the exact path.  Maps this library builds from 16-bit depth are inside the domain by construction. */
+ * all its pixels take the exact path.  Maps this library builds from 16-bit depth are inside the domain by construction.
+ * VALUE tolerance of the class: a selected sample's inverse depth within ~2e-6 relative; a bilinear intensity sample blends the oracle's four texels
+ * with weights that may sit one 1.8 fixed-point step (1/256) off the oracle's -- 1 % of the samples at 640x480, at most 2/256 of the local contrast
+ * (that rounding has a boundary every 1/256 px, far inside any provable coordinate bound, so it is not guarded: DESIGN.md section 4.1). */
 int rgbid_ctx_set_numerics(rgbid_ctx* ctx, int numerics);
 /* orders the context's stream after a hipEvent_t recorded on another stream (interop with the caller's framework streams) */
 int rgbid_ctx_wait_event(rgbid_ctx* ctx, void* hip_event);
