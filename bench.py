@@ -243,7 +243,7 @@ def oracle_check(depth, rgb, lanes_to_check, rows, cols, K, levels, iters, rec, 
 
 
 def run_config(ctx, dev, work_stream, rows, cols, levels, iters, B, Kst, W, reps, n_unique, graph, fused, keyframes, K, dist_env, check_streams=0,
-               fast_numerics=1, inputs=None):
+               fast_numerics=1, inputs=None, defer_maps=0):
     """the timed protocol on one engine configuration; returns (result dict, inputs kept for the PCIe leg)"""
     from rgbid import engine as E
     T = 1 + W + Kst
@@ -252,6 +252,8 @@ def run_config(ctx, dev, work_stream, rows, cols, levels, iters, B, Kst, W, reps
                   keyframe_capacity=keyframes)
     if hasattr(E.EngineConfig, "fast_numerics"):
         cfg_kw["fast_numerics"] = fast_numerics
+    if defer_maps:
+        cfg_kw["defer_keyframe_maps"] = 1
     eng = E.Engine(ctx, E.default_config(**cfg_kw))
     gn_l0 = iters[0] + 1                      # level-0 launches of the dominant kernel per step (10 GN + covariance pass)
     profile_in_timed = not graph
@@ -759,6 +761,20 @@ def main():
                                "engine_bytes_per_frame": rx["engine_bytes_per_frame"], "parity": rx["parity"]})
             except Exception as e:
                 extras.append({"config": name, "error": f"{type(e).__name__}: {e}"})
+        # an output-equivalent schedule: vertex / normal maps of the fused keyframe only where they are consumed (rgbid_engine_config.defer_keyframe_maps; the
+        # headline keeps the reference's per-frame schedule).  Same records, same exported keyframes (tests/test_gpu_engine.py)
+        try:
+            rd, keepd = run_config(ctx, dev, work, rows, cols, args.levels, iters, B, Kst, W, 3, args.streams, args.graph, args.fused, args.keyframes, K,
+                                   {"use_dist": False, "world": 1}, check_streams=0, fast_numerics=args.fast, inputs=inputs, defer_maps=1)
+            same = bool(rd["parity"]["lanes_bit_identical"]) and keepd[4].tobytes() == rec.tobytes()
+            keepd[3].close()
+            del keepd
+            extras.append({"config": "deferred-keyframe-maps: the headline workload with the fused keyframe's vertex / normal maps computed only where consumed "
+                                     "(keyframe export, preview, accessor) instead of after every fusion step; opt-in (defer_keyframe_maps), NOT the headline",
+                           "value": rd["value"], "unit": "frames/s", "ms_per_step": rd["ms_per_step"], "lanes": B, "steps": Kst, "warmup": W, "repetitions": 3,
+                           "records_identical_to_headline_run": same, "engine_bytes_per_frame": rd["engine_bytes_per_frame"]})
+        except Exception as e:
+            extras.append({"config": "deferred-keyframe-maps", "error": f"{type(e).__name__}: {e}"})
         # what smaller batches deliver (the headline needs 2 048 concurrent streams), and the PCIe-inclusive rate
         for Bs in (1, 8, 64, 512):     # 1 lane: ms_per_step is the latency of one stream's frame (what an 8-GPU strong-scaling run approaches)
             if Bs >= B:

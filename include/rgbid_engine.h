@@ -50,6 +50,10 @@ typedef struct rgbid_engine_config {
                               * kernels of the compat bridge).  The float VALUES are then the cheap ones; every discrete decision (point-sampled
                               * source pixel, validity, covisibility counts, fusion gate) is the oracle's (rgbid.h rgbid_ctx_set_numerics,
                               * csrc/guard_band.h) */
+  int defer_keyframe_maps;   /* 0 (default): the vertex / normal maps of the fused keyframe are recomputed after every fusion step, as the reference does
+                              * (visodo.cpp:1758-1762).  1: they are computed only where something consumes them -- right before a keyframe is exported
+                              * (its normals), for the preview (cfg.preview = 1 keeps the per-frame schedule) and on rgbid_engine_keyframe_maps -- from the
+                              * same fused map: every output (pose records, exported keyframes, preview, accessor) is bit-identical, a step writes 24 B/px less */
 } rgbid_engine_config;
 
 #define RGBID_ST_TRACKED    1   /* trackNewFrame returned true */

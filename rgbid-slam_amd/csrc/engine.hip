@@ -621,6 +621,7 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
     return c.fast_numerics != 0 && gn_fast_supported(e->iD_kf[level], e->I_kf[level], e->gxD[level], e->gyD[level], e->gxI[level], e->gyI[level], e->I_curr[level]);
   };
   e->launches = 0;
+  const bool defer_maps = c.defer_keyframe_maps != 0 && !c.preview;   // the preview shades the maps every frame
   double* const sb = e->step_bytes;
   sb[0] = sb[2] = sb[3] = 0.0;
   const double N0 = (double)c.rows * c.cols;
@@ -761,6 +762,16 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
     // the outgoing keyframe leaves for the back-end (:1631-1652) BEFORE computeOverlapping rewrites the mask and the incoming frame
     // overwrites the maps (:2197-2202): the exported mask is the keyframe's overlap with its predecessor
     const size_t N = (size_t)c.rows * c.cols;
+    if (defer_maps) {   // the exported normals: from the fused map as the previous step left it -- what the per-frame schedule computed at the end of that step
+      if (!launch_kf_maps(s, B, e->iD_integr, e->vmap, e->nmap, K0, M(f.sw_int))) {
+        launch_vmap(s, B, e->iD_integr, e->vmap, K0, M(f.sw_int));
+        launch_gradient(s, B, e->iD_integr, e->gxD_integr, e->gyD_integr, M(f.sw_int));
+        launch_nmap_gradients(s, B, e->iD_integr, e->gxD_integr, e->gyD_integr, e->nmap, K0, M(f.sw_int));
+        e->launches += 2;
+      }
+      e->launches++;
+      sb[2] += 28 * N0;
+    }
     KfSrc ks;
     ks.im[0] = e->overlap_mask; ks.im[1] = e->colors_integr; ks.im[2] = e->iD_integr; ks.im[3] = e->nmap;
     ks.row_bytes[0] = c.cols; ks.row_bytes[1] = 3 * c.cols; ks.row_bytes[2] = 4 * c.cols; ks.row_bytes[3] = 4 * c.cols;
@@ -790,7 +801,9 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
       launch_integrate_warped(s, B, e->warped_iD_integr, e->warped_w, e->iD_integr, e->w_integr, M(f.fuse));
     }
   }
-  if (launch_kf_maps(s, B, e->iD_integr, e->vmap, e->nmap, K0, M(f.maps))) {
+  if (defer_maps) {
+    e->launches += 2;                                                             // (the two launches counted with the maps: fusion, integration keyframe)
+  } else if (launch_kf_maps(s, B, e->iD_integr, e->vmap, e->nmap, K0, M(f.maps))) {
     e->launches += 3;
     sb[0] += 28 * N0;
   } else {
@@ -1132,6 +1145,16 @@ static rgbid_img lane_img(const ImgB& im, int lane) {
 
 int rgbid_engine_keyframe_maps(rgbid_engine* e, int lane, rgbid_img* depthinv, rgbid_img* weight, rgbid_img* vmap, rgbid_img* nmap, rgbid_img* overlap_mask) {
   if (!e || lane < 0 || lane >= e->B) return RGBID_E_INVALID;
+  if ((vmap || nmap) && e->cfg.defer_keyframe_maps && !e->cfg.preview) {   // deferred schedule: the maps of the fused keyframe as it stands, now
+    hipSetDevice(e->ctx->device);
+    const IntrP K0{e->cfg.fx, e->cfg.fy, e->cfg.cx, e->cfg.cy};
+    hipStream_t s = e->ctx->stream;
+    if (!launch_kf_maps(s, e->B, e->iD_integr, e->vmap, e->nmap, K0, ALL)) {
+      launch_vmap(s, e->B, e->iD_integr, e->vmap, K0, ALL);
+      launch_gradient(s, e->B, e->iD_integr, e->gxD_integr, e->gyD_integr, ALL);
+      launch_nmap_gradients(s, e->B, e->iD_integr, e->gxD_integr, e->gyD_integr, e->nmap, K0, ALL);
+    }
+  }
   if (depthinv) *depthinv = lane_img(e->iD_integr, lane);
   if (weight) *weight = lane_img(e->w_integr, lane);
   if (vmap) *vmap = lane_img(e->vmap, lane);

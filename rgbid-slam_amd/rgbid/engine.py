@@ -28,6 +28,7 @@ class EngineConfig(C.Structure):
         ("interp_mode", C.c_int), ("delta_t", C.c_float),
         ("use_graph", C.c_int), ("fused_gn", C.c_int), ("chi_square_stats", C.c_int), ("preview", C.c_int),
         ("record_capacity", C.c_int), ("warping", C.c_int), ("keyframe_capacity", C.c_int), ("fast_numerics", C.c_int),
+        ("defer_keyframe_maps", C.c_int),
     ]
 
 

@@ -678,3 +678,39 @@ def test_delta_t_per_frame_reaches_captured_graphs(ctx):
         eng.close()
     assert out[0].tobytes() == out[1].tobytes()
     assert not np.array_equal(out[1]["R"], out[2]["R"])
+
+
+@pytest.mark.parametrize("use_graph", [0, 1])
+def test_deferred_keyframe_maps_change_no_output(ctx, use_graph):
+    """rgbid_engine_config.defer_keyframe_maps: the vertex / normal maps of the fused keyframe computed only where they are consumed (keyframe export, accessor)
+    instead of after every fusion step (visodo.cpp:1758-1762).  Same fused map in, same kernel: pose records, every exported keyframe (mask, colours, inverse
+    depth, NORMALS) and the accessor's maps are bit-identical to the per-frame schedule, on a sequence that switches keyframes."""
+    K = (131.25, 131.25, 79.5, 59.5)
+    n, B = 10, 3
+    seqs = [synth.make_sequence(n, seed=synth.SEED + 7 * l, K=K, rows=120, cols=160, device="cuda", trans_step=(0.01, 0.02), rot_step_deg=(0.5, 1.0)) for l in range(B)]
+    depth = torch.stack([s["depth"] for s in seqs], 1).to(torch.int16).contiguous(); rgb = torch.stack([s["rgb"] for s in seqs], 1).contiguous()
+    out = []
+    for defer in (0, 1):
+        eng = E.Engine(ctx, E.default_config(rows=120, cols=160, lanes=B, K=K, use_graph=use_graph, record_capacity=n, keyframe_capacity=8, visratio_odo=0.985, visratio_integr=0.97,
+                                             defer_keyframe_maps=defer))
+        for k in range(n):
+            eng.step(depth[k], rgb[k])
+        rec = eng.records().copy()
+        counts = eng.keyframe_counts().copy()
+        kfs = []
+        for l in range(B):
+            for q in range(max(0, int(counts[l]) - 8), int(counts[l])):     # what the 8-slot ring still holds
+                kf = eng.read_keyframe(l, q)
+                nrm = kf["normals"].copy(); nrm[:, np.isnan(nrm[0])] = np.nan
+                kfs.append((kf["id"], kf["end_id"], kf["R"].tobytes(), kf["t"].tobytes(), kf["R_rel"].tobytes(), kf["t_rel"].tobytes(), kf["cov_rel"].tobytes(),
+                            kf["overlap_mask"].tobytes(), kf["colors"].tobytes(), kf["depthinv"].tobytes(), nrm.tobytes()))
+        maps = [eng.keyframe_maps(l) for l in range(B)]
+        out.append((rec, counts, kfs, maps, eng.launches_per_step()))
+        eng.close()
+    a, b = out
+    assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]) and int(a[1].sum()) >= 3
+    assert a[2] == b[2]
+    for ma, mb in zip(a[3], b[3]):
+        for x, y in zip(ma, mb):
+            assert np.array_equal(x, y, equal_nan=True)
+    assert b[4] == a[4]      # the export-side launch replaces the end-of-step one
