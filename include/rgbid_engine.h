@@ -75,6 +75,9 @@ typedef struct rgbid_pose_record {
 } rgbid_pose_record;
 
 void rgbid_engine_default_config(rgbid_engine_config* cfg);   /* ctor defaults + shipped ini + factory calibration */
+/* sizeof(rgbid_engine_config) as the LIBRARY was built: a caller compiled against another revision of this header (fields are only ever appended) compares it
+ * with its own sizeof before it hands a config over -- librgbid_host.so, librgbid_dist.so and the Python binding do */
+size_t rgbid_engine_config_size(void);
 int rgbid_engine_create(rgbid_engine** e, rgbid_ctx* ctx, const rgbid_engine_config* cfg);
 /* an engine borrows its context's stream: destroy the engine BEFORE rgbid_ctx_destroy(ctx) */
 int rgbid_engine_destroy(rgbid_engine* e);

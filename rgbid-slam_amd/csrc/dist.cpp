@@ -396,6 +396,11 @@ int rgbid_dist_track_sequence(rgbid_ctx* ctx, const rgbid_seq_config* cfg, const
   if (!cfg || !R || !t || cfg->world < 1 || cfg->rank < 0 || cfg->rank >= cfg->world || cfg->n_chunks < cfg->world || n_frames < cfg->n_chunks + 1 ||
       (cfg->exchange != RGBID_EXCHANGE_RCCL && cfg->exchange != RGBID_EXCHANGE_TCP))
     return RGBID_E_INVALID;
+  if (rgbid_engine_config_size() != sizeof(rgbid_engine_config)) {   // librgbid_hip.so from another revision of rgbid_engine.h
+    fprintf(stderr, "rgbid_dist_track_sequence: librgbid_hip.so and librgbid_dist.so disagree on rgbid_engine_config (%zu vs %zu bytes): rebuild both\n", rgbid_engine_config_size(),
+            sizeof(rgbid_engine_config));
+    return RGBID_E_INVALID;
+  }
   if (!inject && (!ctx || !depth_host || !rgb_host)) return RGBID_E_INVALID;
   if (inject && cfg->world > 1 && cfg->exchange != RGBID_EXCHANGE_TCP) return RGBID_E_INVALID;   // no GPU side: nothing for RCCL to gather from
   if (cfg->world > 1 && (!cfg->master_addr || cfg->master_port <= 0)) return RGBID_E_INVALID;

@@ -848,6 +848,8 @@ void rgbid_engine_default_config(rgbid_engine_config* c) {
   c->fast_numerics = 1;
 }
 
+size_t rgbid_engine_config_size(void) { return sizeof(rgbid_engine_config); }
+
 int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_config* cfg) {
   if (!out || !ctx || !cfg) return RGBID_E_INVALID;
   *out = nullptr;

@@ -690,6 +690,11 @@ bool VisodoTracker::setEngineBacked(bool on) {
 
 bool VisodoTracker::createEngine() {
   if (engine_) { rgbid_engine_destroy(engine_); engine_ = nullptr; }
+  if (rgbid_engine_config_size() != sizeof(rgbid_engine_config)) {   // librgbid_hip.so built from another revision of rgbid_engine.h
+    std::cerr << "VisodoTracker: librgbid_hip.so and librgbid_host.so disagree on rgbid_engine_config (" << rgbid_engine_config_size() << " vs " << sizeof(rgbid_engine_config)
+              << " bytes): rebuild both" << std::endl;
+    return false;
+  }
   rgbid_engine_config c;
   rgbid_engine_default_config(&c);
   c.rows = rows_; c.cols = cols_; c.levels = levels_; c.lanes = 1;

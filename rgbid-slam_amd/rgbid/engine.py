@@ -65,6 +65,9 @@ class Engine:
         self.ctx = ctx
         self.cfg = cfg if cfg is not None else default_config(**kw)
         self.L = _lib.lib()
+        self.L.rgbid_engine_config_size.restype = C.c_size_t
+        if self.L.rgbid_engine_config_size() != C.sizeof(EngineConfig):
+            raise _lib.RgbidError(f"rgbid_engine_config: the library has {self.L.rgbid_engine_config_size()} bytes, this binding {C.sizeof(EngineConfig)} (rebuild / update rgbid/engine.py)")
         self._h = C.c_void_p()
         check(self.L.rgbid_engine_create(C.byref(self._h), ctx._h, C.byref(self.cfg)))
         self._inflight = []

@@ -35,6 +35,10 @@ static int env_int(const char* key, int dflt) { const char* e = std::getenv(key)
 int main(int argc, char* argv[]) {
   // before the HIP runtime comes up: the host driver only supports dmabuf IPC (RCCL across processes)
   setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
+  if (rgbid_engine_config_size() != sizeof(rgbid_engine_config)) {   // this binary and librgbid_hip.so come from different revisions of rgbid_engine.h
+    fprintf(stderr, "rgbid_track_sequence: built against a %zu-byte rgbid_engine_config, the library has %zu: rebuild\n", sizeof(rgbid_engine_config), rgbid_engine_config_size());
+    return 2;
+  }
   std::string folder, match_file, out = "trajectory.txt", inject_file, report_file, exchange = "rccl", addr, s;
   const bool have_eval = arg_value(argc, argv, "-eval", folder);
   arg_value(argc, argv, "-match_file", match_file);

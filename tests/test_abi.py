@@ -93,3 +93,13 @@ def test_headers_are_valid_c(tmp_path):
         src = tmp_path / (h + ".c")
         src.write_text(f'#include "{h}"\nint main(void) {{ return 0; }}\n')
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), str(src)])
+
+
+def test_python_engine_config_matches_the_library():
+    """the ctypes mirror of rgbid_engine_config has the size the library was built with (fields are only appended; a stale mirror or a stale library is an error
+    the engine constructors report instead of corrupting memory)"""
+    import ctypes as C
+    from rgbid import engine as E
+    L = _lib.lib()
+    L.rgbid_engine_config_size.restype = C.c_size_t
+    assert L.rgbid_engine_config_size() == C.sizeof(E.EngineConfig)
