@@ -11,7 +11,8 @@
 // CDNA4 design: one template, k_build_system<params source, 16-byte path, level tag, FUSED, weight variant>.
 //  * FUSED = 0 -- the normal equations on stored W1 / I1: a pure 8-stream read (32 B/px, no reuse -> no LDS staging), 0.83 of the HBM peak.
 //  * FUSED = 2 -- what the engine runs: W1 / I1 are formed in registers from the current frame (fast-numerics gathers), so an iteration
-//    moves 32 instead of 52 B/px and is one launch instead of two.  0.72-0.75 of the HBM peak at 761 VALU instructions per 4-pixel unit:
+//    moves 32 instead of 52 B/px and is one launch instead of two.  0.72-0.75 of the HBM peak at 761 VALU instructions per 4-pixel unit in round 3;
+//    0.65-0.68 since round 4, when the kernel began to take the oracle's discrete decisions at every pixel (guard_band.h: ~ +36 instructions per unit):
 //    memory (6.5 TB/s streaming ceiling), VALU issue (~2.4 ms of the 3.4 ms launch) and the L1 address path (~1.5 ms) all run at 45-90 %
 //    under 4 waves per SIMD -- what is left is their imperfect overlap (profiles/r03_experiments/).  FUSED = 1: the same with the
 //    exact-numerics warps (0.44).
