@@ -68,6 +68,11 @@ int rgbid_tracker_get_odo(const rgbid_tracker* t, int i, double R[9], double tv[
 int rgbid_tracker_last_info(const rgbid_tracker* t, rgbid_tracker_info* info);
 int rgbid_tracker_keyframe_maps(rgbid_tracker* t, float* depthinv_host, float* weight_host);
 
+/* what the application's viewer reads after a tracked frame when the preview is on (scene_view_, intensity_view_, depthinv_view_ under mutex_scene_view_;
+ * getImage, src/visodo.cpp:559-580, 2237-2241): the Phong-shaded keyframe (rows x cols x 3 bytes), the current intensity and the keyframe's inverse depth
+ * (rows x cols floats each).  Any output may be NULL; *changed = scene_view_has_changed_ (then cleared).  RGBID_E_INVALID before the first tracked frame */
+int rgbid_tracker_scene_view(rgbid_tracker* t, uint8_t* rgb, float* intensity, float* depthinv, int* changed);
+
 /* level-0 inverse depth / intensity of the last prepared frame (after undistortion + registration when custom_registration=1), to host */
 int rgbid_tracker_current_maps(const rgbid_tracker* t, float* depthinv, float* intensity);
 

@@ -153,6 +153,20 @@ int rgbid_tracker_keyframe_maps(rgbid_tracker* h, float* depthinv_host, float* w
   return RGBID_OK;
 }
 
+int rgbid_tracker_scene_view(rgbid_tracker* h, uint8_t* rgb, float* intensity, float* depthinv, int* changed) {
+  if (!h) return RGBID_E_INVALID;
+  VisodoTracker& t = *h->t;
+  std::lock_guard<std::mutex> lock(t.mutex_scene_view_);
+  const size_t n = (size_t)t.rows() * t.cols();
+  if (t.scene_view_.size() != n || t.intensity_view_.size() != n || t.depthinv_view_.size() != n) return RGBID_E_INVALID;
+  if (rgb) std::memcpy(rgb, t.scene_view_.data(), n * 3);
+  if (intensity) std::memcpy(intensity, t.intensity_view_.data(), n * sizeof(float));
+  if (depthinv) std::memcpy(depthinv, t.depthinv_view_.data(), n * sizeof(float));
+  if (changed) *changed = t.scene_view_has_changed_ ? 1 : 0;
+  t.scene_view_has_changed_ = false;
+  return RGBID_OK;
+}
+
 int rgbid_tracker_current_maps(const rgbid_tracker* h, float* depthinv, float* intensity) {
   if (!h) return RGBID_E_INVALID;
   h->t->downloadCurrentMaps(depthinv, intensity);

@@ -148,6 +148,14 @@ class Tracker:
     def load_calibration(self, path):
         check(lib().rgbid_tracker_load_calibration(self._h, path.encode()))
 
+    def scene_view(self):
+        """(rgb u8 [rows, cols, 3], intensity f32, keyframe inverse depth f32, changed) of the last tracked frame (preview on)"""
+        r, c = self.cfg.rows, self.cfg.cols
+        rgb = np.empty((r, c, 3), np.uint8); i = np.empty((r, c), np.float32); d = np.empty((r, c), np.float32)
+        ch = C.c_int()
+        check(lib().rgbid_tracker_scene_view(self._h, rgb.ctypes.data_as(C.c_void_p), _p(i), _p(d), C.byref(ch)))
+        return rgb, i, d, bool(ch.value)
+
     def current_maps(self):
         """level-0 (inverse depth, intensity) of the last prepared frame"""
         d = np.empty((self.cfg.rows, self.cfg.cols), np.float32); i = np.empty_like(d)

@@ -575,3 +575,31 @@ def test_engine_backed_mode_refuses_what_only_the_host_loop_offers():
     with pytest.raises(Exception):
         trk.set_engine_backed(True)            # only before the first frame
     trk.close()
+
+
+def test_tracker_preview_is_the_same_in_both_modes():
+    """What the application's viewer reads with the preview on (scene_view_ / intensity_view_ / depthinv_view_, getImage visodo.cpp:559-580, 2237-2241) through
+    rgbid_tracker_scene_view: the host-driven tracker shades with generateImageRGB, the engine-backed one takes the engine's preview -- the same kernel on the same
+    maps with the same light: bit-identical after every tracked frame of a sequence that switches its integration keyframe."""
+    n = 7
+    seq = synth.make_sequence(n, K=SMALL_K, rows=120, cols=160, device="cuda", trans_step=(0.01, 0.02), rot_step_deg=(0.5, 1.0))
+    d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+    kw = dict(rows=120, cols=160, fx=SMALL_K[0], fy=SMALL_K[1], cx=SMALL_K[2], cy=SMALL_K[3], visratio_integr=0.97, preview=1)
+    views = []
+    for eb in (False, True):
+        trk = host.Tracker(host.default_config(**kw), engine_backed=eb)
+        out = []
+        for k in range(n):
+            if trk.track(d[k], c[k]):
+                rgb, inten, dinv, changed = trk.scene_view()
+                assert changed
+                out.append((k, rgb, inten, dinv, bool(trk.last_info().integr_kf_switched)))
+        views.append(out)
+        trk.close()
+    a, b = views
+    assert len(a) == len(b) >= n - 2 and any(v[4] for v in a)
+    for va, vb in zip(a, b):
+        assert va[0] == vb[0] and va[4] == vb[4]
+        assert np.array_equal(va[1], vb[1]), va[0]
+        assert np.array_equal(va[2], vb[2], equal_nan=True) and np.array_equal(va[3], vb[3], equal_nan=True), va[0]
+    assert a[-1][1].any()                                            # something was shaded
