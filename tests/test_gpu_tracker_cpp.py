@@ -354,7 +354,8 @@ def test_cpp_objects_do_not_leak_device_memory():
     assert abs(free_bytes() - torch_free) < (8 << 20), (torch_free, free_bytes())
 
 
-def test_cpp_tracker_load_settings_and_calibration_files(tmp_path):
+@both_modes
+def test_cpp_tracker_load_settings_and_calibration_files(tmp_path, engine_backed):
     """VisodoTracker::loadSettings ([VISODO] keys of config_data/visodoRGBDconfig.ini) and loadCalibration ([CALIBRATION]) switch the
     tracker exactly like the equivalent constructor arguments: trajectory = oracle with that configuration."""
     (tmp_path / "visodo.ini").write_text("[VISODO]\nM_ESTIMATOR = Huber\nMOTION_MODEL = none\nWARP_ORDER = warpFirst\nIMAGE_FILTERING = gradients\n"
@@ -367,6 +368,8 @@ def test_cpp_tracker_load_settings_and_calibration_files(tmp_path):
     trk = host.Tracker(host.default_config(rows=120, cols=160))         # defaults, everything else comes from the two files
     trk.load_settings(str(tmp_path / "visodo.ini"))
     trk.load_calibration(str(tmp_path / "calib.ini"))
+    if engine_backed:
+        trk.set_engine_backed(True)        # after the files: the engine is created from what they set (Huber, no motion model, warp-first, filtered gradients, ...)
     orc = O.Tracker(O.default_config(rows=120, cols=160, fx=K[0], fy=K[1], cx=K[2], cy=K[3], factor_depth=0.96, mestimator=O.HUBER, motion_model=O.NO_MM,
                                      warping=O.WARP_FIRST, image_filtering=O.FILTER_GRADS, sigma_estimator=O.SIGMA_CONS, visratio_integr=0.93,
                                      visratio_odo=0.97, finest_level=1))
