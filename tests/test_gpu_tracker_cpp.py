@@ -325,8 +325,10 @@ def test_cpp_bridge_and_containers(tmp_path):
     assert r.returncode == 0 and "Error: " in r.stdout and "internal.h:" in r.stdout and "FAILED" not in r.stdout, r.stdout + r.stderr
 
 
-def test_cpp_objects_do_not_leak_device_memory():
-    """VisodoTracker and KeyframeAlign allocate dozens of ref-counted device arrays: 15 construct / use / destroy cycles return every byte"""
+@both_modes
+def test_cpp_objects_do_not_leak_device_memory(engine_backed):
+    """VisodoTracker (with its engine in the engine-backed mode) and KeyframeAlign allocate dozens of ref-counted device arrays: 15 construct / use / destroy
+    cycles return every byte"""
     import ctypes as C
     from rgbid import _lib
     L = _lib.lib()
@@ -342,7 +344,7 @@ def test_cpp_objects_do_not_leak_device_memory():
         return f.value
 
     def cycle():
-        trk = host.Tracker(host.default_config(**kw))
+        trk = host.Tracker(host.default_config(**kw), engine_backed=engine_backed)
         trk.track(d[0], c[0]); trk.track(d[1], c[1])
         trk.close()
         host.keyframe_align(iD[0], grey[0], iD[1], grey[1], synth.TUM_K)
