@@ -57,6 +57,7 @@ int rgbid_tracker_set_async_bridge(rgbid_tracker* t, int on);
  * only before the first frame or after reset().  RGBID_E_INVALID for what only the host-driven loop offers: CHI_SQUARED termination,
  * custom_registration = 1, a non-identity initial pose.  VisodoTracker::setEngineBacked. */
 int rgbid_tracker_set_engine_backed(rgbid_tracker* t, int on);
+int rgbid_tracker_reset(rgbid_tracker* t);                                     /* VisodoTracker::reset (src/visodo.cpp:519-553): the next frame is a first frame */
 int rgbid_tracker_load_settings(rgbid_tracker* t, const char* ini_path);      /* VisodoTracker::loadSettings */
 int rgbid_tracker_load_calibration(rgbid_tracker* t, const char* ini_path);   /* VisodoTracker::loadCalibration */
 /* uploads depth (u16 mm, rows x cols) and rgb (u8 r,g,b) from HOST memory and runs trackNewFrame */

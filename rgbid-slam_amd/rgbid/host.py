@@ -139,6 +139,9 @@ class Tracker:
         except Exception:
             pass
 
+    def reset(self):
+        check(lib().rgbid_tracker_reset(self._h))
+
     def load_settings(self, path):
         check(lib().rgbid_tracker_load_settings(self._h, path.encode()))
 

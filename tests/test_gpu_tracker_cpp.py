@@ -608,3 +608,23 @@ def test_tracker_preview_is_the_same_in_both_modes():
         assert np.array_equal(va[1], vb[1]), va[0]
         assert np.array_equal(va[2], vb[2], equal_nan=True) and np.array_equal(va[3], vb[3], equal_nan=True), va[0]
     assert a[-1][1].any()                                            # something was shaded
+
+
+@both_modes
+def test_tracker_reset_starts_over(engine_backed):
+    """VisodoTracker::reset (src/visodo.cpp:519-553): the next frame is a first frame again -- the same frames tracked after a reset give the same poses, bit for
+    bit, as the first pass (in the engine-backed mode the one-lane engine starts over with it)"""
+    n = 5
+    seq = synth.make_sequence(n, K=SMALL_K, rows=120, cols=160, device="cuda", trans_step=(0.01, 0.02), rot_step_deg=(0.5, 1.0))
+    d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+    kw = dict(rows=120, cols=160, fx=SMALL_K[0], fy=SMALL_K[1], cx=SMALL_K[2], cy=SMALL_K[3])
+    trk = host.Tracker(host.default_config(**kw), engine_backed=engine_backed)
+    passes = []
+    for rep in range(2):
+        rets = [trk.track(d[k], c[k]) for k in range(n)]
+        R, t = trk.poses()
+        passes.append((rets, R.copy(), t.copy()))
+        trk.reset()
+    assert passes[0][0] == passes[1][0] and passes[0][0][0] is False and all(passes[0][0][1:])
+    assert np.array_equal(passes[0][1], passes[1][1]) and np.array_equal(passes[0][2], passes[1][2])
+    trk.close()
