@@ -251,6 +251,7 @@ class VisodoTracker {
   int interp_mode_ = RGBID_INTERP_TEX8;
   bool engine_backed_ = false;
   ::rgbid_engine* engine_ = nullptr;
+  ::rgbid_ctx* engine_ctx_ = nullptr;   // the engine's own context (stream): it must outlive the engine, and the per-thread default context ends with its thread
   LastFrameInfo last_info_;
   TrackerSink null_sink_;
 };

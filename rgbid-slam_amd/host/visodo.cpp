@@ -76,6 +76,7 @@ VisodoTracker::VisodoTracker(int optim_dim, int Mestimator, int motion_model, in
 
 VisodoTracker::~VisodoTracker() {
   if (engine_) { rgbid_engine_destroy(engine_); engine_ = nullptr; }
+  if (engine_ctx_) { rgbid_ctx_destroy(engine_ctx_); engine_ctx_ = nullptr; }
   if (visodo_thread_ && visodo_thread_->joinable()) {
     { std::unique_lock<std::mutex> lock(mutex_); exit_ = true; }
     new_frame_cond_.notify_one();
@@ -690,6 +691,8 @@ bool VisodoTracker::setEngineBacked(bool on) {
 
 bool VisodoTracker::createEngine() {
   if (engine_) { rgbid_engine_destroy(engine_); engine_ = nullptr; }
+  // a context of the tracker's own: the per-thread default context (containers.hpp) is destroyed when its thread ends, which may be before this object
+  if (!engine_ctx_ && rgbid_ctx_create(&engine_ctx_, pcl::gpu::current_device().load(), nullptr) != RGBID_OK) return false;
   if (rgbid_engine_config_size() != sizeof(rgbid_engine_config)) {   // librgbid_hip.so built from another revision of rgbid_engine.h
     std::cerr << "VisodoTracker: librgbid_hip.so and librgbid_host.so disagree on rgbid_engine_config (" << rgbid_engine_config_size() << " vs " << sizeof(rgbid_engine_config)
               << " bytes): rebuild both" << std::endl;
@@ -714,16 +717,16 @@ bool VisodoTracker::createEngine() {
   c.record_capacity = 2;
   c.warping = warping_ == device::WARP_FIRST ? RGBID_WARP_FIRST : RGBID_PYR_FIRST;
   c.keyframe_capacity = 2;    // what resetIntegrationKeyframe hands to the back-end is read out right after the step that exported it
-  return rgbid_engine_create(&engine_, default_ctx(), &c) == RGBID_OK;
+  return rgbid_engine_create(&engine_, engine_ctx_, &c) == RGBID_OK;
 }
 
 void VisodoTracker::downloadKeyframeMaps(float* depthinv_host, float* weight_host) const {
   if (engine_backed_ && engine_) {
     rgbid_img d, w;
     rgbidSafeCall(rgbid_engine_keyframe_maps(engine_, 0, &d, &w, nullptr, nullptr, nullptr));
-    rgbidSafeCall(rgbid_ctx_sync(default_ctx()));
-    if (depthinv_host) rgbidSafeCall(rgbid_memcpy2d_d2h(default_ctx(), depthinv_host, (size_t)cols_ * 4, d.data, d.step, (size_t)cols_ * 4, rows_));
-    if (weight_host) rgbidSafeCall(rgbid_memcpy2d_d2h(default_ctx(), weight_host, (size_t)cols_ * 4, w.data, w.step, (size_t)cols_ * 4, rows_));
+    rgbidSafeCall(rgbid_ctx_sync(engine_ctx_));
+    if (depthinv_host) rgbidSafeCall(rgbid_memcpy2d_d2h(engine_ctx_, depthinv_host, (size_t)cols_ * 4, d.data, d.step, (size_t)cols_ * 4, rows_));
+    if (weight_host) rgbidSafeCall(rgbid_memcpy2d_d2h(engine_ctx_, weight_host, (size_t)cols_ * 4, w.data, w.step, (size_t)cols_ * 4, rows_));
     return;
   }
   if (depthinv_host) depthinv_integrKF_.download(depthinv_host, (size_t)cols_ * 4);
@@ -734,9 +737,9 @@ void VisodoTracker::downloadCurrentMaps(float* depthinv_host, float* intensity_h
   if (engine_backed_ && engine_) {
     rgbid_img d, i;
     rgbidSafeCall(rgbid_engine_current_maps(engine_, 0, &d, &i));
-    rgbidSafeCall(rgbid_ctx_sync(default_ctx()));
-    if (depthinv_host) rgbidSafeCall(rgbid_memcpy2d_d2h(default_ctx(), depthinv_host, (size_t)cols_ * 4, d.data, d.step, (size_t)cols_ * 4, rows_));
-    if (intensity_host) rgbidSafeCall(rgbid_memcpy2d_d2h(default_ctx(), intensity_host, (size_t)cols_ * 4, i.data, i.step, (size_t)cols_ * 4, rows_));
+    rgbidSafeCall(rgbid_ctx_sync(engine_ctx_));
+    if (depthinv_host) rgbidSafeCall(rgbid_memcpy2d_d2h(engine_ctx_, depthinv_host, (size_t)cols_ * 4, d.data, d.step, (size_t)cols_ * 4, rows_));
+    if (intensity_host) rgbidSafeCall(rgbid_memcpy2d_d2h(engine_ctx_, intensity_host, (size_t)cols_ * 4, i.data, i.step, (size_t)cols_ * 4, rows_));
     return;
   }
   if (depthinv_host) depthinvs_curr_[0].download(depthinv_host, (size_t)cols_ * 4);
@@ -864,7 +867,7 @@ bool VisodoTracker::trackNewFrameEngine() {
     rgbid_img pv;
     scene_view_.resize((size_t)rows_ * cols_); intensity_view_.resize((size_t)rows_ * cols_); depthinv_view_.resize((size_t)rows_ * cols_);
     rgbidSafeCall(rgbid_engine_preview(engine_, 0, &pv, nullptr));
-    rgbidSafeCall(rgbid_memcpy2d_d2h(default_ctx(), scene_view_.data(), (size_t)cols_ * 3, pv.data, pv.step, (size_t)cols_ * 3, rows_));
+    rgbidSafeCall(rgbid_memcpy2d_d2h(engine_ctx_, scene_view_.data(), (size_t)cols_ * 3, pv.data, pv.step, (size_t)cols_ * 3, rows_));
     downloadCurrentMaps(nullptr, intensity_view_.data());     // getImage :559-580: the current intensity next to the keyframe's inverse depth
     downloadKeyframeMaps(depthinv_view_.data(), nullptr);
     scene_view_has_changed_ = true;

@@ -628,3 +628,35 @@ def test_tracker_reset_starts_over(engine_backed):
     assert passes[0][0] == passes[1][0] and passes[0][0][0] is False and all(passes[0][0][1:])
     assert np.array_equal(passes[0][1], passes[1][1]) and np.array_equal(passes[0][2], passes[1][2])
     trk.close()
+
+
+def test_engine_backed_tracker_outlives_the_thread_that_fed_it():
+    """The reference runs trackNewFrame on a thread of its own and destroys the tracker from the main thread afterwards.  The engine of the engine-backed mode
+    therefore lives on a context the TRACKER owns (the per-thread default context of containers.hpp ends with its thread): frames tracked on a worker thread,
+    results read and the tracker destroyed on the main thread after the worker has exited."""
+    import threading
+    n = 5
+    seq = synth.make_sequence(n, K=SMALL_K, rows=120, cols=160, device="cuda", **SLOW)
+    d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+    kw = dict(rows=120, cols=160, fx=SMALL_K[0], fy=SMALL_K[1], cx=SMALL_K[2], cy=SMALL_K[3])
+    ref = host.Tracker(host.default_config(**kw), engine_backed=True)
+    for k in range(n):
+        ref.track(d[k], c[k])
+    Rr, tr = ref.poses(); kdr, kwr = ref.keyframe_maps()
+    ref.close()
+    trk = host.Tracker(host.default_config(**kw), engine_backed=True)
+    errs = []
+
+    def work():
+        try:
+            for k in range(n):
+                trk.track(d[k], c[k])
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = threading.Thread(target=work); th.start(); th.join()
+    assert not errs, errs
+    R, t = trk.poses(); kd, kw_ = trk.keyframe_maps()          # main thread, after the worker (and its thread-local context) are gone
+    assert np.array_equal(R, Rr) and np.array_equal(t, tr) and np.array_equal(kd, kdr, equal_nan=True) and np.array_equal(kw_, kwr, equal_nan=True)
+    trk.track(d[n - 1], c[n - 1])                              # and it keeps tracking from here
+    trk.close()
