@@ -111,3 +111,50 @@ def test_guard_refuses_motions_outside_the_sign_analysis():
     assert wild["zsafe"] == 0 and np.isinf(wild["d1"]) and np.isinf(wild["db"])
     nan = device.fast_guard([float("nan")] * 9, [0, 0, 0], 640, 480)
     assert nan["zsafe"] == 0 and np.isinf(nan["d1"])
+
+
+@pytest.mark.parametrize("rows,cols", [(480, 640), (120, 160)])
+def test_value_bands_of_the_gates_cover_the_measured_distance(rows, cols):
+    """guard_band.h (5): the relative distance between the oracle's and the FAST class's (a) inverse depth of the point in the other frame (covisibility gate
+    |w' - D| < 0.020) and (b) warped inverse depth (fusion gate), against the bands eps_w = |rcp(Y_2)| g1 + g0 and eps_res = e0 + e1 |rcp(1 - w2 t_z)| the
+    kernels use to decide whether a gate is open.  Same emulation as above."""
+    rng = util.rng(78)
+    s = cols / 640.0
+    K = (525.0 * s, 525.0 * s, 319.5 * s, 239.5 * s)
+    worst_w, worst_r, total = 0.0, 0.0, 0
+    for trial in range(16):
+        trans, rot = [(0.03, 1.5), (0.3, 10.0), (0.005, 0.2), (0.1, 4.0)][trial % 4]
+        Rm, tv = util.small_motion(rng, K, trans, rot)
+        Rp, tp = util.project(K, *util.inv_pose(Rm, tv))
+        g = device.fast_guard(Rp, tp, cols, rows)
+        if not g["zsafe"]:
+            continue
+        n = 200_000
+        x = rng.integers(0, cols, n).astype(f32); y = rng.integers(0, rows, n).astype(f32)
+        w = rng.uniform(0.1, 4.0, n).astype(f32)
+        w2 = rng.uniform(0.1, 4.0, n).astype(f32)                   # the sampled inverse depth of the other frame
+        R = np.asarray(Rp, f32).reshape(-1); t = np.asarray(tp, f32)
+        with np.errstate(all="ignore"):
+            # oracle: register_pixel returns wc = fl(1 / X_2); v = fl(fl(1 / wc) - t_z) * w; res = fl(fl(v / fl(1 - fl(w2 t_z))) * w2)
+            _, _, wc_o = oracle_xs(x, y, w, R, t)
+            v = ((f32(1) / wc_o) - t[2]) * w
+            res_o = (v / (f32(1) - w2 * t[2])) * w2
+            # FAST: w' = ws * rcp(Y_2); res = (q_2 * rcp(1 - w2 t_z)) * w2 with the FMA inside the reciprocal's argument
+            q2 = fma(np.full_like(x, R[6]), x, fma(np.full_like(y, R[7]), y, np.full_like(y, R[8])))
+            Y2 = fma(np.full_like(w, t[2]), w, q2)
+            ry = f32(1) / Y2
+            ry = (ry + rng.integers(-1, 2, n).astype(f32) * np.spacing(np.abs(ry)).astype(f32)).astype(f32)
+            wc_f = w * ry
+            wf = fma(-w2, np.full_like(w2, t[2]), np.full_like(w2, 1.0))
+            rwf = f32(1) / wf
+            rwf = (rwf + rng.integers(-1, 2, n).astype(f32) * np.spacing(np.abs(rwf)).astype(f32)).astype(f32)
+            res_f = (q2 * rwf) * w2
+            ok = np.isfinite(res_o) & np.isfinite(res_f) & (np.abs(rwf) <= 2.0 ** 19) & (np.abs(ry) <= 2.0 ** 9) & (res_o > 0)
+            eps_w = np.abs(ry) * f32(g["g1"]) + f32(g["g0"])
+            eps_r = f32(g["e0"]) + f32(g["e1"]) * np.abs(rwf)
+            rw = (np.abs(wc_f - wc_o) / np.abs(wc_o))[ok] / eps_w[ok]
+            rr = (np.abs(res_f - res_o) / np.abs(res_o))[ok] / eps_r[ok]
+        worst_w = max(worst_w, float(rw.max())); worst_r = max(worst_r, float(rr.max())); total += int(ok.sum())
+    assert total > 1_000_000
+    assert worst_w < 1.0 and worst_r < 1.0, (worst_w, worst_r)
+    print(f"{cols}x{rows}: worst measured / bound: inverse depth in the other frame {worst_w:.3f}, warped inverse depth {worst_r:.3f}")
