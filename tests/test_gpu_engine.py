@@ -28,7 +28,7 @@ def make_lanes(n_lanes, n_frames, rows, cols, K, **kw):
     return seqs, depth, rgb
 
 
-def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, map_outliers=5e-3, sigma_tol=1e-3):
+def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, map_outliers=5e-3, sigma_tol=1e-3, pose_tol=1e-4):
     seqs, depth, rgb = make_lanes(n_lanes, n_frames, rows, cols, K, **seq_kw)
     eng = E.Engine(ctx, E.default_config(rows=rows, cols=cols, lanes=n_lanes, K=K, use_graph=use_graph, record_capacity=n_frames, **cfg_kw))
     for k in range(n_frames):
@@ -93,8 +93,8 @@ def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, m
         for k in range(1, n_frames):
             er, et = rot_angle(Rs[k], rec[k, l]["R"]), float(np.linalg.norm(ts[k] - rec[k, l]["t"]))
             worst_r, worst_t = max(worst_r, er), max(worst_t, et)
-            assert er < 1e-4 and et < 1e-4, (l, k, er, et)
-            assert rot_angle(oR[k], rec[k, l]["odo_R"]) < 1e-4 and np.linalg.norm(ot[k] - rec[k, l]["odo_t"]) < 1e-4
+            assert er < pose_tol and et < pose_tol, (l, k, er, et)
+            assert rot_angle(oR[k], rec[k, l]["odo_R"]) < pose_tol and np.linalg.norm(ot[k] - rec[k, l]["odo_t"]) < pose_tol
             sc = np.sqrt(np.outer(np.diag(ocov[k]), np.diag(ocov[k]))) + 1e-30
             assert (np.abs(ocov[k] - rec[k, l]["odo_cov"]) / sc).max() < 1e-2, (l, k)
         # fused keyframe maps of the lane vs the oracle tracker's
