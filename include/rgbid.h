@@ -125,6 +125,10 @@ int rgbid_selftest_fast_primitives(rgbid_ctx* ctx, unsigned long long* mismatche
  * out[0..9] = d1, c2, d2, q0, q1, db, g0, g1, e0, e1; *zsafe = the per-lane verdict of the sign analysis.  For tests and for hosts that want
  * to know in advance whether a transform runs in the guard band's regular regime. */
 int rgbid_fast_guard(const float R_proj[9], const float t_proj[3], int cols, int rows, float out[10], int* zsafe);
+/* the lane-constant forms the kernels run since round 5 (guard_band.h (3'), (3'')): out[0..3] = bL, cL, kL, wcore -- the point sample is taken at
+ * floor(xs'), xs' = Y_0 wc + bL, and is the oracle's whenever max3(fract(xs'), fract(ys'), |wc| kL) < cL; a bilinear sample whose coordinate lies in
+ * [0, cols - 1] x [0, rows - 1] with |wc| <= wcore is inside the image for the oracle too.  cL = -1: every pixel of the lane takes the exact path. */
+int rgbid_fast_guard_lane(const float R_proj[9], const float t_proj[3], int cols, int rows, float out[4]);
 /* the context's hipStream_t */
 int rgbid_ctx_get_stream(rgbid_ctx* ctx, void** hip_stream);
 /* showGPUMemoryUsage(), src/cuda/misc.cu:526-540 */

@@ -220,6 +220,12 @@ int rgbid_fast_guard(const float R_proj[9], const float t_proj[3], int cols, int
   if (zsafe) *zsafe = g.zsafe;
   return RGBID_OK;
 }
+int rgbid_fast_guard_lane(const float R_proj[9], const float t_proj[3], int cols, int rows, float out[4]) {
+  if (!R_proj || !t_proj || !out || cols < 1 || rows < 1) return RGBID_E_INVALID;
+  const rgbid::fastnum::Guard g = rgbid::fastnum::make_guard(R_proj, t_proj, cols, rows);
+  out[0] = g.bL; out[1] = g.cL; out[2] = g.kL; out[3] = g.wcore;
+  return RGBID_OK;
+}
 int rgbid_ctx_wait_event(rgbid_ctx* c, void* ev) {
   if (!c || !ev) return RGBID_E_INVALID;
   RGBID_HIP(hipStreamWaitEvent(c->stream, (hipEvent_t)ev, 0));

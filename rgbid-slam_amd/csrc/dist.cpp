@@ -95,11 +95,17 @@ void set_io_timeout(int fd, int seconds) {
 }
 // exchanges entered so far, per (port, rank): every rank calls the same sequence of exchanges on a port, so the counters agree across the ranks of
 // a job whether they are processes (the product) or threads of one test process
+std::mutex g_seq_mu;
+std::map<std::pair<int, int>, uint32_t> g_seq;
 uint32_t next_exchange_seq(int port, int rank) {
-  static std::mutex mu;
-  static std::map<std::pair<int, int>, uint32_t> seq;
-  std::lock_guard<std::mutex> lock(mu);
-  return seq[std::make_pair(port, rank)]++;
+  std::lock_guard<std::mutex> lock(g_seq_mu);
+  return g_seq[std::make_pair(port, rank)]++;
+}
+// a new job on this port starts counting at 0 again: a rank whose process was restarted, or a job that reuses the port of an earlier one while rank 0's
+// process lived on, would otherwise be refused (NAK) until the timeout.  Called at the top of rgbid_dist_track_sequence -- the same logical point on every rank.
+void reset_exchange_seq(int port, int rank) {
+  std::lock_guard<std::mutex> lock(g_seq_mu);
+  g_seq[std::make_pair(port, rank)] = 0;
 }
 
 // rank 0: blob -> every rank (gather == false), or every rank's n bytes -> all[world][n] on every rank (gather == true)
@@ -110,9 +116,9 @@ int tcp_exchange(const char* addr, int port, int world, int rank, void* blob, si
   if (rank == 0) hints.ai_flags = AI_PASSIVE;
   addrinfo* res = nullptr;
   const std::string ports = std::to_string(port);
+  const uint32_t seq = next_exchange_seq(port, rank), kind = gather ? 1u : 0u;   // counted before anything can fail: the ranks' counters stay in step
   if (getaddrinfo(addr, ports.c_str(), &hints, &res) != 0 || !res) return RGBID_E_NET;
   const uint64_t nonce = job_nonce();
-  const uint32_t seq = next_exchange_seq(port, rank), kind = gather ? 1u : 0u;
   const auto deadline = Clock::now() + std::chrono::seconds(timeout_s());
   int rc = RGBID_E_NET;
   if (rank == 0) {
@@ -133,7 +139,7 @@ int tcp_exchange(const char* addr, int port, int world, int rank, void* blob, si
     std::vector<int> fds(world, -1);        // gather: connections stay open until every rank's block has arrived
     std::vector<char> served(world, 0);
     if (gather) memcpy(all, blob, n);
-    int n_served = 0;
+    int n_served = 0, n_naks = 0;
     rc = RGBID_OK;
     while (n_served < world - 1) {
       pollfd pf{ls, POLLIN, 0};
@@ -149,6 +155,9 @@ int tcp_exchange(const char* addr, int port, int world, int rank, void* blob, si
       if (!recv_all(fd, &h, sizeof(h)) || h.magic != HELLO_MAGIC || h.nonce != nonce) { ::close(fd); continue; }   // not one of ours: no answer
       const bool mine = h.rank > 0 && h.rank < world && h.kind == kind && h.seq == seq && h.bytes == (uint64_t)n && !served[h.rank];
       const unsigned char answer = mine ? ACK : NAK;   // NAK: one of ours, but for another exchange (or served already): it will come back
+      if (!mine && n_naks++ < 3)   // a desynchronised exchange counter must be visible, not a silent spin until the timeout
+        fprintf(stderr, "rgbid_dist: rank 0 serves exchange (kind %u, seq %u, %zu bytes) on port %d and refused rank %d's hello (kind %u, seq %u, %llu bytes%s)\n", kind, seq, n, port,
+                (int)h.rank, h.kind, h.seq, (unsigned long long)h.bytes, (h.rank > 0 && h.rank < world && served[h.rank]) ? ", served already" : "");
       if (!send_all(fd, &answer, 1) || !mine) { ::close(fd); continue; }
       set_io_timeout(fd, timeout_s());
       bool ok;
@@ -404,6 +413,7 @@ int rgbid_dist_track_sequence(rgbid_ctx* ctx, const rgbid_seq_config* cfg, const
   if (!inject && (!ctx || !depth_host || !rgb_host)) return RGBID_E_INVALID;
   if (inject && cfg->world > 1 && cfg->exchange != RGBID_EXCHANGE_TCP) return RGBID_E_INVALID;   // no GPU side: nothing for RCCL to gather from
   if (cfg->world > 1 && (!cfg->master_addr || cfg->master_port <= 0)) return RGBID_E_INVALID;
+  if (cfg->world > 1) reset_exchange_seq(cfg->master_port, cfg->rank);   // a job's exchanges count from 0 (counters of a restarted rank / a reused port)
   const int world = cfg->world, rank = cfg->rank, n_chunks = cfg->n_chunks;
   const auto t_setup = Clock::now();
   std::vector<int> first(n_chunks), last(n_chunks);

@@ -856,7 +856,7 @@ int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_c
   if (cfg->rows <= 0 || cfg->cols <= 0 || cfg->levels < 1 || cfg->levels > MAXL || cfg->lanes < 1 || cfg->finest_level < 0 ||
       cfg->finest_level >= cfg->levels || (cfg->rows >> (cfg->levels - 1)) < 4 || (cfg->cols >> (cfg->levels - 1)) < 4 ||
       cfg->record_capacity < 1 || (cfg->warping != RGBID_PYR_FIRST && cfg->warping != RGBID_WARP_FIRST) ||
-      cfg->keyframe_capacity < 0 ||
+      cfg->keyframe_capacity < 0 || !(cfg->delta_t > 0.f) || !(cfg->delta_t < INFINITY) ||
       cfg->cols > (1 << 20) || (unsigned long long)cfg->rows * 3ull * (((unsigned long long)cfg->cols * 4 + 255) & ~255ull) >= (1ull << 32))  // 24-bit row-offset arithmetic (common.h row_ptr)
     return RGBID_E_INVALID;
   rgbid_engine* e = new (std::nothrow) rgbid_engine();
@@ -981,7 +981,7 @@ int rgbid_engine_step(rgbid_engine* e, const void* depth_dev, const void* rgb_de
 }
 
 int rgbid_engine_set_delta_t(rgbid_engine* e, float delta_t) {
-  if (!e || !(delta_t == delta_t)) return RGBID_E_INVALID;
+  if (!e || !(delta_t > 0.f) || !(delta_t < INFINITY)) return RGBID_E_INVALID;   // 1 / delta_t scales the velocity of the constant-velocity prediction: 0, negative, inf or NaN would lose the lane
   hipSetDevice(e->ctx->device);
   // the kernels read the value through a device pointer (StepCfg::delta_t): captured graphs stay valid; ordered on the context's stream
   if (hipError_t he = hipMemsetD32Async((hipDeviceptr_t)e->delta_t_dev, __builtin_bit_cast(int, delta_t), 1, e->ctx->stream); he != hipSuccess) return (int)he;

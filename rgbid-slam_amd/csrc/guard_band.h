@@ -35,6 +35,23 @@
 //         d1 = u' (max(M_0, M_1) + 3 max(Q_0, Q_1) + Xb (M_2 + 3 Q_2)),      d2 = u' (10 Xb + 2),       delta = |wc| d1 (1 + 2^-8) + d2
 //     |xs_fast - xs_oracle| <= delta (the factor 1 + 2^-8 covers |wc| against rho).  floor() of the two agrees when no integer lies within
 //     delta of xs_fast:  | frac(xs) - 1/2 | <= 1/2 - delta;  rint() agrees when | frac(xd) - 1/2 | >= delta.
+// (3') GUARD AS A LANE CONSTANT (round 5: the form the kernels run).  (3) costs two v_fract, two subtractions, a max, an FMA and a compare per
+//     projection.  The same verdict for 2 v_fract + 3: fix WCM = 2 (the largest |wc| the lane-constant band is priced for: Y_2 = q_2 + w t_z is 1 +- 0.3 on
+//     indoor data) and dL >= WCM d1 + d2, bias the FAST coordinate DOWN by it -- xs' = fl(Y_0 wc + bL), bL = fl(0.5 - dL), dLa := 0.5 - bL (exact: bL in
+//     [1/4, 1/2]) -- and take the source pixel from floor(xs').  (F) holds for xs' against x* + bL unchanged (the addend is smaller), so for |wc| <= WCM
+//         xs' <= xs_oracle - (dLa - delta) ... xs_oracle <= xs' + dLa + delta,       i.e.   xs_oracle in [xs', xs' + 2 dLa],
+//     and floor(xs_oracle) = floor(xs') whenever xs' - floor(xs') < 1 - 2 dLa.  v_fract_f32(x) = min(fl(x - floor x), 1 - 2^-24) is exact except for x in
+//     (-1, 0), where 1 + x may round by 2^-25 -- and is never above 1 - 2^-24.  With cL = 1 - 2 dLa - 2^-22 and kL >= cL / WCM (1 + 2^-21):
+//         safe  <=>  max3( fract(xs'), fract(ys'), |wc| kL ) < cL          (one multiply, one v_max3_f32, one compare)
+//     implies |wc| <= WCM (so delta <= dLa, and rho <= 2^9 as (3) requires) and both floor() agreements; anything non-finite fails it (|wc| = inf gives inf;
+//     a lane that is not `sane` / not `zsafe` gets cL = -1: never safe).  Pixels with |wc| > WCM -- points closer than half their keyframe depth along the
+//     optical axis -- take the exact path: correct, slower.  Price: the band is 2 dLa wide for every pixel instead of 2 delta(wc): at 640 x 480, |wc| ~ 1,
+//     2 (2 d1 + d2) = 3.2e-3 instead of 2.0e-3 px per axis, i.e. 6.4e-3 instead of 4.0e-3 of the pixels are recomputed.
+// (3'') INSIDE PREDICATE OF THE BILINEAR WARP (:486-487: 0 <= floor(xB + 0.5) < cols).  A FAST coordinate with 0 <= xB <= cols - 1 has the oracle's
+//     xB within delta(wc) of it, hence strictly inside (-0.5, cols - 0.5), whenever delta(wc) <= 1/4: |wc| <= WCORE := (1/4 - d2) / d1.  The hot path takes
+//     "inside" from  xB == med3(xB, 0, hx) (the clamp its tap addresses need anyway), the same in y, and |wc| <= WCORE; every other pixel of the domain -- the half-pixel
+//     ring around the image, projections outside it, |wc| > WCORE -- is classified in the cold path: farther than db inside, farther than db outside
+//     (both at |wc| <= RHO_BORDER), or by the oracle's own coordinates.
 // (4) SIGN of the warped inverse depth res = v / (1 - w2 t_z) * w2, v = (1/w3 - t_z) w  (oracle) = q_2 (FAST; (X_2 - t_z) w = q_2 exactly):
 //     the oracle's 1/w3 - t_z = q_2* Z + e, |e| <= u' (Z M_2 + |t_2|) + 2 u |X_2| (+ the rounding of the difference, relative): it has the sign of
 //     q_2* with at least half its magnitude when |q_2*| >= 2 u' (M_2 + Q_2 + 3 |Y_2*|); FAST's q_2 needs |q_2*| > 2 u Q_2.  Required by the guard:
@@ -78,7 +95,14 @@ struct Guard {
   float db;         // intensity warp, in-image predicate: band around the image border at |wc| <= RHO_BORDER
   float g0, g1;     // gates: eps_w = |wc| g1 + g0 (relative distance of the inverse depth in the other frame)
   float e0, e1;     //        eps_res = e0 + e1 |rcp(1 - w2 t_z)| (relative distance of the warped inverse depth)
+  float bL, cL, kL; // (3'): xs' = Y_0 wc + bL;  safe  <=>  max3(fract(xs'), fract(ys'), |wc| kL) < cL
+  float gL;         // gate band of the covisibility check, lane constant: eps_w = |1 / Y_2| g1 + g0 <= gL for every pixel whose gate is taken from the fast w'
+  float wcore;      // (3''): a projection with 0 <= xB <= cols - 1, 0 <= yB <= rows - 1 and |wc| <= wcore has the oracle's inside verdict
 };
+#ifndef RGBID_WCM
+#define RGBID_WCM 2.f
+#endif
+constexpr float WCM = RGBID_WCM;   // (3')
 
 RGBID_GB_HD inline Guard make_guard(const float R[9], const float t[3], int cols, int rows) {
   const float u1 = 0x1p-24f * (1.f + 0x1p-10f);
@@ -114,6 +138,19 @@ RGBID_GB_HD inline Guard make_guard(const float R[9], const float t[3], int cols
   g.e0 = g.zsafe ? u1 * ((M2 + 7.f * Q2 + 3.f * (Q2 + W_HI * fabsf(t[2]))) / qmin + 12.f) : INFINITY;
   if (!sane || !g.zsafe) { g.d1 = INFINITY; g.db = INFINITY; }
   if (!sane) { g.q0 = INFINITY; g.g1 = INFINITY; }
+  // (3') / (3''): the lane-constant forms
+  const float dL = WCM * g.d1 + g.d2 + 0x1p-24f;
+  if (dL < 0.125f) {                                   // also false for inf / NaN
+    g.bL = 0.5f - dL;
+    const float dLa = 0.5f - g.bL;                     // exact
+    g.cL = 1.f - 2.f * dLa - 0x1p-22f;
+    g.kL = (g.cL / WCM) * (1.f + 0x1p-20f);
+    g.wcore = fminf((0.25f - g.d2) / g.d1 * (1.f - 0x1p-20f), 0x1p9f);
+    // the covisibility gate is taken from the fast w' only for pixels with |1 / Y_2| d1 + d2 < 1/2 (vis_project)
+    g.gL = (0.5f / g.d1) * g.g1 + g.g0;
+  } else {                                             // every pixel of the lane is recomputed the oracle's way
+    g.bL = 0.5f; g.cL = -1.f; g.kL = 1.f; g.wcore = 0.f; g.gL = INFINITY;
+  }
   return g;
 }
 

@@ -151,7 +151,6 @@ __global__ __launch_bounds__(256) void k_warp_pair_fast(ImgB src_iD, ImgB src_I,
   // the ray of a pixel is a function of the pixel alone (warp_device.h ray_at), so this kernel, the fused normal-equation kernel and the
   // sigma / nu lattice agree bit for bit
   const fastnum::Guard GB = fastnum::lane_guard(P, dst_iD.cols, dst_iD.rows);
-  const fastnum::BorderBand BB = fastnum::border_band(GB, SI.cols, SI.rows);
   // phases over the thread's RPB pixels (a branch between a gather and its use would serialise their chains): projections (+ the oracle's
   // coordinates inside the guard band) -> point-sample gathers -> warped inverse depths -> tap loads (+ the oracle's in-image predicate) -> blends
   fastnum::Ray q[RPB];
@@ -178,7 +177,7 @@ __global__ __launch_bounds__(256) void k_warp_pair_fast(ImgB src_iD, ImgB src_I,
 #pragma unroll
   for (int i = 0; i < RPB; ++i) {
     bool bd;
-    tp[i] = fastnum::intensity_taps(SI, q[i], w1[i], P, BB, interp_mode, bd);
+    tp[i] = fastnum::intensity_taps(SI, q[i], w1[i], P, GB, interp_mode, bd);
     if (__builtin_expect(bd, 0)) tp[i].ok = fastnum::intensity_fix_border(SI, q[i], x, yb + i * TY, w1[i], P, GB);
   }
 #pragma unroll

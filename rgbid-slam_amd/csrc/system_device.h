@@ -9,7 +9,10 @@
 namespace rgbid {
 
 static constexpr int SYS_T = 256;
-static constexpr int FUSED_WAVES = 4;   // waves per SIMD the fused fast kernel's register allocation must allow (<= 128 VGPRs; a 96-VGPR schedule spills 25 registers)
+#ifndef RGBID_FUSED_WAVES
+#define RGBID_FUSED_WAVES 4
+#endif
+static constexpr int FUSED_WAVES = RGBID_FUSED_WAVES;   // waves per SIMD the fused fast kernel's register allocation must allow (<= 128 VGPRs; a 96-VGPR schedule spills 25 registers)
 // a scheduling fence between the four pixels of a unit: each pixel's tap loads are waited for where its rows are built, not all at the top
 #define RGBID_SYS_PIXEL_FENCE __builtin_amdgcn_sched_barrier(0)
 
@@ -89,6 +92,69 @@ __device__ __forceinline__ void accumulate_pixel(float acc[SYS_TERMS], float px_
   float eiu = fmaf(ei, C.inv_si, -C.be_i);
   float wi;
   if (minw) {  // MIN_WEIGHT (:403-406): the minimum is taken on the true weights
+    wi = snu ? C.nui1 * __builtin_amdgcn_rcpf(fmaf(eiu, eiu, P.nu_i)) : m_weight(eiu, mest);
+    wi = vi ? wi * C.wmul_i : 0.f;
+    wi = fminf(wd, wi) * C.rho2;
+  } else {
+    wi = snu ? C.nui1_s * __builtin_amdgcn_rcpf(fmaf(eiu, eiu, P.nu_i)) : m_weight(eiu, mest) * C.wmul_i_s;
+    wi = vi ? wi : 0.f;
+  }
+  float sd = nfac * wd;
+  int s = 0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    float a = wi * Ji[r], d = sd * Jd[r];
+#pragma unroll
+    for (int c = r; c < 6; ++c) { acc[s] = fmaf(a, Ji[c], acc[s]); acc[s] = fmaf(d, Jd[c], acc[s]); ++s; }
+    acc[s] = fmaf(a, ei, acc[s]); acc[s] = fmaf(d, ed, acc[s]); ++s;
+  }
+}
+
+// The same pixel for the fused fast kernel, whose warps hand over validity as MASKS instead of NaN values: w0s = the keyframe inverse depth sanitised to the
+// FAST domain (finite, positive: fastnum::sanitised), w1 finite, okd = the warped inverse depth is valid (implies a valid w0), oki = the warped intensity is
+// valid (implies okd).  Saves the w0 / w1 / i1 NaN tests and four selects per pixel; the sums are the same bit for bit (an invalid row has weight 0 either way).
+template <int WM>
+__device__ __forceinline__ void accumulate_pixel_m(float acc[SYS_TERMS], float px_, float py_, float pp_y, float w0, float i0, float gwx, float gwy,
+                                                   float gix, float giy, float w1, float i1, bool okd, bool oki, const SysParams& P, const SysConst& C) {
+  const bool snu = WM == 1 ? true : WM == 2 ? false : (P.student_nu != 0);
+  const bool minw = WM != 0 ? false : (P.weighting == 1);
+  const int mest = WM == 2 ? 3 : P.mestimator;
+  const bool vd = okd && !(isnan(gwx) || isnan(gwy));
+  const bool vi = oki && !(isnan(i0) || isnan(gix) || isnan(giy));
+  gwx = vd ? gwx : 0.f; gwy = vd ? gwy : 0.f;
+  gix = vi ? gix : 0.f; giy = vi ? giy : 0.f;
+  // ---- inverse-depth row (times sigma_d)
+  float gx = gwx * P.fx, gy = gwy * P.fy;
+  float gz = -fmaf(gx, px_, gy * py_);
+  float gz0 = gz + w0, gz1 = gz + w1;
+  float mm = fmaf(gx, gx, fmaf(gy, gy, gz0 * gz0)), pp = fmaf(px_, px_, pp_y);
+  float nfac = fabsf(w0) * __builtin_amdgcn_rsqf(mm * pp);             // |n^ . p^|
+  float Jd[6];
+  Jd[0] = gx * w0;
+  Jd[1] = gy * w0;
+  Jd[2] = gz1 * w0;
+  Jd[3] = fmaf(gz1, py_, -gy);
+  Jd[4] = fmaf(-gz1, px_, gx);
+  Jd[5] = fmaf(gy, px_, -(gx * py_));
+  float ed = w0 - w1;
+  float eu = fmaf(ed, C.inv_sd, -C.be_d);
+  float wd = snu ? C.nud1_m * __builtin_amdgcn_rcpf(fmaf(eu, eu, P.nu_d)) : m_weight(eu, mest) * C.wmul_d;
+  wd = vd ? wd : 0.f;
+  // ---- intensity row (times sigma_i; its weight carries rho2)
+  float hx = gix * P.fx, hy = giy * P.fy;
+  float hz = -fmaf(hx, px_, hy * py_);
+  float Ji[6];
+  Ji[0] = hx * w0;
+  Ji[1] = hy * w0;
+  Ji[2] = hz * w0;
+  Ji[3] = fmaf(hz, py_, -hy);
+  Ji[4] = fmaf(-hz, px_, hx);
+  Ji[5] = fmaf(hy, px_, -(hx * py_));
+  float ei = i0 - i1;
+  ei = vi ? ei : 0.f;
+  float eiu = fmaf(ei, C.inv_si, -C.be_i);
+  float wi;
+  if (minw) {
     wi = snu ? C.nui1 * __builtin_amdgcn_rcpf(fmaf(eiu, eiu, P.nu_i)) : m_weight(eiu, mest);
     wi = vi ? wi * C.wmul_i : 0.f;
     wi = fminf(wd, wi) * C.rho2;
@@ -217,7 +283,6 @@ __device__ __forceinline__ void build_system_block(const ImgB& W0, const ImgB& I
       auto unit_off = [&](int yy, int xx) { return __umul24((unsigned)yy, pitch_b) + ((unsigned)xx << 2); };
       const int im = WM == 1 ? 1 : fa.interp_mode;   // variant 1 also fixes the 1.8 fixed-point bilinear weights (launcher)
       const fastnum::Guard G = fastnum::lane_guard(WP, Wc.cols, Wc.rows);
-      const fastnum::BorderBand BB = fastnum::border_band(G, Ic.cols, Ic.rows);
       bool live = nt > 0 && xu < upr && y < rows;               // ragged right / bottom tiles
       float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (live) w0 = ld_stream4(reinterpret_cast<const float*>(bW0 + unit_off(y, xu << 2)));
@@ -254,23 +319,25 @@ __device__ __forceinline__ void build_system_block(const ImgB& W0, const ImgB& I
         fastnum::IdProj p3 = fastnum::id_project(r3, w0.w, WP, G, Wc.cols, Wc.rows, fc);
         if (__builtin_expect(fc, 0)) fastnum::id_fix_coords(p3, x + 3, y, WP, Wc.cols, Wc.rows);
         const float s3 = Wc.at(p3.iy, p3.ix);
+        // validity travels as masks (SGPR pairs), not as NaN values: w1 is finite at every pixel, k0..k3 say where it is the warped inverse depth
         float4 w1;
-        w1.x = fastnum::id_finish(p0, s0, WP, G, f0); w1.y = fastnum::id_finish(p1, s1, WP, G, f1);
-        w1.z = fastnum::id_finish(p2, s2, WP, G, f2); w1.w = fastnum::id_finish(p3, s3, WP, G, f3);
+        bool k0, k1, k2, k3;
+        w1.x = fastnum::id_finish_m(p0, s0, WP, G, k0, f0); w1.y = fastnum::id_finish_m(p1, s1, WP, G, k1, f1);
+        w1.z = fastnum::id_finish_m(p2, s2, WP, G, k2, f2); w1.w = fastnum::id_finish_m(p3, s3, WP, G, k3, f3);
         if (__builtin_expect(f0 | f1 | f2 | f3, 0)) {   // the sign of the oracle's value is not implied by the fast one (never on data of the stated domain and sane motion)
-          if (f0) w1.x = warp_invdepth_px(Wc, x, y, w0.x, WP);
-          if (f1) w1.y = warp_invdepth_px(Wc, x + 1, y, w0.y, WP);
-          if (f2) w1.z = warp_invdepth_px(Wc, x + 2, y, w0.z, WP);
-          if (f3) w1.w = warp_invdepth_px(Wc, x + 3, y, w0.w, WP);
+          if (f0) { const float e = warp_invdepth_px(Wc, x, y, w0.x, WP); k0 = e == e; w1.x = k0 ? e : p0.ws; }
+          if (f1) { const float e = warp_invdepth_px(Wc, x + 1, y, w0.y, WP); k1 = e == e; w1.y = k1 ? e : p1.ws; }
+          if (f2) { const float e = warp_invdepth_px(Wc, x + 2, y, w0.z, WP); k2 = e == e; w1.z = k2 ? e : p2.ws; }
+          if (f3) { const float e = warp_invdepth_px(Wc, x + 3, y, w0.w, WP); k3 = e == e; w1.w = k3 ? e : p3.ws; }
         }
         bool bd;
-        fastnum::IntensityTaps t0 = fastnum::intensity_taps(Ic, r0, w1.x, WP, BB, im, bd);
-        if (__builtin_expect(bd, 0)) t0.ok = fastnum::intensity_fix_border(Ic, r0, x, y, w1.x, WP, G);   // not safely inside the image: surely outside, or the oracle's predicate
-        fastnum::IntensityTaps t1 = fastnum::intensity_taps(Ic, r1, w1.y, WP, BB, im, bd);
+        fastnum::IntensityTaps t0 = fastnum::intensity_taps(Ic, r0, w1.x, WP, G, im, bd, k0);
+        if (__builtin_expect(bd, 0)) t0.ok = fastnum::intensity_fix_border(Ic, r0, x, y, w1.x, WP, G);   // not in the core of the image: surely inside, surely outside, or the oracle's predicate
+        fastnum::IntensityTaps t1 = fastnum::intensity_taps(Ic, r1, w1.y, WP, G, im, bd, k1);
         if (__builtin_expect(bd, 0)) t1.ok = fastnum::intensity_fix_border(Ic, r1, x + 1, y, w1.y, WP, G);
-        fastnum::IntensityTaps t2 = fastnum::intensity_taps(Ic, r2, w1.z, WP, BB, im, bd);
+        fastnum::IntensityTaps t2 = fastnum::intensity_taps(Ic, r2, w1.z, WP, G, im, bd, k2);
         if (__builtin_expect(bd, 0)) t2.ok = fastnum::intensity_fix_border(Ic, r2, x + 2, y, w1.z, WP, G);
-        fastnum::IntensityTaps t3 = fastnum::intensity_taps(Ic, r3, w1.w, WP, BB, im, bd);
+        fastnum::IntensityTaps t3 = fastnum::intensity_taps(Ic, r3, w1.w, WP, G, im, bd, k3);
         if (__builtin_expect(bd, 0)) t3.ok = fastnum::intensity_fix_border(Ic, r3, x + 3, y, w1.w, WP, G);
         if (live_n) w0n = ld_stream4(reinterpret_cast<const float*>(bW0 + unit_off(yn, xn << 2)));
         float py_ = ((float)y - C.cy_f) * C.inv_fy, pp_y = fmaf(py_, py_, 1.f);
@@ -278,21 +345,21 @@ __device__ __forceinline__ void build_system_block(const ImgB& W0, const ImgB& I
         // each pixel's taps are waited for where its rows are built (RGBID_SYS_PIXEL_FENCE keeps the scheduler from hoisting all four
         // waits to the top of the unit when the per-pixel code is branch-free): the later gathers land under the earlier pixels' updates
         bool nt;
-        float i1v = fastnum::intensity_finish(t0, nt);
-        if (__builtin_expect(nt, 0)) i1v = warp_intensity_px(Ic, x, y, w1.x, WP, im);   // a NaN tap (corner pixels of levels >= 1): the oracle's texel pair decides
-        accumulate_pixel<WM>(acc, px0, py_, pp_y, w0.x, i0.x, a.x, b.x, c.x, d.x, w1.x, i1v, P, C);
+        float i1v = fastnum::intensity_finish_m(t0, nt);
+        if (__builtin_expect(nt, 0)) i1v = warp_intensity_px(Ic, x, y, w1.x, WP, im);   // a NaN tap (corner pixels of levels >= 1): the oracle's texel pair decides (never NaN inside the image: fminf)
+        accumulate_pixel_m<WM>(acc, px0, py_, pp_y, p0.ws, i0.x, a.x, b.x, c.x, d.x, w1.x, i1v, k0, t0.ok, P, C);
         RGBID_SYS_PIXEL_FENCE;
-        i1v = fastnum::intensity_finish(t1, nt);
+        i1v = fastnum::intensity_finish_m(t1, nt);
         if (__builtin_expect(nt, 0)) i1v = warp_intensity_px(Ic, x + 1, y, w1.y, WP, im);
-        accumulate_pixel<WM>(acc, px0 + C.inv_fx, py_, pp_y, w0.y, i0.y, a.y, b.y, c.y, d.y, w1.y, i1v, P, C);
+        accumulate_pixel_m<WM>(acc, px0 + C.inv_fx, py_, pp_y, p1.ws, i0.y, a.y, b.y, c.y, d.y, w1.y, i1v, k1, t1.ok, P, C);
         RGBID_SYS_PIXEL_FENCE;
-        i1v = fastnum::intensity_finish(t2, nt);
+        i1v = fastnum::intensity_finish_m(t2, nt);
         if (__builtin_expect(nt, 0)) i1v = warp_intensity_px(Ic, x + 2, y, w1.z, WP, im);
-        accumulate_pixel<WM>(acc, fmaf(2.f, C.inv_fx, px0), py_, pp_y, w0.z, i0.z, a.z, b.z, c.z, d.z, w1.z, i1v, P, C);
+        accumulate_pixel_m<WM>(acc, fmaf(2.f, C.inv_fx, px0), py_, pp_y, p2.ws, i0.z, a.z, b.z, c.z, d.z, w1.z, i1v, k2, t2.ok, P, C);
         RGBID_SYS_PIXEL_FENCE;
-        i1v = fastnum::intensity_finish(t3, nt);
+        i1v = fastnum::intensity_finish_m(t3, nt);
         if (__builtin_expect(nt, 0)) i1v = warp_intensity_px(Ic, x + 3, y, w1.w, WP, im);
-        accumulate_pixel<WM>(acc, fmaf(3.f, C.inv_fx, px0), py_, pp_y, w0.w, i0.w, a.w, b.w, c.w, d.w, w1.w, i1v, P, C);
+        accumulate_pixel_m<WM>(acc, fmaf(3.f, C.inv_fx, px0), py_, pp_y, p3.ws, i0.w, a.w, b.w, c.w, d.w, w1.w, i1v, k3, t3.ok, P, C);
         } else if (live_n) w0n = ld_stream4(reinterpret_cast<const float*>(bW0 + unit_off(yn, xn << 2)));
         w0 = w0n; live = live_n; y = yn; xu = xn; ty = tyn; sx = sxn;
       }

@@ -210,9 +210,11 @@ __device__ __forceinline__ Guard lane_guard(const WarpParams& P, int cols, int r
   Guard g = make_guard(P.R, P.t, cols, rows);
   g.d1 = uniform_f(g.d1); g.c2 = uniform_f(g.c2); g.d2 = uniform_f(g.d2); g.q0 = uniform_f(g.q0); g.q1 = uniform_f(g.q1); g.db = uniform_f(g.db);
   g.g0 = uniform_f(g.g0); g.g1 = uniform_f(g.g1); g.e0 = uniform_f(g.e0); g.e1 = uniform_f(g.e1);
+  g.bL = uniform_f(g.bL); g.cL = uniform_f(g.cL); g.kL = uniform_f(g.kL); g.wcore = uniform_f(g.wcore); g.gL = uniform_f(g.gL);
   g.zsafe = __builtin_amdgcn_readfirstlane(g.zsafe);
 #ifdef RGBID_EXPERIMENT_GUARD_NEVER_FIRES   // timing experiment only (tools/build_variant.sh): the checks run, no pixel is ever recomputed
   g.d1 = uniform_f(0.f); g.c2 = uniform_f(10.f); g.db = uniform_f(-1e9f); g.d2 = uniform_f(0.f);
+  g.bL = uniform_f(0.5f); g.cL = uniform_f(10.f); g.kL = uniform_f(0.f);
 #endif
   return g;
 }
@@ -242,6 +244,9 @@ __device__ __forceinline__ float sanitised(float w, bool& valid) {
   return ws;
 }
 
+// v_max3_f32 (1.35 FMA-equivalents on this chip; v_max_f32 costs 1.5): NaN operands are skipped -- callers make sure a NaN cannot hide an open decision
+__device__ __forceinline__ float max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 // ---- trafo3DKernelInvDepthGridStride (:505-546), one pixel, in steps so that a kernel can run the steps of several pixels side by side:
 // id_project (coordinates + guard verdict) -> [id_fix_coords for flagged pixels] -> gather -> id_finish -> [exact pixel where the sign is open]
 struct IdProj {
@@ -257,13 +262,14 @@ __device__ __forceinline__ IdProj id_project(const Ray& q, float w, const WarpPa
   r.q2 = q.q2;
   const Scaled Y = scaled_point(q, r.ws, P);
   const float wc = rcp(Y.y2);
-  const float xs = __builtin_fmaf(Y.y0, wc, 0.5f), ys = __builtin_fmaf(Y.y1, wc, 0.5f);
+  // guard_band.h (3'): the coordinate biased DOWN by the lane's band dLa (bL = 0.5 - dLa); the oracle's coordinate then lies in [xs, xs + 2 dLa] and
+  // floor() of the two agrees when fract(xs) < 1 - 2 dLa -- two v_fract, one multiply, one v_max3, one compare for both axes and the bound on |wc|
+  const float xs = __builtin_fmaf(Y.y0, wc, G.bL), ys = __builtin_fmaf(Y.y1, wc, G.bL);
   r.ix = cvt_flr(xs); r.iy = cvt_flr(ys);
   r.ok = valid & inside(r.ix, r.iy, cols, rows);
-  const float ex = __builtin_amdgcn_fractf(xs) - 0.5f, ey = __builtin_amdgcn_fractf(ys) - 0.5f;
-  // guard_band.h (3); NaN / inf anywhere: not safe.  A lane whose sign analysis (4) does not hold has d1 = inf: none of its pixels is safe
-  const bool safe_xy = fmaxf(fabsf(ex), fabsf(ey)) <= __builtin_fmaf(-fabsf(wc), G.d1, G.c2);
-  fixc = valid & !safe_xy;
+  // NaN / inf: wc is finite or +-inf for a sane lane (Y_2 finite), |wc| = inf fails the test; a lane that is not sane has cL = -1 (never safe)
+  const float m = max3(__builtin_amdgcn_fractf(xs), __builtin_amdgcn_fractf(ys), fabsf(wc) * G.kL);
+  fixc = valid & !(m < G.cL);
   return r;
 }
 // cold path: the oracle's coordinates (register_pixel: no contraction, IEEE reciprocals) of a valid pixel
@@ -281,6 +287,15 @@ __device__ __forceinline__ float id_finish(const IdProj& r, float w2, const Warp
   const float res = (r.q2 * rwf) * w2;   // v1_z = (X.z - t_z) w = q_z
   fixr = r.ok & ((G.zsafe == 0) | (fabsf(rwf) > 0x1p19f));   // guard_band.h (4): per lane (wave-uniform), and per pixel
   return (r.ok & (res > 0.f)) ? res : qnan();
+}
+// the same for callers that carry validity as a mask (the fused normal-equation kernel): `okd` = the warped value is valid; the returned value is finite
+// either way (the sanitised keyframe inverse depth stands in for an invalid one, so that a residual formed from it stays finite under a zero weight)
+__device__ __forceinline__ float id_finish_m(const IdProj& r, float w2, const WarpParams& P, const Guard& G, bool& okd, bool& fixr) {
+  const float rwf = rcp(__builtin_fmaf(-w2, P.t[2], 1.f));
+  const float res = (r.q2 * rwf) * w2;
+  fixr = r.ok & ((G.zsafe == 0) | (fabsf(rwf) > 0x1p19f));
+  okd = r.ok & (res > 0.f);
+  return okd ? res : r.ws;
 }
 // the whole pixel for kernels with one pixel per thread (lattice pre-pass, scalar path of the normal equations)
 __device__ __forceinline__ float warp_invdepth_px(const FMap& src, const Ray& q, int x, int y, float w, const WarpParams& P, const Guard& G) {
@@ -322,40 +337,44 @@ struct IntensityTaps { float2 p0, p1; float a, b; bool ok; };
 // this warp are the in-image predicate (:486-487) -- taken as "inside" / "outside" when the coordinate is farther than the guard band from the
 // image border, and from the oracle's coordinates otherwise (`border`: the caller runs intensity_fix_border for those pixels) -- and the texel
 // pair of a sample that meets a NaN texel (intensity_finish).
-struct BorderBand { float x0, x1, y0, y1; };   // safe-inside interval of the coordinate (wave-uniform)
-__device__ __forceinline__ BorderBand border_band(const Guard& G, int cols, int rows) {
-  return BorderBand{uniform_f(-0.5f + G.db), uniform_f((float)cols - 0.5f - G.db), uniform_f(-0.5f + G.db), uniform_f((float)rows - 0.5f - G.db)};
+// Round 5 (guard_band.h (3'')): the hot path takes "inside" where it is certain at no extra cost -- the coordinate equals its own clamp to [0, n - 1) (the
+// v_med3_f32 the tap addresses need anyway) and |wc| <= wcore -- and leaves every other pixel of the domain (the half-pixel ring around the image,
+// projections outside it) to the cold path intensity_fix_border, which sorts them into surely inside / surely outside / the oracle's coordinates.
+__device__ __forceinline__ float tex8_weight(float a) {
+  // rint(a * 256) / 256 for a in [0, 1] in two full-rate adds: 1.5 * 2^15 has ulp 2^-8, round-to-nearest-even on the same grid as rintf (bit-identical)
+  return (a + 49152.f) - 49152.f;
 }
-__device__ __forceinline__ IntensityTaps intensity_taps(const FMap& src, const Ray& q, float w, const WarpParams& P, const BorderBand& B, int interp_mode, bool& border) {
+// `valid_in`: what the caller already knows about w (true: nothing; the fused kernel passes the mask of its warped inverse depth)
+__device__ __forceinline__ IntensityTaps intensity_taps(const FMap& src, const Ray& q, float w, const WarpParams& P, const Guard& G, int interp_mode, bool& border, bool valid_in = true) {
   IntensityTaps t;
   bool valid;
   const float ws = sanitised(w, valid);
+  valid &= valid_in;
   const Scaled Y = scaled_point(q, ws, P);
   const float wc = rcp(Y.y2);
   const float xB = Y.y0 * wc, yB = Y.y1 * wc;
-  const bool safe_in = (xB >= B.x0) & (xB < B.x1) & (yB >= B.y0) & (yB < B.y1) & (fabsf(wc) <= RHO_BORDER);
-  t.ok = valid & safe_in;
-  border = valid & !safe_in;
   const float hx = __builtin_bit_cast(float, __builtin_bit_cast(int, (float)(src.cols - 1)) - 1);   // wave-uniform
   const float hy = __builtin_bit_cast(float, __builtin_bit_cast(int, (float)(src.rows - 1)) - 1);
   const float xc = __builtin_amdgcn_fmed3f(xB, 0.f, hx), yc = __builtin_amdgcn_fmed3f(yB, 0.f, hy);
+  const bool core = (xc == xB) & (yc == yB) & (fabsf(wc) <= G.wcore);   // NaN anywhere: not core
+  t.ok = valid & core;
+  border = valid & !core;
   t.a = __builtin_amdgcn_fractf(xc); t.b = __builtin_amdgcn_fractf(yc);   // v_fract_f32: x - floor(x), kept below 1
-  if (interp_mode == 1) {
-    t.a = rintf(t.a * 256.f) * 0.00390625f;
-    t.b = rintf(t.b * 256.f) * 0.00390625f;
-  }
+  if (interp_mode == 1) { t.a = tex8_weight(t.a); t.b = tex8_weight(t.b); }
   const unsigned off = src.row(cvt_flr(yc)) + ((unsigned)cvt_flr(xc) << 2);
   t.p0 = src.at2_raw(off, 0u); t.p1 = src.at2_raw(off, src.pitch_b);
   return t;
 }
-// cold path of a pixel whose projection is not safely inside: surely outside (farther than the band beyond the border), or the oracle's predicate
+// cold path of a pixel whose projection is not in the core: safely inside (farther than the band from the border), surely outside, or the oracle's predicate
 __device__ __forceinline__ bool intensity_fix_border(const FMap& src, const Ray& q, int x, int y, float w, const WarpParams& P, const Guard& G) {
 #pragma clang fp contract(off)
   const Scaled Y = scaled_point(q, w, P);
   const float wc = rcp(Y.y2);
   const float xB = Y.y0 * wc, yB = Y.y1 * wc;
-  const bool surely_out = (fabsf(wc) <= RHO_BORDER) & ((xB < -0.5f - G.db) | (xB >= (float)src.cols - 0.5f + G.db) | (yB < -0.5f - G.db) | (yB >= (float)src.rows - 0.5f + G.db));
-  if (surely_out) return false;
+  const bool priced = fabsf(wc) <= RHO_BORDER;   // db = RHO_BORDER d1 + d2
+  const bool surely_in = priced & (xB >= -0.5f + G.db) & (xB < (float)src.cols - 0.5f - G.db) & (yB >= -0.5f + G.db) & (yB < (float)src.rows - 0.5f - G.db);
+  const bool surely_out = priced & ((xB < -0.5f - G.db) | (xB >= (float)src.cols - 0.5f + G.db) | (yB < -0.5f - G.db) | (yB >= (float)src.rows - 0.5f + G.db));
+  if (surely_in | surely_out) return surely_in;
   float xe, ye;
   register_pixel(xe, ye, x, y, w, P);
   xe += 0.5f; ye += 0.5f;
@@ -368,14 +387,21 @@ __device__ __forceinline__ float intensity_finish(const IntensityTaps& t, bool& 
   const float top = __builtin_fmaf(t.a, t.p0.y - t.p0.x, t.p0.x), bot = __builtin_fmaf(t.a, t.p1.y - t.p1.x, t.p1.x);
   float res = __builtin_fmaf(t.b, bot - top, top);
   nan_tap = t.ok & (res != res);
-  res = fmaxf(0.f, fminf(res, 255.f));
+  res = __builtin_amdgcn_fmed3f(res, 0.f, 255.f);   // the clamp to [0, 255] as one instruction; a NaN blend is replaced by the caller (nan_tap)
   return t.ok ? res : qnan();
+}
+// for callers that carry validity as a mask (t.ok): no NaN is written into the value
+__device__ __forceinline__ float intensity_finish_m(const IntensityTaps& t, bool& nan_tap) {
+  const float top = __builtin_fmaf(t.a, t.p0.y - t.p0.x, t.p0.x), bot = __builtin_fmaf(t.a, t.p1.y - t.p1.x, t.p1.x);
+  const float res = __builtin_fmaf(t.b, bot - top, top);
+  nan_tap = t.ok & (res != res);
+  return __builtin_amdgcn_fmed3f(res, 0.f, 255.f);
 }
 
 // trafo3DKernelIntensityWithInvDepthGridStride (:465-501), one pixel; bilinear tap in the lerp form
 __device__ __forceinline__ float warp_intensity_px(const FMap& src, const Ray& q, int x, int y, float w, const WarpParams& P, const Guard& G, int interp_mode) {
   bool border, nan_tap;
-  IntensityTaps t = intensity_taps(src, q, w, P, border_band(G, src.cols, src.rows), interp_mode, border);
+  IntensityTaps t = intensity_taps(src, q, w, P, G, interp_mode, border);
   if (__builtin_expect(border, 0)) t.ok = intensity_fix_border(src, q, x, y, w, P, G);
   float res = intensity_finish(t, nan_tap);
   if (__builtin_expect(nan_tap, 0)) res = rgbid::warp_intensity_px(src, x, y, w, P, interp_mode);
@@ -417,10 +443,11 @@ __device__ __forceinline__ VisProj vis_project(int cols, int rows, const Ray& q,
 __device__ __forceinline__ bool vis_gate(const VisProj& v, float d, int x, int y, const WarpParams& P, const Guard& G) {
 #pragma clang fp contract(off)
   float dgap = fabsf(v.wc - d);
-  // the gate is open within eps_w |w'| of the threshold (guard_band.h (5)); screened by a fixed band first
-  if (__builtin_expect(v.ok & !v.exact & (fabsf(dgap - 0.020f) <= 0x1p-10f), 0)) {
-    const float band = __builtin_fmaf(fabsf(v.wc), __builtin_fmaf(fabsf(v.ry), G.g1, G.g0), 4.f * 0x1p-24f * 0.020f);
-    if (!(fabsf(dgap - 0.020f) > band) | !(band < 0x1p-10f)) {
+  // the gate is open within eps_w |w'| of the threshold (guard_band.h (5)); screened first with the lane constant gL >= eps_w (every pixel that is not
+  // `exact` has |1 / Y_2| d1 + d2 < 1/2, vis_project), so that the screen cannot miss an open gate however large |w'| is (round 4 screened with a fixed 2^-10)
+  const float off = fabsf(dgap - 0.020f), c0 = 4.f * 0x1p-24f * 0.020f;
+  if (__builtin_expect(v.ok & !v.exact & !(off > __builtin_fmaf(fabsf(v.wc), G.gL, c0)), 0)) {
+    if (!(off > __builtin_fmaf(fabsf(v.wc), __builtin_fmaf(fabsf(v.ry), G.g1, G.g0), c0))) {
       float xe, ye;
       dgap = fabsf(register_pixel(xe, ye, x, y, v.ws, P) - d);
     }

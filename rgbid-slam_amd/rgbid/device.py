@@ -326,11 +326,14 @@ def error_lattice_size(rows, cols, min_nsamples):
 
 
 def fast_guard(R_proj, t_proj, cols, rows):
-    """guard-band constants of one projection (csrc/guard_band.h, host evaluation; no GPU): dict d1, c2, d2, q0, q1, db, g0, g1, e0, e1, zsafe"""
+    """guard-band constants of one projection (csrc/guard_band.h, host evaluation; no GPU): dict d1, c2, d2, q0, q1, db, g0, g1, e0, e1, zsafe + the lane-constant forms bL, cL, kL, wcore"""
     from ._lib import lib
     out = (C.c_float * 10)()
     z = C.c_int()
     check(lib().rgbid_fast_guard(_fa(R_proj, 9), _fa(t_proj, 3), int(cols), int(rows), out, C.byref(z)))
     d = dict(zip(("d1", "c2", "d2", "q0", "q1", "db", "g0", "g1", "e0", "e1"), [float(v) for v in out]))
     d["zsafe"] = int(z.value)
+    out4 = (C.c_float * 4)()
+    check(lib().rgbid_fast_guard_lane(_fa(R_proj, 9), _fa(t_proj, 3), int(cols), int(rows), out4))
+    d.update(zip(("bL", "cL", "kL", "wcore"), [float(v) for v in out4]))
     return d

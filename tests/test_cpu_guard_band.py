@@ -31,14 +31,20 @@ def oracle_xs(x, y, w, R, t):
     return X0 * wc + f32(0.5), X1 * wc + f32(0.5), wc
 
 
-def fast_xs(x, y, w, R, t, rng):
-    """fastnum::ray + scaled_point + id_project (csrc/warp_device.h): two FMAs per ray component, one per scaled component, v_rcp_f32, one per coordinate"""
+def fast_xs(x, y, w, R, t, rng, bias=0.5):
+    """fastnum::ray + scaled_point + id_project (csrc/warp_device.h): two FMAs per ray component, one per scaled component, v_rcp_f32, one per coordinate
+    (`bias`: the addend of the last FMA -- 0.5 for the bound (3) of guard_band.h, the lane's bL for the form (3') the kernels run)"""
     q = [fma(np.full_like(x, R[3 * r]), x, fma(np.full_like(y, R[3 * r + 1]), y, np.full_like(y, R[3 * r + 2]))) for r in range(3)]
     Y = [fma(np.full_like(w, t[r]), w, q[r]) for r in range(3)]
     wc = (f32(1) / Y[2])
     ulp = np.spacing(np.abs(wc)).astype(f32)
     wc = (wc + rng.integers(-1, 2, wc.shape).astype(f32) * ulp).astype(f32)       # 1 ulp reciprocal
-    return fma(Y[0], wc, np.full_like(wc, 0.5)), fma(Y[1], wc, np.full_like(wc, 0.5)), wc
+    return fma(Y[0], wc, np.full_like(wc, bias)), fma(Y[1], wc, np.full_like(wc, bias)), wc
+
+
+def fract(x):
+    """v_fract_f32: min(fl(x - floor x), 1 - 2^-24) (verified on the device for all 2^32 inputs by rgbid_selftest_fast_primitives)"""
+    return np.minimum((x - np.floor(x)).astype(f32), f32(1) - f32(2.0 ** -24))
 
 
 @pytest.mark.parametrize("rows,cols", [(480, 640), (960, 1280), (120, 160), (61, 83)])
@@ -46,7 +52,7 @@ def test_guard_band_covers_the_measured_distance(rows, cols):
     rng = util.rng(77)
     s = cols / 640.0
     K = (525.0 * s, 525.0 * s, 319.5 * s, 239.5 * s)
-    worst, flagged, total = 0.0, 0, 0
+    worst, flagged, total, flagged_lane, total_lane = 0.0, 0, 0, 0, 0
     for trial in range(24):
         trans, rot = [(0.03, 1.5), (0.3, 10.0), (0.005, 0.2), (1.0, 25.0)][trial % 4]
         Rm, tv = util.small_motion(rng, K, trans, rot)
@@ -71,10 +77,22 @@ def test_guard_band_covers_the_measured_distance(rows, cols):
         # and the decision itself: wherever the guard does not fire, floor() of the two evaluations agrees
         same = (np.floor(fx) == np.floor(ox)) & (np.floor(fy) == np.floor(oy))
         assert same[open_][~amb].all()
+        # (3'), the form the kernels run: the coordinate biased down by the lane's band; wherever max3(fract, fract, |wc| kL) < cL the pixel floor()
+        # selects is the oracle's (and |wc| is inside the range the lane constant is priced for)
+        with np.errstate(all="ignore"):
+            bx, by, wcb = fast_xs(x, y, w, R, t, rng, bias=f32(g["bL"]))
+            m = np.maximum(np.maximum(fract(bx), fract(by)), (np.abs(wcb) * f32(g["kL"])).astype(f32))
+            safe = m < f32(g["cL"])
+        assert (np.abs(wcb[safe]) <= 2.0).all()
+        assert ((np.floor(bx) == np.floor(ox)) & (np.floor(by) == np.floor(oy)))[safe].all()
+        in_range = np.abs(wcb) <= 2.0
+        flagged_lane += int((~safe & in_range & open_).sum()); total_lane += int((in_range & open_).sum())
     assert total > 1_000_000
+    assert 0 < flagged_lane < 0.02 * total_lane                     # the lane-constant band costs a few pixels per thousand, not per cent
     assert worst < 1.0, worst                                       # the proven bound holds ...
     assert worst > 0.02                                             # ... and is not absurdly loose (typical: 0.1 - 0.3 of the bound)
-    print(f"{cols}x{rows}: worst measured |xs_fast - xs_oracle| / delta = {worst:.3f}; pixels inside the guard band: {flagged / total:.2e}")
+    print(f"{cols}x{rows}: worst measured |xs_fast - xs_oracle| / delta = {worst:.3f}; pixels inside the guard band: {flagged / total:.2e} "
+          f"(per-pixel band), {flagged_lane / max(total_lane, 1):.2e} (lane-constant band, |wc| <= 2)")
 
 
 def test_emulated_oracle_path_is_the_c_oracle():
@@ -109,8 +127,10 @@ def test_guard_refuses_motions_outside_the_sign_analysis():
     assert ok["zsafe"] == 1 and 1e-4 < ok["d1"] + ok["d2"] < 3e-3 and np.isfinite(ok["e0"])
     wild = device.fast_guard(*util.project(K, *util.inv_pose(*util.small_motion(r, K, 0.1, 120.0))), 640, 480)
     assert wild["zsafe"] == 0 and np.isinf(wild["d1"]) and np.isinf(wild["db"])
+    assert wild["cL"] == -1.0 and wild["wcore"] == 0.0               # the lane-constant forms: never safe, never core
+    assert 0.49 < ok["bL"] < 0.5 and 0.99 < ok["cL"] < 1.0 and 100.0 < ok["wcore"] <= 512.0
     nan = device.fast_guard([float("nan")] * 9, [0, 0, 0], 640, 480)
-    assert nan["zsafe"] == 0 and np.isinf(nan["d1"])
+    assert nan["zsafe"] == 0 and np.isinf(nan["d1"]) and nan["cL"] == -1.0 and nan["wcore"] == 0.0
 
 
 @pytest.mark.parametrize("rows,cols", [(480, 640), (120, 160)])
