@@ -16,33 +16,40 @@
 // Device compilations evaluate these functions WITHOUT fused multiply-add contraction (hipcc's default would fuse a * b + c wherever its optimiser
 // sees one, differently in different kernels): every translation unit that inlines them -- the engine's per-lane kernels, the persistent
 // Gauss-Newton level kernel -- then computes bit-identical poses, and the device agrees with the host build (g++ does not contract on x86-64).
+// The pragma sits INSIDE each function body: including this header changes nothing about the floating-point state of the including file.
+// Evaluate a function body WITHOUT fused multiply-add contraction, whatever the including translation unit's -ffp-contract / pragma state is, and
+// without changing that state for the code that follows (the pragma is scoped to the compound statement it opens).
+#ifndef RGBID_FP_STRICT
 #if defined(__clang__)
-#pragma clang fp contract(off)
+#define RGBID_FP_STRICT _Pragma("clang fp contract(off)")
+#else
+#define RGBID_FP_STRICT
+#endif
 #endif
 
 namespace rgbid {
 namespace se3 {
 
-RGBID_HD void m3_copy(const double* A, double* B) { for (int i = 0; i < 9; ++i) B[i] = A[i]; }
-RGBID_HD void m3_id(double* A) { for (int i = 0; i < 9; ++i) A[i] = 0.0; A[0] = A[4] = A[8] = 1.0; }
-RGBID_HD void m3_mul(const double* A, const double* B, double* C) {
+RGBID_HD void m3_copy(const double* A, double* B) { RGBID_FP_STRICT for (int i = 0; i < 9; ++i) B[i] = A[i]; }
+RGBID_HD void m3_id(double* A) { RGBID_FP_STRICT for (int i = 0; i < 9; ++i) A[i] = 0.0; A[0] = A[4] = A[8] = 1.0; }
+RGBID_HD void m3_mul(const double* A, const double* B, double* C) { RGBID_FP_STRICT
   double T[9];
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) T[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
   m3_copy(T, C);
 }
-RGBID_HD void m3_mulv(const double* A, const double* v, double* r) {
+RGBID_HD void m3_mulv(const double* A, const double* v, double* r) { RGBID_FP_STRICT
   double t0 = A[0] * v[0] + A[1] * v[1] + A[2] * v[2];
   double t1 = A[3] * v[0] + A[4] * v[1] + A[5] * v[2];
   double t2 = A[6] * v[0] + A[7] * v[1] + A[8] * v[2];
   r[0] = t0; r[1] = t1; r[2] = t2;
 }
-RGBID_HD void m3_T(const double* A, double* T) {
+RGBID_HD void m3_T(const double* A, double* T) { RGBID_FP_STRICT
   double t[9] = {A[0], A[3], A[6], A[1], A[4], A[7], A[2], A[5], A[8]};
   m3_copy(t, T);
 }
 // cofactor inverse (what Eigen's fixed-size 3x3 inverse() computes)
-RGBID_HD void m3_inv(const double* A, double* I) {
+RGBID_HD void m3_inv(const double* A, double* I) { RGBID_FP_STRICT
   double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
   double id = 1.0 / (A[0] * c00 + A[1] * c01 + A[2] * c02);
   double t[9];
@@ -51,7 +58,7 @@ RGBID_HD void m3_inv(const double* A, double* I) {
   t[6] = c02 * id; t[7] = (A[1] * A[6] - A[0] * A[7]) * id; t[8] = (A[0] * A[4] - A[1] * A[3]) * id;
   m3_copy(t, I);
 }
-RGBID_HD void skew(const double* w, double* S) {
+RGBID_HD void skew(const double* w, double* S) { RGBID_FP_STRICT
   S[0] = 0; S[1] = -w[2]; S[2] = w[1];
   S[3] = w[2]; S[4] = 0; S[5] = -w[0];
   S[6] = -w[1]; S[7] = w[0]; S[8] = 0;
@@ -59,7 +66,7 @@ RGBID_HD void skew(const double* w, double* S) {
 
 // forceOrthogonalisation (util_funcs.cpp:150-155): U V^T of the SVD = the orthogonal polar factor
 // R = M (M^T M)^(-1/2); the symmetric 3x3 inverse square root comes from cyclic Jacobi rotations.
-RGBID_HD void force_orthogonal(const double* M, double* R) {
+RGBID_HD void force_orthogonal(const double* M, double* R) { RGBID_FP_STRICT
   double S[9], V[9], Mt[9];
   m3_T(M, Mt);
   m3_mul(Mt, M, S);
@@ -102,7 +109,7 @@ RGBID_HD void force_orthogonal(const double* M, double* R) {
 }
 
 // expMapRot util_funcs.cpp:124-148
-RGBID_HD void expmap_rot(const double* w, double* R) {
+RGBID_HD void expmap_rot(const double* w, double* R) { RGBID_FP_STRICT
   double theta = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
   double O[9], O2[9], Rr[9];
   skew(w, O);
@@ -116,7 +123,7 @@ RGBID_HD void expmap_rot(const double* w, double* R) {
 }
 
 // expMap util_funcs.cpp:86-122
-RGBID_HD void expmap(const double* w, const double* v, double* R, double* t) {
+RGBID_HD void expmap(const double* w, const double* v, double* R, double* t) { RGBID_FP_STRICT
   double theta = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
   double O[9], O2[9], Rr[9], Q[9];
   skew(w, O);
@@ -134,7 +141,7 @@ RGBID_HD void expmap(const double* w, const double* v, double* R, double* t) {
 }
 
 // logMap util_funcs.cpp:31-83 -> twist = (v, omega)
-RGBID_HD void logmap(const double* M, const double* trans, double* twist) {
+RGBID_HD void logmap(const double* M, const double* trans, double* twist) { RGBID_FP_STRICT
   double R[9];
   force_orthogonal(M, R);
   double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
@@ -164,7 +171,7 @@ RGBID_HD void logmap(const double* M, const double* trans, double* twist) {
 }
 
 // A.llt().solve(b): Cholesky; a non-PD matrix propagates NaN exactly like Eigen (no pivoting, sqrt of a negative)
-RGBID_HD void llt_solve6(const double* A, const double* b, double* x) {
+RGBID_HD void llt_solve6(const double* A, const double* b, double* x) { RGBID_FP_STRICT
   double L[36];
   for (int i = 0; i < 36; ++i) L[i] = 0.0;
   for (int j = 0; j < 6; ++j) {
@@ -192,7 +199,7 @@ RGBID_HD void llt_solve6(const double* A, const double* b, double* x) {
 }
 
 // general 6x6 inverse, Gauss-Jordan with partial pivoting (Eigen: PartialPivLU)
-RGBID_HD void inverse6(const double* A, double* Ainv) {
+RGBID_HD void inverse6(const double* A, double* Ainv) { RGBID_FP_STRICT
   double M[6][12];
   for (int i = 0; i < 6; ++i)
     for (int j = 0; j < 6; ++j) { M[i][j] = A[i * 6 + j]; M[i][6 + j] = (i == j) ? 1.0 : 0.0; }
@@ -210,12 +217,12 @@ RGBID_HD void inverse6(const double* A, double* Ainv) {
   for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Ainv[i * 6 + j] = M[i][6 + j];
 }
 
-RGBID_HD void m6_zero(double* A) { for (int i = 0; i < 36; ++i) A[i] = 0.0; }
-RGBID_HD void m6_set_block(double* A, int r0, int c0, const double* B, double scale) {
+RGBID_HD void m6_zero(double* A) { RGBID_FP_STRICT for (int i = 0; i < 36; ++i) A[i] = 0.0; }
+RGBID_HD void m6_set_block(double* A, int r0, int c0, const double* B, double scale) { RGBID_FP_STRICT
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[(r0 + i) * 6 + c0 + j] = scale * B[i * 3 + j];
 }
 // out += J C J^T
-RGBID_HD void m6_JCJt_add(const double* J, const double* C, double* out) {
+RGBID_HD void m6_JCJt_add(const double* J, const double* C, double* out) { RGBID_FP_STRICT
   double T[36];
   for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) {
     double s = 0; for (int k = 0; k < 6; ++k) s += J[i * 6 + k] * C[k * 6 + j];
@@ -228,7 +235,7 @@ RGBID_HD void m6_JCJt_add(const double* J, const double* C, double* out) {
 }
 
 // K R K^-1 and K t in float, as the host does with Eigen float matrices (visodo.cpp:1108-1114): (K*Rf)*Kinv
-RGBID_HD void project_trafo(float fx, float fy, float cx, float cy, const double* R, const double* tv, float* Rp, float* tp) {
+RGBID_HD void project_trafo(float fx, float fy, float cx, float cy, const double* R, const double* tv, float* Rp, float* tp) { RGBID_FP_STRICT
   float K[9] = {fx, 0.f, cx, 0.f, fy, cy, 0.f, 0.f, 1.f};
   float Ki[9] = {1.f / fx, 0.f, -cx / fx, 0.f, 1.f / fy, -cy / fy, 0.f, 0.f, 1.f};
   float Rf[9], T[9];
@@ -241,7 +248,7 @@ RGBID_HD void project_trafo(float fx, float fy, float cx, float cy, const double
   for (int i = 0; i < 3; ++i) tp[i] = K[i * 3] * tf[0] + K[i * 3 + 1] * tf[1] + K[i * 3 + 2] * tf[2];
 }
 
-RGBID_HD bool has_nan(const double* R, const double* t) {
+RGBID_HD bool has_nan(const double* R, const double* t) { RGBID_FP_STRICT
   for (int i = 0; i < 9; ++i) if (R[i] != R[i]) return true;
   for (int i = 0; i < 3; ++i) if (t[i] != t[i]) return true;
   return false;
@@ -250,6 +257,3 @@ RGBID_HD bool has_nan(const double* R, const double* t) {
 }  // namespace se3
 }  // namespace rgbid
 
-#if defined(__clang__) && defined(__HIPCC__)
-#pragma clang fp contract(fast)   // hipcc's default again for whatever the including translation unit defines next
-#endif

@@ -139,12 +139,13 @@ class VisodoTracker {
   // trackNewFrame ignores the milliseconds its device calls return, so by default it runs them through a ScopedAsyncBridge
   // (include/rgbid/containers.hpp): no per-call timing events / synchronisation, results identical.  Off = the reference's fully synchronous calls.
   void setAsyncBridge(bool on) { async_bridge_ = on; }
-  // Opt-in: trackNewFrame drives a ONE-LANE device-resident engine (include/rgbid_engine.h, exact numerics class) instead of
-  // issuing ~800 bridge calls per frame from the host -- the whole frame is one launch sequence without host round trips (2.8 -> ~1 ms per
-  // 640x480 frame).  Same public surface, same streams to the back-end, poses / covariances / keyframes equal to the host-driven path to double
-  // rounding (tests/test_gpu_tracker_cpp.py runs the tracker tests in both modes).  Returns false (and stays host-driven) for what only the
-  // host-driven path implements: CHI_SQUARED termination, custom calibration / registration, a non-identity initial pose; must be chosen before
-  // the first frame (or after reset()).
+  // DEFAULT since round 5: trackNewFrame drives a ONE-LANE device-resident engine (include/rgbid_engine.h, exact numerics class) instead of issuing ~330
+  // bridge calls per frame from the host -- the whole frame is one launch sequence without host round trips (2.8 -> ~1 ms per 640x480 frame).  Same
+  // public surface, same streams to the back-end, results bit-identical to the host-driven loop (tests/test_gpu_tracker_cpp.py runs the tracker tests
+  // in both modes), every configuration the reference ships (CHI_SQUARED termination and custom calibration included).  What the engine cannot take
+  // over -- a non-identity initial pose, more than 8 levels, RGBID_VISODO_HOST_DRIVEN in the environment -- runs host-driven: decided at the first frame
+  // with the configuration as it is then, and logged.  setEngineBacked(false) selects the host-driven loop; setEngineBacked(true) returns false when an
+  // obstacle exists.  Only before the first frame (or after reset()).
   bool setEngineBacked(bool on);
   bool engineBacked() const { return engine_backed_; }
   // fused inverse depth + weight of the integration keyframe / the current frame's level-0 maps, wherever they live (tracker buffers or the engine)
@@ -183,6 +184,8 @@ class VisodoTracker {
 
  private:
   bool trackNewFrameEngine();
+  const char* engineObstacle() const;
+  void stereoProjections(float dRc_proj[9], float t_dc_proj[3], float cRd_proj[9]);
   bool createEngine();
   float computeInterframeTime();
   void allocateBuffers(int rows_arg, int cols_arg);
@@ -249,7 +252,8 @@ class VisodoTracker {
   bool preview_, verbose_;
   bool async_bridge_ = true;
   int interp_mode_ = RGBID_INTERP_TEX8;
-  bool engine_backed_ = false;
+  bool engine_backed_ = true;    // see setEngineBacked
+  bool engine_auto_ = true;      // nobody has chosen: the default
   ::rgbid_engine* engine_ = nullptr;
   ::rgbid_ctx* engine_ctx_ = nullptr;   // the engine's own context (stream): it must outlive the engine, and the per-thread default context ends with its thread
   LastFrameInfo last_info_;

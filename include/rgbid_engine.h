@@ -54,6 +54,17 @@ typedef struct rgbid_engine_config {
                               * (visodo.cpp:1758-1762).  1: they are computed only where something consumes them -- right before a keyframe is exported
                               * (its normals), for the preview (cfg.preview = 1 keeps the per-frame schedule) and on rgbid_engine_keyframe_maps -- from the
                               * same fused map: every output (pose records, exported keyframes, preview, accessor) is bit-identical, a step writes 24 B/px less */
+  /* ---- round 5: the two configurations that were host-driven only ---- */
+  int termination;           /* RGBID_ALL_ITERS (default) or RGBID_CHI_SQUARED (visodo.cpp:1134-1164): from its second iteration on a level re-evaluates the
+                              * full-lattice chi-square RMSE of the level-0 warped maps; when it grows the last increment is undone and the level ends -- per lane,
+                              * as a flag that masks the rest of the level.  The test reads the STORED warped maps, so this mode runs the reference's kernel
+                              * sequence (fused_gn is ignored, as with RGBID_WARP_FIRST) */
+  int custom_registration;   /* 1: prepareImagesCustomCalibration (visodo.cpp:775-824) instead of prepareImages -- undistort the intensity, correct + undistort
+                              * the inverse depth, register it onto the colour camera -- with the calibration below (config_data/calibration_custom*.ini) */
+  float rgb_dist[5];         /* k1 .. k5 of the colour camera (its fx .. cy are the engine's) */
+  rgbid_intr_k depth_intr;   /* the depth camera: fx, fy, cx, cy, k1 .. k5 */
+  rgbid_depth_dist depth_dist;   /* c1, c0, q0[9], q1[9], xshift, yshift */
+  float dRc_proj[9], t_dc_proj[3], cRd_proj[9];   /* K_d dRc K_c^-1, K_d t_dc, its inverse: float products as visodo.cpp:792-801 forms them (the caller's) */
 } rgbid_engine_config;
 
 #define RGBID_ST_TRACKED    1   /* trackNewFrame returned true */
@@ -78,6 +89,9 @@ void rgbid_engine_default_config(rgbid_engine_config* cfg);   /* ctor defaults +
 /* sizeof(rgbid_engine_config) as the LIBRARY was built: a caller compiled against another revision of this header (fields are only ever appended) compares it
  * with its own sizeof before it hands a config over -- librgbid_host.so, librgbid_dist.so and the Python binding do */
 size_t rgbid_engine_config_size(void);
+/* custom calibration: fills cfg->dRc_proj / t_dc_proj / cRd_proj from the depth -> colour extrinsics (rotation dRc row-major, translation t_dc: [STEREO_DEPTH2RGB] of
+ * config_data/calibration_custom*.ini) and the config's two intrinsics (fx .. cy, depth_intr), with the float arithmetic of src/visodo.cpp:792-801 */
+int rgbid_engine_config_set_stereo(rgbid_engine_config* cfg, const float dRc[9], const float t_dc[3]);
 int rgbid_engine_create(rgbid_engine** e, rgbid_ctx* ctx, const rgbid_engine_config* cfg);
 /* an engine borrows its context's stream: destroy the engine BEFORE rgbid_ctx_destroy(ctx) */
 int rgbid_engine_destroy(rgbid_engine* e);

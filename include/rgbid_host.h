@@ -51,12 +51,15 @@ int rgbid_tracker_destroy(rgbid_tracker* t);
 /* 1 (default): trackNewFrame enqueues its device calls without per-call timing events / synchronisation (it ignores the returned milliseconds);
  * 0: every bridge call synchronous and timed, as in the reference.  Results are identical. */
 int rgbid_tracker_set_async_bridge(rgbid_tracker* t, int on);
-/* 1: trackNewFrame runs the frame as ONE step of a one-lane device-resident engine (rgbid_engine.h: the same kernels in the bit-exact numerics
- * class, ~116 launches and no host round trip per Gauss-Newton iteration) instead of ~330 synchronous bridge calls; the tracker's
- * observable state (poses, odometry constraints, keyframe stream, lastInfo) is maintained from the step's pose record.  Opt-in (default 0);
- * only before the first frame or after reset().  RGBID_E_INVALID for what only the host-driven loop offers: CHI_SQUARED termination,
- * custom_registration = 1, a non-identity initial pose.  VisodoTracker::setEngineBacked. */
+/* 1 (the DEFAULT since round 5): trackNewFrame runs the frame as ONE step of a one-lane device-resident engine (rgbid_engine.h: the same kernels in the
+ * bit-exact numerics class, ~100 launches and no host round trip per Gauss-Newton iteration) instead of ~330 synchronous bridge calls; the tracker's
+ * observable state (poses, odometry constraints, keyframe stream, lastInfo) is maintained from the step's pose record -- bit-identical to the host-driven
+ * loop, every shipped configuration (CHI_SQUARED termination, custom_registration = 1 included).  0: the host-driven loop.  Only before the first frame or
+ * after reset() (else RGBID_E_INVALID).  1 also returns RGBID_E_INVALID when the engine cannot take the run over (non-identity initial pose, > 8 levels);
+ * left at its default such a run falls back to the host-driven loop by itself, with one line on stderr.  VisodoTracker::setEngineBacked. */
 int rgbid_tracker_set_engine_backed(rgbid_tracker* t, int on);
+/* the current mode (VisodoTracker::engineBacked): settled for good once the first frame has been taken */
+int rgbid_tracker_get_engine_backed(const rgbid_tracker* t, int* on);
 int rgbid_tracker_reset(rgbid_tracker* t);                                     /* VisodoTracker::reset (src/visodo.cpp:519-553): the next frame is a first frame */
 int rgbid_tracker_load_settings(rgbid_tracker* t, const char* ini_path);      /* VisodoTracker::loadSettings */
 int rgbid_tracker_load_calibration(rgbid_tracker* t, const char* ini_path);   /* VisodoTracker::loadCalibration */

@@ -9,6 +9,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Evaluate a function body WITHOUT fused multiply-add contraction, whatever the including translation unit's -ffp-contract / pragma state is, and
+// without changing that state for the code that follows (the pragma is scoped to the compound statement it opens).
+#ifndef RGBID_FP_STRICT
+#if defined(__clang__)
+#define RGBID_FP_STRICT _Pragma("clang fp contract(off)")
+#else
+#define RGBID_FP_STRICT
+#endif
+#endif
+
 namespace rgbid {
 
 struct ImgB {
@@ -159,6 +169,21 @@ __device__ __forceinline__ TileId xcd_slab_tile() {
   t.lane = (int)(r / ny);
   t.by = (int)(r - (unsigned)t.lane * ny);
   return t;
+}
+
+// For PREDICATED launches (only some lanes work: keyframe switches) a slab of whole lanes per XCD would leave the XCDs unevenly loaded.  This variant keeps the
+// lane of a workgroup (blockIdx.z) and renumbers only the tiles INSIDE the lane: XCD k owns the contiguous eighth [k nt / 8, (k + 1) nt / 8) of every lane's
+// tiles -- every active lane loads all eight XCDs equally, and spatial neighbours still meet in one L2.  Needs nt % 8 == 0 (640x480, 1280x960 tilings);
+// otherwise the natural order is kept.
+__device__ __forceinline__ TileId xcd_lane_local_tile() {
+  const unsigned nx = gridDim.x, nt = nx * gridDim.y;
+  const unsigned r = blockIdx.x + nx * blockIdx.y;
+  const unsigned t = (nt & 7u) == 0 ? (r & 7u) * (nt >> 3) + (r >> 3) : r;
+  TileId o;
+  o.lane = (int)blockIdx.z;
+  o.by = (int)(t / nx);
+  o.bx = (int)(t - (unsigned)o.by * nx);
+  return o;
 }
 
 // the same renumbering for a 1-D grid: hardware id -> logical id such that XCD k owns the contiguous range [k n / 8, (k + 1) n / 8)

@@ -111,6 +111,7 @@ __global__ void k_step_begin(LaneState* st, Flags f, WarpParams* wp, SysParams* 
     return;
   }
   s.status = 0; s.gn_failed = 0; s.vis_odo = 0.f; s.vis_int = 0.f;
+  s.rmse_prev = 9999.f;   // RMSE_prev of estimateVisualOdometry (:1134): per frame, carried across the levels
   if (s.global_time == 0) {
     f.first[lane] = 1; f.track[lane] = 0; f.gn[lane] = 0; f.sw_odo[lane] = 1; f.sw_int[lane] = 1; f.maps[lane] = 1;
     s.global_time = 1;
@@ -153,10 +154,37 @@ __global__ __launch_bounds__(256) void k_solve_update(const double* partials, in
                                                       StepCfg c, int next_level, SysParams* sp, int sys_level, int sys_cov) {
   int lane = blockIdx.x;
   if (sys_level >= 0 && threadIdx.x == 64) set_sys_lane(sp, st, f.track, c, sys_level, sys_cov, lane);
-  if (!f.gn[lane]) return;
+  if (!f.lvl[lane]) return;   // lvl == gn unless CHI_SQUARED termination has ended this lane's level early
   __shared__ double sm[8][32];
   __shared__ double sums[SYS_TERMS];
   solve_update_block(partials, nblk, st, f, wp, c, next_level, lane, (int)threadIdx.x, sm, sums);
+}
+
+// ---- CHI_SQUARED termination (visodo.cpp:1134-1164) ------------------------------------------------------------------------------------
+// a level begins: every lane whose Gauss-Newton is alive iterates it
+__global__ void k_level_begin(Flags f, int B) {
+  int lane = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lane < B) f.lvl[lane] = f.gn[lane];
+}
+// before iteration `iter` >= 1 of a level, after the warp: RMSE of the full-lattice chi-square (chi_out[lane] = {chi_square, chi_test, Ndof}); from the
+// third iteration on a growing RMSE undoes the previous increment and ends the level FOR THIS LANE (the flag masks the level's remaining launches); the
+// next stage's first warp is projected from the restored pose
+__global__ void k_chi_decide(LaneState* st, Flags f, const float* chi_out, WarpParams* wp, StepCfg c, int iter, int after_level, int B) {
+  int lane = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lane >= B || !f.lvl[lane]) return;
+  LaneState& s = st[lane];
+  const float RMSE = sqrtf(chi_out[3 * lane + 0]) / sqrtf(chi_out[3 * lane + 2]);
+  if (iter != 1 && RMSE > s.rmse_prev) {
+    double d[3], tmp[3];
+    for (int i = 0; i < 3; ++i) d[i] = s.cur_t[i] - s.inc_t[i];
+    se3::m3_mulv(s.inc_inv_R, d, tmp);
+    for (int i = 0; i < 3; ++i) s.cur_t[i] = tmp[i];
+    se3::m3_mul(s.inc_inv_R, s.cur_R, s.cur_R);
+    f.lvl[lane] = 0;
+    set_warp_from_pose(c, after_level, s.cur_R, s.cur_t, wp[lane]);
+    return;
+  }
+  s.rmse_prev = RMSE;
 }
 
 // ---- end of estimateVisualOdometry + pose bookkeeping of trackNewFrame (visodo.cpp:1367-1468, 2051-2170) -----
@@ -465,6 +493,7 @@ struct rgbid_engine {
   ImgB gxI[MAXL], gyI[MAXL], gxD[MAXL], gyD[MAXL], gxI_c[MAXL], gyI_c[MAXL], gxD_c[MAXL], gyD_c[MAXL];
   ImgB wiD[MAXL], wI[MAXL];
   ImgB r_curr, g_curr, b_curr;
+  ImgB I_dist, iD_dist, iD_corr, iD_prereg, reg_f, reg_i;   // custom calibration (cfg.custom_registration): distorted maps, corrected map, pre-registration map, 3 x 3 enlarged splat canvases
   ImgB iD_integr, iD_integr_raw, w_integr, warped_iD_integr, warped_w, vmap, nmap, gxD_integr, gyD_integr, colors_integr, overlap_mask, preview;
   float *res_I = nullptr, *res_D = nullptr;
   float* lat_res = nullptr;        // fused path: residual lattice of both channels, [B][2 * lat_cap]
@@ -628,9 +657,26 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   Flags& f = e->flags;
   // ---- prepareImages (visodo.cpp:760-773)
   const LaneMask fed = M(e->active_dev);   // lanes without a frame this step keep their current-frame pyramids untouched
+  if (c.custom_registration) {
+    // prepareImagesCustomCalibration (visodo.cpp:775-824): the converters write the DISTORTED maps; undistort the intensity (bilinear), correct the depth
+    // sensor's distortion and undistort the inverse depth (point sample), register it onto the colour camera (z-buffer splat + homography)
+    launch_prep_frame(s, B, e->cur_depth, e->cur_rgb, e->iD_dist, e->I_dist, e->r_curr, e->g_curr, e->b_curr, c.factor_depth, fed);
+    const IntrK kc{c.fx, c.fy, c.cx, c.cy, c.rgb_dist[0], c.rgb_dist[1], c.rgb_dist[2], c.rgb_dist[3], c.rgb_dist[4]};
+    const IntrK kd{c.depth_intr.fx, c.depth_intr.fy, c.depth_intr.cx, c.depth_intr.cy, c.depth_intr.k1, c.depth_intr.k2, c.depth_intr.k3, c.depth_intr.k4, c.depth_intr.k5};
+    DepthDistP dp;
+    dp.c1 = c.depth_dist.c1; dp.c0 = c.depth_dist.c0; dp.xshift = c.depth_dist.xshift; dp.yshift = c.depth_dist.yshift;
+    for (int i = 0; i < 9; ++i) { dp.q0[i] = c.depth_dist.q0[i]; dp.q1[i] = c.depth_dist.q1[i]; }
+    launch_undistort(s, B, e->I_dist, e->I_curr[0], kc, true, c.interp_mode, fed);
+    launch_depthinv_correction(s, B, e->iD_dist, e->iD_corr, kd, dp, fed);
+    launch_undistort(s, B, e->iD_corr, e->iD_prereg, kd, false, 0, fed);
+    launch_register_depthinv(s, B, e->iD_prereg, e->reg_f, e->reg_i, e->iD_curr[0], c.dRc_proj, c.t_dc_proj, c.cRd_proj, fed);
+    e->launches += 8;
+    sb[0] += (25 + 12 + 8 + 8 + 9 * 4 + 8 + 9 * 8 + 8) * N0;                        // converters, three per-pixel resamplings, canvas clear / splat / conversion (9 N0 texels), homography
+  } else {
   launch_prep_frame(s, B, e->cur_depth, e->cur_rgb, e->iD_curr[0], e->I_curr[0], e->r_curr, e->g_curr, e->b_curr, c.factor_depth, fed);
   e->launches += 1;
   sb[0] += 25 * N0;                                                               // 2 + 3 B/px read, five fp32 planes written
+  }
   for (int i = 1; i < L; ++i) {
     launch_pyr_down2(s, B, e->I_curr[i - 1], e->I_curr[i], e->iD_curr[i - 1], e->iD_curr[i], fed);
     e->launches += 1;
@@ -647,9 +693,12 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   // The first step after reset() is host-known to be every lane's first frame (visodo.cpp:1994-2045): only the
   // keyframe-creation part of the sequence below is enqueued (k_step_begin has set first / sw_odo / sw_int / maps).
   // ---- estimateVisualOdometry (visodo.cpp:1041-1281), PYR_FIRST
+  const bool chi_stop = c.termination == RGBID_CHI_SQUARED;
+  const LaneMask LV = M(f.lvl);   // the lanes iterating the current level (== f.gn unless chi_stop)
   for (int level = L - 1; !first && level >= c.finest_level; --level) {
     int iters = c.iters[level];
     if (iters > 0) ++stage;     // stage_level[stage]: what follows this level
+    if (chi_stop && iters > 0) { hipLaunchKernelGGL(k_level_begin, dim3(gb), dim3(tb), 0, s, f, B); e->launches++; }
     for (int it = 0; it < iters; ++it) {
       bool last_of_level = (it == iters - 1);
       // level whose intrinsics project the NEXT warp: same level, the next lower level that iterates, or (after the very last
@@ -676,38 +725,53 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
       if (c.fused_gn) {
         if (c.sigma_estimator == RGBID_SIGMA_PDF) {
           launch_sigma_pair_fused(s, B, e->iD_curr[level], e->iD_kf[level], e->I_curr[level], e->I_kf[level], e->wp, c.interp_mode, c.nsamples,
-                                  e->sp, c.mestimator, M(f.gn), fast_at(level), e->lat_res, 2 * e->lat_cap, e->lat_kf[level], 2 * e->lat_cap);
+                                  e->sp, c.mestimator, LV, fast_at(level), e->lat_res, 2 * e->lat_cap, e->lat_kf[level], 2 * e->lat_cap);
           e->launches += 2;
         }
         if (prof) { set_system_kernel_events(e->prof_ev[e->prof_used], e->prof_ev[e->prof_used + 1]); e->prof_used += 2; }
         nblk = launch_gn_fused(s, B, e->iD_kf[level], e->I_kf[level], e->gxD[level], e->gyD[level], e->gxI[level], e->gyI[level],
-                               e->iD_curr[level], e->I_curr[level], e->wp, c.interp_mode, e->sp, e->partials, M(f.gn), level < 2 ? level : 2, fast_at(level),
+                               e->iD_curr[level], e->I_curr[level], e->wp, c.interp_mode, e->sp, e->partials, LV, level < 2 ? level : 2, fast_at(level),
                                c.weighting == RGBID_MIN_WEIGHT ? 0 : 1);   // k_set_sys: the Gauss-Newton iterations always estimate nu
         if (nblk < 0) return RGBID_E_INVALID;
       } else {
         if (c.warping == RGBID_WARP_FIRST) {
           // :1078-1105: warp the full-resolution frame, then reduce the WARPED maps down to the working level
           // (k_step_begin / k_solve_update project the pose with the level-0 intrinsics in this mode)
-          if (!(fast_at(0) && launch_warp_pair_fast(s, B, e->iD_curr[0], e->I_curr[0], e->iD_kf[0], e->wiD[0], e->wI[0], nullptr, e->wp, c.interp_mode, M(f.gn))))
-            launch_warp_pair(s, B, e->iD_curr[0], e->I_curr[0], e->iD_kf[0], e->wiD[0], e->wI[0], e->wp, c.interp_mode, M(f.gn));
+          if (!(fast_at(0) && launch_warp_pair_fast(s, B, e->iD_curr[0], e->I_curr[0], e->iD_kf[0], e->wiD[0], e->wI[0], nullptr, e->wp, c.interp_mode, LV)))
+            launch_warp_pair(s, B, e->iD_curr[0], e->I_curr[0], e->iD_kf[0], e->wiD[0], e->wI[0], e->wp, c.interp_mode, LV);
           e->launches += 1;
           for (int i = 1; i <= level; ++i) {
-            launch_pyr_down(s, B, e->wI[i - 1], e->wI[i], M(f.gn));
-            launch_pyr_down(s, B, e->wiD[i - 1], e->wiD[i], M(f.gn));
+            launch_pyr_down(s, B, e->wI[i - 1], e->wI[i], LV);
+            launch_pyr_down(s, B, e->wiD[i - 1], e->wiD[i], LV);
             e->launches += 2;
           }
         } else {
-          if (!(fast_at(level) && launch_warp_pair_fast(s, B, e->iD_curr[level], e->I_curr[level], e->iD_kf[level], e->wiD[level], e->wI[level], nullptr, e->wp, c.interp_mode, M(f.gn))))
-            launch_warp_pair(s, B, e->iD_curr[level], e->I_curr[level], e->iD_kf[level], e->wiD[level], e->wI[level], e->wp, c.interp_mode, M(f.gn));
+          if (!(fast_at(level) && launch_warp_pair_fast(s, B, e->iD_curr[level], e->I_curr[level], e->iD_kf[level], e->wiD[level], e->wI[level], nullptr, e->wp, c.interp_mode, LV)))
+            launch_warp_pair(s, B, e->iD_curr[level], e->I_curr[level], e->iD_kf[level], e->wiD[level], e->wI[level], e->wp, c.interp_mode, LV);
           e->launches += 1;
         }
+        if (chi_stop && it != 0) {
+          // :1134-1164 -- the full-lattice residuals of the LEVEL-0 warped maps (fresh with WARP_FIRST; with PYR_FIRST whatever the last level-0 warp left
+          // there, as in the reference), their chi-square, and the per-lane decision
+          int n, lr, lc, st_;
+          lattice_geometry(e->wI[0].rows, e->wI[0].cols, 9999999, &n, &lr, &lc, &st_);
+          launch_error_lattice(s, B, e->wI[0], e->I_kf[0], e->res_I, (size_t)c.rows * c.cols, lr, lc, st_, LV);
+          launch_error_lattice(s, B, e->wiD[0], e->iD_kf[0], e->res_D, (size_t)c.rows * c.cols, lr, lc, st_, LV);
+          launch_chi_square(s, B, e->res_I, e->res_D, (size_t)c.rows * c.cols, n, 5.f, 0.0025f, c.mestimator, e->chi_out, LV);
+          int after_level = c.finest_level; bool more_below = false;
+          for (int l = level - 1; l >= c.finest_level; --l) if (c.iters[l] > 0) { after_level = l; more_below = true; break; }
+          if (c.warping == RGBID_WARP_FIRST) after_level = more_below ? 0 : c.finest_level;
+          hipLaunchKernelGGL(k_chi_decide, dim3(gb), dim3(tb), 0, s, e->state, f, e->chi_out, e->wp, sc, it, after_level, B);
+          e->launches += 4;
+          sb[0] += 2 * 12 * N0 + 8 * N0;
+        }
         if (c.sigma_estimator == RGBID_SIGMA_PDF) {
-          launch_sigma_pair(s, B, e->wiD[level], e->iD_kf[level], e->wI[level], e->I_kf[level], c.nsamples, e->sp, c.mestimator, M(f.gn));
+          launch_sigma_pair(s, B, e->wiD[level], e->iD_kf[level], e->wI[level], e->I_kf[level], c.nsamples, e->sp, c.mestimator, LV);
           e->launches++;
         }
         if (prof) { set_system_kernel_events(e->prof_ev[e->prof_used], e->prof_ev[e->prof_used + 1]); e->prof_used += 2; }
         nblk = launch_build_system(s, B, e->iD_kf[level], e->I_kf[level], e->gxD[level], e->gyD[level], e->gxI[level], e->gyI[level],
-                                   e->wiD[level], e->wI[level], nullptr, e->sp, e->partials, M(f.gn), level < 2 ? level : 2);
+                                   e->wiD[level], e->wI[level], nullptr, e->sp, e->partials, LV, level < 2 ? level : 2);
       }
       hipLaunchKernelGGL(k_solve_update, dim3(B), dim3(256), 0, s, e->partials, nblk, e->state, f, e->wp, sc, next_level, e->sp,
                          last_of_level ? stage_level[stage] : -1, (last_of_level && stage == n_gn_stages) ? 1 : 0);
@@ -846,8 +910,37 @@ void rgbid_engine_default_config(rgbid_engine_config* c) {
   c->warping = RGBID_PYR_FIRST;
   c->keyframe_capacity = 0;
   c->fast_numerics = 1;
+  c->termination = RGBID_ALL_ITERS;
+  c->custom_registration = 0;
 }
 
+// K_d dRc K_c^-1, K_d t_dc and the inverse of the first, in float with Eigen's cofactor inverse: the constants prepareImagesCustomCalibration forms per frame
+// (src/visodo.cpp:792-801), from the config's two intrinsics and the depth -> colour extrinsics
+int rgbid_engine_config_set_stereo(rgbid_engine_config* c, const float dRc[9], const float t_dc[3]) {
+  if (!c || !dRc || !t_dc) return RGBID_E_INVALID;
+  auto mul = [](const float* A, const float* B, float* C) {
+    float T[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+    for (int i = 0; i < 9; ++i) C[i] = T[i];
+  };
+  auto inv = [](const float* A, float* I) {
+    float c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+    float det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+    float id = 1.f / det;
+    float T[9] = {c00 * id, (A[2] * A[7] - A[1] * A[8]) * id, (A[1] * A[5] - A[2] * A[4]) * id,
+                  c01 * id, (A[0] * A[8] - A[2] * A[6]) * id, (A[2] * A[3] - A[0] * A[5]) * id,
+                  c02 * id, (A[1] * A[6] - A[0] * A[7]) * id, (A[0] * A[4] - A[1] * A[3]) * id};
+    for (int i = 0; i < 9; ++i) I[i] = T[i];
+  };
+  const float Kc[9] = {c->fx, 0.f, c->cx, 0.f, c->fy, c->cy, 0.f, 0.f, 1.f};
+  const float Kd[9] = {c->depth_intr.fx, 0.f, c->depth_intr.cx, 0.f, c->depth_intr.fy, c->depth_intr.cy, 0.f, 0.f, 1.f};
+  float Kci[9], T[9];
+  inv(Kc, Kci);
+  mul(Kd, dRc, T); mul(T, Kci, c->dRc_proj);
+  for (int i = 0; i < 3; ++i) c->t_dc_proj[i] = Kd[i * 3] * t_dc[0] + Kd[i * 3 + 1] * t_dc[1] + Kd[i * 3 + 2] * t_dc[2];
+  inv(c->dRc_proj, c->cRd_proj);
+  return RGBID_OK;
+}
 size_t rgbid_engine_config_size(void) { return sizeof(rgbid_engine_config); }
 
 int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_config* cfg) {
@@ -856,13 +949,16 @@ int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_c
   if (cfg->rows <= 0 || cfg->cols <= 0 || cfg->levels < 1 || cfg->levels > MAXL || cfg->lanes < 1 || cfg->finest_level < 0 ||
       cfg->finest_level >= cfg->levels || (cfg->rows >> (cfg->levels - 1)) < 4 || (cfg->cols >> (cfg->levels - 1)) < 4 ||
       cfg->record_capacity < 1 || (cfg->warping != RGBID_PYR_FIRST && cfg->warping != RGBID_WARP_FIRST) ||
-      cfg->keyframe_capacity < 0 || !(cfg->delta_t > 0.f) || !(cfg->delta_t < INFINITY) ||
-      cfg->cols > (1 << 20) || (unsigned long long)cfg->rows * 3ull * (((unsigned long long)cfg->cols * 4 + 255) & ~255ull) >= (1ull << 32))  // 24-bit row-offset arithmetic (common.h row_ptr)
+      cfg->keyframe_capacity < 0 || (cfg->termination != RGBID_ALL_ITERS && cfg->termination != RGBID_CHI_SQUARED) || (cfg->custom_registration != 0 && cfg->custom_registration != 1) ||
+      !(cfg->delta_t > 0.f) || !(cfg->delta_t < INFINITY) ||
+      cfg->cols > (1 << 20) || (unsigned long long)cfg->rows * 3ull * (((unsigned long long)cfg->cols * 4 + 255) & ~255ull) >= (1ull << 32) ||  // 24-bit row-offset arithmetic (common.h row_ptr)
+      (cfg->custom_registration && (unsigned long long)cfg->rows * 3ull * (((unsigned long long)cfg->cols * 12 + 255) & ~255ull) >= (1ull << 32)))   // ... of the 3 x 3 registration canvases
     return RGBID_E_INVALID;
   rgbid_engine* e = new (std::nothrow) rgbid_engine();
   if (!e) return RGBID_E_NOMEM;
   e->ctx = ctx; e->cfg = *cfg; e->B = cfg->lanes; e->L = cfg->levels;
   if (cfg->warping == RGBID_WARP_FIRST) e->cfg.fused_gn = 0;   // warp-first pyramids the WARPED maps: they must exist in memory
+  if (cfg->termination == RGBID_CHI_SQUARED) e->cfg.fused_gn = 0;   // the chi-square test reads the stored warped maps
   hipSetDevice(ctx->device);
   const int B = e->B, rows = cfg->rows, cols = cfg->cols;
   int r = RGBID_OK;
@@ -881,8 +977,12 @@ int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_c
   A_IMG(e->gxD_integr, rows, cols, 4); A_IMG(e->gyD_integr, rows, cols, 4);
   A_IMG(e->colors_integr, rows, cols, 3); A_IMG(e->overlap_mask, rows, cols, 1);
   if (cfg->preview) A_IMG(e->preview, rows, cols, 3);
+  if (cfg->custom_registration) {
+    A_IMG(e->I_dist, rows, cols, 4); A_IMG(e->iD_dist, rows, cols, 4); A_IMG(e->iD_corr, rows, cols, 4); A_IMG(e->iD_prereg, rows, cols, 4);
+    A_IMG(e->reg_f, 3 * rows, 3 * cols, 4); A_IMG(e->reg_i, 3 * rows, 3 * cols, 4);   // depthinv_register_trans_ / _as_int_ (visodo.cpp:623-624)
+  }
 #undef A_IMG
-  if (cfg->chi_square_stats) {
+  if (cfg->chi_square_stats || cfg->termination == RGBID_CHI_SQUARED) {
     if (!r) r = alloc_dev(e, (void**)&e->res_I, sizeof(float) * (size_t)rows * cols * B);
     if (!r) r = alloc_dev(e, (void**)&e->res_D, sizeof(float) * (size_t)rows * cols * B);
     if (!r) r = alloc_dev(e, (void**)&e->chi_out, sizeof(float) * 3 * B);
@@ -898,6 +998,8 @@ int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_c
   if (!r) r = alloc_dev(e, (void**)&e->state, sizeof(LaneState) * B);
   int** fl[] = {&e->flags.track, &e->flags.first, &e->flags.gn, &e->flags.vis, &e->flags.sw_odo, &e->flags.sw_int, &e->flags.overlap, &e->flags.fuse, &e->flags.maps};
   for (int** p : fl) if (!r) r = alloc_dev(e, (void**)p, sizeof(int) * B);
+  if (cfg->termination == RGBID_CHI_SQUARED) { if (!r) r = alloc_dev(e, (void**)&e->flags.lvl, sizeof(int) * B); }
+  else e->flags.lvl = e->flags.gn;   // one array: a level ends for every lane together
   WarpParams** wps[] = {&e->wp, &e->vis_ab, &e->vis_ba, &e->ivis_ab, &e->ivis_ba, &e->fuse_wp};
   for (WarpParams** p : wps) if (!r) r = alloc_dev(e, (void**)p, sizeof(WarpParams) * B);
   if (!r) r = alloc_dev(e, (void**)&e->sp, sizeof(SysParams) * B);

@@ -6,7 +6,7 @@
 #include "kernels.h"
 #include "../../include/rgbid/se3.h"
 
-#pragma clang fp contract(off)   // as se3.h: the per-lane double-precision logic is evaluated operation by operation in every kernel that inlines it
+// as se3.h: the per-lane double-precision logic is evaluated operation by operation (RGBID_FP_STRICT inside each body) in every kernel that inlines it
 
 namespace rgbid {
 namespace eng {
@@ -30,10 +30,14 @@ struct LaneState {
   int status;       // RGBID_ST_* bits of the current step
   float vis_odo, vis_int;
   float rec_sigma_i, rec_sigma_d, rec_nu_i, rec_nu_d;  // scale estimates of the last GN iteration (diagnostics)
+  // CHI_SQUARED termination (visodo.cpp:1134-1164): the last increment (to undo it) and the previous RMSE of estimateVisualOdometry
+  double inc_inv_R[9], inc_t[3];
+  float rmse_prev;
 };
 
 struct Flags {  // int[B] each; consumed through LaneMask
   int *track, *first, *gn, *vis, *sw_odo, *sw_int, *overlap, *fuse, *maps;
+  int* lvl;      // lanes still iterating the CURRENT pyramid level: == gn (the same array) unless termination is CHI_SQUARED, which ends levels per lane
   int* kf_slot;  // ring slot the lane exports its outgoing integration keyframe into this step, or -1 (not a LaneMask flag)
 };
 
@@ -49,7 +53,7 @@ struct StepCfg {  // by-value kernel argument with what the scalar kernels need
   const int* active;     // per-lane 0/1: lanes without a new frame this step sit it out (nullptr: every lane is fed)
 };
 
-__device__ inline void set_warp_from_pose(const StepCfg& c, int level, const double* R, const double* t, WarpParams& wp) {
+__device__ inline void set_warp_from_pose(const StepCfg& c, int level, const double* R, const double* t, WarpParams& wp) { RGBID_FP_STRICT
   // inverse pose, projected with the level's K (visodo.cpp:1066-1067,1108-1114)
   double Ri[9], ti[3];
   se3::m3_inv(R, Ri);
@@ -61,7 +65,7 @@ __device__ inline void set_warp_from_pose(const StepCfg& c, int level, const dou
 
 
 // the per-level constants of the lane's SysParams before a level's iterations / the covariance pass (k_set_sys)
-__device__ inline void set_sys_lane(SysParams* sp, LaneState* st, const int* track, const StepCfg& c, int level, int cov_pass, int lane) {
+__device__ inline void set_sys_lane(SysParams* sp, LaneState* st, const int* track, const StepCfg& c, int level, int cov_pass, int lane) { RGBID_FP_STRICT
   int div = 1 << level;
   SysParams& p = sp[lane];
   if (cov_pass && track[lane]) {
@@ -84,7 +88,7 @@ __device__ inline void set_sys_lane(SysParams* sp, LaneState* st, const int* tra
 // one GN update of one lane by the first 256 threads of a workgroup (every thread of the workgroup must call it: two barriers): fixed-order reduction
 // of the lane's partial sums, LLT solve, exp-map, pose update, next warp (visodo.cpp:1242-1274).  sm: [8][32] doubles, sums: [SYS_TERMS] doubles of LDS.
 __device__ inline void solve_update_block(const double* partials, int nblk, LaneState* st, const Flags& f, WarpParams* wp, const StepCfg& c, int next_level, int lane,
-                                          int tid, double (*sm)[32], double* sums) {
+                                          int tid, double (*sm)[32], double* sums) { RGBID_FP_STRICT
   int k = tid & 31, sl = tid >> 5;
   if (tid < 256) {
     double t = 0.0;
@@ -119,9 +123,11 @@ __device__ inline void solve_update_block(const double* partials, int nblk, Lane
   se3::m3_mulv(inc, s.cur_t, tmp);
   for (int i = 0; i < 3; ++i) s.cur_t[i] = tmp[i] + tinc[i];
   se3::m3_mul(inc, s.cur_R, s.cur_R);
+  se3::m3_copy(inc_inv, s.inc_inv_R);   // cam_rot_incremental_inv / cam_trans_incremental: what a CHI_SQUARED stop undoes
+  for (int i = 0; i < 3; ++i) s.inc_t[i] = tinc[i];
   if (se3::has_nan(s.cur_R, s.cur_t)) {  // :1265-1274
     s.gn_failed = 1;
-    f.gn[lane] = 0;
+    f.gn[lane] = 0; f.lvl[lane] = 0;
     return;
   }
   set_warp_from_pose(c, next_level, s.cur_R, s.cur_t, wp[lane]);
@@ -130,4 +136,3 @@ __device__ inline void solve_update_block(const double* partials, int nblk, Lane
 }  // namespace eng
 }  // namespace rgbid
 
-#pragma clang fp contract(fast)   // the including translation unit's default again

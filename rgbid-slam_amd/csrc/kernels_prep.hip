@@ -556,18 +556,22 @@ struct BilSet { ImgB src, dst; float sigma; DivConst dc; };
 template <int MODE>   // 0: IEEE division per tap, 1: the verified 3-instruction exact division, 2: reference-build-class numerics
 __global__ __launch_bounds__(256) void k_bilateral(BilSet b0, BilSet b1, int ny, LaneMask m) {
   constexpr bool FAST = MODE == 1;
-  int lane = blockIdx.z;
+  // XCD-contiguous tile order inside the lane (common.h xcd_lane_local_tile; the launch is predicated): neighbouring tiles share halo columns / rows (a
+  // 68-float row segment spans 6 cache lines, 4 of them its own), and with the natural order the neighbours of a tile always run on other XCDs (round 4
+  // counted 1.68 x the algorithmic traffic)
+  const TileId tid_ = xcd_lane_local_tile();
+  const int lane = tid_.lane;
   if (!m.on(lane)) return;
-  const bool second = (int)blockIdx.y >= ny;
+  const bool second = tid_.by >= ny;
   const BilSet& S = second ? b1 : b0;
   const ImgB& src = S.src; const ImgB& dst = S.dst;
   const float sigma_floatmap = S.sigma;
   const DivConst dc = S.dc;
-  const int tile_y = (int)blockIdx.y - (second ? ny : 0);
+  const int tile_y = tid_.by - (second ? ny : 0);
   // one halo tile of BIL_TILES x TY rows per workgroup (16 + 4 rows x 68 columns: 1.33 loads per output, ONE barrier and ONE exposed memory round
   // trip per four outputs of a thread; four separate 4-row tiles cost 2.1 loads per output and four round trips)
   __shared__ float tile[TY * BIL_TILES + 2 * BR][TX + 2 * BR + 1];
-  const int x0 = blockIdx.x * TX;
+  const int x0 = tid_.bx * TX;
   const float sigma_space = 5.f;
   const float s2ih = (float)(0.5 / (double)(sigma_space * sigma_space));
   const int y0 = tile_y * (TY * BIL_TILES);

@@ -6,7 +6,7 @@
 #include "warp_device.h"
 #include <type_traits>
 
-#pragma clang fp contract(off)
+// no FMA contraction in any function of this header: RGBID_FP_STRICT (se3.h / common.h) opens every body, so the including file's own state is untouched
 
 namespace rgbid {
 
@@ -27,7 +27,7 @@ struct BlockSum {
   int phase;
   __device__ __forceinline__ explicit BlockSum(double* p) : sm(p), phase(0) {}
 };
-__device__ __forceinline__ void block_sum4(const float in[4], double out[4], BlockSum& bs) {
+__device__ __forceinline__ void block_sum4(const float in[4], double out[4], BlockSum& bs) { RGBID_FP_STRICT
   float w[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) w[k] = wave_sum_l63(in[k]);
@@ -64,7 +64,7 @@ struct Samples {
   float neg_ninv;    // -(number of invalid slots among this thread's cnt slots)
   Getter get;
   int n, tid, cnt;
-  __device__ __forceinline__ Samples(const Getter& g, int n_, int tid_) : zero_slot(0.f), neg_ninv(0.f), get(g), n(n_), tid(tid_) {
+  __device__ __forceinline__ Samples(const Getter& g, int n_, int tid_) : zero_slot(0.f), neg_ninv(0.f), get(g), n(n_), tid(tid_) { RGBID_FP_STRICT
     cnt = (n + SIG_T - 1) / SIG_T;
     if constexpr (REG) {
       // the thread's samples tid, tid + SIG_T, ... are visited through the getter's cursor (seek once, then fixed strides): a lattice
@@ -85,7 +85,7 @@ struct Samples {
   // After the last moments pass the residuals themselves are no longer needed: the nu bisection only uses en^2 = ((e - bias)/sigma)^2,
   // the same for every candidate nu, so the register copy is overwritten with it once (no extra VGPRs, 3 instructions less per
   // sample and pass).  The streaming path recomputes it on the fly.
-  __device__ __forceinline__ void to_squared_normalised(float bias, float inv_sigma) {
+  __device__ __forceinline__ void to_squared_normalised(float bias, float inv_sigma) { RGBID_FP_STRICT
     if constexpr (REG) {
 #pragma unroll
       for (int j = 0; j < SIG_MAXPT; ++j) { float en = (e[j] - bias) * inv_sigma; e[j] = en * en; }
@@ -94,7 +94,7 @@ struct Samples {
     }
   }
   template <class F>
-  __device__ __forceinline__ void for_each_en2(float bias, float inv_sigma, F&& f) const {  // f(en^2, validity flag); f linear in the flag
+  __device__ __forceinline__ void for_each_en2(float bias, float inv_sigma, F&& f) const { RGBID_FP_STRICT  // f(en^2, validity flag); f linear in the flag
     if constexpr (REG) {
 #pragma unroll
       for (int j = 0; j < SIG_MAXPT; ++j)
@@ -110,7 +110,7 @@ struct Samples {
     }
   }
   template <class F>
-  __device__ __forceinline__ void for_each(F&& f) const {  // f(residual, validity flag); f linear in the flag
+  __device__ __forceinline__ void for_each(F&& f) const { RGBID_FP_STRICT  // f(residual, validity flag); f linear in the flag
     if constexpr (REG) {
 #pragma unroll
       for (int j = 0; j < SIG_MAXPT; ++j)
@@ -127,15 +127,15 @@ struct Samples {
 };
 
 // x * y + a in the accumulator's precision (fp32 for the register path, double for the streaming path)
-__device__ __forceinline__ float mad_acc(float x, float y, float a) { return fmaf(x, y, a); }
-__device__ __forceinline__ double mad_acc(float x, float y, double a) { return fma((double)x, (double)y, a); }
+__device__ __forceinline__ float mad_acc(float x, float y, float a) { RGBID_FP_STRICT return fmaf(x, y, a); }
+__device__ __forceinline__ double mad_acc(float x, float y, double a) { RGBID_FP_STRICT return fma((double)x, (double)y, a); }
 
 // one moments pass: partialBiasAndSigmaStudent (:258-332) when student_variant, else partialBiasAndSigma (:179-255).
 // Per-sample divisions are reciprocal multiplies (<= 1 ulp) and the per-thread partial sums are fp32: the pass
 // is VALU-bound, and the moments only feed a 10%-tolerance fixed point.
 template <class SM>
 __device__ __forceinline__ void pass_moments(const SM& S, float bias, float sigma, float nu, int mest, bool student_variant,
-                                             BlockSum& sm, float& swsr, float& swr, float& sw, float& nel) {
+                                             BlockSum& sm, float& swsr, float& swr, float& sw, float& nel) { RGBID_FP_STRICT
   typename SM::Acc a[4] = {0, 0, 0, 0};
   const float inv_sigma = 1.f / sigma, nup1 = nu + 1.f;
   auto acc = [&](float er, float weight, float valid) {  // weight is already 0 for an invalid sample
@@ -176,7 +176,7 @@ __device__ __forceinline__ void pass_moments(const SM& S, float bias, float sigm
 }
 
 // finalReductionBiasAndSigma :361-407
-__device__ __forceinline__ void final_bias_sigma(float swsr, float swr, float sw, float nel, float& bias, float& sigma) {
+__device__ __forceinline__ void final_bias_sigma(float swsr, float swr, float sw, float nel, float& bias, float& sigma) { RGBID_FP_STRICT
   float b = swr / sw;
   bias = b;
   sigma = sqrtf((swsr - 2.f * b * swr + b * b * sw) / nel);
@@ -184,7 +184,7 @@ __device__ __forceinline__ void final_bias_sigma(float swsr, float swr, float sw
 
 // partialFuncWeightsNu :410-468 + finalReductionFuncWeightsNu :471-512 (S holds en^2 after to_squared_normalised)
 template <class SM>
-__device__ __forceinline__ float func_weights_nu(const SM& S, float bias, float inv_sigma, float nu, BlockSum& sm) {
+__device__ __forceinline__ float func_weights_nu(const SM& S, float bias, float inv_sigma, float nu, BlockSum& sm) { RGBID_FP_STRICT
   typename SM::Acc a[4] = {0, 0, 0, 0};
   const float nup1 = nu + 1.f;
   // sum ln w = N ln(nu+1) + ln 2 * sum log2 r  and  sum w = (nu+1) sum r  with r = 1 / (nu + en^2) (finite and positive also for a
@@ -202,14 +202,14 @@ __device__ __forceinline__ float func_weights_nu(const SM& S, float bias, float 
 }
 
 // C(nu) = -psi(nu/2) + ln(nu/2) + mean(ln w - w) + 1 + psi((nu+1)/2) - ln((nu+1)/2)   (sigmaFuncs.cu:951)
-__device__ __forceinline__ float C_nu(const NuTable& T, float nu, float fw) {
+__device__ __forceinline__ float C_nu(const NuTable& T, float nu, float fw) { RGBID_FP_STRICT
   int k = (int)((nu - 2.f) * 2.f);  // exact: nu is a multiple of 0.5 in [2,10]
   return T.t[k][0] + T.t[k][1] + fw + 1.f + T.t[k][2] - T.t[k][3];
 }
 
 // bisection of C(nu) on [2,10]: sigmaFuncs.cu:934-1039 == :1100-1205
 template <class SM>
-__device__ __forceinline__ float estimate_nu(SM& S, const NuTable& T, float bias, float sigma_, BlockSum& sm) {
+__device__ __forceinline__ float estimate_nu(SM& S, const NuTable& T, float bias, float sigma_, BlockSum& sm) { RGBID_FP_STRICT
   const float sigma = 1.f / sigma_;  // inv_sigma; S.e becomes en^2 (the residuals are not used after this point)
   S.to_squared_normalised(bias, sigma);
   float nu_up = 10.f, nu_down = 2.f, nu_new = 0.f, nu;
@@ -232,7 +232,7 @@ __device__ __forceinline__ float estimate_nu(SM& S, const NuTable& T, float bias
 
 // the three host wrappers of the reference as one device routine over a sample set
 template <class SM>
-__device__ __forceinline__ void sigma_core(SM& S, const NuTable& T, int mode, int mestimator, float& bias, float& sigma, float& nu, BlockSum& sm) {
+__device__ __forceinline__ void sigma_core(SM& S, const NuTable& T, int mode, int mestimator, float& bias, float& sigma, float& nu, BlockSum& sm) { RGBID_FP_STRICT
   float swsr, swr, sw, nel;
   if (mode == 0) {
     // computeSigmaAndNuStudent :858-1066
@@ -266,10 +266,10 @@ __device__ __forceinline__ void sigma_core(SM& S, const NuTable& T, int mode, in
 struct ArrayGetter {
   const float* p;
   int pos;
-  __device__ __forceinline__ float operator()(int i) const { return p[i]; }
-  __device__ __forceinline__ void seek(int i) { pos = i; }
-  __device__ __forceinline__ float load() const { return p[pos]; }
-  __device__ __forceinline__ void step() { pos += SIG_T; }
+  __device__ __forceinline__ float operator()(int i) const { RGBID_FP_STRICT return p[i]; }
+  __device__ __forceinline__ void seek(int i) { RGBID_FP_STRICT pos = i; }
+  __device__ __forceinline__ float load() const { RGBID_FP_STRICT return p[pos]; }
+  __device__ __forceinline__ void step() { RGBID_FP_STRICT pos += SIG_T; }
 };
 
 // fused engine path: the lattice residuals are warped on the fly (W1, I1 are never materialised)
@@ -279,10 +279,10 @@ struct FusedLatticeGetter {
   int lane, stride, interp_mode;
   int fast;            // the same arithmetic as the normal-equation kernel that follows (warp_device.h fastnum)
   // both channels of one lattice sample (the inverse-depth warp is shared)
-  __device__ __forceinline__ void both(int ly, int lx, float& rd, float& ri) const {
+  __device__ __forceinline__ void both(int ly, int lx, float& rd, float& ri) const { RGBID_FP_STRICT
     both_given(ly, lx, px<float>(W0, lane, ly * stride, lx * stride), px<float>(I0, lane, ly * stride, lx * stride), rd, ri);
   }
-  __device__ __forceinline__ void both_given(int ly, int lx, float w0, float i0v, float& rd, float& ri) const {
+  __device__ __forceinline__ void both_given(int ly, int lx, float w0, float i0v, float& rd, float& ri) const { RGBID_FP_STRICT
     int y = ly * stride, x = lx * stride;
     float w1, i1;
     if (fast) {
@@ -301,4 +301,3 @@ struct FusedLatticeGetter {
 
 }  // namespace rgbid
 
-#pragma clang fp contract(fast)   // the translation unit's default again (hipcc: fast); kernels_sigma.hip switches it off for its own kernels

@@ -101,6 +101,7 @@ int rgbid_tracker_set_engine_backed(rgbid_tracker* h, int on) {
   if (!h) return RGBID_E_INVALID;
   return h->t->setEngineBacked(on != 0) ? RGBID_OK : RGBID_E_INVALID;
 }
+int rgbid_tracker_get_engine_backed(const rgbid_tracker* h, int* on) { if (!h || !on) return RGBID_E_INVALID; *on = h->t->engineBacked() ? 1 : 0; return RGBID_OK; }
 int rgbid_tracker_reset(rgbid_tracker* h) { if (!h) return RGBID_E_INVALID; h->t->reset(); return RGBID_OK; }
 int rgbid_tracker_load_settings(rgbid_tracker* h, const char* ini_path) {
   if (!h || !ini_path) return RGBID_E_INVALID;

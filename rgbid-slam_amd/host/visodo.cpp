@@ -140,6 +140,16 @@ void m3f_inv(const float* A, float* I) {
 }
 }  // namespace
 
+// K_d dRc K_c^-1, K_d t_dc and the inverse of the first (src/visodo.cpp:792-801), in float: shared by the host-driven front-end and the engine's configuration
+void VisodoTracker::stereoProjections(float dRc_proj[9], float t_dc_proj[3], float cRd_proj[9]) {
+  Matrix3f Kc = getCalibMatrix(0), Kd = getCalibMatrixDepth(0);
+  float Kci[9], T[9];
+  m3f_inv(Kc.m, Kci);
+  m3f_mul(Kd.m, dRc_, T); m3f_mul(T, Kci, dRc_proj);
+  for (int i = 0; i < 3; ++i) t_dc_proj[i] = Kd.m[i * 3] * t_dc_[0] + Kd.m[i * 3 + 1] * t_dc_[1] + Kd.m[i * 3 + 2] * t_dc_[2];
+  m3f_inv(dRc_proj, cRd_proj);
+}
+
 void VisodoTracker::prepareImagesCustomCalibration(const DepthMap& depth_raw, const View& colors_raw) {
   // src/visodo.cpp:775-824: undistort both images, correct the depth-sensor distortion, register depth onto the RGB camera
   if (depthinv_distorted_.rows() != rows_) {  // allocateBuffers :619-624 (only needed on this path)
@@ -157,12 +167,8 @@ void VisodoTracker::prepareImagesCustomCalibration(const DepthMap& depth_raw, co
   convertDepth2InvDepth(depth_raw, depthinv_distorted_, factor_depth_);
   undistortIntensity(intensity_distorted_, intensities_curr_[0], rgb_intrinsics);
   undistortDepthInv(depthinv_distorted_, depthinv_corr_distorted_, depthinv_preregister_, depth_intrinsics, depth_spdist);
-  Matrix3f Kc = getCalibMatrix(0), Kd = getCalibMatrixDepth(0);
-  float Kci[9], T[9], dRc_proj[9], cRd_proj[9], t_dc_proj[3];
-  m3f_inv(Kc.m, Kci);
-  m3f_mul(Kd.m, dRc_, T); m3f_mul(T, Kci, dRc_proj);
-  for (int i = 0; i < 3; ++i) t_dc_proj[i] = Kd.m[i * 3] * t_dc_[0] + Kd.m[i * 3 + 1] * t_dc_[1] + Kd.m[i * 3 + 2] * t_dc_[2];
-  m3f_inv(dRc_proj, cRd_proj);
+  float dRc_proj[9], cRd_proj[9], t_dc_proj[3];
+  stereoProjections(dRc_proj, t_dc_proj, cRd_proj);
   Mat33 dRc_dev, cRd_dev; float3 t_dev;
   for (int i = 0; i < 3; ++i) {
     dRc_dev.data[i].x = dRc_proj[i * 3]; dRc_dev.data[i].y = dRc_proj[i * 3 + 1]; dRc_dev.data[i].z = dRc_proj[i * 3 + 2];
@@ -680,12 +686,21 @@ float VisodoTracker::computeInterframeTime() {
 }
 
 // ---- engine-backed mode: the same trackNewFrame, driven through a one-lane device-resident engine (include/rgbid_engine.h) ---------------------------
-bool VisodoTracker::setEngineBacked(bool on) {
-  if (!on) { engine_backed_ = false; return true; }
-  if (global_time_ != 0) return false;                                  // before the first frame (or after reset())
+// What the one-lane engine cannot take over from the host-driven loop; nullptr = nothing (round 5: CHI_SQUARED termination and custom calibration are
+// engine configurations now)
+const char* VisodoTracker::engineObstacle() const {
   const bool identity_start = std::memcmp(init_Rcam_.m, Matrix3ft::Identity().m, sizeof(init_Rcam_.m)) == 0 && init_tcam_[0] == 0.0 && init_tcam_[1] == 0.0 && init_tcam_[2] == 0.0;
-  if (termination_ == device::CHI_SQUARED || custom_registration_ || !identity_start || levels_ > 8) return false;   // host-driven only
-  engine_backed_ = true;
+  if (!identity_start) return "a non-identity initial camera pose";
+  if (levels_ > 8) return "more than 8 pyramid levels";
+  if (std::getenv("RGBID_VISODO_HOST_DRIVEN")) return "RGBID_VISODO_HOST_DRIVEN is set";
+  return nullptr;
+}
+
+bool VisodoTracker::setEngineBacked(bool on) {
+  if (global_time_ != 0) return false;                                  // before the first frame (or after reset())
+  if (!on) { engine_backed_ = false; engine_auto_ = false; return true; }
+  if (engineObstacle()) return false;                                   // stays as it was
+  engine_backed_ = true; engine_auto_ = false;
   return true;
 }
 
@@ -700,6 +715,7 @@ bool VisodoTracker::createEngine() {
   }
   rgbid_engine_config c;
   rgbid_engine_default_config(&c);
+  if (real_time_flag_) visodo_iterations_[0] = 5;   // :961-964 (estimateVisualOdometry does this on every frame; the engine's schedule is fixed at its creation)
   c.rows = rows_; c.cols = cols_; c.levels = levels_; c.lanes = 1;
   for (int i = 0; i < 8; ++i) c.iters[i] = i < levels_ ? visodo_iterations_[i] : 0;
   c.mestimator = Mestimator_; c.motion_model = motion_model_; c.sigma_estimator = sigma_estimator_; c.weighting = weighting_;
@@ -717,6 +733,18 @@ bool VisodoTracker::createEngine() {
   c.record_capacity = 2;
   c.warping = warping_ == device::WARP_FIRST ? RGBID_WARP_FIRST : RGBID_PYR_FIRST;
   c.keyframe_capacity = 2;    // what resetIntegrationKeyframe hands to the back-end is read out right after the step that exported it
+  c.termination = termination_ == device::CHI_SQUARED ? RGBID_CHI_SQUARED : RGBID_ALL_ITERS;
+  c.custom_registration = custom_registration_ ? 1 : 0;
+  if (custom_registration_) {   // prepareImagesCustomCalibration's constants (:775-801), formed exactly as the host-driven path forms them
+    const float kc[5] = {k1_, k2_, k3_, k4_, k5_};
+    for (int i = 0; i < 5; ++i) c.rgb_dist[i] = kc[i];
+    c.depth_intr = rgbid_intr_k{fxd_, fyd_, cxd_, cyd_, k1d_, k2d_, k3d_, k4d_, k5d_};
+    const DepthDist dd(c1_, c0_, q0_[0], q0_[1], q0_[2], q0_[3], q0_[4], q0_[5], q0_[6], q0_[7], q0_[8], q1_[0], q1_[1], q1_[2], q1_[3], q1_[4], q1_[5], q1_[6], q1_[7], q1_[8]);
+    c.depth_dist = device::c_depth_dist(dd);   // the same conversion the bridge call undistortDepthInv applies (default pixel shifts included)
+    float t_dc_proj[3];
+    stereoProjections(c.dRc_proj, t_dc_proj, c.cRd_proj);
+    for (int i = 0; i < 3; ++i) c.t_dc_proj[i] = t_dc_proj[i];
+  }
   return rgbid_engine_create(&engine_, engine_ctx_, &c) == RGBID_OK;
 }
 
@@ -878,6 +906,14 @@ bool VisodoTracker::trackNewFrameEngine() {
 
 bool VisodoTracker::trackNewFrame() {
   // src/visodo.cpp:1967-2247
+  if (global_time_ == 0 && engine_backed_) {
+    // the mode of a run is settled at its first frame, with the configuration as it is NOW (settings / calibration files may have been loaded after
+    // setEngineBacked): what the engine cannot take over runs host-driven -- same results, ~330 bridge calls per frame instead of one launch sequence
+    if (const char* why = engineObstacle()) {
+      std::cerr << "VisodoTracker: host-driven frame loop (" << why << "; the device-resident engine is used otherwise)" << std::endl;
+      engine_backed_ = false;
+    }
+  }
   if (engine_backed_) return trackNewFrameEngine();
   pcl::gpu::ScopedAsyncBridge bridge_scope(async_bridge_);
   delta_t_ = computeInterframeTime();

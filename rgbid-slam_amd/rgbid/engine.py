@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import Img, check
-from .device import Context
+from .device import Context, DepthDist, IntrK
 
 ST_TRACKED, ST_LOST, ST_ODO_KF, ST_INTEGR_KF, ST_FIRST, ST_KF_EXPORTED = 1, 2, 4, 8, 16, 32
 
@@ -29,6 +29,9 @@ class EngineConfig(C.Structure):
         ("use_graph", C.c_int), ("fused_gn", C.c_int), ("chi_square_stats", C.c_int), ("preview", C.c_int),
         ("record_capacity", C.c_int), ("warping", C.c_int), ("keyframe_capacity", C.c_int), ("fast_numerics", C.c_int),
         ("defer_keyframe_maps", C.c_int),
+        ("termination", C.c_int), ("custom_registration", C.c_int), ("rgb_dist", C.c_float * 5),
+        ("depth_intr", IntrK), ("depth_dist", DepthDist),
+        ("dRc_proj", C.c_float * 9), ("t_dc_proj", C.c_float * 3), ("cRd_proj", C.c_float * 9),
     ]
 
 
@@ -191,6 +194,19 @@ class Engine:
             host = np.empty((im.rows, im.cols, 3), np.uint8)
             check(self.L.rgbid_memcpy2d_d2h(self.ctx._h, host.ctypes.data_as(C.c_void_p), C.c_size_t(im.cols * 3), C.c_void_p(im.data), C.c_size_t(im.step),
                                             C.c_size_t(im.cols * 3), C.c_size_t(im.rows)))
+            outs.append(host)
+        return outs
+
+    def current_maps(self, lane):
+        """Host copies of a lane's current-frame level-0 maps: inverse depth, intensity (rgbid_engine_current_maps)."""
+        imgs = [Img() for _ in range(2)]
+        check(self.L.rgbid_engine_current_maps(self._h, int(lane), *[C.byref(i) for i in imgs]))
+        self.ctx.sync()
+        outs = []
+        for im in imgs:
+            host = np.empty((im.rows, im.cols), np.float32)
+            check(self.L.rgbid_memcpy2d_d2h(self.ctx._h, host.ctypes.data_as(C.c_void_p), C.c_size_t(im.cols * 4), C.c_void_p(im.data), C.c_size_t(im.step),
+                                            C.c_size_t(im.cols * 4), C.c_size_t(im.rows)))
             outs.append(host)
         return outs
 

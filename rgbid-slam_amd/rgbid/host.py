@@ -117,16 +117,22 @@ def default_config(**kw):
 class Tracker:
     """RGBID_SLAM::VisodoTracker (C++, host-driven) on device `device`; frames are passed as host numpy arrays."""
 
-    def __init__(self, cfg=None, device=0, engine_backed=False, **kw):
+    def __init__(self, cfg=None, device=0, engine_backed=None, **kw):
+        """engine_backed: None = the class default (the device-resident engine, host-driven fallback decided at the first frame), True / False = chosen"""
         self.cfg = cfg if cfg is not None else default_config(**kw)
         self._h = C.c_void_p()
         check(lib().rgbid_tracker_create(C.byref(self._h), C.byref(self.cfg), int(device)))
-        if engine_backed:
-            self.set_engine_backed(True)
+        if engine_backed is not None:
+            self.set_engine_backed(bool(engine_backed))
 
     def set_engine_backed(self, on):
         """VisodoTracker::setEngineBacked: each trackNewFrame is one step of a one-lane device-resident engine (bit-exact numerics class)."""
         check(lib().rgbid_tracker_set_engine_backed(self._h, int(bool(on))))
+
+    def engine_backed(self):
+        on = C.c_int()
+        check(lib().rgbid_tracker_get_engine_backed(self._h, C.byref(on)))
+        return bool(on.value)
 
     def close(self):
         if self._h:

@@ -12,6 +12,7 @@ import torch
 from oracle import oracle as O
 from rgbid import device, synth
 from rgbid import engine as E
+from tests.util import assert_bits
 
 pytestmark = pytest.mark.gpu
 
@@ -34,7 +35,7 @@ def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, m
     for k in range(n_frames):
         eng.step(depth[k], rgb[k])
     rec = eng.records()
-    okw = {k: v for k, v in cfg_kw.items() if k != "fused_gn"}
+    okw = {k: v for k, v in cfg_kw.items() if k not in ("fused_gn", "fast_numerics")}
     okw.update(rows=rows, cols=cols, fx=K[0], fy=K[1], cx=K[2], cy=K[3])
     worst_r = worst_t = 0.0
     imposed = 0
@@ -394,6 +395,9 @@ def test_engine_step_accepts_torch_temporaries_async():
     ("geometric only", 120, 160, dict(weighting=O.GEOM_ONLY)),
     ("photometric only, exact bilinear", 120, 160, dict(weighting=O.PHOT_ONLY, interp_mode=O.INTERP_EXACT)),
     ("keyframe counters", 120, 160, dict(max_odoKF_count=2, max_integrKF_count=3)),
+    # round 5: termination = CHI_SQUARED (visodo.cpp:1134-1164) inside the engine -- a per-lane flag ends the level; with WARP_FIRST the level-0 warped maps the
+    # test reads are fresh at every level; exact numerics class (an RMSE comparison is a discontinuity the value tolerance of the FAST class could sit on)
+    ("chi-squared termination, warp first", 120, 160, dict(termination=O.CHI_SQUARED, warping=O.WARP_FIRST, fast_numerics=0)),
 ])
 def test_engine_configurations(ctx, name, rows, cols, cfg_kw):
     """every run-time switch of the tracker through the batched engine, each held to the oracle (1e-4 rad / 1e-4 m, same keyframe decisions)"""
@@ -408,6 +412,72 @@ def test_engine_configurations(ctx, name, rows, cols, cfg_kw):
     geom = cfg_kw.get("weighting") == O.GEOM_ONLY
     run_case(ctx, rows, cols, K, n_lanes=2, n_frames=5, cfg_kw=cfg_kw, seq_kw=dict(trans_step=(0.003, 0.01), rot_step_deg=(0.1, 0.6)), use_graph=0,
              map_outliers=4e-2 if geom else 5e-3, sigma_tol=5e-3 if geom else 1e-3)
+
+
+def test_engine_chi_squared_stops_lanes_independently(ctx):
+    """the CHI_SQUARED stop is taken PER LANE: a batch of different streams equals the same streams run one lane at a time, bit for bit, and the early exit
+    really fires (the records differ from an ALL_ITERS run)"""
+    K = (131.25, 131.25, 79.5, 59.5)
+    T, B = 5, 3
+    seqs, depth, rgb = make_lanes(B, T, 120, 160, K, trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8))
+
+    def run(lanes, term):
+        eng = E.Engine(ctx, E.default_config(rows=120, cols=160, lanes=len(lanes), K=K, use_graph=0, record_capacity=T, termination=term, warping=O.WARP_FIRST, fast_numerics=0))
+        for k in range(T):
+            eng.step(depth[k][lanes].contiguous(), rgb[k][lanes].contiguous())
+        r = eng.records().copy(); eng.close()
+        return r
+    batch = run([0, 1, 2], O.CHI_SQUARED)
+    for l in range(B):
+        single = run([l], O.CHI_SQUARED)
+        assert batch[:, l].tobytes() == single[:, 0].tobytes(), l
+    allit = run([0, 1, 2], O.ALL_ITERS)
+    assert np.abs(batch["R"] - allit["R"]).max() > 1e-7
+
+
+def test_engine_custom_calibration(ctx):
+    """cfg.custom_registration = 1 (round 5): prepareImagesCustomCalibration (visodo.cpp:775-824) as predicated prep-stage launches of the engine -- undistort,
+    depth-distortion correction, depth -> colour registration -- per lane: the registered inverse depth and the undistorted intensity are the oracle's bit
+    for bit, the poses within the north-star tolerance"""
+    import ctypes as C
+    from rgbid import _lib
+    from rgbid.device import IntrK, depth_dist
+    rows, cols, T, B = 480, 640, 3, 2
+    K = synth.TUM_K
+    seqs, depth, rgb = make_lanes(B, T, rows, cols, K)
+    rgbk = (0.02, -0.04, 0.0005, -0.0004, 0.01)
+    dk = (571.0, 572.5, 316.0, 241.5, -0.015, 0.03, 0.0003, 0.0002, -0.008)
+    dd = dict(c1=1.01, c0=-0.002, q0=(0.001, -0.002, 0.001, 0.0, 0.0005, -0.0004, 0.0, 0.0, 0.0), q1=(0.005, 0.01, 0.0, 0.0, -0.002, 0.001, 0.0, 0.0, 0.0))
+    dRc = [0.99995, -0.008, 0.006, 0.00803, 0.99995, -0.005, -0.00596, 0.00505, 0.99997]
+    t_dc = (0.0251, -0.0012, 0.0031)
+    cfg = E.default_config(rows=rows, cols=cols, lanes=B, K=K, use_graph=0, record_capacity=T, custom_registration=1)
+    for i, v in enumerate(rgbk):
+        cfg.rgb_dist[i] = v
+    cfg.depth_intr = IntrK(*dk)
+    cfg.depth_dist = depth_dist(**dd)
+    _lib.check(_lib.lib().rgbid_engine_config_set_stereo(C.byref(cfg), (C.c_float * 9)(*dRc), (C.c_float * 3)(*t_dc)))
+    eng = E.Engine(ctx, cfg)
+    orcs = []
+    for l in range(B):
+        o = O.Tracker(O.default_config(rows=rows, cols=cols, fx=K[0], fy=K[1], cx=K[2], cy=K[3]))
+        o.set_custom_calibration((K[0], K[1], K[2], K[3]) + rgbk, dk, O.depth_dist(**dd), dRc, t_dc)
+        orcs.append(o)
+    for k in range(T):
+        eng.step(depth[k], rgb[k])
+        for l in range(B):
+            orcs[l].track(depth[k, l].cpu().numpy().view(np.uint16), rgb[k, l].cpu().numpy())
+            iD, I = eng.current_maps(l)
+            assert_bits(iD, orcs[l].cur_depthinv(), 0, f"registered iD, lane {l} frame {k}")
+            assert_bits(I, orcs[l].cur_intensity(), 0, f"undistorted intensity, lane {l} frame {k}")
+    rec = eng.records()
+    for l in range(B):
+        Rs, ts = orcs[l].poses()
+        for k in range(1, T):
+            assert rec[k, l]["status"] & E.ST_TRACKED
+            assert rot_angle(Rs[k], rec[k, l]["R"]) < 1e-4 and np.linalg.norm(ts[k] - rec[k, l]["t"]) < 1e-4, (l, k)
+        assert np.isfinite(orcs[l].cur_depthinv()).mean() > 0.6
+        orcs[l].close()
+    eng.close()
 
 
 def test_engine_negative_fy_icl_nuim_calibration(ctx):

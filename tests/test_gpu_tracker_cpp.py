@@ -15,7 +15,7 @@ def rot_angle(Ra, Rb):
 
 
 # the compat tracker in its two modes: host-driven through the bridge (the reference's call sequence), and backed by the one-lane engine
-# (VisodoTracker::setEngineBacked, opt-in)
+# (VisodoTracker::setEngineBacked: the class default since round 5)
 both_modes = pytest.mark.parametrize("engine_backed", [False, True], ids=["host", "engine"])
 
 
@@ -88,11 +88,13 @@ def test_cpp_tracker_sigma_const_no_motion_model(engine_backed):
     run(120, 160, SMALL_K, 4, dict(sigma_estimator=O.SIGMA_CONS, motion_model=O.NO_MM), SLOW, engine_backed=engine_backed)
 
 
-def test_cpp_tracker_chi_squared_termination():
+@both_modes
+def test_cpp_tracker_chi_squared_termination(engine_backed):
     """termination = CHI_SQUARED (visodo.cpp:1134-1164): a level ends, and the last increment is undone, as soon as the full-lattice
-    RMSE grows.  Run with WARP_FIRST, where the level-0 warped maps the test reads are fresh at every level."""
+    RMSE grows.  Run with WARP_FIRST, where the level-0 warped maps the test reads are fresh at every level.  Engine-backed (round 5): the stop is a
+    per-lane flag written by a decision kernel that masks the rest of the level."""
     kw = dict(warping=O.WARP_FIRST, termination=O.CHI_SQUARED)
-    run(120, 160, SMALL_K, 5, kw, SLOW)
+    run(120, 160, SMALL_K, 5, kw, SLOW, engine_backed=engine_backed)
     # the early exit really fires on this sequence: the oracle's trajectory differs from the all-iterations one
     seq = synth.make_sequence(5, K=SMALL_K, rows=120, cols=160, device="cuda", **SLOW)
     d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
@@ -516,7 +518,7 @@ def test_async_bridge_changes_nothing_but_the_time():
     kw = dict(rows=120, cols=160, fx=SMALL_K[0], fy=SMALL_K[1], cx=SMALL_K[2], cy=SMALL_K[3], visratio_odo=0.985, visratio_integr=0.97)
     out = []
     for on in (0, 1):
-        trk = host.Tracker(host.default_config(**kw)); trk.set_async_bridge(on); trk.collect()
+        trk = host.Tracker(host.default_config(**kw), engine_backed=False); trk.set_async_bridge(on); trk.collect()
         for k in range(n):
             trk.track(d[k], c[k])
         R, t = trk.poses(); oR, ot, ocov = trk.odometry(); kd, kw_ = trk.keyframe_maps()
@@ -567,19 +569,73 @@ def test_engine_backed_tracker_equals_host_driven_tracker():
         assert qa[0] == qb[0] and all(np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True) for x, y in zip(qa[1:], qb[1:])), qa[0]
 
 
-def test_engine_backed_mode_refuses_what_only_the_host_loop_offers():
+def test_engine_backed_is_the_default_and_the_mode_is_settled_at_the_first_frame(capfd):
+    """Round 5: an unchanged caller gets the device-resident engine; what the engine cannot take over falls back to the host-driven loop by itself (logged),
+    decided at the first frame with the configuration as it is THEN (a calibration loaded after setEngineBacked must not be ignored); the mode
+    cannot change once a frame has been taken."""
+    import os
     kw = dict(rows=120, cols=160, fx=SMALL_K[0], fy=SMALL_K[1], cx=SMALL_K[2], cy=SMALL_K[3])
-    trk = host.Tracker(host.default_config(termination=O.CHI_SQUARED, **kw))
-    with pytest.raises(Exception):
-        trk.set_engine_backed(True)
-    trk.close()
     seq = synth.make_sequence(2, K=SMALL_K, rows=120, cols=160, device="cuda", **SLOW)
     d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
     trk = host.Tracker(host.default_config(**kw))
+    assert trk.engine_backed()
     trk.track(d[0], c[0])
+    assert trk.engine_backed()
     with pytest.raises(Exception):
-        trk.set_engine_backed(True)            # only before the first frame
+        trk.set_engine_backed(False)           # only before the first frame
     trk.close()
+    # CHI_SQUARED termination is an engine configuration now
+    trk = host.Tracker(host.default_config(termination=O.CHI_SQUARED, **kw)); trk.set_engine_backed(True); trk.track(d[0], c[0]); assert trk.engine_backed(); trk.close()
+    # an obstacle (here: the environment override) -> explicit request refused, default falls back with one line on stderr
+    os.environ["RGBID_VISODO_HOST_DRIVEN"] = "1"
+    try:
+        trk = host.Tracker(host.default_config(**kw))
+        with pytest.raises(Exception):
+            trk.set_engine_backed(True)
+        capfd.readouterr()
+        trk.track(d[0], c[0])
+        assert not trk.engine_backed() and "host-driven frame loop" in capfd.readouterr().err
+        trk.close()
+    finally:
+        del os.environ["RGBID_VISODO_HOST_DRIVEN"]
+
+
+@pytest.mark.parametrize("case", ["chi_squared_warp_first", "custom_calibration"])
+def test_engine_backed_equals_host_driven_in_the_round5_configurations(case, tmp_path):
+    """The two configurations that were host-driven only until round 4 -- CHI_SQUARED termination (visodo.cpp:1134-1164) and the custom-calibration front-end
+    (prepareImagesCustomCalibration, :775-824) -- through the engine: poses, covariances, lastInfo, current and fused maps IDENTICAL to the host-driven loop."""
+    n = 6
+    full = case == "custom_calibration"
+    rows, cols, K = (480, 640, synth.TUM_K) if full else (120, 160, SMALL_K)
+    seq = synth.make_sequence(n, K=K, rows=rows, cols=cols, device="cuda", **SLOW)
+    d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+    kw = dict(rows=rows, cols=cols, fx=K[0], fy=K[1], cx=K[2], cy=K[3])
+    if not full:
+        kw.update(warping=O.WARP_FIRST, termination=O.CHI_SQUARED)
+    out = []
+    for eb in (False, True):
+        trk = host.Tracker(host.default_config(**kw), engine_backed=eb)
+        if full:
+            from tests.test_gpu_calib import CALIB_INI
+            (tmp_path / "calib.ini").write_text(CALIB_INI)
+            trk.load_calibration(str(tmp_path / "calib.ini"))
+        rets, infos, maps = [], [], []
+        for k in range(n):
+            rets.append(trk.track(d[k], c[k]))
+            i = trk.last_info()
+            infos.append((i.lost, i.odo_kf_switched, i.integr_kf_switched, i.visratio_odo, i.visratio_integr, i.sigma_int, i.sigma_depthinv, i.nu_int, i.nu_depthinv))
+            maps.append(trk.current_maps())
+        assert trk.engine_backed() == eb
+        R, t = trk.poses(); oR, ot, ocov = trk.odometry(); kd, kw_ = trk.keyframe_maps()
+        out.append(dict(rets=rets, infos=np.array(infos, dtype=np.float64), R=R, t=t, oR=oR, ot=ot, ocov=ocov, kd=kd, kw=kw_,
+                        cd=np.stack([m[0] for m in maps]), ci=np.stack([m[1] for m in maps])))
+        trk.close()
+    a, b = out
+    assert a["rets"] == b["rets"] and sum(a["rets"]) == n - 1
+    for key in ("infos", "R", "t", "oR", "ot", "ocov", "kd", "kw", "cd", "ci"):
+        assert np.array_equal(np.asarray(a[key]), np.asarray(b[key]), equal_nan=True), key
+    if full:
+        assert np.isfinite(a["cd"][-1]).mean() > 0.6
 
 
 def test_tracker_preview_is_the_same_in_both_modes():
