@@ -508,6 +508,25 @@ def extra_config4(ctx, dev, K, world, rank, n_frames, chunks_per_gpu, fused, fas
                               "lane_steps_per_transition": c * repc["chunk_len"] / (n_frames - 1), "traj_max_trans_m_vs_unsharded": float(np.abs(tc - ts).max()),
                               "ate_rmse_m": _ate_rmse(tc, tg), "frames_lost": int(np.count_nonzero(stc & E.ST_LOST))})
             out["chunk_count_sweep_1gpu"] = sweep
+            # round 5: the chunk OVERLAP (rgbid_seq_config.warmup_frames: every chunk but the first tracks w frames before its own first frame, so its first
+            # recorded transition has a velocity prior and a settled keyframe), at the chunk count of the headline run.  Full sweep: tools/shard_sweep.py --warmup
+            # -> profiles/r05_shard_warmup.json; DESIGN section 6 states the rule that picks the recommended value
+            heads = np.array([a + 1 for (a, b) in ranges[1:]])
+            wsweep = []
+            for w in (0, 2, 4):
+                Rw = tw = stw = repw = None
+                for _ in range(2):
+                    Rw, tw, stw, _, repw = D.track_sequence(ctx, cfg, depth_h, rgb_h, chunks, warmup_frames=w)
+                hr = np.array([_rot_angle(Rw[k - 1].T @ Rw[k], Rs[k - 1].T @ Rs[k]) for k in heads])
+                ht = np.array([float(np.linalg.norm(Rw[k - 1].T @ (tw[k] - tw[k - 1]) - Rs[k - 1].T @ (ts[k] - ts[k - 1]))) for k in heads])
+                wsweep.append({"warmup_frames": w, "frames_per_s": 1e3 * n_frames / repw["total_ms"], "frames_per_lane_step": (n_frames - 1) / (chunks * (repw["chunk_len"] + w)),
+                               "chunk_head_vs_unsharded": {"max_rot_rad": float(hr.max()), "max_trans_m": float(ht.max()), "median_rot_rad": float(np.median(hr)),
+                                                           "median_trans_m": float(np.median(ht)), "share_within_1e-4": float(np.mean((hr < 1e-4) & (ht < 1e-4)))},
+                               "trajectory_vs_unsharded": {"max_rot_rad": max(_rot_angle(Rw[k], Rs[k]) for k in range(n_frames)), "max_trans_m": float(np.abs(tw - ts).max())},
+                               "ate_rmse_m": _ate_rmse(tw, tg), "frames_lost": int(np.count_nonzero(stw & E.ST_LOST))})
+            out["chunk_warmup_sweep_1gpu"] = {"points": wsweep, "bar": "north_star 1e-4 rad / 1e-4 m, chunk-head transition vs the unsharded run",
+                                              "rule": "the product default stays 0 (throughput: every warm-up frame is one more lock-step step); where chunk-head accuracy matters the "
+                                                      "recommended value is the one with the best ATE among those that cost <= 15 % of the frames/s of w = 0 (DESIGN section 6)"}
     del depth_h, rgb_h
     return out
 

@@ -4,6 +4,7 @@
 // intensity warp sampled on the KEYFRAME inverse depth.  OpenCV-free: keyframes are passed as host arrays.
 #pragma once
 #include "visodo.h"
+#include "../rgbid_kfalign.h"
 
 namespace RGBID_SLAM {
 
@@ -17,6 +18,16 @@ class KeyframeAlign {
  public:
   enum { LEVELS = 4 };            // keyframe_align.h:50
   KeyframeAlign(int rows = 480, int cols = 640);
+  ~KeyframeAlign();
+  KeyframeAlign(const KeyframeAlign&) = delete;
+  KeyframeAlign& operator=(const KeyframeAlign&) = delete;
+  // Default since round 5: alignKeyframes runs as the 1-pair case of the batched, device-resident aligner (include/rgbid_kfalign.h: one launch sequence, poses and
+  // solves on the device) instead of ~300 synchronous bridge calls; the result is the host-driven loop's bit for bit (tests/test_gpu_tracker_cpp.py).
+  // setHostDriven(true) selects the reference's call sequence through the bridge.
+  void setHostDriven(bool on) { host_driven_ = on; }
+  // loop-closure verification is a batch of candidate pairs: pairs alignments in lock-step (rgbid_kfalign_batched_host); arrays as documented there
+  bool alignKeyframesBatched(int pairs, const float* depthinv_ini, const unsigned char* grey_ini, const float* depthinv_end, const unsigned char* grey_end,
+                             const float* K, double* R, double* t, double* cov);
   // rotation/translation_ini2end: in = initial guess, out = aligned pose; covariance = A_final.inverse()
   bool alignKeyframes(const KeyframeImages& kf_ini, const KeyframeImages& kf_end, Matrix3ft& rotation_ini2end, Vector3ft& translation_ini2end,
                       Matrix6d& covariance_ini2end);
@@ -32,6 +43,12 @@ class KeyframeAlign {
   DeviceArray2D<device::float_type> gbuf_;
   DeviceArray<device::float_type> sumbuf_;
   std::vector<float> grey_f_;
+  bool host_driven_ = false;
+  ::rgbid_kfalign* aligner_ = nullptr;
+  ::rgbid_ctx* aligner_ctx_ = nullptr;
+  int aligner_cap_ = 0;
+  bool ensureAligner(int pairs);
+  void allocateHostDrivenBuffers();
 };
 
 }  // namespace RGBID_SLAM

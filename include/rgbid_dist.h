@@ -93,9 +93,12 @@ typedef struct rgbid_seq_config {
   const char* master_addr;      /* rank 0's address for the rendezvous (world > 1) */
   int master_port;
   int inject_chunk_len;         /* with `inject`: records per chunk in that buffer; must equal the chunk length the partition implies (else RGBID_E_INVALID) */
+  int warmup_frames;            /* round 5: every chunk but the first starts tracking this many frames BEFORE its first frame (as many as the sequence has), so that its
+                                 * first recorded transition is estimated with a velocity prior and a keyframe that is not brand new -- what the unsharded tracker has
+                                 * there.  Costs warmup_frames extra lock-step steps (the first chunk's lane sits them out); the warm-up transitions are discarded.  0 = off */
 } rgbid_seq_config;
 typedef struct rgbid_seq_report {
-  int lanes, chunk_len, n_chunks, world, rccl_ranks;
+  int lanes, chunk_len, n_chunks, world, rccl_ranks;   /* chunk_len: recorded frames per lane (the lock-step steps taken are chunk_len + warmup_frames) */
   double setup_ms;      /* communicator + engine creation, staging allocation (not part of the per-sequence cost of a resident service) */
   double track_ms;      /* uploads + chunk_len engine steps + record pack, until the engine's stream is idle */
   double gather_ms;     /* the all-gather + the D2H of the gathered records */

@@ -106,6 +106,10 @@ int rgbid_tracker_pop_keyframe(rgbid_tracker* t);          /* buffer_keyframes_.
 int rgbid_keyframe_align(int device, int rows, int cols, const float* depthinv_ini, const unsigned char* grey_ini,
                          const float* depthinv_end, const unsigned char* grey_end, float fx, float fy, float cx, float cy,
                          double R[9], double t[3], double cov[36]);
+/* the same with the loop chosen (host_driven = 1: the reference's call sequence through the bridge; 0: the class default, the device-resident aligner) */
+int rgbid_keyframe_align_mode(int device, int rows, int cols, const float* depthinv_ini, const unsigned char* grey_ini,
+                              const float* depthinv_end, const unsigned char* grey_end, float fx, float fy, float cx, float cy,
+                              double R[9], double t[3], double cov[36], int host_driven);
 
 /* ---- dataset I/O (tools/evaluation.cpp:122-351,380-439): PNG codec, TUM/ICL association files, trajectory writer ---- */
 int rgbid_png_info(const char* path, int* rows, int* cols, int* channels, int* bit_depth);

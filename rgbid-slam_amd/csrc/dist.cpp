@@ -434,6 +434,8 @@ int rgbid_dist_track_sequence(rgbid_ctx* ctx, const rgbid_seq_config* cfg, const
   rep.lanes = lanes; rep.chunk_len = L; rep.n_chunks = n_chunks; rep.world = world; rep.rccl_ranks = 0;
   double track_ms = 0.0, gather_ms = 0.0;
 
+  const int W = cfg->warmup_frames;
+  if (W < 0 || W > 64 || (inject && W != 0)) return RGBID_E_INVALID;   // injected records carry no warm-up
   if (inject) {
     if (cfg->inject_chunk_len != L) return RGBID_E_INVALID;   // the caller's buffer is laid out for another chunk length
     rep.setup_ms = ms_since(t_setup);
@@ -462,18 +464,20 @@ int rgbid_dist_track_sequence(rgbid_ctx* ctx, const rgbid_seq_config* cfg, const
       rep.rccl_ranks = rgbid_dist_world(S.comm);
     }
     rgbid_engine_config e2 = ec;
-    e2.lanes = lanes; e2.record_capacity = L; e2.use_graph = 0;   // eager steps read the staged frames in place
+    e2.lanes = lanes; e2.record_capacity = L + W; e2.use_graph = 0;   // eager steps read the staged frames in place
     if ((r = rgbid_engine_create(&S.eng, ctx, &e2))) return r;
     size_t eb = 0; rgbid_engine_bytes(S.eng, &eb); rep.engine_bytes = eb;
     const size_t fd = (size_t)ec.rows * ec.cols * 2, fc = (size_t)ec.rows * ec.cols * 3;
-    rep.staged_bytes = (fd + fc) * n_local;
-    hipError_t he = hipMalloc(&S.d_depth, fd * n_local);
-    if (he == hipSuccess) he = hipMalloc(&S.d_rgb, fc * n_local);
+    const int steps = L + W;                                   // lock-step steps: W warm-up steps, then the chunk
+    const size_t n_staged = (size_t)lanes * steps;
+    rep.staged_bytes = (fd + fc) * n_staged;
+    hipError_t he = hipMalloc(&S.d_depth, fd * n_staged);
+    if (he == hipSuccess) he = hipMalloc(&S.d_rgb, fc * n_staged);
     if (he == hipSuccess) he = hipMalloc(&S.d_local, sizeof(rgbid_gather_record) * n_local);
     if (he == hipSuccess && world > 1 && S.comm) he = hipMalloc(&S.d_all, sizeof(rgbid_gather_record) * n_local * world);
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&S.copy, hipStreamNonBlocking);
-    S.ev.resize(L, nullptr);
-    for (int j = 0; j < L && he == hipSuccess; ++j) he = hipEventCreateWithFlags(&S.ev[j], hipEventDisableTiming);
+    S.ev.resize(steps, nullptr);
+    for (int j = 0; j < steps && he == hipSuccess; ++j) he = hipEventCreateWithFlags(&S.ev[j], hipEventDisableTiming);
     if (he != hipSuccess) { (void)hipGetLastError(); return he == hipErrorOutOfMemory ? RGBID_E_NOMEM : (int)he; }
     AsyncGuard async_guard(ctx);   // declared after S: the stream is drained before the engine / staging buffers go
     rgbid_ctx_sync(ctx);
@@ -481,20 +485,27 @@ int rgbid_dist_track_sequence(rgbid_ctx* ctx, const rgbid_seq_config* cfg, const
     if (S.comm && (r = rgbid_dist_barrier(S.comm))) return r;   // ranks start their clocks together
     // ---- uploads on the copy stream, one event per step; step j waits for its frames only, so step j + 1's frames travel while step j runs
     const auto t0 = Clock::now();
-    for (int j = 0; j < L; ++j) {
+    // warm-up (cfg->warmup_frames): lane l of chunk c starts at frame first[c] - wc, wc = min(W, first[c]); step j of the lock-step run feeds it frame
+    // first[c] - W + j once that frame exists (j >= W - wc) and lets it sit the step out before (rgbid_engine_set_active), so that EVERY lane takes its
+    // chunk's first frame at step W and the records of steps W .. W + L - 1 are the chunk's
+    std::vector<int> active(lanes, 1), active_prev(lanes, 1);
+    for (int j = 0; j < steps; ++j) {
       for (int l = 0; l < lanes; ++l) {
         const int c = owned[l];
-        const size_t k = (size_t)std::min(first[c] + j, last[c]);   // a shorter chunk repeats its last frame (its records past the chunk are not read)
+        const int wc = std::min(W, first[c]);
+        active[l] = j >= W - wc;
+        const size_t k = (size_t)std::min(std::max(first[c] - W + j, first[c] - wc), last[c]);   // a shorter chunk repeats its last frame (its records past the chunk are not read)
         he = hipMemcpyAsync((char*)S.d_depth + ((size_t)j * lanes + l) * fd, (const char*)depth_host + k * fd, fd, hipMemcpyHostToDevice, S.copy);
         if (he == hipSuccess) he = hipMemcpyAsync((char*)S.d_rgb + ((size_t)j * lanes + l) * fc, rgb_host + k * fc, fc, hipMemcpyHostToDevice, S.copy);
         if (he != hipSuccess) { (void)hipGetLastError(); return (int)he; }
       }
       he = hipEventRecord(S.ev[j], S.copy);
       if (he != hipSuccess) { (void)hipGetLastError(); return (int)he; }
+      if (W && (j == 0 || active != active_prev)) { if ((r = rgbid_engine_set_active(S.eng, active.data()))) return r; active_prev = active; }
       if ((r = rgbid_ctx_wait_event(ctx, S.ev[j]))) return r;
       if ((r = rgbid_engine_step(S.eng, (char*)S.d_depth + (size_t)j * lanes * fd, (char*)S.d_rgb + (size_t)j * lanes * fc))) return r;
     }
-    if ((r = rgbid_engine_pack_gather_records(S.eng, 0, L, (rgbid_gather_record*)S.d_local))) return r;
+    if ((r = rgbid_engine_pack_gather_records(S.eng, W, L, (rgbid_gather_record*)S.d_local))) return r;
     if ((r = rgbid_ctx_sync(ctx))) return r;
     track_ms = ms_since(t0);
     // ---- the exchange: ONE all-gather of the records
@@ -515,6 +526,22 @@ int rgbid_dist_track_sequence(rgbid_ctx* ctx, const rgbid_seq_config* cfg, const
     gather_ms = ms_since(t1);
   }
   const auto t2 = Clock::now();
+  if (W) {
+    // a warmed-up lane numbers its chunk's first frame wc (its warm-up frames came first), not 0: renumber the chunk from its own head, so that the
+    // composition's check of the ids (0 on the head, then 1 .. j, non-decreasing) holds what it held before.  A head that is not ahead of 0 although the
+    // chunk warmed up, i.e. a lane that did not run its warm-up, is refused.
+    for (int c = 0; c < n_chunks; ++c) {
+      const int wc = std::min(W, first[c]);
+      if (!wc) continue;
+      int s0 = 0, cnt = 0, owner = -1;
+      for (int rk = 0; rk < world; ++rk) { rgbid_dist_rank_chunks(n_chunks, world, rk, &s0, &cnt); if (c >= s0 && c < s0 + cnt) { owner = rk; break; } }
+      if (owner < 0) return RGBID_E_INVALID;
+      rgbid_gather_record* rec = all.data() + ((size_t)owner * lanes + (c - s0)) * L;
+      const int head = rec[0].frame_id;
+      if (head < 1 || head > wc) return RGBID_E_INVALID;
+      for (int j = 0; j < last[c] - first[c] + 1; ++j) rec[j].frame_id -= head;
+    }
+  }
   r = rgbid_dist_compose_trajectory(all.data(), world, lanes, n_chunks, L, first.data(), last.data(), R, t, status, cov);
   if (r) return r;
   rep.track_ms = track_ms; rep.gather_ms = gather_ms; rep.compose_ms = ms_since(t2);

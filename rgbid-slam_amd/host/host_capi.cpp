@@ -255,19 +255,24 @@ int rgbid_tracker_pop_keyframe(rgbid_tracker* h) {
   return RGBID_OK;
 }
 
-int rgbid_keyframe_align(int device, int rows, int cols, const float* depthinv_ini, const unsigned char* grey_ini, const float* depthinv_end,
-                         const unsigned char* grey_end, float fx, float fy, float cx, float cy, double R[9], double t[3], double cov[36]) {
+int rgbid_keyframe_align_mode(int device, int rows, int cols, const float* depthinv_ini, const unsigned char* grey_ini, const float* depthinv_end,
+                              const unsigned char* grey_end, float fx, float fy, float cx, float cy, double R[9], double t[3], double cov[36], int host_driven) {
   if (!depthinv_ini || !grey_ini || !depthinv_end || !grey_end || !R || !t || !cov) return RGBID_E_INVALID;
   int n = 0;
   if (rgbid_device_count(&n) != RGBID_OK || device < 0 || device >= n) return RGBID_E_NODEV;
   pcl::gpu::setDevice(device);
   KeyframeAlign ka(rows, cols);
+  ka.setHostDriven(host_driven != 0);
   KeyframeImages a = {depthinv_ini, grey_ini, fx, fy, cx, cy}, b = {depthinv_end, grey_end, fx, fy, cx, cy};
   Matrix3ft Rm; Vector3ft tv; Matrix6d c;
   std::memcpy(Rm.m, R, 72); std::memcpy(tv.v, t, 24);
   ka.alignKeyframes(a, b, Rm, tv, c);
   std::memcpy(R, Rm.m, 72); std::memcpy(t, tv.v, 24); std::memcpy(cov, c.data(), 288);
   return RGBID_OK;
+}
+int rgbid_keyframe_align(int device, int rows, int cols, const float* depthinv_ini, const unsigned char* grey_ini, const float* depthinv_end,
+                         const unsigned char* grey_end, float fx, float fy, float cx, float cy, double R[9], double t[3], double cov[36]) {
+  return rgbid_keyframe_align_mode(device, rows, cols, depthinv_ini, grey_ini, depthinv_end, grey_end, fx, fy, cx, cy, R, t, cov, 0);
 }
 
 struct rgbid_dataset { Evaluation* e; };

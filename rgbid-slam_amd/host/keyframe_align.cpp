@@ -2,6 +2,8 @@
 #include "../../include/rgbid/keyframe_align.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <iostream>
 
 #include "../../include/rgbid/se3.h"
 
@@ -14,6 +16,17 @@ KeyframeAlign::KeyframeAlign(int rows, int cols) : rows_(rows), cols_(cols), fin
   // keyframe_align.cpp:34-98
   const int iters[] = {5, 5, 3, 0};
   std::copy(iters, iters + LEVELS, alignment_iterations_);
+}
+
+KeyframeAlign::~KeyframeAlign() {
+  if (aligner_) rgbid_kfalign_destroy(aligner_);
+  if (aligner_ctx_) rgbid_ctx_destroy(aligner_ctx_);
+}
+
+// the containers of the host-driven loop (allocated on its first use: the device-resident aligner has its own)
+void KeyframeAlign::allocateHostDrivenBuffers() {
+  if (!depthinvs_ini_.empty()) return;
+  const int rows = rows_, cols = cols_;
   depthinvs_ini_.resize(LEVELS); depthinvs_end_.resize(LEVELS); warped_depthinvs_end_.resize(LEVELS);
   intensities_ini_.resize(LEVELS); intensities_end_.resize(LEVELS); warped_intensities_end_.resize(LEVELS);
   xGradsDepthinv_ini_.resize(LEVELS); yGradsDepthinv_ini_.resize(LEVELS); xGradsIntensity_ini_.resize(LEVELS); yGradsIntensity_ini_.resize(LEVELS);
@@ -29,12 +42,37 @@ KeyframeAlign::KeyframeAlign(int rows, int cols) : rows_(rows), cols_(cols), fin
   grey_f_.resize((size_t)rows * cols);
 }
 
+bool KeyframeAlign::ensureAligner(int pairs) {
+  // a context of the object's own (the per-thread default context ends with its thread, see VisodoTracker::createEngine)
+  if (!aligner_ctx_ && rgbid_ctx_create(&aligner_ctx_, pcl::gpu::current_device().load(), nullptr) != RGBID_OK) return false;
+  if (aligner_ && aligner_cap_ >= pairs) return true;
+  if (aligner_) { rgbid_kfalign_destroy(aligner_); aligner_ = nullptr; }
+  if (rgbid_kfalign_create(&aligner_, aligner_ctx_, rows_, cols_, pairs) != RGBID_OK) return false;
+  aligner_cap_ = pairs;
+  return true;
+}
+
+bool KeyframeAlign::alignKeyframesBatched(int pairs, const float* depthinv_ini, const unsigned char* grey_ini, const float* depthinv_end, const unsigned char* grey_end,
+                                          const float* K, double* R, double* t, double* cov) {
+  if (pairs < 1 || !ensureAligner(pairs)) return false;
+  return rgbid_kfalign_batched_host(aligner_, pairs, depthinv_ini, grey_ini, depthinv_end, grey_end, K, R, t, cov) == RGBID_OK;
+}
+
 bool KeyframeAlign::alignKeyframes(const KeyframeImages& a, const KeyframeImages& b, Affine3d& pose, Matrix6d& cov) {
   return alignKeyframes(a, b, pose.R, pose.t, cov);
 }
 
 bool KeyframeAlign::alignKeyframes(const KeyframeImages& kf_ini, const KeyframeImages& kf_end, Matrix3ft& rotation_ini2end,
                                    Vector3ft& translation_ini2end, Matrix6d& covariance_ini2end) {
+  if (!host_driven_) {
+    // the 1-pair case of the batched, device-resident aligner: the same kernels in the same order, the pose algebra in per-pair kernels
+    const float K[4] = {kf_ini.fx, kf_ini.fy, kf_ini.cx, kf_ini.cy};
+    if (!alignKeyframesBatched(1, kf_ini.depthinv, kf_ini.grey, kf_end.depthinv, kf_end.grey, K, rotation_ini2end.m, translation_ini2end.v, covariance_ini2end.data())) {
+      std::cerr << "KeyframeAlign: the device-resident aligner could not run" << std::endl; std::exit(0);   // as pcl::gpu::error()
+    }
+    return true;
+  }
+  allocateHostDrivenBuffers();
   pcl::gpu::ScopedAsyncBridge bridge_scope;   // the returned kernel times are not used here either (see include/rgbid/containers.hpp)
   Intr cam_intrinsics(kf_ini.fx, kf_ini.fy, kf_ini.cx, kf_ini.cy, 0.075f);
   // uploads (:120-129); grey_image_.convertTo(CV_32F)

@@ -139,7 +139,7 @@ class SeqReport(C.Structure):
 
 
 def track_sequence(ctx, engine_cfg, depth_host, rgb_host, n_chunks, world=1, rank=0, exchange=EXCHANGE_RCCL, master_addr="127.0.0.1", master_port=0,
-                   inject=None, n_frames=None):
+                   inject=None, n_frames=None, warmup_frames=0):
     """rgbid_dist_track_sequence: the C++ sharded-sequence driver (csrc/dist.cpp) on host frames depth [T, rows, cols] uint16 / rgb [T, rows, cols, 3]
     uint8 (numpy arrays, or CPU torch tensors -- pinned ones upload asynchronously).  inject (GATHER_DTYPE [n_chunks, chunk_len]) + n_frames: compose
     the given per-chunk records instead of running the engine (ctx / frames may be None).  Returns (R [T,3,3], t [T,3], status [T], cov [T,6,6], report)."""
@@ -147,7 +147,7 @@ def track_sequence(ctx, engine_cfg, depth_host, rgb_host, n_chunks, world=1, ran
 
     class SeqConfig(C.Structure):
         _fields_ = [("engine", EngineConfig), ("n_chunks", C.c_int), ("world", C.c_int), ("rank", C.c_int), ("exchange", C.c_int),
-                    ("master_addr", C.c_char_p), ("master_port", C.c_int), ("inject_chunk_len", C.c_int)]
+                    ("master_addr", C.c_char_p), ("master_port", C.c_int), ("inject_chunk_len", C.c_int), ("warmup_frames", C.c_int)]
 
     def ptr(a):
         if a is None:
@@ -158,6 +158,7 @@ def track_sequence(ctx, engine_cfg, depth_host, rgb_host, n_chunks, world=1, ran
     C.memmove(C.byref(cfg.engine), C.byref(engine_cfg), C.sizeof(EngineConfig))
     cfg.n_chunks = int(n_chunks); cfg.world = int(world); cfg.rank = int(rank); cfg.exchange = int(exchange)
     cfg.master_addr = master_addr.encode(); cfg.master_port = int(master_port)
+    cfg.warmup_frames = int(warmup_frames)
     T = int(n_frames) if n_frames is not None else int(depth_host.shape[0])
     inj = None
     if inject is not None:

@@ -245,13 +245,14 @@ class Tracker:
         return d, w
 
 
-def keyframe_align(depthinv_ini, grey_ini, depthinv_end, grey_end, K, R0=None, t0=None, device=0):
-    """KeyframeAlign::alignKeyframes on host arrays; returns (R, t, cov)."""
+def keyframe_align(depthinv_ini, grey_ini, depthinv_end, grey_end, K, R0=None, t0=None, device=0, host_driven=False):
+    """KeyframeAlign::alignKeyframes on host arrays; returns (R, t, cov).  host_driven: the reference's call sequence through the bridge instead of the
+    class default (the 1-pair case of the device-resident aligner, rgbid_kfalign.h)"""
     a = np.ascontiguousarray(depthinv_ini, np.float32); b = np.ascontiguousarray(depthinv_end, np.float32)
     ga = np.ascontiguousarray(grey_ini, np.uint8); gb = np.ascontiguousarray(grey_end, np.uint8)
     R = np.eye(3).reshape(9).copy() if R0 is None else _d(R0, 9).copy()
     t = np.zeros(3) if t0 is None else _d(t0, 3).copy()
     cov = np.zeros(36)
-    check(lib().rgbid_keyframe_align(int(device), a.shape[0], a.shape[1], _p(a), _p(ga), _p(b), _p(gb), C.c_float(K[0]), C.c_float(K[1]),
-                                     C.c_float(K[2]), C.c_float(K[3]), _p(R), _p(t), _p(cov)))
+    check(lib().rgbid_keyframe_align_mode(int(device), a.shape[0], a.shape[1], _p(a), _p(ga), _p(b), _p(gb), C.c_float(K[0]), C.c_float(K[1]),
+                                          C.c_float(K[2]), C.c_float(K[3]), _p(R), _p(t), _p(cov), int(bool(host_driven))))
     return R.reshape(3, 3), t, cov.reshape(6, 6)

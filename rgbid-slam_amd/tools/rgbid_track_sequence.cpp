@@ -116,6 +116,7 @@ int main(int argc, char* argv[]) {
     inject_chunk_len = (int)(inject.size() / (size_t)chunks);   // the driver refuses it unless it is the chunk length -frames / -chunks imply
   }
   cfg.inject_chunk_len = inject_chunk_len;
+  cfg.warmup_frames = arg_int(argc, argv, "-warmup", 0);   // frames every chunk but the first tracks before its own first frame (velocity prior, settled keyframe)
   rgbid_ctx* ctx = nullptr;
   if (inject.empty()) {
     int e = rgbid_ctx_create(&ctx, gpu, nullptr);

@@ -20,6 +20,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     names = _declared("rgbid.h")
     names += _declared("rgbid_engine.h")
+    names += _declared("rgbid_kfalign.h")
     batched = _declared("rgbid_batched.h")
     from rgbid import batched as BT
     assert set(batched) == set(BT.BATCHED_EXPORTS), set(batched) ^ set(BT.BATCHED_EXPORTS)

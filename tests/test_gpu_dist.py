@@ -69,6 +69,35 @@ def test_chunked_tracking_through_the_cabi_gather(ctx):
     assert np.array_equal(Ra, Rb) and np.array_equal(ta, tb)
 
 
+def test_sharded_sequence_with_warm_up_frames(ctx):
+    """rgbid_seq_config.warmup_frames (round 5): every chunk but the first tracks w frames before its own first frame, so that its first recorded transition
+    has a velocity prior and a settled keyframe.  w = 0 is the old behaviour bit for bit; with w > 0 the chunk heads come closer to the unsharded run, no
+    frame is lost, the run costs w more lock-step steps."""
+    from rgbid import device
+    K = (131.25, 131.25, 79.5, 59.5)
+    T, chunks = 41, 5
+    seq = synth.make_sequence(T, K=K, rows=120, cols=160, device="cuda", trans_step=(0.004, 0.012), rot_step_deg=(0.2, 0.8))
+    depth = seq["depth"].to(torch.int16).cpu().contiguous(); rgb = seq["rgb"].cpu().contiguous()
+    cfg = E.default_config(rows=120, cols=160, K=K)
+    R1, t1, st1, _, _ = D.track_sequence(ctx, cfg, depth, rgb, 1)
+    out = {}
+    for w in (0, 2, 4):
+        R, t, st, cov, rep = D.track_sequence(ctx, cfg, depth, rgb, chunks, warmup_frames=w)
+        assert rep["chunk_len"] == 9 and all(int(x) & E.ST_TRACKED for x in st[1:])
+        heads = [8 * c + 1 for c in range(1, chunks)]          # the first transition of every chunk but the first
+        dr = dt = 0.0
+        for k in heads:
+            dRa = R[k - 1].T @ R[k]; dRb = R1[k - 1].T @ R1[k]
+            dta = R[k - 1].T @ (t[k] - t[k - 1]); dtb = R1[k - 1].T @ (t1[k] - t1[k - 1])
+            dr = max(dr, rot_angle(dRa, dRb)); dt = max(dt, float(np.linalg.norm(dta - dtb)))
+        out[w] = (dr, dt, R, t)
+    Rz, tz, _ = sequence.track_chunked(ctx, seq["depth"].to(torch.int16).contiguous(), seq["rgb"].contiguous(), chunks, K)
+    assert np.array_equal(out[0][2], Rz) and np.array_equal(out[0][3], tz)          # w = 0: the driver as it was
+    print("chunk-head deviation vs the unsharded run (rad, m):", {w: (round(v[0], 7), round(v[1], 7)) for w, v in out.items()})
+    assert out[2][0] <= out[0][0] and out[2][1] <= out[0][1] and out[4][1] <= 1.2 * out[2][1] + 1e-6
+    assert out[4][0] < 2e-3 and out[4][1] < 5e-3
+
+
 def _run_bench(extra_args, env_extra=None, timeout=1500):
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

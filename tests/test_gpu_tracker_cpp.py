@@ -124,19 +124,75 @@ def test_cpp_tracker_four_levels_1280x960(engine_backed):
     run(960, 1280, K, 3, dict(levels=4, iters=[10, 5, 3, 3]), dict(), engine_backed=engine_backed)
 
 
-def test_keyframe_align_vs_oracle():
-    """KeyframeAlign (second consumer of the kernels: 4 levels, computeNuStudent, KF-iD sampling grid)."""
+def _kf_pair(seq, d, c, a, b):
+    iD = [O.depth2invdepth(d[k]) for k in (a, b)]
+    grey = [np.clip(np.rint(O.intensity(c[k])), 0, 255).astype(np.uint8) for k in (a, b)]
+    Rg, tg = [x.numpy() for x in synth.relative_pose(seq["R_wc"][a], seq["t_wc"][a], seq["R_wc"][b], seq["t_wc"][b])]
+    return iD, grey, Rg, tg
+
+
+@pytest.mark.parametrize("host_driven", [True, False], ids=["host", "device-resident"])
+def test_keyframe_align_vs_oracle(host_driven):
+    """KeyframeAlign (second consumer of the kernels: 4 levels, computeNuStudent, KF-iD sampling grid), in both of its loops: the reference's
+    call sequence through the bridge, and (the class default since round 5) the 1-pair case of the device-resident batched aligner."""
     seq = synth.make_sequence(4, device="cuda", trans_step=(0.01, 0.02), rot_step_deg=(0.5, 1.0))
     d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
-    iD = [O.depth2invdepth(d[k]) for k in (0, 3)]
-    grey = [np.clip(np.rint(O.intensity(c[k])), 0, 255).astype(np.uint8) for k in (0, 3)]
-    Rg, tg = [a.numpy() for a in synth.relative_pose(seq["R_wc"][0], seq["t_wc"][0], seq["R_wc"][3], seq["t_wc"][3])]
-    R, t, cov = host.keyframe_align(iD[0], grey[0], iD[1], grey[1], synth.TUM_K)
+    iD, grey, Rg, tg = _kf_pair(seq, d, c, 0, 3)
+    R, t, cov = host.keyframe_align(iD[0], grey[0], iD[1], grey[1], synth.TUM_K, host_driven=host_driven)
     Ro, to, covo = O.keyframe_align(iD[0], grey[0], iD[1], grey[1], synth.TUM_K)
     assert rot_angle(R, Ro) < 1e-4 and np.linalg.norm(t - to) < 1e-4, (rot_angle(R, Ro), np.linalg.norm(t - to))
     sc = np.sqrt(np.outer(np.diag(covo), np.diag(covo)))
     assert (np.abs(cov - covo) / sc).max() < 1e-2
     assert rot_angle(R, Rg) < 3e-3 and np.linalg.norm(t - tg) < 1e-2     # and it finds the true relative pose
+
+
+def test_keyframe_align_device_resident_equals_host_driven():
+    """the 1-pair case of rgbid_kfalign_batched runs the same kernels in the same order as the host-driven KeyframeAlign: pose and covariance IDENTICAL"""
+    seq = synth.make_sequence(4, device="cuda", trans_step=(0.01, 0.02), rot_step_deg=(0.5, 1.0))
+    d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+    iD, grey, _, _ = _kf_pair(seq, d, c, 0, 3)
+    a = host.keyframe_align(iD[0], grey[0], iD[1], grey[1], synth.TUM_K, host_driven=True)
+    b = host.keyframe_align(iD[0], grey[0], iD[1], grey[1], synth.TUM_K, host_driven=False)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("rows,cols", [(120, 160), (480, 640)])
+def test_keyframe_align_batched(rows, cols):
+    """rgbid_kfalign_batched: N keyframe pairs with their own intrinsics and initial guesses in lock-step, no host round trip: every pair within the north-star
+    tolerance of orc_keyframe_align, independent of its batch (a pair's result is the same bits whatever else rides along at a size where the launch plan
+    does not change, and within rounding otherwise), host and device entry points identical."""
+    import torch
+    from rgbid import device, kfalign
+    s = cols / 640.0
+    K0 = (525.0 * s, 525.0 * s, (319.5 + 0.5) * s - 0.5, (239.5 + 0.5) * s - 0.5)
+    n = 5
+    iDa, ga, iDb, gb, Ks, Rgs, tgs = [], [], [], [], [], [], []
+    for i in range(n):
+        seq = synth.make_sequence(4, seed=synth.SEED + 31 * i, K=K0, rows=rows, cols=cols, device="cuda", trans_step=(0.008, 0.02), rot_step_deg=(0.3, 1.0))
+        d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+        iD, grey, Rg, tg = _kf_pair(seq, d, c, 0, 2 + (i & 1))
+        iDa.append(iD[0]); iDb.append(iD[1]); ga.append(grey[0]); gb.append(grey[1]); Ks.append(K0); Rgs.append(Rg); tgs.append(tg)
+    iDa, iDb, ga, gb = [np.stack(x) for x in (iDa, iDb, ga, gb)]
+    Ks = np.asarray(Ks, np.float32)
+    # initial guesses: identity, and the ground truth perturbed (what a loop closer's PnP hands over)
+    R0 = np.stack([np.eye(3) if i % 2 == 0 else Rgs[i] for i in range(n)]); t0 = np.stack([np.zeros(3) if i % 2 == 0 else tgs[i] + 0.004 for i in range(n)])
+    ctx = device.Context(0)
+    al = kfalign.KfAlign(ctx, rows, cols, n)
+    R, t, cov = al.align(iDa, ga, iDb, gb, Ks, R0, t0)                                            # host entry point
+    Rd, td, covd = al.align(*[torch.from_numpy(x).cuda() for x in (iDa, ga, iDb, gb)], Ks, R0, t0)   # device entry point
+    assert np.array_equal(R, Rd) and np.array_equal(t, td) and np.array_equal(cov, covd)
+    assert al.launches() == 4 + 6 + 4 + 1 + 13 * 7 + 1
+    for i in range(n):
+        Ro, to, covo = O.keyframe_align(iDa[i], ga[i], iDb[i], gb[i], K0, R0=R0[i], t0=t0[i])
+        assert rot_angle(R[i], Ro) < 1e-4 and np.linalg.norm(t[i] - to) < 1e-4, (i, rot_angle(R[i], Ro), np.linalg.norm(t[i] - to))
+        sc = np.sqrt(np.outer(np.diag(covo), np.diag(covo)))
+        assert (np.abs(cov[i] - covo) / sc).max() < 1e-2
+        assert rot_angle(R[i], Rgs[i]) < 4e-3 and np.linalg.norm(t[i] - tgs[i]) < 1.5e-2
+        # the pair on its own
+        R1, t1, c1 = al.align(iDa[i:i + 1], ga[i:i + 1], iDb[i:i + 1], gb[i:i + 1], Ks[i:i + 1], R0[i:i + 1], t0[i:i + 1])
+        assert rot_angle(R1[0], R[i]) < 2e-6 and np.linalg.norm(t1[0] - t[i]) < 2e-6
+    al.close(); ctx.close()
 
 
 def test_cli_eval_harness_on_tum_layout(tmp_path):

@@ -10,7 +10,7 @@ base="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno
 make -C $C -j8 > /dev/null
 /opt/rocm/bin/hipcc $base $flags -c $C/$file -o /tmp/variant_$name.o
 objs=""
-for f in c_api c_api_batched kernels_prep kernels_warp kernels_sigma kernels_system kernels_calib engine; do
+for f in c_api c_api_batched kernels_prep kernels_warp kernels_sigma kernels_system kernels_calib engine kfalign; do
   if [ "$f.hip" = "$file" ]; then objs="$objs /tmp/variant_$name.o"; else objs="$objs $C/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/rgbid-slam_amd/lib/librgbid_hip_$name.so $objs

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--frames", type=int, default=2500)
     ap.add_argument("--chunks", default="8,16,32,64,128,256,512")
     ap.add_argument("--json", default="")
+    ap.add_argument("--warmup", default="0", help="comma list of rgbid_seq_config.warmup_frames to sweep for every chunk count (round 5: chunk overlap)")
     args = ap.parse_args()
     import bench as B
     from rgbid import device, dist as D, engine as E, synth
@@ -42,10 +43,10 @@ def main():
     Rs, ts, sts, _, rep1 = D.track_sequence(ctx, cfg, depth_h, rgb_h, 1)
     rows_out = [dict(chunks=1, frames_per_s=1e3 * F / rep1["total_ms"], total_ms=rep1["total_ms"], chunk_len=rep1["chunk_len"], lane_steps=rep1["chunk_len"],
                      efficiency=(F - 1) / rep1["chunk_len"], ate_rmse_m=B._ate_rmse(ts, tg), frames_lost=int(np.count_nonzero(sts & E.ST_LOST)))]
-    for chunks in [int(c) for c in args.chunks.split(",")]:
+    for chunks, warm in [(int(c), int(w)) for c in args.chunks.split(",") for w in args.warmup.split(",")]:
         reps = []
         for i in range(2):      # the first call pays the first touch of the engine's fresh memory
-            R, t, st, cov, rep = D.track_sequence(ctx, cfg, depth_h, rgb_h, chunks)
+            R, t, st, cov, rep = D.track_sequence(ctx, cfg, depth_h, rgb_h, chunks, warmup_frames=warm)
             reps.append(rep)
         rep = reps[-1]
         ranges = D.chunk_ranges(F, chunks)
@@ -55,21 +56,24 @@ def main():
             dRc, dtc = R[k - 1].T @ R[k], R[k - 1].T @ (t[k] - t[k - 1])
             dRs, dts = Rs[k - 1].T @ Rs[k], Rs[k - 1].T @ (ts[k] - ts[k - 1])
             head_r = max(head_r, B._rot_angle(dRc, dRs)); head_t = max(head_t, float(np.linalg.norm(dtc - dts)))
-        lane_steps = chunks * rep["chunk_len"]
-        rows_out.append(dict(chunks=chunks, frames_per_s=1e3 * F / rep["total_ms"], total_ms=rep["total_ms"], track_ms=rep["track_ms"], first_call_ms=reps[0]["total_ms"],
+        lane_steps = chunks * (rep["chunk_len"] + warm)
+        heads = np.array([a + 1 for (a, b) in ranges[1:]])
+        hr = np.array([B._rot_angle(R[k - 1].T @ R[k], Rs[k - 1].T @ Rs[k]) for k in heads]); ht = np.array([float(np.linalg.norm(R[k - 1].T @ (t[k] - t[k - 1]) - Rs[k - 1].T @ (ts[k] - ts[k - 1]))) for k in heads])
+        rows_out.append(dict(chunks=chunks, warmup_frames=warm, chunk_head_median_rot_rad=float(np.median(hr)), chunk_head_median_trans_m=float(np.median(ht)),
+                             chunk_heads_within_1e4=float(np.mean((hr < 1e-4) & (ht < 1e-4))), frames_per_s=1e3 * F / rep["total_ms"], total_ms=rep["total_ms"], track_ms=rep["track_ms"], first_call_ms=reps[0]["total_ms"],
                              chunk_len=rep["chunk_len"], lane_steps=lane_steps, efficiency=(F - 1) / lane_steps,
-                             ms_per_step=rep["track_ms"] / rep["chunk_len"],
+                             ms_per_step=rep["track_ms"] / (rep["chunk_len"] + warm),
                              chunk_head_max_rot_rad=head_r, chunk_head_max_trans_m=head_t,
                              traj_max_rot_rad=max(B._rot_angle(R[k], Rs[k]) for k in range(F)), traj_max_trans_m=float(np.abs(t - ts).max()),
                              ate_rmse_m=B._ate_rmse(t, tg), frames_lost=int(np.count_nonzero(st & E.ST_LOST)), engine_gb=rep["engine_bytes"] / 1e9))
         print(json.dumps(rows_out[-1]), flush=True)
-    print("| chunks | frames/s | ms | steps per lane | ms per step | lane-steps / transitions | chunk head dR / dt | trajectory dR / dt | ATE mm | lost |")
+    print("| chunks (warm-up) | frames/s | ms | steps per lane | ms per step | lane-steps / transitions | chunk head dR / dt | trajectory dR / dt | ATE mm | lost |")
     print("|---|---|---|---|---|---|---|---|---|---|")
     for r in rows_out:
         if r["chunks"] == 1:
             print(f"| 1 (unsharded) | {r['frames_per_s']:.0f} | {r['total_ms']:.0f} | {r['chunk_len']} | {r['total_ms'] / r['chunk_len']:.2f} | 1.00 | -- | -- | {1e3 * r['ate_rmse_m']:.2f} | {r['frames_lost']} |")
         else:
-            print(f"| {r['chunks']} | {r['frames_per_s']:.0f} | {r['total_ms']:.1f} | {r['chunk_len']} | {r['ms_per_step']:.2f} | {1 / r['efficiency']:.2f} | {r['chunk_head_max_rot_rad']:.1e} / {1e3 * r['chunk_head_max_trans_m']:.2f} mm | "
+            print(f"| {r['chunks']} ({r['warmup_frames']}) | {r['frames_per_s']:.0f} | {r['total_ms']:.1f} | {r['chunk_len']} | {r['ms_per_step']:.2f} | {1 / r['efficiency']:.2f} | {r['chunk_head_max_rot_rad']:.1e} / {1e3 * r['chunk_head_max_trans_m']:.2f} mm | "
                   f"{r['traj_max_rot_rad']:.1e} / {1e3 * r['traj_max_trans_m']:.2f} mm | {1e3 * r['ate_rmse_m']:.2f} | {r['frames_lost']} |")
     if args.json:
         json.dump(dict(frames=F, rows=rows_out), open(args.json, "w"), indent=1)
