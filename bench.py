@@ -531,6 +531,55 @@ def extra_config4(ctx, dev, K, world, rank, n_frames, chunks_per_gpu, fused, fas
     return out
 
 
+def extra_kfalign(ctx, dev, K):
+    """SURVEY 8 f-1 as a workload (round 5): KeyframeAlign::alignKeyframes (src/keyframe_align.cpp:115-357: 4 levels, {5,5,3,0} iterations, nu by bisection, intensity
+    sampled on the keyframe inverse depth) for N candidate pairs in lock-step through rgbid_kfalign_batched -- the loop closer's dense verification as a batch.
+    Pairs/s with the keyframes resident in HBM at 1 / 64 / 1 024 pairs; two pairs of every run checked against the CPU oracle (orc_keyframe_align)."""
+    from oracle import oracle as O
+    from rgbid import kfalign, synth
+    rows, cols = 480, 640
+    n_distinct = 8
+    iDa, ga, iDb, gb = [], [], [], []
+    for i in range(n_distinct):
+        seq = synth.make_sequence(4, seed=synth.SEED + 31 * i, K=K, rows=rows, cols=cols, device=dev, trans_step=(0.008, 0.02), rot_step_deg=(0.3, 1.0))
+        d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+        for k, (iD, g) in zip((0, 3), ((iDa, ga), (iDb, gb))):
+            iD.append(O.depth2invdepth(d[k])); g.append(np.clip(np.rint(O.intensity(c[k])), 0, 255).astype(np.uint8))
+    iDa, ga, iDb, gb = [torch.from_numpy(np.stack(x)).to(dev) for x in (iDa, ga, iDb, gb)]
+    points = []
+    worst_r = worst_t = 0.0
+    for n in (1, 64, 1024):
+        idx = torch.arange(n, device=dev) % n_distinct
+        ins = [x[idx].contiguous() for x in (iDa, ga, iDb, gb)]
+        al = kfalign.KfAlign(ctx, rows, cols, n)
+        al.align(*ins, K)                               # first touch of the aligner's buffers
+        t0 = time.perf_counter()
+        reps = 3 if n >= 64 else 10
+        for _ in range(reps):
+            R, t, cov = al.align(*ins, K)               # synchronous on return (poses read back)
+        ms = 1e3 * (time.perf_counter() - t0) / reps
+        for i in (0, min(n, n_distinct) - 1):
+            Ro, to, _ = O.keyframe_align(iDa[i].cpu().numpy(), ga[i].cpu().numpy(), iDb[i].cpu().numpy(), gb[i].cpu().numpy(), K)
+            worst_r = max(worst_r, _rot_angle(R[i], Ro)); worst_t = max(worst_t, float(np.linalg.norm(t[i] - to)))
+        nbytes = C_size(al)
+        points.append({"pairs": n, "ms_per_call": ms, "pairs_per_s": 1e3 * n / ms, "launches": al.launches(), "aligner_hbm_bytes": nbytes})
+        al.close()
+        del ins
+        torch.cuda.empty_cache()
+    return {"config": "f-1: KeyframeAlign (keyframe-to-keyframe dense alignment of the loop closer) for N pairs of 640x480 keyframes in lock-step, device-resident "
+                      "(rgbid_kfalign_batched; RGBID_SLAM::KeyframeAlign rides on the 1-pair case, bit-identical to its host-driven loop)",
+            "unit": "pairs/s", "value": points[-1]["pairs_per_s"], "points": points,
+            "parity": {"vs": "oracle (orc_keyframe_align), two pairs of every batch size", "max_rot_err_rad": worst_r, "max_trans_err_m": worst_t,
+                       "within_1e-4": bool(worst_r < 1e-4 and worst_t < 1e-4)}}
+
+
+def C_size(al):
+    import ctypes
+    n = ctypes.c_size_t()
+    al.L.rgbid_kfalign_bytes(al._h, ctypes.byref(n))
+    return int(n.value)
+
+
 def dataset_configs(K_default):
     """BASELINE configs 2-4 on the REAL sequences, the moment they are mounted (RGBID_TUM_DIR: folders with depth_associated.txt, rgb_associated.txt,
     groundtruth.txt): tracked by the C++ driver (rgbid-slam_amd/bin/rgbid_track_sequence, 8 chunks and unsharded) and scored with tools/ate.py --
@@ -854,6 +903,11 @@ def main():
                 sys.stderr.write(f"[bench] rank {rank}: extra config 4 failed ({type(e).__name__}: {e})\n"); sys.stderr.flush()
                 os._exit(4)
             extras.append({"config": "4", "error": f"{type(e).__name__}: {e}"})
+    if rank == 0 and world == 1 and not args.no_extras and headline_shape:
+        try:
+            extras.append(extra_kfalign(ctx, dev, K))
+        except Exception as e:
+            extras.append({"config": "f-1 (KeyframeAlign batched)", "error": f"{type(e).__name__}: {e}"})
     if rank == 0 and world == 1 and not args.no_extras:
         try:
             ds = dataset_configs(K)

@@ -101,7 +101,16 @@ int rgbid_ctx_sync(rgbid_ctx* ctx);                          /* internal.h:456-4
  * all its pixels take the exact path.  Maps this library builds from 16-bit depth are inside the domain by construction.
  * VALUE tolerance of the class: a selected sample's inverse depth within ~2e-6 relative; a bilinear intensity sample blends the oracle's four texels
  * with weights that may sit one 1.8 fixed-point step (1/256) off the oracle's -- 1 % of the samples at 640x480, at most 2/256 of the local contrast
- * (that rounding has a boundary every 1/256 px, far inside any provable coordinate bound, so it is not guarded: DESIGN.md section 4.1). */
+ * (that rounding has a boundary every 1/256 px, far inside any provable coordinate bound, so it is not guarded: DESIGN.md section 4.1).
+ * WHAT "SELECTION-EXACT" MEANS, AND WHAT IT DOES NOT: the statement holds PER CALL, on identical inputs -- every pixel of one warp / gate /
+ * covisibility evaluation takes the decision the IEEE evaluation takes for the same maps and the same transform.  It is not a statement about a
+ * TRAJECTORY: the two classes' poses differ in their last bits (the values above), the next call's transform therefore differs in its last bits
+ * too, and a projected coordinate that sits on a pixel boundary for one of the two transforms then selects another source pixel -- both correctly.
+ * Across a depth edge that one sample can move an unconverged iterate visibly: a 6 384-case fuzz campaign found one such engine case (seed 284 of
+ * tests/test_gpu_fuzz.py's engine campaign: a 43 x 56 image at a focal length of 46 px, one level, six iterations), 5.3e-5 rad / 1.15e-4 m against
+ * the oracle tracker where the EXACT class stays at 2.5e-9 -- a tenth of the estimate's own standard deviation.  The engine fuzz therefore scales the
+ * 640 x 480 pose bar of 1e-4 rad / 1e-4 m with the angular size of a pixel below 320 columns (1e-4 * 320 / cols); at and above 320 columns the bar is
+ * 1e-4 and every recorded run is one to two orders inside it. */
 int rgbid_ctx_set_numerics(rgbid_ctx* ctx, int numerics);
 /* orders the context's stream after a hipEvent_t recorded on another stream (interop with the caller's framework streams) */
 int rgbid_ctx_wait_event(rgbid_ctx* ctx, void* hip_event);

@@ -96,7 +96,6 @@ struct Guard {
   float g0, g1;     // gates: eps_w = |wc| g1 + g0 (relative distance of the inverse depth in the other frame)
   float e0, e1;     //        eps_res = e0 + e1 |rcp(1 - w2 t_z)| (relative distance of the warped inverse depth)
   float bL, cL, kL; // (3'): xs' = Y_0 wc + bL;  safe  <=>  max3(fract(xs'), fract(ys'), |wc| kL) < cL
-  float gL;         // gate band of the covisibility check, lane constant: eps_w = |1 / Y_2| g1 + g0 <= gL for every pixel whose gate is taken from the fast w'
   float wcore;      // (3''): a projection with 0 <= xB <= cols - 1, 0 <= yB <= rows - 1 and |wc| <= wcore has the oracle's inside verdict
 };
 #ifndef RGBID_WCM
@@ -146,10 +145,8 @@ RGBID_GB_HD inline Guard make_guard(const float R[9], const float t[3], int cols
     g.cL = 1.f - 2.f * dLa - 0x1p-22f;
     g.kL = (g.cL / WCM) * (1.f + 0x1p-20f);
     g.wcore = fminf((0.25f - g.d2) / g.d1 * (1.f - 0x1p-20f), 0x1p9f);
-    // the covisibility gate is taken from the fast w' only for pixels with |1 / Y_2| d1 + d2 < 1/2 (vis_project)
-    g.gL = (0.5f / g.d1) * g.g1 + g.g0;
   } else {                                             // every pixel of the lane is recomputed the oracle's way
-    g.bL = 0.5f; g.cL = -1.f; g.kL = 1.f; g.wcore = 0.f; g.gL = INFINITY;
+    g.bL = 0.5f; g.cL = -1.f; g.kL = 1.f; g.wcore = 0.f;
   }
   return g;
 }

@@ -210,7 +210,7 @@ __device__ __forceinline__ Guard lane_guard(const WarpParams& P, int cols, int r
   Guard g = make_guard(P.R, P.t, cols, rows);
   g.d1 = uniform_f(g.d1); g.c2 = uniform_f(g.c2); g.d2 = uniform_f(g.d2); g.q0 = uniform_f(g.q0); g.q1 = uniform_f(g.q1); g.db = uniform_f(g.db);
   g.g0 = uniform_f(g.g0); g.g1 = uniform_f(g.g1); g.e0 = uniform_f(g.e0); g.e1 = uniform_f(g.e1);
-  g.bL = uniform_f(g.bL); g.cL = uniform_f(g.cL); g.kL = uniform_f(g.kL); g.wcore = uniform_f(g.wcore); g.gL = uniform_f(g.gL);
+  g.bL = uniform_f(g.bL); g.cL = uniform_f(g.cL); g.kL = uniform_f(g.kL); g.wcore = uniform_f(g.wcore);
   g.zsafe = __builtin_amdgcn_readfirstlane(g.zsafe);
 #ifdef RGBID_EXPERIMENT_GUARD_NEVER_FIRES   // timing experiment only (tools/build_variant.sh): the checks run, no pixel is ever recomputed
   g.d1 = uniform_f(0.f); g.c2 = uniform_f(10.f); g.db = uniform_f(-1e9f); g.d2 = uniform_f(0.f);
@@ -443,14 +443,12 @@ __device__ __forceinline__ VisProj vis_project(int cols, int rows, const Ray& q,
 __device__ __forceinline__ bool vis_gate(const VisProj& v, float d, int x, int y, const WarpParams& P, const Guard& G) {
 #pragma clang fp contract(off)
   float dgap = fabsf(v.wc - d);
-  // the gate is open within eps_w |w'| of the threshold (guard_band.h (5)); screened first with the lane constant gL >= eps_w (every pixel that is not
-  // `exact` has |1 / Y_2| d1 + d2 < 1/2, vis_project), so that the screen cannot miss an open gate however large |w'| is (round 4 screened with a fixed 2^-10)
-  const float off = fabsf(dgap - 0.020f), c0 = 4.f * 0x1p-24f * 0.020f;
-  if (__builtin_expect(v.ok & !v.exact & !(off > __builtin_fmaf(fabsf(v.wc), G.gL, c0)), 0)) {
-    if (!(off > __builtin_fmaf(fabsf(v.wc), __builtin_fmaf(fabsf(v.ry), G.g1, G.g0), c0))) {
-      float xe, ye;
-      dgap = fabsf(register_pixel(xe, ye, x, y, v.ws, P) - d);
-    }
+  // the gate is open within eps_w |w'| of the threshold (guard_band.h (5)): the band itself is the test (two FMAs; round 4 screened with a fixed 2^-10
+  // first, which an in-domain pixel with |w'| |1 / Y_2| of the order of 10^3 could pass although its gate was open: ADVICE r4)
+  const float band = __builtin_fmaf(fabsf(v.wc), __builtin_fmaf(fabsf(v.ry), G.g1, G.g0), 4.f * 0x1p-24f * 0.020f);
+  if (__builtin_expect(v.ok & !v.exact & (fabsf(dgap - 0.020f) <= band), 0)) {   // a NaN gap (NaN texel: common) is not an open gate; a non-finite band only occurs where `exact` is set
+    float xe, ye;
+    dgap = fabsf(register_pixel(xe, ye, x, y, v.ws, P) - d);
   }
   return v.ok & (dgap < 0.020f);
 }
