@@ -19,6 +19,10 @@
 #include <new>
 #include <vector>
 
+// The per-lane scalar kernels hold 6x6 / 3x3 double matrices in registers: one wave per SIMD may take the whole register file (the default budget of 128
+// VGPRs spilled 660 - 1 250 bytes per thread to scratch, and dependent scratch round trips were most of these kernels' run time)
+#define RGBID_SCALAR_KERNEL __attribute__((amdgpu_waves_per_eu(1, 1)))
+
 #pragma clang fp contract(off)   // the per-lane scalar kernels below (double-precision tracker logic): no FMA contraction, as se3.h / engine_device.h
 
 using namespace rgbid;
@@ -97,7 +101,7 @@ __device__ void reset_integration_keyframe(LaneState& s, const StepCfg& c, const
 // ---- step begin: first-frame initialisation or GN start (visodo.cpp:1994-2045, 1012-1035) ------------------
 // Also what two tiny launches used to do: the lane's eight covisibility counters are zeroed (was a memset node), and the SysParams of the first
 // Gauss-Newton stage are set (was the first k_set_sys; the later stages' are set by the k_solve_update that ends the stage before them).
-__global__ void k_step_begin(LaneState* st, Flags f, WarpParams* wp, SysParams* sp, StepCfg c, int B, unsigned int* counts, int sys_level, int sys_cov) {
+__global__ __launch_bounds__(64) RGBID_SCALAR_KERNEL void k_step_begin(LaneState* st, Flags f, WarpParams* wp, SysParams* sp, StepCfg c, int B, unsigned int* counts, int sys_level, int sys_cov) {
   int lane = blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= B) return;
   LaneState& s = st[lane];
@@ -150,7 +154,7 @@ __global__ void k_step_begin(LaneState* st, Flags f, WarpParams* wp, SysParams* 
 // ---- one GN update: reduce partials, LLT solve, exp-map, pose update, next warp (visodo.cpp:1242-1274) -------
 // sys_level >= 0: this is the last update of a stage -- the per-level constants of the lane's SysParams for the stage that follows (the next level's
 // iterations, or the covariance pass: sys_cov) are set here (every lane, as the separate k_set_sys launch did; nothing of the solve reads them)
-__global__ __launch_bounds__(256) void k_solve_update(const double* partials, int nblk, LaneState* st, Flags f, WarpParams* wp,
+__global__ __launch_bounds__(256) RGBID_SCALAR_KERNEL void k_solve_update(const double* partials, int nblk, LaneState* st, Flags f, WarpParams* wp,
                                                       StepCfg c, int next_level, SysParams* sp, int sys_level, int sys_cov) {
   int lane = blockIdx.x;
   if (sys_level >= 0 && threadIdx.x == 64) set_sys_lane(sp, st, f.track, c, sys_level, sys_cov, lane);
@@ -169,7 +173,7 @@ __global__ void k_level_begin(Flags f, int B) {
 // before iteration `iter` >= 1 of a level, after the warp: RMSE of the full-lattice chi-square (chi_out[lane] = {chi_square, chi_test, Ndof}); from the
 // third iteration on a growing RMSE undoes the previous increment and ends the level FOR THIS LANE (the flag masks the level's remaining launches); the
 // next stage's first warp is projected from the restored pose
-__global__ void k_chi_decide(LaneState* st, Flags f, const float* chi_out, WarpParams* wp, StepCfg c, int iter, int after_level, int B) {
+__global__ __launch_bounds__(64) RGBID_SCALAR_KERNEL void k_chi_decide(LaneState* st, Flags f, const float* chi_out, WarpParams* wp, StepCfg c, int iter, int after_level, int B) {
   int lane = blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= B || !f.lvl[lane]) return;
   LaneState& s = st[lane];
@@ -188,7 +192,7 @@ __global__ void k_chi_decide(LaneState* st, Flags f, const float* chi_out, WarpP
 }
 
 // ---- end of estimateVisualOdometry + pose bookkeeping of trackNewFrame (visodo.cpp:1367-1468, 2051-2170) -----
-__global__ __launch_bounds__(256) void k_frame_finish(const double* partials, int nblk, LaneState* st, Flags f, const SysParams* sp,
+__global__ __launch_bounds__(256) RGBID_SCALAR_KERNEL void k_frame_finish(const double* partials, int nblk, LaneState* st, Flags f, const SysParams* sp,
                                                       WarpParams* vis_ab, WarpParams* vis_ba, WarpParams* ivis_ab, WarpParams* ivis_ba,
                                                       rgbid_pose_record* rec, StepCfg c) {
   int lane = blockIdx.x;
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(256) void k_frame_finish(const double* partials, in
 
 // counts: [4][B][2] = {odo B->A, odo A->B, integr B->A, integr A->B} x {visible, valid}
 // The lane's first counter pair is handed back zeroed: computeOverlapping counts into it next (was a memset node).
-__global__ void k_decide(LaneState* st, Flags f, unsigned int* counts, WarpParams* fuse_wp, StepCfg c, int B) {
+__global__ __launch_bounds__(64) RGBID_SCALAR_KERNEL void k_decide(LaneState* st, Flags f, unsigned int* counts, WarpParams* fuse_wp, StepCfg c, int B) {
   int lane = blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= B || !f.vis[lane]) return;
   LaneState& s = st[lane];

@@ -18,6 +18,10 @@
 #include <new>
 #include <vector>
 
+// The per-lane scalar kernels hold 6x6 / 3x3 double matrices in registers: one wave per SIMD may take the whole register file (the default budget of 128
+// VGPRs spilled 660 - 1 250 bytes per thread to scratch, and dependent scratch round trips were most of these kernels' run time)
+#define RGBID_SCALAR_KERNEL __attribute__((amdgpu_waves_per_eu(1, 1)))
+
 #pragma clang fp contract(off)   // the per-pair scalar kernels below: operation by operation, as the host loop of KeyframeAlign (g++, no contraction)
 
 using namespace rgbid;
@@ -56,7 +60,7 @@ __device__ void kfa_set_iteration(const KfaState& s, int level, SysParams& p, Si
   io.bias = 0.f; io.sigma = 0.0025f; io.nu = 5.f;
 }
 
-__global__ void k_kfa_begin(KfaState* st, const double* R, const double* t, const float* K, WarpParams* wp, SysParams* sp, SigmaIO* io, int level, int B) {
+__global__ __launch_bounds__(64) RGBID_SCALAR_KERNEL void k_kfa_begin(KfaState* st, const double* R, const double* t, const float* K, WarpParams* wp, SysParams* sp, SigmaIO* io, int level, int B) {
   const int lane = blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= B) return;
   KfaState& s = st[lane];
@@ -76,7 +80,7 @@ __global__ void k_kfa_set_nu(const SigmaIO* io, SysParams* sp, int B) {
 
 // one update of one pair: fixed-order reduction of its partial sums (the order of k_reduce_system, kernels_system.hip), LLT solve, exp-map, pre-multiplied
 // pose update (:312-335), then what the next iteration needs (warp at next_level, start values)
-__global__ __launch_bounds__(256) void k_kfa_solve(const double* partials, int nblk, KfaState* st, WarpParams* wp, SysParams* sp, SigmaIO* io, int next_level) {
+__global__ __launch_bounds__(256) RGBID_SCALAR_KERNEL void k_kfa_solve(const double* partials, int nblk, KfaState* st, WarpParams* wp, SysParams* sp, SigmaIO* io, int next_level) {
   const int lane = blockIdx.x, tid = threadIdx.x;
   __shared__ double sm[8][32];
   __shared__ double sums[SYS_TERMS];
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256) void k_kfa_solve(const double* partials, int n
   }
 }
 
-__global__ void k_kfa_finish(const KfaState* st, double* R, double* t, double* cov, int B) {
+__global__ __launch_bounds__(64) RGBID_SCALAR_KERNEL void k_kfa_finish(const KfaState* st, double* R, double* t, double* cov, int B) {
   const int lane = blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= B) return;
   const KfaState& s = st[lane];
