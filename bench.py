@@ -552,17 +552,19 @@ def extra_kfalign(ctx, dev, K):
         idx = torch.arange(n, device=dev) % n_distinct
         ins = [x[idx].contiguous() for x in (iDa, ga, iDb, gb)]
         al = kfalign.KfAlign(ctx, rows, cols, n)
-        al.align(*ins, K)                               # first touch of the aligner's buffers
-        t0 = time.perf_counter()
-        reps = 3 if n >= 64 else 10
-        for _ in range(reps):
+        for _ in range(2):
+            al.align(*ins, K)                           # first touch of the aligner's buffers
+        times = []
+        for _ in range(5 if n >= 64 else 15):
+            t0 = time.perf_counter()
             R, t, cov = al.align(*ins, K)               # synchronous on return (poses read back)
-        ms = 1e3 * (time.perf_counter() - t0) / reps
+            times.append(1e3 * (time.perf_counter() - t0))
+        ms = float(np.median(times))
         for i in (0, min(n, n_distinct) - 1):
             Ro, to, _ = O.keyframe_align(iDa[i].cpu().numpy(), ga[i].cpu().numpy(), iDb[i].cpu().numpy(), gb[i].cpu().numpy(), K)
             worst_r = max(worst_r, _rot_angle(R[i], Ro)); worst_t = max(worst_t, float(np.linalg.norm(t[i] - to)))
         nbytes = C_size(al)
-        points.append({"pairs": n, "ms_per_call": ms, "pairs_per_s": 1e3 * n / ms, "launches": al.launches(), "aligner_hbm_bytes": nbytes})
+        points.append({"pairs": n, "ms_per_call": ms, "ms_per_call_min_max": [min(times), max(times)], "pairs_per_s": 1e3 * n / ms, "launches": al.launches(), "aligner_hbm_bytes": nbytes})
         al.close()
         del ins
         torch.cuda.empty_cache()

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -1025,6 +1026,12 @@ int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_c
   }
   if (!r) { hipError_t he = hipStreamSynchronize(ctx->stream); if (he != hipSuccess) r = (int)he; }
   if (r) { rgbid_engine_destroy(e); return r; }
+  if (getenv("RGBID_ENGINE_DEBUG_ALLOC")) {   // diagnostics: where the level-0 maps of the dominant kernel landed (placement sensitivity of the 1280x960 case)
+    const ImgB* m[] = {&e->iD_kf[0], &e->I_kf[0], &e->gxD[0], &e->gyD[0], &e->gxI[0], &e->gyI[0], &e->iD_curr[0], &e->I_curr[0]};
+    fprintf(stderr, "rgbid_engine %dx%d x %d lanes: level-0 maps at", cfg->cols, cfg->rows, B);
+    for (const ImgB* im : m) fprintf(stderr, " %p", im->base);
+    fprintf(stderr, " (lane stride %zu)\n", e->iD_kf[0].lane_stride);
+  }
   *out = e;
   return RGBID_OK;
 }

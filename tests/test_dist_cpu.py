@@ -140,6 +140,19 @@ def test_sequence_driver_refuses_injected_records_of_another_chunk_length():
             D.track_sequence(None, E.default_config(rows=48, cols=64, lanes=1), None, None, chunks, inject=bad, n_frames=F)
 
 
+def test_sequence_driver_refuses_a_warm_up_on_injected_records():
+    """rgbid_seq_config.warmup_frames (round 5) makes every chunk but the first track frames before its own first one: injected records carry no such
+    frames, so the combination is refused (and w = 0 is the driver as it was); absurd values are refused too"""
+    from rgbid import engine as E
+    from rgbid._lib import RgbidError
+    F, chunks = 25, 4
+    good, _, _, _, L = _chain_records(F, chunks)
+    R0, t0, _, _, _ = D.track_sequence(None, E.default_config(rows=48, cols=64, lanes=1), None, None, chunks, inject=good, n_frames=F, warmup_frames=0)
+    for w in (1, 4, -1, 1000):
+        with pytest.raises(RgbidError):
+            D.track_sequence(None, E.default_config(rows=48, cols=64, lanes=1), None, None, chunks, inject=good, n_frames=F, warmup_frames=w)
+
+
 def test_tcp_rendezvous_ignores_strangers_and_duplicates():
     """rank 0 keeps accepting when something that is not a rank of this job connects (a port scanner, a stale process with another nonce, a
     rank that was served already); host names resolve (getaddrinfo)"""
