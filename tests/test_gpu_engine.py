@@ -421,8 +421,8 @@ def test_engine_chi_squared_stops_lanes_independently(ctx):
     T, B = 5, 3
     seqs, depth, rgb = make_lanes(B, T, 120, 160, K, trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8))
 
-    def run(lanes, term):
-        eng = E.Engine(ctx, E.default_config(rows=120, cols=160, lanes=len(lanes), K=K, use_graph=0, record_capacity=T, termination=term, warping=O.WARP_FIRST, fast_numerics=0))
+    def run(lanes, term, graph=0):
+        eng = E.Engine(ctx, E.default_config(rows=120, cols=160, lanes=len(lanes), K=K, use_graph=graph, record_capacity=T, termination=term, warping=O.WARP_FIRST, fast_numerics=0))
         for k in range(T):
             eng.step(depth[k][lanes].contiguous(), rgb[k][lanes].contiguous())
         r = eng.records().copy(); eng.close()
@@ -433,9 +433,11 @@ def test_engine_chi_squared_stops_lanes_independently(ctx):
         assert batch[:, l].tobytes() == single[:, 0].tobytes(), l
     allit = run([0, 1, 2], O.ALL_ITERS)
     assert np.abs(batch["R"] - allit["R"]).max() > 1e-7
+    assert run([0, 1, 2], O.CHI_SQUARED, graph=1).tobytes() == batch.tobytes()     # the per-lane stop is data in flag arrays: the step stays one replayable hipGraph
 
 
-def test_engine_custom_calibration(ctx):
+@pytest.mark.parametrize("use_graph", [0, 1])
+def test_engine_custom_calibration(ctx, use_graph):
     """cfg.custom_registration = 1 (round 5): prepareImagesCustomCalibration (visodo.cpp:775-824) as predicated prep-stage launches of the engine -- undistort,
     depth-distortion correction, depth -> colour registration -- per lane: the registered inverse depth and the undistorted intensity are the oracle's bit
     for bit, the poses within the north-star tolerance"""
@@ -450,7 +452,7 @@ def test_engine_custom_calibration(ctx):
     dd = dict(c1=1.01, c0=-0.002, q0=(0.001, -0.002, 0.001, 0.0, 0.0005, -0.0004, 0.0, 0.0, 0.0), q1=(0.005, 0.01, 0.0, 0.0, -0.002, 0.001, 0.0, 0.0, 0.0))
     dRc = [0.99995, -0.008, 0.006, 0.00803, 0.99995, -0.005, -0.00596, 0.00505, 0.99997]
     t_dc = (0.0251, -0.0012, 0.0031)
-    cfg = E.default_config(rows=rows, cols=cols, lanes=B, K=K, use_graph=0, record_capacity=T, custom_registration=1)
+    cfg = E.default_config(rows=rows, cols=cols, lanes=B, K=K, use_graph=use_graph, record_capacity=T, custom_registration=1)
     for i, v in enumerate(rgbk):
         cfg.rgb_dist[i] = v
     cfg.depth_intr = IntrK(*dk)
