@@ -20,7 +20,7 @@ static constexpr int SIG_T = 512, SIG_MAXPT = 40, SIG_W = SIG_T / 64;
 
 // block-wide sum of 4 per-thread fp32 partials: DPP wave reduction in fp32, then the SIG_W wave totals are
 // added in double in a fixed order and broadcast.  Two alternating LDS buffers (the passes are strictly sequential) make the
-// write-after-read barrier of a single buffer unnecessary: 2 barriers per pass.  sm: 2 * (SIG_W*4 + 4) doubles of LDS.
+// write-after-read barrier of a single buffer unnecessary (round 5: and every thread forms the block totals itself): 1 barrier per pass.  sm: 2 * (SIG_W*4 + 4) doubles of LDS.
 static constexpr int SIG_SM = 2 * (SIG_W * 4 + 4);
 struct BlockSum {
   double* sm;
@@ -39,14 +39,16 @@ __device__ __forceinline__ void block_sum4(const float in[4], double out[4], Blo
     for (int k = 0; k < 4; ++k) sm[wid * 4 + k] = (double)w[k];
   }
   __syncthreads();
-  if (threadIdx.x < 4) {
-    double t = 0.0;
-    for (int i = 0; i < SIG_W; ++i) t += sm[i * 4 + threadIdx.x];  // fixed order: deterministic
-    sm[SIG_W * 4 + threadIdx.x] = t;
-  }
-  __syncthreads();
+  // every thread adds the SIG_W wave totals itself, in the same fixed order (broadcast LDS reads; the same doubles as a designated thread would form):
+  // ONE barrier per pass instead of two.  The two alternating buffers keep that safe: a buffer is rewritten two passes later, and every thread that
+  // gets there has passed the barrier of the pass in between, i.e. all reads of this pass are done.
 #pragma unroll
-  for (int k = 0; k < 4; ++k) out[k] = sm[SIG_W * 4 + k];
+  for (int k = 0; k < 4; ++k) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < SIG_W; ++i) t += sm[i * 4 + k];  // fixed order: deterministic
+    out[k] = t;
+  }
 }
 
 // Per-thread residual samples, produced by a getter get(i) (a plain array for the bridge calls; a lattice
