@@ -33,6 +33,87 @@ __device__ __forceinline__ float m_weight(float e, int mest) {  // computeWeight
   return weight;
 }
 
+// ---- packed accumulation: the upper triangle of the 7-column row update [J | e] tiled by DOMINOES --------------------------
+// v_pk_fma_f32 does two IEEE fp32 FMAs for ~1.45 x the issue cost of one v_fma_f32 on gfx950 (tools/experiments/valu_rate5.hip), so a packed update only
+// pays when no half is wasted.  With the row vector in aligned pairs V = (J0 J1 | J2 J3 | J4 J5) the 27 products tile as 9 horizontal dominoes
+// {(r,c),(r,c+1)}, c even  [scalar (w J_r) broadcast through op_sel times a pair of V], 3 vertical dominoes {(r,6),(r+1,6)}, r even  [the pair
+// (w J_r, w J_r+1) times the broadcast residual] and the 3 odd diagonal terms (1,1), (3,3), (5,5) as plain FMAs: 12 packed + 3 scalar issues per row
+// instead of 27, the 6 weighted-row multiplies as 3 packed ones.  (Round 4's packing -- horizontal pairs only, 9 wasted halves, 18 issues per row --
+// had no issue-cost advantage at all: profiles/r04_experiments/packed_fma_accumulate.md.)  Every sum is the same fmaf(w J_r, J_c, acc) chain, intensity
+// row first, as the scalar form: bit-identical partial sums.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct AccPk { f32x2 p[12]; float s[3]; };
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ void acc_pk_zero(AccPk& A) {
+#pragma unroll
+  for (int k = 0; k < 12; ++k) A.p[k] = f32x2{0.f, 0.f};
+  A.s[0] = A.s[1] = A.s[2] = 0.f;
+}
+// one weighted row: V = the row in pairs, e = its residual, w = its weight
+__device__ __forceinline__ void acc_pk_row(AccPk& A, const f32x2 V[3], float e, float w) {
+  const f32x2 ww = {w, w}, ee = {e, e};
+  const f32x2 W0 = V[0] * ww, W1 = V[1] * ww, W2 = V[2] * ww;
+  const f32x2 a0 = {W0.x, W0.x}, a1 = {W0.y, W0.y}, a2 = {W1.x, W1.x}, a3 = {W1.y, W1.y}, a4 = {W2.x, W2.x};
+  A.p[0] = pk_fma(a0, V[0], A.p[0]); A.p[1] = pk_fma(a0, V[1], A.p[1]); A.p[2] = pk_fma(a0, V[2], A.p[2]); A.p[3] = pk_fma(W0, ee, A.p[3]);
+  A.s[0] = fmaf(W0.y, V[0].y, A.s[0]); A.p[4] = pk_fma(a1, V[1], A.p[4]); A.p[5] = pk_fma(a1, V[2], A.p[5]);
+  A.p[6] = pk_fma(a2, V[1], A.p[6]); A.p[7] = pk_fma(a2, V[2], A.p[7]); A.p[8] = pk_fma(W1, ee, A.p[8]);
+  A.s[1] = fmaf(W1.y, V[1].y, A.s[1]); A.p[9] = pk_fma(a3, V[2], A.p[9]);
+  A.p[10] = pk_fma(a4, V[2], A.p[10]); A.p[11] = pk_fma(W2, ee, A.p[11]);
+  A.s[2] = fmaf(W2.y, V[2].y, A.s[2]);
+}
+// the 27 sums in kernels.h order (row r: columns r..5, then the right-hand side)
+__device__ __forceinline__ void acc_pk_unpack(const AccPk& A, float acc[SYS_TERMS]) {
+  acc[0] = A.p[0].x; acc[1] = A.p[0].y; acc[2] = A.p[1].x; acc[3] = A.p[1].y; acc[4] = A.p[2].x; acc[5] = A.p[2].y; acc[6] = A.p[3].x;
+  acc[7] = A.s[0]; acc[8] = A.p[4].x; acc[9] = A.p[4].y; acc[10] = A.p[5].x; acc[11] = A.p[5].y; acc[12] = A.p[3].y;
+  acc[13] = A.p[6].x; acc[14] = A.p[6].y; acc[15] = A.p[7].x; acc[16] = A.p[7].y; acc[17] = A.p[8].x;
+  acc[18] = A.s[1]; acc[19] = A.p[9].x; acc[20] = A.p[9].y; acc[21] = A.p[8].y;
+  acc[22] = A.p[10].x; acc[23] = A.p[10].y; acc[24] = A.p[11].x;
+  acc[25] = A.s[2]; acc[26] = A.p[11].y;
+}
+
+#ifndef RGBID_PK_ACC
+#define RGBID_PK_ACC 1
+#endif
+#if RGBID_PK_ACC
+using AccM = AccPk;
+#else
+struct AccM { float a[SYS_TERMS]; };
+#endif
+// both weighted rows of a pixel into the sums: intensity row (weight wi, residual ei) first, then the inverse-depth row (weight sd, residual ed)
+__device__ __forceinline__ void accumulate_rows(AccM& accm, const float Ji[6], float ei, float wi, const float Jd[6], float ed, float sd) {
+#if RGBID_PK_ACC
+  const f32x2 Vi[3] = {{Ji[0], Ji[1]}, {Ji[2], Ji[3]}, {Ji[4], Ji[5]}}, Vd[3] = {{Jd[0], Jd[1]}, {Jd[2], Jd[3]}, {Jd[4], Jd[5]}};
+  acc_pk_row(accm, Vi, ei, wi);
+  acc_pk_row(accm, Vd, ed, sd);
+#else
+  float* acc = accm.a;
+  int s = 0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    float a = wi * Ji[r], d = sd * Jd[r];
+#pragma unroll
+    for (int c = r; c < 6; ++c) { acc[s] = fmaf(a, Ji[c], acc[s]); acc[s] = fmaf(d, Jd[c], acc[s]); ++s; }
+    acc[s] = fmaf(a, ei, acc[s]); acc[s] = fmaf(d, ed, acc[s]); ++s;
+  }
+#endif
+}
+__device__ __forceinline__ void acc_zero(AccM& A) {
+#if RGBID_PK_ACC
+  acc_pk_zero(A);
+#else
+#pragma unroll
+  for (int k = 0; k < SYS_TERMS; ++k) A.a[k] = 0.f;
+#endif
+}
+__device__ __forceinline__ void acc_unpack(const AccM& A, float acc[SYS_TERMS]) {
+#if RGBID_PK_ACC
+  acc_pk_unpack(A, acc);
+#else
+#pragma unroll
+  for (int k = 0; k < SYS_TERMS; ++k) acc[k] = A.a[k];
+#endif
+}
+
 // One pixel: invDepthConstraint (:214-262) + intensityConstraint (:176-212) + the 27-term update (:408-418).
 // VALU issue is a co-limiter of every variant (see the file header), so the row algebra is arranged for the fewest instructions, not for the
 // reference's order of operations (the sums agree with the oracle to ~1e-6 relative; tolerance 2e-5):
@@ -49,7 +130,7 @@ __device__ __forceinline__ float m_weight(float e, int mest) {  // computeWeight
 // 2 = the covariance pass's fixed-nu Student-t weights, both with a weighting other than MIN_WEIGHT; 0 = decided per pixel from P (every
 // other configuration).  Same arithmetic either way.
 template <int WM>
-__device__ __forceinline__ void accumulate_pixel(float acc[SYS_TERMS], float px_, float py_, float pp_y, float w0, float i0, float gwx, float gwy,
+__device__ __forceinline__ void accumulate_pixel(AccM& accm, float px_, float py_, float pp_y, float w0, float i0, float gwx, float gwy,
                                                  float gix, float giy, float w1, float i1, const SysParams& P, const SysConst& C) {
   const bool snu = WM == 1 ? true : WM == 2 ? false : (P.student_nu != 0);
   const bool minw = WM != 0 ? false : (P.weighting == 1);
@@ -100,21 +181,14 @@ __device__ __forceinline__ void accumulate_pixel(float acc[SYS_TERMS], float px_
     wi = vi ? wi : 0.f;
   }
   float sd = nfac * wd;
-  int s = 0;
-#pragma unroll
-  for (int r = 0; r < 6; ++r) {
-    float a = wi * Ji[r], d = sd * Jd[r];
-#pragma unroll
-    for (int c = r; c < 6; ++c) { acc[s] = fmaf(a, Ji[c], acc[s]); acc[s] = fmaf(d, Jd[c], acc[s]); ++s; }
-    acc[s] = fmaf(a, ei, acc[s]); acc[s] = fmaf(d, ed, acc[s]); ++s;
-  }
+  accumulate_rows(accm, Ji, ei, wi, Jd, ed, sd);
 }
 
 // The same pixel for the fused fast kernel, whose warps hand over validity as MASKS instead of NaN values: w0s = the keyframe inverse depth sanitised to the
 // FAST domain (finite, positive: fastnum::sanitised), w1 finite, okd = the warped inverse depth is valid (implies a valid w0), oki = the warped intensity is
 // valid (implies okd).  Saves the w0 / w1 / i1 NaN tests and four selects per pixel; the sums are the same bit for bit (an invalid row has weight 0 either way).
 template <int WM>
-__device__ __forceinline__ void accumulate_pixel_m(float acc[SYS_TERMS], float px_, float py_, float pp_y, float w0, float i0, float gwx, float gwy,
+__device__ __forceinline__ void accumulate_pixel_m(AccM& accm, float px_, float py_, float pp_y, float w0, float i0, float gwx, float gwy,
                                                    float gix, float giy, float w1, float i1, bool okd, bool oki, const SysParams& P, const SysConst& C) {
   const bool snu = WM == 1 ? true : WM == 2 ? false : (P.student_nu != 0);
   const bool minw = WM != 0 ? false : (P.weighting == 1);
@@ -163,14 +237,7 @@ __device__ __forceinline__ void accumulate_pixel_m(float acc[SYS_TERMS], float p
     wi = vi ? wi : 0.f;
   }
   float sd = nfac * wd;
-  int s = 0;
-#pragma unroll
-  for (int r = 0; r < 6; ++r) {
-    float a = wi * Ji[r], d = sd * Jd[r];
-#pragma unroll
-    for (int c = r; c < 6; ++c) { acc[s] = fmaf(a, Ji[c], acc[s]); acc[s] = fmaf(d, Jd[c], acc[s]); ++s; }
-    acc[s] = fmaf(a, ei, acc[s]); acc[s] = fmaf(d, ed, acc[s]); ++s;
-  }
+  accumulate_rows(accm, Ji, ei, wi, Jd, ed, sd);
 }
 
 __device__ __forceinline__ SysConst make_const(const SysParams& P) {
@@ -249,9 +316,8 @@ __device__ __forceinline__ void build_system_block(const ImgB& W0, const ImgB& I
   WarpParams WP;
   if (FUSED) WP = fa.wp[lane];
   const FMap Wc(W1, lane), Ic(I1, lane);  // FUSED: the current frame's maps travel in the W1 / I1 slots
-  float acc[SYS_TERMS];
-#pragma unroll
-  for (int k = 0; k < SYS_TERMS; ++k) acc[k] = 0.f;
+  AccM accm;   // the 27 sums (packed pairs + three scalars: acc_pk_row)
+  acc_zero(accm);
   const int rows = W0.rows, cols = W0.cols;
   auto pixel_loop = [&](auto wm_tag) {
   constexpr int WM = decltype(wm_tag)::value;
@@ -347,19 +413,19 @@ __device__ __forceinline__ void build_system_block(const ImgB& W0, const ImgB& I
         bool nt;
         float i1v = fastnum::intensity_finish_m(t0, nt);
         if (__builtin_expect(nt, 0)) i1v = warp_intensity_px(Ic, x, y, w1.x, WP, im);   // a NaN tap (corner pixels of levels >= 1): the oracle's texel pair decides (never NaN inside the image: fminf)
-        accumulate_pixel_m<WM>(acc, px0, py_, pp_y, p0.ws, i0.x, a.x, b.x, c.x, d.x, w1.x, i1v, k0, t0.ok, P, C);
+        accumulate_pixel_m<WM>(accm, px0, py_, pp_y, p0.ws, i0.x, a.x, b.x, c.x, d.x, w1.x, i1v, k0, t0.ok, P, C);
         RGBID_SYS_PIXEL_FENCE;
         i1v = fastnum::intensity_finish_m(t1, nt);
         if (__builtin_expect(nt, 0)) i1v = warp_intensity_px(Ic, x + 1, y, w1.y, WP, im);
-        accumulate_pixel_m<WM>(acc, px0 + C.inv_fx, py_, pp_y, p1.ws, i0.y, a.y, b.y, c.y, d.y, w1.y, i1v, k1, t1.ok, P, C);
+        accumulate_pixel_m<WM>(accm, px0 + C.inv_fx, py_, pp_y, p1.ws, i0.y, a.y, b.y, c.y, d.y, w1.y, i1v, k1, t1.ok, P, C);
         RGBID_SYS_PIXEL_FENCE;
         i1v = fastnum::intensity_finish_m(t2, nt);
         if (__builtin_expect(nt, 0)) i1v = warp_intensity_px(Ic, x + 2, y, w1.z, WP, im);
-        accumulate_pixel_m<WM>(acc, fmaf(2.f, C.inv_fx, px0), py_, pp_y, p2.ws, i0.z, a.z, b.z, c.z, d.z, w1.z, i1v, k2, t2.ok, P, C);
+        accumulate_pixel_m<WM>(accm, fmaf(2.f, C.inv_fx, px0), py_, pp_y, p2.ws, i0.z, a.z, b.z, c.z, d.z, w1.z, i1v, k2, t2.ok, P, C);
         RGBID_SYS_PIXEL_FENCE;
         i1v = fastnum::intensity_finish_m(t3, nt);
         if (__builtin_expect(nt, 0)) i1v = warp_intensity_px(Ic, x + 3, y, w1.w, WP, im);
-        accumulate_pixel_m<WM>(acc, fmaf(3.f, C.inv_fx, px0), py_, pp_y, p3.ws, i0.w, a.w, b.w, c.w, d.w, w1.w, i1v, k3, t3.ok, P, C);
+        accumulate_pixel_m<WM>(accm, fmaf(3.f, C.inv_fx, px0), py_, pp_y, p3.ws, i0.w, a.w, b.w, c.w, d.w, w1.w, i1v, k3, t3.ok, P, C);
         } else if (live_n) w0n = ld_stream4(reinterpret_cast<const float*>(bW0 + unit_off(yn, xn << 2)));
         w0 = w0n; live = live_n; y = yn; xu = xn; ty = tyn; sx = sxn;
       }
@@ -390,10 +456,10 @@ __device__ __forceinline__ void build_system_block(const ImgB& W0, const ImgB& I
         }
         float py_ = ((float)y - C.cy_f) * C.inv_fy, pp_y = fmaf(py_, py_, 1.f);
         float px0 = ((float)x - C.cx_f) * C.inv_fx;
-        accumulate_pixel<WM>(acc, px0, py_, pp_y, w0.x, i0.x, a.x, b.x, c.x, d.x, w1.x, i1.x, P, C);
-        accumulate_pixel<WM>(acc, px0 + C.inv_fx, py_, pp_y, w0.y, i0.y, a.y, b.y, c.y, d.y, w1.y, i1.y, P, C);
-        accumulate_pixel<WM>(acc, fmaf(2.f, C.inv_fx, px0), py_, pp_y, w0.z, i0.z, a.z, b.z, c.z, d.z, w1.z, i1.z, P, C);
-        accumulate_pixel<WM>(acc, fmaf(3.f, C.inv_fx, px0), py_, pp_y, w0.w, i0.w, a.w, b.w, c.w, d.w, w1.w, i1.w, P, C);
+        accumulate_pixel<WM>(accm, px0, py_, pp_y, w0.x, i0.x, a.x, b.x, c.x, d.x, w1.x, i1.x, P, C);
+        accumulate_pixel<WM>(accm, px0 + C.inv_fx, py_, pp_y, w0.y, i0.y, a.y, b.y, c.y, d.y, w1.y, i1.y, P, C);
+        accumulate_pixel<WM>(accm, fmaf(2.f, C.inv_fx, px0), py_, pp_y, w0.z, i0.z, a.z, b.z, c.z, d.z, w1.z, i1.z, P, C);
+        accumulate_pixel<WM>(accm, fmaf(3.f, C.inv_fx, px0), py_, pp_y, w0.w, i0.w, a.w, b.w, c.w, d.w, w1.w, i1.w, P, C);
       }
     }
   } else {
@@ -413,13 +479,15 @@ __device__ __forceinline__ void build_system_block(const ImgB& W0, const ImgB& I
         else if (FUSED) { w1 = warp_invdepth_px(Wc, x, y, w0, WP); i1 = warp_intensity_px(Ic, x, y, w1, WP, fa.interp_mode); }
         else { w1 = px<float>(W1, lane, y, x); i1 = px<float>(I1, lane, y, x); }
         float py_ = ((float)y - C.cy_f) * C.inv_fy, pp_y = fmaf(py_, py_, 1.f);
-        accumulate_pixel<WM>(acc, ((float)x - C.cx_f) * C.inv_fx, py_, pp_y, w0, px<float>(I0, lane, y, x), px<float>(gWx, lane, y, x),
+        accumulate_pixel<WM>(accm, ((float)x - C.cx_f) * C.inv_fx, py_, pp_y, w0, px<float>(I0, lane, y, x), px<float>(gWx, lane, y, x),
                          px<float>(gWy, lane, y, x), px<float>(gIx, lane, y, x), px<float>(gIy, lane, y, x), w1, i1, P, C);
       }
     }
   }
   };
   pixel_loop(std::integral_constant<int, WMK>{});
+  float acc[SYS_TERMS];
+  acc_unpack(accm, acc);
   block_reduce_store(acc, out, (double)C.inv_sd * (double)C.inv_sd, tid, sm);
 }
 
