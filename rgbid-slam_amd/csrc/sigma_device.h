@@ -57,18 +57,27 @@ __device__ __forceinline__ void block_sum4(const float in[4], double out[4], Blo
 // the passes run branch-free.  Every sum a pass forms is LINEAR in the validity flag: sum_valid f(e_i) = sum_all f(e_i) - n_invalid f(0).
 // The register path therefore keeps no per-sample flag at all: it sums f over all its slots with flag 1 and then calls f once more on the
 // value an invalid slot holds with flag -n_invalid (SIG_MAXPT VGPRs and one multiply per sample, sum and pass less).
+// Round 5: the register path keeps its slots in PAIRS (f32x2) and the passes that dominate the kernel -- the Student-t moments and the nu
+// bisection's weight sums -- run two samples per instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two IEEE fp32 operations for ~1.45 x the
+// issue cost of one on gfx950, tools/experiments/valu_rate5.hip; the kernel is VALU-bound at every lane count).  A thread's even and odd slots then sum
+// into the two halves of a pair, added once per pass; the slot count is rounded up to even, the padding slot counted as invalid.
+typedef float sig_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ sig_f32x2 sig_pk_fma(sig_f32x2 a, sig_f32x2 b, sig_f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 template <bool REG, class Getter>
 struct Samples {
+  static constexpr bool reg = REG;
   // register path: <= SIG_MAXPT fp32 adds per thread; streaming path (up to a full frame per thread-stride): double
   using Acc = typename std::conditional<REG, float, double>::type;
-  float e[REG ? SIG_MAXPT : 1];
+  sig_f32x2 e2[REG ? SIG_MAXPT / 2 : 1];
   float zero_slot;   // what an invalid slot currently holds (0, or its image under to_squared_normalised)
   float neg_ninv;    // -(number of invalid slots among this thread's cnt slots)
   Getter get;
-  int n, tid, cnt;
+  int n, tid, cnt;   // cnt: the thread's slots that the passes visit (register path: even)
   __device__ __forceinline__ Samples(const Getter& g, int n_, int tid_) : zero_slot(0.f), neg_ninv(0.f), get(g), n(n_), tid(tid_) { RGBID_FP_STRICT
     cnt = (n + SIG_T - 1) / SIG_T;
     if constexpr (REG) {
+      static_assert(SIG_MAXPT % 2 == 0, "slots are visited in pairs");
+      cnt = (cnt + 1) & ~1;
       // the thread's samples tid, tid + SIG_T, ... are visited through the getter's cursor (seek once, then fixed strides): a lattice
       // getter turns that into one integer division per thread instead of one per sample
       Getter cur = get;
@@ -79,28 +88,40 @@ struct Samples {
         float v = (i < n) ? cur.load() : qnan();
         cur.step();
         bool ok = fabsf(v) < __builtin_inff();  // !isinf && !isnan
-        e[j] = ok ? v : 0.f;
+        if (j & 1) e2[j >> 1].y = ok ? v : 0.f; else e2[j >> 1].x = ok ? v : 0.f;
         if (j < cnt) neg_ninv -= ok ? 0.f : 1.f;
       }
     }
   }
+  // number of slots the passes visit, as the float the count sums add up to (exact)
+  __device__ __forceinline__ float slots() const { return (float)cnt; }
   // After the last moments pass the residuals themselves are no longer needed: the nu bisection only uses en^2 = ((e - bias)/sigma)^2,
   // the same for every candidate nu, so the register copy is overwritten with it once (no extra VGPRs, 3 instructions less per
   // sample and pass).  The streaming path recomputes it on the fly.
   __device__ __forceinline__ void to_squared_normalised(float bias, float inv_sigma) { RGBID_FP_STRICT
     if constexpr (REG) {
+      const sig_f32x2 b2 = {bias, bias}, s2 = {inv_sigma, inv_sigma};
 #pragma unroll
-      for (int j = 0; j < SIG_MAXPT; ++j) { float en = (e[j] - bias) * inv_sigma; e[j] = en * en; }
+      for (int j = 0; j < SIG_MAXPT / 2; ++j) { sig_f32x2 en = (e2[j] - b2) * s2; e2[j] = en * en; }
       float en = (zero_slot - bias) * inv_sigma;
       zero_slot = en * en;
     }
+  }
+  // register path: f2(pair of slots) over the visited slots, then f1(value of an invalid slot, -number of invalid slots)
+  template <class F2, class F1>
+  __device__ __forceinline__ void for_each_pair(F2&& f2, F1&& f1) const { RGBID_FP_STRICT
+    static_assert(REG, "register path only");
+#pragma unroll
+    for (int j = 0; j < SIG_MAXPT / 2; ++j)
+      if (2 * j < cnt) f2(e2[j]);  // wave-uniform
+    f1(zero_slot, neg_ninv);
   }
   template <class F>
   __device__ __forceinline__ void for_each_en2(float bias, float inv_sigma, F&& f) const { RGBID_FP_STRICT  // f(en^2, validity flag); f linear in the flag
     if constexpr (REG) {
 #pragma unroll
-      for (int j = 0; j < SIG_MAXPT; ++j)
-        if (j < cnt) f(e[j], 1.f);
+      for (int j = 0; j < SIG_MAXPT / 2; ++j)
+        if (2 * j < cnt) { f(e2[j].x, 1.f); f(e2[j].y, 1.f); }
       f(zero_slot, neg_ninv);
     } else {
       for (int i = tid; i < n; i += SIG_T) {
@@ -115,8 +136,8 @@ struct Samples {
   __device__ __forceinline__ void for_each(F&& f) const { RGBID_FP_STRICT  // f(residual, validity flag); f linear in the flag
     if constexpr (REG) {
 #pragma unroll
-      for (int j = 0; j < SIG_MAXPT; ++j)
-        if (j < cnt) f(e[j], 1.f);  // wave-uniform
+      for (int j = 0; j < SIG_MAXPT / 2; ++j)
+        if (2 * j < cnt) { f(e2[j].x, 1.f); f(e2[j].y, 1.f); }  // wave-uniform
       f(zero_slot, neg_ninv);
     } else {
       for (int i = tid; i < n; i += SIG_T) {
@@ -146,6 +167,36 @@ __device__ __forceinline__ void pass_moments(const SM& S, float bias, float sigm
     a[0] += wsr; a[1] += wr; a[2] += weight; a[3] += valid;
   };
   if (student_variant) {
+    if constexpr (SM::reg) {
+      // two samples per instruction; the even / odd slots sum into the halves of a pair.  The count sums are known: slots - invalid ones.
+      sig_f32x2 A0 = {0.f, 0.f}, A1 = {0.f, 0.f}, A2 = {0.f, 0.f};
+      float t0, t1, t2;   // the invalid slots' correction (a value times -n_invalid)
+      if (mest == 0) {
+        S.for_each_pair([&](sig_f32x2 er) { A0 += er * er; A1 += er; },
+                        [&](float er, float mv) { const float wr = er * mv; t0 = wr * er; t1 = wr; t2 = mv; });
+        a[0] = (A0.x + A0.y) + t0; a[1] = (A1.x + A1.y) + t1; a[2] = S.slots() + t2; a[3] = a[2];
+      } else {
+        // w = (nu + 1) / (nu + en^2): the constant numerator is applied to the three weighted sums once, after the loop, and the
+        // normalisation is one FMA -- per PAIR of samples 3 packed FMAs, 3 packed multiplies / adds and 2 reciprocals
+        const float nb = -bias * inv_sigma;
+        const sig_f32x2 is2 = {inv_sigma, inv_sigma}, nb2 = {nb, nb}, nu2 = {nu, nu};
+        S.for_each_pair([&](sig_f32x2 er) {
+                          const sig_f32x2 en = sig_pk_fma(er, is2, nb2);
+                          const sig_f32x2 t = sig_pk_fma(en, en, nu2);
+                          const sig_f32x2 r = {__builtin_amdgcn_rcpf(t.x), __builtin_amdgcn_rcpf(t.y)};
+                          const sig_f32x2 wr = er * r;
+                          A0 = sig_pk_fma(wr, er, A0); A1 += wr; A2 += r;
+                        },
+                        [&](float er, float mv) {
+                          const float en = fmaf(er, inv_sigma, nb);
+                          const float r = __builtin_amdgcn_rcpf(fmaf(en, en, nu)) * mv;
+                          const float wr = er * r;
+                          t0 = wr * er; t1 = wr; t2 = r;
+                        });
+        a[0] = ((A0.x + A0.y) + t0) * nup1; a[1] = ((A1.x + A1.y) + t1) * nup1; a[2] = ((A2.x + A2.y) + t2) * nup1;
+        a[3] = S.slots() + S.neg_ninv;
+      }
+    } else {
     if (mest == 0) S.for_each([&](float er, float mv) { acc(er, mv, mv); });
     else {
       // w = (nu + 1) / (nu + en^2): the constant numerator is applied to the three weighted sums once, after the loop, and the
@@ -158,6 +209,7 @@ __device__ __forceinline__ void pass_moments(const SM& S, float bias, float sigm
         a[0] = mad_acc(wr, er, a[0]); a[1] += wr; a[2] += r; a[3] += mv;
       });
       a[0] *= nup1; a[1] *= nup1; a[2] *= nup1;
+    }
     }
   } else {
     S.for_each([&](float er, float mv) {
@@ -191,10 +243,27 @@ __device__ __forceinline__ float func_weights_nu(const SM& S, float bias, float 
   const float nup1 = nu + 1.f;
   // sum ln w = N ln(nu+1) + ln 2 * sum log2 r  and  sum w = (nu+1) sum r  with r = 1 / (nu + en^2) (finite and positive also for a
   // sanitised sample): 3 VALU + reciprocal + log2 per sample, the constants once per thread
+  if constexpr (SM::reg) {
+    sig_f32x2 A0 = {0.f, 0.f}, A1 = {0.f, 0.f};
+    float t0, t1;
+    const sig_f32x2 nu2 = {nu, nu};
+    S.for_each_pair([&](sig_f32x2 en2) {
+                      const sig_f32x2 t = en2 + nu2;
+                      const sig_f32x2 r = {__builtin_amdgcn_rcpf(t.x), __builtin_amdgcn_rcpf(t.y)};
+                      const sig_f32x2 l = {__builtin_amdgcn_logf(r.x), __builtin_amdgcn_logf(r.y)};
+                      A0 += l; A1 += r;
+                    },
+                    [&](float en2, float mv) {
+                      const float r = __builtin_amdgcn_rcpf(nu + en2);
+                      t0 = __builtin_amdgcn_logf(r) * mv; t1 = r * mv;
+                    });
+    a[0] = (A0.x + A0.y) + t0; a[1] = (A1.x + A1.y) + t1; a[2] = S.slots() + S.neg_ninv;
+  } else {
   S.for_each_en2(bias, inv_sigma, [&](float en2, float mv) {
     const float r = __builtin_amdgcn_rcpf(nu + en2);
     a[0] = mad_acc(__builtin_amdgcn_logf(r), mv, a[0]); a[1] = mad_acc(r, mv, a[1]); a[2] += mv;
   });
+  }
   a[0] = (typename SM::Acc)0.69314718055994531 * a[0] + (typename SM::Acc)__logf(nup1) * a[2];
   a[1] *= nup1;
   double t[4];
