@@ -244,20 +244,22 @@ __device__ __forceinline__ float func_weights_nu(const SM& S, float bias, float 
   // sum ln w = N ln(nu+1) + ln 2 * sum log2 r  and  sum w = (nu+1) sum r  with r = 1 / (nu + en^2) (finite and positive also for a
   // sanitised sample): 3 VALU + reciprocal + log2 per sample, the constants once per thread
   if constexpr (SM::reg) {
-    sig_f32x2 A0 = {0.f, 0.f}, A1 = {0.f, 0.f};
-    float t0, t1;
+    // log2 r1 + log2 r2 = log2(r1 r2): ONE logarithm per pair of samples (the transcendental unit is what bounds this kernel when the chip is full:
+    // 2 reciprocals + 1 logarithm per pair instead of 2 + 2).  r <= 1 / 2, and r1 r2 stays a normal fp32 number unless both |en| exceed ~3e9
+    // (a product that underflows gives -inf where the sum of the two logarithms would be < -126: C(nu) is hugely negative either way)
+    sig_f32x2 A1 = {0.f, 0.f};
+    float A0 = 0.f, t0, t1;
     const sig_f32x2 nu2 = {nu, nu};
     S.for_each_pair([&](sig_f32x2 en2) {
                       const sig_f32x2 t = en2 + nu2;
                       const sig_f32x2 r = {__builtin_amdgcn_rcpf(t.x), __builtin_amdgcn_rcpf(t.y)};
-                      const sig_f32x2 l = {__builtin_amdgcn_logf(r.x), __builtin_amdgcn_logf(r.y)};
-                      A0 += l; A1 += r;
+                      A0 += __builtin_amdgcn_logf(r.x * r.y); A1 += r;
                     },
                     [&](float en2, float mv) {
                       const float r = __builtin_amdgcn_rcpf(nu + en2);
                       t0 = __builtin_amdgcn_logf(r) * mv; t1 = r * mv;
                     });
-    a[0] = (A0.x + A0.y) + t0; a[1] = (A1.x + A1.y) + t1; a[2] = S.slots() + S.neg_ninv;
+    a[0] = A0 + t0; a[1] = (A1.x + A1.y) + t1; a[2] = S.slots() + S.neg_ninv;
   } else {
   S.for_each_en2(bias, inv_sigma, [&](float en2, float mv) {
     const float r = __builtin_amdgcn_rcpf(nu + en2);
