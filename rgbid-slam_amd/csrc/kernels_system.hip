@@ -14,8 +14,11 @@
 //    moves 32 instead of 52 B/px and is one launch instead of two.  0.72-0.75 of the HBM peak at 761 VALU instructions per 4-pixel unit in round 3;
 //    0.65-0.68 since round 4, when the kernel began to take the oracle's discrete decisions at every pixel (guard_band.h: ~ +36 instructions per unit):
 //    memory (6.5 TB/s streaming ceiling), VALU issue (~2.4 ms of the 3.4 ms launch) and the L1 address path (~1.5 ms) all run at 45-90 %
-//    under 4 waves per SIMD -- what is left is their imperfect overlap (profiles/r03_experiments/).  FUSED = 1: the same with the
-//    exact-numerics warps (0.44).
+//    under 4 waves per SIMD -- what is left is their imperfect overlap (profiles/r03_experiments/).  Round 5: the guard as lane constants (guard_band.h (3'),
+//    (3'')) and the 27-term update as domino-tiled PACKED FMAs (system_device.h acc_pk_row: 12 v_pk_fma_f32 + 3 v_fma_f32 per row instead of 27; a packed
+//    instruction is two IEEE operations for ~1.45 issue slots on gfx950) bring the unit to 626 VALU instructions: 0.70-0.73 of the peak = 0.89-0.92 of the
+//    chip's measured copy ceiling (6.29 TB/s) -- further instruction trimming no longer moves the launch (profiles/r05_experiments/packed_fp32.md).
+//    FUSED = 1: the same with the exact-numerics warps (0.44).
 // Each lane of a wave64 owns 4 consecutive pixels (16-byte loads, 1 KiB per wave per map, fully coalesced); 27 fp32 accumulators live in
 // VGPRs; the workgroup (4 waves) reduces with DPP wave reductions -> 4x27 floats of LDS -> doubles, and writes ONE 27-double partial row
 // per workgroup.  Partials are summed in a fixed order by a second tiny kernel (or by the batched engine's solve kernel), so results are
