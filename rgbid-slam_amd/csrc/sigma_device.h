@@ -60,7 +60,7 @@ __device__ __forceinline__ void block_sum4(const float in[4], double out[4], Blo
 // Round 5: the register path keeps its slots in PAIRS (f32x2) and the passes that dominate the kernel -- the Student-t moments and the nu
 // bisection's weight sums -- run two samples per instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two IEEE fp32 operations for ~1.45 x the
 // issue cost of one on gfx950, tools/experiments/valu_rate5.hip; the kernel is VALU-bound at every lane count).  A thread's even and odd slots then sum
-// into the two halves of a pair, added once per pass; the slot count is rounded up to even, the padding slot counted as invalid.
+// into the two halves of a pair, added once per pass; the slot count is rounded up to a multiple of 8 (one uniform branch per four pairs), padding slots counted as invalid.
 typedef float sig_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ sig_f32x2 sig_pk_fma(sig_f32x2 a, sig_f32x2 b, sig_f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 template <bool REG, class Getter>
@@ -72,12 +72,12 @@ struct Samples {
   float zero_slot;   // what an invalid slot currently holds (0, or its image under to_squared_normalised)
   float neg_ninv;    // -(number of invalid slots among this thread's cnt slots)
   Getter get;
-  int n, tid, cnt;   // cnt: the thread's slots that the passes visit (register path: even)
+  int n, tid, cnt;   // cnt: the thread's slots that the passes visit (register path: a multiple of 8)
   __device__ __forceinline__ Samples(const Getter& g, int n_, int tid_) : zero_slot(0.f), neg_ninv(0.f), get(g), n(n_), tid(tid_) { RGBID_FP_STRICT
     cnt = (n + SIG_T - 1) / SIG_T;
     if constexpr (REG) {
-      static_assert(SIG_MAXPT % 2 == 0, "slots are visited in pairs");
-      cnt = (cnt + 1) & ~1;
+      static_assert(SIG_MAXPT % 8 == 0, "slots are visited in groups of four pairs");
+      cnt = (cnt + 7) & ~7;   // one wave-uniform branch per four pairs (a branch per pair is if-converted into two selects per pair and pass)
       // the thread's samples tid, tid + SIG_T, ... are visited through the getter's cursor (seek once, then fixed strides): a lattice
       // getter turns that into one integer division per thread instead of one per sample
       Getter cur = get;
@@ -98,13 +98,20 @@ struct Samples {
   // After the last moments pass the residuals themselves are no longer needed: the nu bisection only uses en^2 = ((e - bias)/sigma)^2,
   // the same for every candidate nu, so the register copy is overwritten with it once (no extra VGPRs, 3 instructions less per
   // sample and pass).  The streaming path recomputes it on the fly.
+  // en^2 is capped at 2^60 (|en| ~ 1e9: residuals sit within a few 1e4 sigma of the bias on any data with noise): the product of two nu + en^2 then stays
+  // finite, which func_weights_nu's shared reciprocal / logarithm of a PAIR needs; 1 / (nu + en^2) of such a sample is < 1e-18 either way
+  static constexpr float EN2_MAX = 0x1p60f;
   __device__ __forceinline__ void to_squared_normalised(float bias, float inv_sigma) { RGBID_FP_STRICT
     if constexpr (REG) {
       const sig_f32x2 b2 = {bias, bias}, s2 = {inv_sigma, inv_sigma};
 #pragma unroll
-      for (int j = 0; j < SIG_MAXPT / 2; ++j) { sig_f32x2 en = (e2[j] - b2) * s2; e2[j] = en * en; }
+      for (int j = 0; j < SIG_MAXPT / 2; ++j) {
+        const sig_f32x2 en = (e2[j] - b2) * s2, q = en * en;
+        e2[j].x = q.x > EN2_MAX ? EN2_MAX : q.x; e2[j].y = q.y > EN2_MAX ? EN2_MAX : q.y;   // NaN stays NaN
+      }
       float en = (zero_slot - bias) * inv_sigma;
-      zero_slot = en * en;
+      en = en * en;
+      zero_slot = en > EN2_MAX ? EN2_MAX : en;
     }
   }
   // register path: f2(pair of slots) over the visited slots, then f1(value of an invalid slot, -number of invalid slots)
@@ -112,8 +119,10 @@ struct Samples {
   __device__ __forceinline__ void for_each_pair(F2&& f2, F1&& f1) const { RGBID_FP_STRICT
     static_assert(REG, "register path only");
 #pragma unroll
-    for (int j = 0; j < SIG_MAXPT / 2; ++j)
-      if (2 * j < cnt) f2(e2[j]);  // wave-uniform
+    for (int g = 0; g < SIG_MAXPT / 8; ++g)
+      if (8 * g < cnt) {  // wave-uniform
+        f2(e2[4 * g]); f2(e2[4 * g + 1]); f2(e2[4 * g + 2]); f2(e2[4 * g + 3]);
+      }
     f1(zero_slot, neg_ninv);
   }
   template <class F>
@@ -244,22 +253,23 @@ __device__ __forceinline__ float func_weights_nu(const SM& S, float bias, float 
   // sum ln w = N ln(nu+1) + ln 2 * sum log2 r  and  sum w = (nu+1) sum r  with r = 1 / (nu + en^2) (finite and positive also for a
   // sanitised sample): 3 VALU + reciprocal + log2 per sample, the constants once per thread
   if constexpr (SM::reg) {
-    // log2 r1 + log2 r2 = log2(r1 r2): ONE logarithm per pair of samples (the transcendental unit is what bounds this kernel when the chip is full:
-    // 2 reciprocals + 1 logarithm per pair instead of 2 + 2).  r <= 1 / 2, and r1 r2 stays a normal fp32 number unless both |en| exceed ~3e9
-    // (a product that underflows gives -inf where the sum of the two logarithms would be < -126: C(nu) is hugely negative either way)
-    sig_f32x2 A1 = {0.f, 0.f};
-    float A0 = 0.f, t0, t1;
+    // The transcendental unit is what bounds this kernel when the chip is full, so a PAIR of samples shares its two transcendentals: with t = nu + en^2,
+    //   log2 r1 + log2 r2 = -log2(t1 t2)   and   r1 + r2 = (t1 + t2) / (t1 t2)
+    // -- one v_log_f32 and one v_rcp_f32 of the product t1 t2 per pair instead of two of each per pair (2 <= t <= 2 + 2^60: the product is a normal
+    // fp32 number).  The sums feed the sign of C(nu) on the bisection grid; the pairing changes them by a few ulp.
+    float A0 = 0.f, A1 = 0.f, t0, t1;
     const sig_f32x2 nu2 = {nu, nu};
     S.for_each_pair([&](sig_f32x2 en2) {
                       const sig_f32x2 t = en2 + nu2;
-                      const sig_f32x2 r = {__builtin_amdgcn_rcpf(t.x), __builtin_amdgcn_rcpf(t.y)};
-                      A0 += __builtin_amdgcn_logf(r.x * r.y); A1 += r;
+                      const float p = t.x * t.y, ts = t.x + t.y;
+                      A0 -= __builtin_amdgcn_logf(p);
+                      A1 = fmaf(ts, __builtin_amdgcn_rcpf(p), A1);
                     },
                     [&](float en2, float mv) {
                       const float r = __builtin_amdgcn_rcpf(nu + en2);
                       t0 = __builtin_amdgcn_logf(r) * mv; t1 = r * mv;
                     });
-    a[0] = A0 + t0; a[1] = (A1.x + A1.y) + t1; a[2] = S.slots() + S.neg_ninv;
+    a[0] = A0 + t0; a[1] = A1 + t1; a[2] = S.slots() + S.neg_ninv;
   } else {
   S.for_each_en2(bias, inv_sigma, [&](float en2, float mv) {
     const float r = __builtin_amdgcn_rcpf(nu + en2);
