@@ -155,15 +155,20 @@ __global__ __launch_bounds__(64) RGBID_SCALAR_KERNEL void k_step_begin(LaneState
 // ---- one GN update: reduce partials, LLT solve, exp-map, pose update, next warp (visodo.cpp:1242-1274) -------
 // sys_level >= 0: this is the last update of a stage -- the per-level constants of the lane's SysParams for the stage that follows (the next level's
 // iterations, or the covariance pass: sys_cov) are set here (every lane, as the separate k_set_sys launch did; nothing of the solve reads them)
-__global__ __launch_bounds__(256) RGBID_SCALAR_KERNEL void k_solve_update(const double* partials, int nblk, LaneState* st, Flags f, WarpParams* wp,
+// Register budget: the 256-thread form takes the whole register file (RGBID_SCALAR_KERNEL: the first builds spilled under the default budget); the kernel needs 147
+// VGPRs, so the one-wave form may share a SIMD three ways (170 VGPRs each): 12 lanes per compute unit at a time, 2 048 lanes in one round.
+template <int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, NT == 64 ? 3 : 1))) void k_solve_update(const double* partials, int nblk, LaneState* st, Flags f, WarpParams* wp,
                                                       StepCfg c, int next_level, SysParams* sp, int sys_level, int sys_cov) {
   int lane = blockIdx.x;
-  if (sys_level >= 0 && threadIdx.x == 64) set_sys_lane(sp, st, f.track, c, sys_level, sys_cov, lane);
+  if (sys_level >= 0 && threadIdx.x == NT / 4) set_sys_lane(sp, st, f.track, c, sys_level, sys_cov, lane);   // NT = 256: a wave of its own, beside thread 0's solve
   if (!f.lvl[lane]) return;   // lvl == gn unless CHI_SQUARED termination has ended this lane's level early
   __shared__ double sm[8][32];
   __shared__ double sums[SYS_TERMS];
-  solve_update_block(partials, nblk, st, f, wp, c, next_level, lane, (int)threadIdx.x, sm, sums);
+  solve_update_block<NT>(partials, nblk, st, f, wp, c, next_level, lane, (int)threadIdx.x, sm, sums);
 }
+// workgroup size of the per-lane reduce-and-solve kernels (engine_device.h reduce_partials): one wave per lane once there are more lanes than compute units
+inline int scalar_block_threads(int B) { return B > 256 ? 64 : 256; }
 
 // ---- CHI_SQUARED termination (visodo.cpp:1134-1164) ------------------------------------------------------------------------------------
 // a level begins: every lane whose Gauss-Newton is alive iterates it
@@ -193,29 +198,17 @@ __global__ __launch_bounds__(64) RGBID_SCALAR_KERNEL void k_chi_decide(LaneState
 }
 
 // ---- end of estimateVisualOdometry + pose bookkeeping of trackNewFrame (visodo.cpp:1367-1468, 2051-2170) -----
-__global__ __launch_bounds__(256) RGBID_SCALAR_KERNEL void k_frame_finish(const double* partials, int nblk, LaneState* st, Flags f, const SysParams* sp,
+template <int NT>
+__global__ __launch_bounds__(NT) RGBID_SCALAR_KERNEL void k_frame_finish(const double* partials, int nblk, LaneState* st, Flags f, const SysParams* sp,
                                                       WarpParams* vis_ab, WarpParams* vis_ba, WarpParams* ivis_ab, WarpParams* ivis_ba,
                                                       rgbid_pose_record* rec, StepCfg c) {
   int lane = blockIdx.x;
   if (!f.track[lane]) return;
   __shared__ double sm[8][32];
   __shared__ double sums[SYS_TERMS];
-  int k = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  double t = 0.0;
   LaneState& s = st[lane];
   bool ok = !s.gn_failed;
-  if (ok && k < SYS_TERMS) {
-    const double* p = partials + (size_t)lane * nblk * SYS_TERMS + k;
-    for (int b = sl; b < nblk; b += 8) t += p[(size_t)b * SYS_TERMS];
-  }
-  sm[sl][k] = t;
-  __syncthreads();
-  if (threadIdx.x < SYS_TERMS) {
-    double r = 0.0;
-    for (int i = 0; i < 8; ++i) r += sm[i][threadIdx.x];
-    sums[threadIdx.x] = r;
-  }
-  __syncthreads();
+  reduce_partials<NT>(partials, ok ? nblk : 0, lane, (int)threadIdx.x, sm, sums);   // a failed lane's sums are not used (zeros, as before)
   if (threadIdx.x != 0) return;
   rgbid_pose_record& R = rec[lane];
   R.frame = s.global_time;
@@ -778,8 +771,12 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
         nblk = launch_build_system(s, B, e->iD_kf[level], e->I_kf[level], e->gxD[level], e->gyD[level], e->gxI[level], e->gyI[level],
                                    e->wiD[level], e->wI[level], nullptr, e->sp, e->partials, LV, level < 2 ? level : 2);
       }
-      hipLaunchKernelGGL(k_solve_update, dim3(B), dim3(256), 0, s, e->partials, nblk, e->state, f, e->wp, sc, next_level, e->sp,
-                         last_of_level ? stage_level[stage] : -1, (last_of_level && stage == n_gn_stages) ? 1 : 0);
+      if (scalar_block_threads(B) == 64)
+        hipLaunchKernelGGL(k_solve_update<64>, dim3(B), dim3(64), 0, s, e->partials, nblk, e->state, f, e->wp, sc, next_level, e->sp,
+                           last_of_level ? stage_level[stage] : -1, (last_of_level && stage == n_gn_stages) ? 1 : 0);
+      else
+        hipLaunchKernelGGL(k_solve_update<256>, dim3(B), dim3(256), 0, s, e->partials, nblk, e->state, f, e->wp, sc, next_level, e->sp,
+                           last_of_level ? stage_level[stage] : -1, (last_of_level && stage == n_gn_stages) ? 1 : 0);
       e->launches += 2;
     }
   }
@@ -813,8 +810,12 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
       launch_chi_square(s, B, e->res_I, e->res_D, (size_t)c.rows * c.cols, n, 5.f, 0.0025f, c.mestimator, e->chi_out, M(f.gn));
       e->launches += 3;
     }
-    hipLaunchKernelGGL(k_frame_finish, dim3(B), dim3(256), 0, s, e->partials, nblk, e->state, f, e->sp, e->vis_ab, e->vis_ba,
-                       e->ivis_ab, e->ivis_ba, e->rec_cur, sc);
+    if (scalar_block_threads(B) == 64)
+      hipLaunchKernelGGL(k_frame_finish<64>, dim3(B), dim3(64), 0, s, e->partials, nblk, e->state, f, e->sp, e->vis_ab, e->vis_ba,
+                         e->ivis_ab, e->ivis_ba, e->rec_cur, sc);
+    else
+      hipLaunchKernelGGL(k_frame_finish<256>, dim3(B), dim3(256), 0, s, e->partials, nblk, e->state, f, e->sp, e->vis_ab, e->vis_ba,
+                         e->ivis_ab, e->ivis_ba, e->rec_cur, sc);
     e->launches++;
   }
   // ---- covisibility with both keyframes (visodo.cpp:2172-2188), 4 ratio evaluations

@@ -85,18 +85,24 @@ __device__ inline void set_sys_lane(SysParams* sp, LaneState* st, const int* tra
   }
 }
 
-// one GN update of one lane by the first 256 threads of a workgroup (every thread of the workgroup must call it: two barriers): fixed-order reduction
-// of the lane's partial sums, LLT solve, exp-map, pose update, next warp (visodo.cpp:1242-1274).  sm: [8][32] doubles, sums: [SYS_TERMS] doubles of LDS.
-__device__ inline void solve_update_block(const double* partials, int nblk, LaneState* st, const Flags& f, WarpParams* wp, const StepCfg& c, int next_level, int lane,
-                                          int tid, double (*sm)[32], double* sums) { RGBID_FP_STRICT
-  int k = tid & 31, sl = tid >> 5;
-  if (tid < 256) {
-    double t = 0.0;
-    if (k < SYS_TERMS) {
-      const double* p = partials + (size_t)lane * nblk * SYS_TERMS + k;
-      for (int b = sl; b < nblk; b += 8) t += p[(size_t)b * SYS_TERMS];
+// Fixed-order reduction of a lane's partial rows by the NT (256 or 64) threads of a workgroup (every thread of the workgroup must call it: two barriers): slice sl of 8
+// sums the rows sl, sl + 8, ... of one term, then the 8 slice sums are added in order -- the same doubles whatever NT is.  NT = 256: one slice per thread, the
+// shortest path for a few lanes; NT = 64: four slices per thread, ONE wave per lane -- the kernels that follow keep the whole register file per wave
+// (RGBID_SCALAR_KERNEL), so a 256-thread workgroup occupies a compute unit alone while three of its waves idle: with thousands of lanes the 64-thread form runs four
+// lanes per compute unit at a time.  sm: [8][32] doubles, sums: [SYS_TERMS] doubles of LDS.
+template <int NT>
+__device__ inline void reduce_partials(const double* partials, int nblk, int lane, int tid, double (*sm)[32], double* sums) { RGBID_FP_STRICT
+  static_assert(NT == 256 || NT == 64, "8 slices of 32 threads, or 2 x 4");
+  const int k = tid & 31;
+  if (tid < NT) {
+    for (int sl = tid >> 5; sl < 8; sl += NT / 32) {
+      double t = 0.0;
+      if (k < SYS_TERMS) {
+        const double* p = partials + (size_t)lane * nblk * SYS_TERMS + k;
+        for (int b = sl; b < nblk; b += 8) t += p[(size_t)b * SYS_TERMS];
+      }
+      sm[sl][k] = t;
     }
-    sm[sl][k] = t;
   }
   __syncthreads();
   if (tid < SYS_TERMS) {
@@ -105,6 +111,14 @@ __device__ inline void solve_update_block(const double* partials, int nblk, Lane
     sums[tid] = r;
   }
   __syncthreads();
+}
+
+// one GN update of one lane by the first NT threads of a workgroup (every thread of the workgroup must call it: two barriers): fixed-order reduction
+// of the lane's partial sums, LLT solve, exp-map, pose update, next warp (visodo.cpp:1242-1274).  sm: [8][32] doubles, sums: [SYS_TERMS] doubles of LDS.
+template <int NT = 256>
+__device__ inline void solve_update_block(const double* partials, int nblk, LaneState* st, const Flags& f, WarpParams* wp, const StepCfg& c, int next_level, int lane,
+                                          int tid, double (*sm)[32], double* sums) { RGBID_FP_STRICT
+  reduce_partials<NT>(partials, nblk, lane, tid, sm, sums);
   if (tid != 0) return;
   LaneState& s = st[lane];
   double A[36], b[6], x[6];

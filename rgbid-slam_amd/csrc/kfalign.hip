@@ -80,17 +80,23 @@ __global__ void k_kfa_set_nu(const SigmaIO* io, SysParams* sp, int B) {
 
 // one update of one pair: fixed-order reduction of its partial sums (the order of k_reduce_system, kernels_system.hip), LLT solve, exp-map, pre-multiplied
 // pose update (:312-335), then what the next iteration needs (warp at next_level, start values)
-__global__ __launch_bounds__(256) RGBID_SCALAR_KERNEL void k_kfa_solve(const double* partials, int nblk, KfaState* st, WarpParams* wp, SysParams* sp, SigmaIO* io, int next_level) {
+// NT: 256 threads per pair, or ONE wave per pair once there are more pairs than compute units (the kernel keeps the whole register file per wave: a 256-thread
+// workgroup occupies a compute unit alone while three of its waves idle) -- four slices of the reduction per thread then, the same doubles in the same order
+template <int NT>
+__global__ __launch_bounds__(NT) RGBID_SCALAR_KERNEL void k_kfa_solve(const double* partials, int nblk, KfaState* st, WarpParams* wp, SysParams* sp, SigmaIO* io, int next_level) {
+  static_assert(NT == 256 || NT == 64, "8 slices of 32 threads, or 2 x 4");
   const int lane = blockIdx.x, tid = threadIdx.x;
   __shared__ double sm[8][32];
   __shared__ double sums[SYS_TERMS];
-  const int k = tid & 31, sl = tid >> 5;
-  double acc = 0.0;
-  if (k < SYS_TERMS) {
-    const double* p = partials + (size_t)lane * nblk * SYS_TERMS + k;
-    for (int b = sl; b < nblk; b += 8) acc += p[(size_t)b * SYS_TERMS];
+  const int k = tid & 31;
+  for (int sl = tid >> 5; sl < 8; sl += NT / 32) {
+    double acc = 0.0;
+    if (k < SYS_TERMS) {
+      const double* p = partials + (size_t)lane * nblk * SYS_TERMS + k;
+      for (int b = sl; b < nblk; b += 8) acc += p[(size_t)b * SYS_TERMS];
+    }
+    sm[sl][k] = acc;
   }
-  sm[sl][k] = acc;
   __syncthreads();
   if (tid < SYS_TERMS) {
     double r = 0.0;
@@ -265,7 +271,8 @@ int rgbid_kfalign_batched(rgbid_kfalign* a, int pairs, const float* iD_ini_dev, 
       hipLaunchKernelGGL(k_kfa_set_nu, dim3(gb), dim3(tb), 0, s, a->io, a->sp, B);
       const int nblk = launch_build_system(s, B, a->iD_ini[l], a->I_ini[l], a->gxD[l], a->gyD[l], a->gxI[l], a->gyI[l], a->W1[l], a->I1[l], nullptr, a->sp, a->partials, ALL,
                                            l < 2 ? l : 2);
-      hipLaunchKernelGGL(k_kfa_solve, dim3(B), dim3(256), 0, s, a->partials, nblk, a->state, a->wp, a->sp, a->io, next_level);
+      if (B > 256) hipLaunchKernelGGL(k_kfa_solve<64>, dim3(B), dim3(64), 0, s, a->partials, nblk, a->state, a->wp, a->sp, a->io, next_level);
+      else hipLaunchKernelGGL(k_kfa_solve<256>, dim3(B), dim3(256), 0, s, a->partials, nblk, a->state, a->wp, a->sp, a->io, next_level);
       a->launches += 7;
     }
   }

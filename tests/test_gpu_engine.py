@@ -786,3 +786,27 @@ def test_deferred_keyframe_maps_change_no_output(ctx, use_graph):
         for x, y in zip(ma, mb):
             assert np.array_equal(x, y, equal_nan=True)
     assert b[4] == a[4]      # the export-side launch replaces the end-of-step one
+
+
+def test_engine_one_wave_scalar_kernels(ctx):
+    """More lanes than compute units: the per-lane reduce-and-solve kernels (k_solve_update, k_frame_finish) run as ONE wave per lane instead of four
+    (engine_device.h reduce_partials<64>: four slices per thread, the same doubles in the same order as the 256-thread form).  320 lanes carrying 4 distinct
+    streams: duplicates are bit-identical, and every stream agrees with a 4-lane engine (256-thread workgroups; another launch plan of the normal equations,
+    so another rounding of the fp32 partial sums) far inside the pose bar, with the same keyframe decisions."""
+    rows, cols, K = 120, 160, (131.25, 131.25, 79.875, 59.875)
+    n_frames, n_streams, B = 6, 4, 320
+    seqs, depth, rgb = make_lanes(n_streams, n_frames, rows, cols, K)
+    idx = torch.arange(B, device="cuda") % n_streams
+    few = E.Engine(ctx, E.default_config(rows=rows, cols=cols, lanes=n_streams, K=K, record_capacity=n_frames))
+    many = E.Engine(ctx, E.default_config(rows=rows, cols=cols, lanes=B, K=K, record_capacity=n_frames))
+    for k in range(n_frames):
+        few.step(depth[k], rgb[k])
+        many.step(depth[k][idx].contiguous(), rgb[k][idx].contiguous())
+    a, b = few.records(), many.records()
+    for l in range(n_streams, B):
+        assert a.dtype == b.dtype and b[:, l].tobytes() == b[:, l % n_streams].tobytes(), l     # duplicates: every byte
+    for l in range(n_streams):
+        assert np.array_equal(a["status"][:, l], b["status"][:, l])
+        for k in range(n_frames):
+            assert rot_angle(a["R"][k, l], b["R"][k, l]) < 2e-5 and np.abs(a["t"][k, l] - b["t"][k, l]).max() < 2e-5, (k, l)
+    few.close(); many.close()
