@@ -75,7 +75,22 @@ RGBID_HD void skew(const double* w, double* S) { RGBID_FP_STRICT
 
 // forceOrthogonalisation (util_funcs.cpp:150-155): U V^T of the SVD = the orthogonal polar factor
 // R = M (M^T M)^(-1/2); the symmetric 3x3 inverse square root comes from cyclic Jacobi rotations.
+// Fast path for what this library actually feeds it -- a rotation up to rounding (exp-map output, products of rotations): ONE Newton step of the polar iteration
+// X <- (X + X^-T) / 2 squares the distance to U V^T (1e-16 -> 1e-32), so when the step moves M by less than 2^-40 its result IS the polar factor to the last bit
+// or two (~95 instructions instead of ~700: the per-lane solve kernels run on one thread).  Anything farther from a rotation takes the general path below.
 RGBID_HD void force_orthogonal(const double* M, double* R) { RGBID_FP_STRICT
+  {
+    double Xi[9], N[9], moved = 0.0;
+    m3_inv(M, Xi);
+    RGBID_UNROLL for (int i = 0; i < 3; ++i)
+      RGBID_UNROLL for (int j = 0; j < 3; ++j) {
+        const double n = 0.5 * (M[i * 3 + j] + Xi[j * 3 + i]);
+        const double d = fabs(n - M[i * 3 + j]);
+        N[i * 3 + j] = n;
+        moved = d > moved ? d : moved;   // a NaN never raises `moved`: it travels into R and is caught by the caller's has_nan
+      }
+    if (moved < 0x1p-40) { m3_copy(N, R); return; }
+  }
   double S[9], V[9], Mt[9];
   m3_T(M, Mt);
   m3_mul(Mt, M, S);

@@ -51,6 +51,21 @@ def test_force_orthogonal_is_polar_factor():
         assert np.abs(R.T @ R - np.eye(3)).max() < 1e-14
 
 
+def test_force_orthogonal_fast_path_on_rotations():
+    """A rotation up to rounding (what expMap / logMap feed it) takes the one-Newton-step path of se3.h: still the polar factor of the SVD."""
+    r = np.random.default_rng(41)
+    for _ in range(50):
+        w = r.standard_normal(3) * r.choice([1e-6, 1e-2, 1.0, 3.0])
+        th = np.linalg.norm(w); k = w / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        M = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx + 1e-15 * r.standard_normal((3, 3))   # Rodrigues + rounding-size noise
+        U, _, Vt = np.linalg.svd(M)
+        R = host.force_orthogonal(M)
+        assert np.abs(R - U @ Vt).max() < 5e-15                # a few ulp: LAPACK's own U @ Vt carries as much
+        assert np.abs(R.T @ R - np.eye(3)).max() < 1e-15
+        assert np.abs(R - O.force_orthogonal(M)).max() < 5e-15
+
+
 def test_llt_and_inverse():
     r = np.random.default_rng(5)
     for _ in range(10):
