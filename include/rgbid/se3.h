@@ -240,8 +240,8 @@ RGBID_HD void inverse6(const double* A, double* Ainv) { RGBID_FP_STRICT
       const bool sw = p == r;
       RGBID_UNROLL for (int j = 0; j < 12; ++j) { const double t = M[c][j]; M[c][j] = sw ? M[r][j] : t; M[r][j] = sw ? t : M[r][j]; }
     }
-    double piv = M[c][c];
-    RGBID_UNROLL for (int j = 0; j < 12; ++j) M[c][j] /= piv;
+    const double ipiv = 1.0 / M[c][c];   // one division per pivot row instead of twelve
+    RGBID_UNROLL for (int j = 0; j < 12; ++j) M[c][j] *= ipiv;
     RGBID_UNROLL for (int r = 0; r < 6; ++r) if (r != c) {
       double f = M[r][c];
       if (f != 0.0) RGBID_UNROLL for (int j = 0; j < 12; ++j) M[r][j] -= f * M[c][j];
