@@ -13,6 +13,13 @@ dur, uniform = {}, {}
 for r in csv.DictReader(open(f"{d}/sq_kernels_rgbid.csv")):
     dur[r["Name"]] = float(r["MaxNs"])
     uniform[r["Name"]] = float(r["MaxNs"]) < 1.6 * float(r["AverageActiveNs"])   # (nearly) all active launches have the size of the largest
+    n = int(r["CallsActive"])
+    if not uniform[r["Name"]] and n > 2:
+        # ONE slow launch among equal ones (the launch that first touches freshly allocated memory: tens of ms): take the mean of the others
+        rest = (float(r["AverageActiveNs"]) * n - float(r["MaxNs"])) / (n - 1)
+        if float(r["MinNs"]) > 0.7 * rest:
+            dur[r["Name"]] = rest
+            uniform[r["Name"]] = True
 rows = []
 for k, c in ctr.items():
     if "rgbid::" not in k or c.get("SQ_WAVES", 0) < 1000 or not uniform.get(k, False):
