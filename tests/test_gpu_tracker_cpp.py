@@ -195,6 +195,37 @@ def test_keyframe_align_batched(rows, cols):
     al.close(); ctx.close()
 
 
+def test_keyframe_align_batched_many_pairs_one_wave_solve():
+    """More pairs than compute units: the per-pair reduce-and-solve kernel runs as ONE wave per pair (kfalign.hip k_kfa_solve<64>: four slices of the fixed-order
+    reduction per thread, the same doubles).  272 pairs carrying 4 distinct ones: duplicates agree to the last bit, and every pair agrees with its 4-pair run
+    (256-thread workgroups; another launch plan of the normal equations) far inside the tolerance (1e-5 here, 1e-4 the bar)."""
+    from rgbid import device, kfalign
+    rows, cols = 120, 160
+    K0 = (131.25, 131.25, 79.875, 59.875)
+    n, B = 4, 272
+    iDa, ga, iDb, gb = [], [], [], []
+    for i in range(n):
+        seq = synth.make_sequence(4, seed=synth.SEED + 31 * i, K=K0, rows=rows, cols=cols, device="cuda", trans_step=(0.008, 0.02), rot_step_deg=(0.3, 1.0))
+        d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+        iD, grey, _, _ = _kf_pair(seq, d, c, 0, 2 + (i & 1))
+        iDa.append(iD[0]); iDb.append(iD[1]); ga.append(grey[0]); gb.append(grey[1])
+    iDa, iDb, ga, gb = [np.stack(x) for x in (iDa, iDb, ga, gb)]
+    idx = np.arange(B) % n
+    Ks = np.tile(np.asarray(K0, np.float32), (B, 1))
+    R0 = np.tile(np.eye(3), (B, 1, 1)); t0 = np.zeros((B, 3))
+    ctx = device.Context(0)
+    few = kfalign.KfAlign(ctx, rows, cols, n)
+    Rf, tf, cf = few.align(iDa, ga, iDb, gb, Ks[:n], R0[:n], t0[:n])
+    few.close()
+    many = kfalign.KfAlign(ctx, rows, cols, B)
+    R, t, cov = many.align(iDa[idx], ga[idx], iDb[idx], gb[idx], Ks, R0, t0)
+    many.close(); ctx.close()
+    for l in range(B):
+        assert np.array_equal(R[l], R[l % n]) and np.array_equal(t[l], t[l % n]) and np.array_equal(cov[l], cov[l % n]), l
+    for l in range(n):
+        assert rot_angle(R[l], Rf[l]) < 1e-5 and np.linalg.norm(t[l] - tf[l]) < 1e-5, (l, rot_angle(R[l], Rf[l]), np.linalg.norm(t[l] - tf[l]))
+
+
 def test_cli_eval_harness_on_tum_layout(tmp_path):
     """a TUM-layout dataset on disk (16-bit PNG depth x5000, 8-bit RGB PNG, association files) played through
     the `rgbid_slam_eval -eval` harness gives the oracle tracker's trajectory in the TUM trajectory format."""
