@@ -198,7 +198,7 @@ def test_keyframe_align_batched(rows, cols):
 def test_keyframe_align_batched_many_pairs_one_wave_solve():
     """More pairs than compute units: the per-pair reduce-and-solve kernel runs as ONE wave per pair (kfalign.hip k_kfa_solve<64>: four slices of the fixed-order
     reduction per thread, the same doubles).  272 pairs carrying 4 distinct ones: duplicates agree to the last bit, and every pair agrees with its 4-pair run
-    (256-thread workgroups; another launch plan of the normal equations) far inside the tolerance (1e-5 here, 1e-4 the bar)."""
+    (256-thread workgroups; another launch plan of the normal equations) inside the tolerance (3e-5 here at 160x120, where a flipped nu bisection step moves a pose by ~1e-5; 1e-4 the bar)."""
     from rgbid import device, kfalign
     rows, cols = 120, 160
     K0 = (131.25, 131.25, 79.875, 59.875)
@@ -223,7 +223,7 @@ def test_keyframe_align_batched_many_pairs_one_wave_solve():
     for l in range(B):
         assert np.array_equal(R[l], R[l % n]) and np.array_equal(t[l], t[l % n]) and np.array_equal(cov[l], cov[l % n]), l
     for l in range(n):
-        assert rot_angle(R[l], Rf[l]) < 1e-5 and np.linalg.norm(t[l] - tf[l]) < 1e-5, (l, rot_angle(R[l], Rf[l]), np.linalg.norm(t[l] - tf[l]))
+        assert rot_angle(R[l], Rf[l]) < 3e-5 and np.linalg.norm(t[l] - tf[l]) < 3e-5, (l, rot_angle(R[l], Rf[l]), np.linalg.norm(t[l] - tf[l]))
 
 
 def test_cli_eval_harness_on_tum_layout(tmp_path):
