@@ -99,21 +99,27 @@ static void system_plan(int rows, int cols, int B, bool vec, int* upt, int* nblk
     // a multiple of it), the workgroups of neighbouring strips work on the same image rows at the same time and the cache lines their gathers share
     // across the strip border are fetched once; with u = 17 on 60-tile strips (2 048 lanes at 640x480) neighbours are ~9 tile steps = ~50 us apart, the
     // shared lines are long gone from the XCD's L2, and the launch moved 1.07 x its algorithmic bytes (1.01 x at 512 lanes, where u = 15).
-    // Among those strip-aligned values the one with the shortest schedule is taken: rounds of the chip's resident capacity (4 four-wave workgroups of the
-    // fused kernel per compute unit) times the length of a workgroup (u tiles + its epilogue, ~0.6 of a tile).  With thousands of lanes that is the plan
-    // above (60 tiles, whole rounds); with 8 .. 200 lanes it replaces 4 800 short workgroups in 4.7 rounds (the last one two-thirds full) by one round of
-    // 960 long ones (round 5; 64 lanes: u 4 -> 20).
     const long long ty = system_tiles(rows, cols).tiles_y;
-    const long long slots = (long long)device_cus() * 4;
-    long long best = u;
-    double best_cost = 1e300;
-    for (long long d = 1; d <= max_upt && d <= steps; ++d) {
-      if (!(ty % d == 0 || d % ty == 0)) continue;
-      const long long wgs = ((steps + d - 1) / d) * (long long)B;
-      const double cost = (double)((wgs + slots - 1) / slots) * ((double)d + 0.6);
-      if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && d > best)) { best_cost = cost; best = d; }
+    long long best = 0;
+    for (long long d = 1; d <= u; ++d) if (ty % d == 0 || d % ty == 0) best = d;
+    if (best * 4 >= u * 3) u = best;                         // at most a third more workgroups
+    // Few lanes (round 5): the plan above makes thousands of short workgroups (32 lanes: 4 800 of 2 tiles, 4.7 rounds of the chip's resident capacity), each with
+    // its own start-up and epilogue.  Up to 32 lanes the strip-aligned value with the shortest schedule is taken instead -- rounds of 4 four-wave workgroups per
+    // compute unit times the length of a workgroup (u tiles + an epilogue of ~0.6 tile): ONE round of up to 1 024 long workgroups (32 lanes: u = 10).  Measured in
+    // the bench: +10 % frames/s at 16 lanes, +2 % at 31 (the level-0 launch alone: -12 % at 8 lanes, -9 % at 32); at 64 lanes the level-0 launch is 6 % SLOWER in
+    // the bench with it (3 % faster alone) and at 128 lanes 4.7 % slower -- a second round of long workgroups balances worse than six of short ones -- so it stops at 32.
+    if (B <= 32) {
+      const long long slots = (long long)device_cus() * 4;
+      long long pick = u;
+      double pick_cost = 1e300;
+      for (long long d = 1; d <= max_upt && d <= steps; ++d) {
+        if (!(ty % d == 0 || d % ty == 0)) continue;
+        const long long wgs = ((steps + d - 1) / d) * (long long)B;
+        const double cost = (double)((wgs + slots - 1) / slots) * ((double)d + 0.6);
+        if (cost < pick_cost - 1e-9 || (cost < pick_cost + 1e-9 && d > pick)) { pick_cost = cost; pick = d; }
+      }
+      u = pick;
     }
-    u = best;
   }
   nb = (steps + u - 1) / u;                                  // drop workgroups that would get no step
   *upt = (int)u;
