@@ -85,6 +85,7 @@ int rgbid_ctx_set_stream(rgbid_ctx* ctx, void* stream);
 int rgbid_ctx_set_async(rgbid_ctx* ctx, int async_on);       /* default 0: synchronous on return */
 int rgbid_ctx_get_async(rgbid_ctx* ctx, int* async_on);
 int rgbid_ctx_set_interp_mode(rgbid_ctx* ctx, int mode);     /* default RGBID_INTERP_TEX8 */
+int rgbid_ctx_get_interp_mode(rgbid_ctx* ctx, int* mode);
 int rgbid_ctx_sync(rgbid_ctx* ctx);                          /* internal.h:456-457 sync() */
 /* Arithmetic class of the bridge calls that have two implementations (today: rgbid_bilateral_filter; rgbid_warp_pair takes it per call):
  * RGBID_NUMERICS_EXACT (default) = the IEEE evaluation of the oracle, bit for bit; RGBID_NUMERICS_FAST = the reference BUILD's class of

@@ -194,8 +194,12 @@ RGBID_HD void logmap(const double* M, const double* trans, double* twist) { RGBI
   twist[3] = rx; twist[4] = ry; twist[5] = rz;
 }
 
-// A.llt().solve(b): Cholesky; a non-PD matrix propagates NaN exactly like Eigen (no pivoting, sqrt of a negative).  One reciprocal per pivot, used by its column
-// and by both substitutions: 6 double-precision divisions instead of 27 (each ~12 dependent instructions on the one thread the device solve runs on)
+// A.llt().solve(b): Cholesky without pivoting; a non-PD matrix propagates NaN as Eigen's does (sqrt of a negative).  NOT operation for operation Eigen's
+// LLT: Eigen divides every column entry and every substituted element by the pivot; here ONE reciprocal per pivot is taken and multiplied in by its column
+// and by both substitutions -- 6 double-precision divisions instead of 27 (each ~12 dependent instructions on the one thread the device solve runs on).
+// A product with the rounded reciprocal is within 1.5 ulp of the quotient (0.5 reciprocal + 0.5 product, relative), so x agrees with a dividing solve to
+// a few ulp times the condition number: tests/test_cpu_host.py compares both on matrices up to cond 1e12 (host and device share this body, so both
+// tracker modes and the oracle's double-precision solve stay within the pose bar by > 4 orders of magnitude).
 RGBID_HD void llt_solve6(const double* A, const double* b, double* x) { RGBID_FP_STRICT
   double L[36], iL[6];
   RGBID_UNROLL for (int i = 0; i < 36; ++i) L[i] = 0.0;
@@ -232,7 +236,8 @@ RGBID_HD void inverse6(const double* A, double* Ainv) { RGBID_FP_STRICT
     RGBID_UNROLL for (int j = 0; j < 6; ++j) { M[i][j] = A[i * 6 + j]; M[i][6 + j] = (i == j) ? 1.0 : 0.0; }
   RGBID_UNROLL for (int c = 0; c < 6; ++c) {
     // partial pivoting without a dynamic row index: the candidate rows are compared in the reference order (first strict maximum wins), then the pivot
-    // row is brought up by selects -- the same values in the same places as "swap rows c and p"
+    // row is brought up by selects -- the same values in the same places as "swap rows c and p".  The pivot row is then scaled by ONE reciprocal
+    // (<= 1.5 ulp per entry from a dividing elimination; Eigen's PartialPivLU divides): same pivots, last-bit differences in the inverse
     int p = c;
     double best = fabs(M[c][c]);
     RGBID_UNROLL for (int r = c + 1; r < 6; ++r) { const double v = fabs(M[r][c]); const bool g = v > best; p = g ? r : p; best = g ? v : best; }

@@ -58,6 +58,7 @@ class FrameInfo(C.Structure):
         ("delta_R", C.c_double * 9), ("delta_t", C.c_double * 3), ("delta_cov", C.c_double * 36),
         ("odo_kf_natural", C.c_int), ("integr_kf_natural", C.c_int),
         ("sigma_stop_margin_int", C.c_float), ("sigma_stop_margin_depthinv", C.c_float), ("sigma_stop_margin_frame", C.c_float),
+        ("chi_stop_margin_frame", C.c_float), ("chi_stops_frame", C.c_int),
     ]
 
 

@@ -196,6 +196,9 @@ typedef struct {
   int odo_kf_natural, integr_kf_natural;         /* what the two covisibility tests decided on their own (see the hook below) */
   float sigma_stop_margin_int, sigma_stop_margin_depthinv; /* last GN iteration: distance of the sigma iteration's stopping ratio from its threshold */
   float sigma_stop_margin_frame;                           /* the smallest such distance over ALL Gauss-Newton iterations of the frame, both channels */
+  float chi_stop_margin_frame;                             /* TEST DIAGNOSTIC (termination = CHI_SQUARED): the smallest |RMSE - RMSE_prev| / RMSE_prev over the frame's
+                                                            * RMSE comparisons (visodo.cpp:1150): how close the frame came to taking the other branch.  1e30 if none ran */
+  int chi_stops_frame;                                     /* how many levels of the frame ended early on that test */
 } orc_frame_info;
 void orc_tracker_last_info(const orc_tracker* t, orc_frame_info* info);
 /* TEST HOOK (no counterpart in the reference): impose the two keyframe decisions of the NEXT tracked frame (-1 = decide naturally,

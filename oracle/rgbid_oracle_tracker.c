@@ -634,7 +634,9 @@ static int estimate_visual_odometry(orc_tracker* t, double R_io[9], double t_io[
         orc_chi_square(t->res_I, t->res_D, nI, sigma_int_ref, sigma_depthinv_ref, c->mestimator, &chi_square, &chi_test, &ndof);
         RMSE = sqrtf(chi_square) / sqrtf(ndof);
         if (iter != 1) {
+          { float m_ = fabsf(RMSE - RMSE_prev) / fmaxf(RMSE_prev, 1e-30f); if (m_ < t->info.chi_stop_margin_frame) t->info.chi_stop_margin_frame = m_; }   /* test diagnostic */
           if (RMSE > RMSE_prev) {
+            ++t->info.chi_stops_frame;
             double d[3], tmp2[3];
             for (int i = 0; i < 3; ++i) d[i] = curt[i] - last_tinc[i];
             m3_mulv(last_inc_inv, d, tmp2);
@@ -728,6 +730,7 @@ static int tracker_track(orc_tracker* t, const uint16_t* depth, const uint8_t* r
   t->delta_t = c->delta_t; /* computeInterframeTime :1929-1964 with compute_deltat_flag_ off */
   memset(&t->info, 0, sizeof(t->info));
   t->info.sigma_stop_margin_frame = 1e30f;
+  t->info.chi_stop_margin_frame = 1e30f; t->info.chi_stops_frame = 0;
   const int force_odo = t->force_odo, force_integr = t->force_integr;   /* one-shot */
   t->force_odo = t->force_integr = -1;
   prepare_images(t, depth, rgb);

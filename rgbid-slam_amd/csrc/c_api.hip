@@ -126,6 +126,7 @@ int rgbid_ctx_set_interp_mode(rgbid_ctx* c, int mode) {
   c->interp_mode = mode;
   return RGBID_OK;
 }
+int rgbid_ctx_get_interp_mode(rgbid_ctx* c, int* mode) { if (!c || !mode) return RGBID_E_INVALID; *mode = c->interp_mode; return RGBID_OK; }
 int rgbid_ctx_set_numerics(rgbid_ctx* c, int numerics) {
   if (!c || (numerics != RGBID_NUMERICS_EXACT && numerics != RGBID_NUMERICS_FAST)) return RGBID_E_INVALID;
   c->numerics = numerics;

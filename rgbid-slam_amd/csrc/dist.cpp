@@ -332,6 +332,29 @@ int rgbid_dist_barrier(rgbid_dist* d) {
   return he == hipSuccess ? RGBID_OK : (int)he;
 }
 
+int rgbid_dist_renumber_warmed_chunks(rgbid_gather_record* all, int world, int lanes_per_rank, int n_chunks, int chunk_len, const int* first, const int* last,
+                                      int warmup_frames) {
+  if (!all || !first || !last || world < 1 || lanes_per_rank < 1 || n_chunks < 1 || chunk_len < 1 || warmup_frames < 0) return RGBID_E_INVALID;
+  // a warmed-up lane numbers its chunk's first frame wc (its warm-up frames came first), not 0: renumber the chunk from its own head, so that the
+  // composition's check of the ids (0 on the head, then 1 .. j, non-decreasing) holds what it held before.  A head that is not ahead of 0 although the
+  // chunk warmed up, i.e. a lane that did not run its warm-up, is refused.
+  for (int c = 0; c < n_chunks; ++c) {
+    const int wc = std::min(warmup_frames, first[c]);
+    if (!wc) continue;
+    int s0 = 0, cnt = 0, owner = -1;
+    for (int rk = 0; rk < world; ++rk) { rgbid_dist_rank_chunks(n_chunks, world, rk, &s0, &cnt); if (c >= s0 && c < s0 + cnt) { owner = rk; break; } }
+    if (owner < 0 || c - s0 >= lanes_per_rank || last[c] - first[c] + 1 > chunk_len) return RGBID_E_INVALID;
+    rgbid_gather_record* rec = all + ((size_t)owner * lanes_per_rank + (c - s0)) * chunk_len;
+    const int head = rec[0].frame_id;
+    if (head < 1 || head > wc) return RGBID_E_INVALID;
+    // a lane that is lost across the chunk boundary (lost during warm-up, still lost on the chunk's first transitions) repeats the head's id
+    // (visodo.cpp:2051-2117): after renumbering such a frame would read 0, which only a chunk HEAD may carry -- it keeps the smallest id of a
+    // tracked position (1) and its LOST status, which is what the composed trajectory reports for it
+    for (int j = 0; j < last[c] - first[c] + 1; ++j) { rec[j].frame_id -= head; if (j && rec[j].frame_id < 1) rec[j].frame_id = 1; }
+  }
+  return RGBID_OK;
+}
+
 int rgbid_dist_compose_trajectory(const rgbid_gather_record* all, int world, int lanes_per_rank, int n_chunks, int chunk_len,
                                   const int* first, const int* last, double* R, double* t, int* status, double* cov) {
   if (!all || !first || !last || !R || !t || world < 1 || lanes_per_rank < 1 || n_chunks < 1 || chunk_len < 1) return RGBID_E_INVALID;
@@ -526,22 +549,7 @@ int rgbid_dist_track_sequence(rgbid_ctx* ctx, const rgbid_seq_config* cfg, const
     gather_ms = ms_since(t1);
   }
   const auto t2 = Clock::now();
-  if (W) {
-    // a warmed-up lane numbers its chunk's first frame wc (its warm-up frames came first), not 0: renumber the chunk from its own head, so that the
-    // composition's check of the ids (0 on the head, then 1 .. j, non-decreasing) holds what it held before.  A head that is not ahead of 0 although the
-    // chunk warmed up, i.e. a lane that did not run its warm-up, is refused.
-    for (int c = 0; c < n_chunks; ++c) {
-      const int wc = std::min(W, first[c]);
-      if (!wc) continue;
-      int s0 = 0, cnt = 0, owner = -1;
-      for (int rk = 0; rk < world; ++rk) { rgbid_dist_rank_chunks(n_chunks, world, rk, &s0, &cnt); if (c >= s0 && c < s0 + cnt) { owner = rk; break; } }
-      if (owner < 0) return RGBID_E_INVALID;
-      rgbid_gather_record* rec = all.data() + ((size_t)owner * lanes + (c - s0)) * L;
-      const int head = rec[0].frame_id;
-      if (head < 1 || head > wc) return RGBID_E_INVALID;
-      for (int j = 0; j < last[c] - first[c] + 1; ++j) rec[j].frame_id -= head;
-    }
-  }
+  if (W) { r = rgbid_dist_renumber_warmed_chunks(all.data(), world, lanes, n_chunks, L, first.data(), last.data(), W); if (r) return r; }
   r = rgbid_dist_compose_trajectory(all.data(), world, lanes, n_chunks, L, first.data(), last.data(), R, t, status, cov);
   if (r) return r;
   rep.track_ms = track_ms; rep.gather_ms = gather_ms; rep.compose_ms = ms_since(t2);

@@ -195,8 +195,12 @@ int rgbid_kfalign_create(rgbid_kfalign** out, rgbid_ctx* ctx, int rows, int cols
     for (ImgB* im : maps) if (!r) r = kfa_img(a, im, pr, pc);
     const size_t n = (size_t)lattice_samples(pr, pc, KFA_NSAMPLES);
     if (n > a->res_cap) a->res_cap = n;
-    const int nb = system_blocks_per_lane(pr, pc, 1);   // the 1-pair plan has the most blocks per pair
-    if (nb > a->nblk_cap) a->nblk_cap = nb;
+    // the partials buffer must hold the launch plan of EVERY pair count up to max_pairs: the plan of few pairs (<= 32) comes from a schedule-length
+    // model, so blocks per pair are not monotonic in the pair count
+    for (int b = 1; b <= max_pairs; b = (b < 64 || b == max_pairs) ? b + 1 : (2 * b < max_pairs ? 2 * b : max_pairs)) {   // 1 .. 64, powers of two, max_pairs
+      const int nb = system_blocks_per_lane(pr, pc, b);
+      if (nb > a->nblk_cap) a->nblk_cap = nb;
+    }
   }
   const size_t N = (size_t)rows * cols, B = (size_t)max_pairs;
   if (!r) r = kfa_alloc(a, (void**)&a->grey_a, N * B);
@@ -233,6 +237,8 @@ int rgbid_kfalign_batched(rgbid_kfalign* a, int pairs, const float* iD_ini_dev, 
   const int B = pairs, rows = a->rows, cols = a->cols;
   const int tb = 64, gb = div_up(B, tb);
   a->launches = 0;
+  for (int l = 0; l < KFA_LEVELS; ++l)   // the normal equations' launch plan of THIS pair count must fit the partials buffer (sized at creation)
+    if (system_blocks_per_lane(rows >> l, cols >> l, B) > a->nblk_cap) return RGBID_E_INVALID;
 #define KFA_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
   KFA_HIP(hipMemcpyAsync(a->R_dev, R, sizeof(double) * 9 * B, hipMemcpyHostToDevice, s));
   KFA_HIP(hipMemcpyAsync(a->t_dev, t, sizeof(double) * 3 * B, hipMemcpyHostToDevice, s));

@@ -45,6 +45,10 @@ void KeyframeAlign::allocateHostDrivenBuffers() {
 bool KeyframeAlign::ensureAligner(int pairs) {
   // a context of the object's own (the per-thread default context ends with its thread, see VisodoTracker::createEngine)
   if (!aligner_ctx_ && rgbid_ctx_create(&aligner_ctx_, pcl::gpu::current_device().load(), nullptr) != RGBID_OK) return false;
+  // the host-driven loop samples with the thread's default context, whose interpolation mode VisodoTracker::setInterpMode changes: the aligner's own
+  // context follows it at every call, so both modes sample alike whatever the application selected
+  int mode = RGBID_INTERP_TEX8;
+  if (rgbid_ctx_get_interp_mode(pcl::gpu::default_ctx(), &mode) == RGBID_OK) rgbid_ctx_set_interp_mode(aligner_ctx_, mode);
   if (aligner_ && aligner_cap_ >= pairs) return true;
   if (aligner_) { rgbid_kfalign_destroy(aligner_); aligner_ = nullptr; }
   if (rgbid_kfalign_create(&aligner_, aligner_ctx_, rows_, cols_, pairs) != RGBID_OK) return false;

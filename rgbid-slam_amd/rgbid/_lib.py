@@ -59,7 +59,7 @@ def check(err):
 # every symbol include/rgbid.h declares (checked by the CPU test-suite against the built library)
 EXPORTS = [
     "rgbid_version", "rgbid_error_string", "rgbid_device_count", "rgbid_get_device_prop", "rgbid_set_device", "rgbid_ctx_create", "rgbid_ctx_destroy",
-    "rgbid_ctx_set_stream", "rgbid_ctx_set_async", "rgbid_ctx_get_async", "rgbid_ctx_set_interp_mode", "rgbid_ctx_set_numerics", "rgbid_ctx_sync", "rgbid_selftest_rcp", "rgbid_selftest_div_const", "rgbid_selftest_cvt_flr", "rgbid_selftest_fast_primitives", "rgbid_fast_guard", "rgbid_fast_guard_lane", "rgbid_ctx_wait_event", "rgbid_ctx_get_stream", "rgbid_mem_info",
+    "rgbid_ctx_set_stream", "rgbid_ctx_set_async", "rgbid_ctx_get_async", "rgbid_ctx_set_interp_mode", "rgbid_ctx_get_interp_mode", "rgbid_ctx_set_numerics", "rgbid_ctx_sync", "rgbid_selftest_rcp", "rgbid_selftest_div_const", "rgbid_selftest_cvt_flr", "rgbid_selftest_fast_primitives", "rgbid_fast_guard", "rgbid_fast_guard_lane", "rgbid_ctx_wait_event", "rgbid_ctx_get_stream", "rgbid_mem_info",
     "rgbid_malloc", "rgbid_malloc_pitch", "rgbid_free", "rgbid_malloc_host", "rgbid_free_host", "rgbid_memcpy_h2d", "rgbid_memcpy_d2h", "rgbid_memcpy_d2d",
     "rgbid_memcpy2d_h2d", "rgbid_memcpy2d_d2h", "rgbid_memcpy2d_d2d",
     "rgbid_depth_to_float", "rgbid_float_to_rgb", "rgbid_create_nmap", "rgbid_integrate_warped_rgb",

@@ -28,7 +28,7 @@ assert GATHER_DTYPE.itemsize == 392
 DIST_LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "librgbid_dist.so")
 DIST_EXPORTS = ["rgbid_dist_chunk_ranges", "rgbid_dist_rank_chunks", "rgbid_dist_new_id", "rgbid_dist_exchange_id", "rgbid_dist_broadcast_bytes",
                 "rgbid_dist_allgather_bytes_tcp", "rgbid_dist_init", "rgbid_dist_destroy", "rgbid_dist_world", "rgbid_dist_rank", "rgbid_dist_gather_records",
-                "rgbid_dist_barrier", "rgbid_dist_compose_trajectory", "rgbid_dist_track_sequence"]
+                "rgbid_dist_barrier", "rgbid_dist_compose_trajectory", "rgbid_dist_renumber_warmed_chunks", "rgbid_dist_track_sequence"]
 TRACK_SEQUENCE_BIN = os.path.join(os.path.dirname(os.path.dirname(_lib.LIB_PATH)), "bin", "rgbid_track_sequence")
 EXCHANGE_RCCL, EXCHANGE_TCP = 0, 1
 _dl = None
@@ -86,6 +86,15 @@ def compose_trajectory(all_records, world, n_chunks, ranges):
     check(dlib().rgbid_dist_compose_trajectory(_ip(a), int(world), int(a.shape[1]), int(n_chunks), int(a.shape[2]), _ip(first), _ip(last),
                                                 _ip(R), _ip(t), _ip(st), _ip(cov)))
     return R, t, st, cov
+
+
+def renumber_warmed_chunks(all_records, world, n_chunks, ranges, warmup_frames):
+    """in place: the ids of chunks that ran a warm-up, renumbered from their own head (rgbid_dist_renumber_warmed_chunks)"""
+    a = all_records
+    assert a.dtype == GATHER_DTYPE and a.ndim == 3 and a.shape[0] == world and a.flags["C_CONTIGUOUS"]
+    first = np.array([r[0] for r in ranges], np.int32); last = np.array([r[1] for r in ranges], np.int32)
+    check(dlib().rgbid_dist_renumber_warmed_chunks(_ip(a), int(world), int(a.shape[1]), int(n_chunks), int(a.shape[2]), _ip(first), _ip(last), int(warmup_frames)))
+    return a
 
 
 class Comm:

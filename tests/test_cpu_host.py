@@ -80,6 +80,50 @@ def test_llt_and_inverse():
     assert np.isnan(host.llt_solve6(A, np.ones(6))).any()
 
 
+def _llt_dividing(A, b):
+    """Eigen's LLT + two triangular solves as Eigen runs them: every column entry and every substituted element DIVIDED by the pivot"""
+    L = np.zeros((6, 6))
+    for j in range(6):
+        L[j, j] = np.sqrt(A[j, j] - np.dot(L[j, :j], L[j, :j]))
+        for i in range(j + 1, 6):
+            s_ = A[i, j]
+            for k in range(j):
+                s_ -= L[i, k] * L[j, k]
+            L[i, j] = s_ / L[j, j]
+    y = np.zeros(6); x = np.zeros(6)
+    for i in range(6):
+        s_ = b[i]
+        for k in range(i):
+            s_ -= L[i, k] * y[k]
+        y[i] = s_ / L[i, i]
+    for i in range(5, -1, -1):
+        s_ = y[i]
+        for k in range(i + 1, 6):
+            s_ -= L[k, i] * x[k]
+        x[i] = s_ / L[i, i]
+    return x
+
+
+def test_reciprocal_per_pivot_against_a_dividing_solve_on_ill_conditioned_systems():
+    """se3.h's llt_solve6 / inverse6 multiply by one reciprocal per pivot where Eigen divides.  Held here to a DIVIDING Cholesky solve of the same
+    operation order and to LAPACK on normal equations of condition 1e2 .. 1e12: the deviation is a few ulp times the condition number, the bound every
+    backward-stable solve has -- far inside the pose bar (1e-4) for the tracker's systems (cond <= 1e8)."""
+    r = np.random.default_rng(77)
+    eps = np.finfo(np.float64).eps
+    for cond in (1e2, 1e5, 1e8, 1e10, 1e12):
+        for _ in range(5):
+            U, _ = np.linalg.qr(r.standard_normal((6, 6)))
+            A = (U * np.geomspace(1.0, 1.0 / cond, 6)) @ U.T
+            A = 0.5 * (A + A.T)
+            xt = r.standard_normal(6); b = A @ xt
+            x = host.llt_solve6(A, b); xd = _llt_dividing(A, b)
+            assert np.linalg.norm(x - xd) <= 50 * eps * cond * np.linalg.norm(xd), (cond, x, xd)
+            assert np.linalg.norm(x - xt) <= 200 * eps * cond * np.linalg.norm(xt)
+            Ai = host.inverse6(A)
+            assert np.linalg.norm(Ai - np.linalg.inv(A)) <= 200 * eps * cond * np.linalg.norm(Ai)
+            assert np.abs(Ai @ A - np.eye(6)).max() <= 200 * eps * cond
+
+
 QUERIES = [("VISODO", "M_ESTIMATOR"), ("VISODO", "SIGMA_ESTIMATOR"), ("VISODO", "INTEGRATION_VISRATIO_THRESHOLD"),
            ("VISODO", "ODOMETRY_VISRATIO_THRESHOLD"), ("VISODO", "FINEST_PYR_LEVEL"), ("VISODO", "WARP_ORDER"), ("VISODO", "IMAGE_FILTERING"),
            ("VISODO", "LATE_KEY"), ("CALIBRATION", "fx"), ("CALIBRATION", "fy"), ("CALIBRATION", "kd"), ("CALIBRATION", "novalue"),

@@ -153,6 +153,44 @@ def test_sequence_driver_refuses_a_warm_up_on_injected_records():
             D.track_sequence(None, E.default_config(rows=48, cols=64, lanes=1), None, None, chunks, inject=good, n_frames=F, warmup_frames=w)
 
 
+def test_warmed_chunks_renumber_and_a_lane_lost_across_the_chunk_boundary():
+    """records of a chunk that ran w warm-up frames number their head w: rgbid_dist_renumber_warmed_chunks brings them back to 0 .. n - 1 and the composition
+    is what it is without warm-up.  ADVICE r5: a lane that lost tracking during the warm-up and is still lost on the chunk's first transitions repeats the
+    head's id -- the sequence must compose (those frames carry LOST), not be refused; a lane that never ran its warm-up (head 0) is refused."""
+    from rgbid._lib import RgbidError
+    F, chunks, world, w = 41, 5, 2, 3
+    rec, Rg, tg, ranges, L = _chain_records(F, chunks)
+    lanes = D.lanes_per_rank(chunks, world)
+
+    def gathered(r):
+        a = np.zeros((world, lanes, L), D.GATHER_DTYPE)
+        for rk in range(world):
+            for i, c in enumerate(D.rank_chunks(chunks, world, rk)):
+                a[rk, i] = r[c]
+        return a
+    R0, t0, st0, _ = D.compose_trajectory(gathered(rec), world, chunks, ranges)
+    warmed = rec.copy()
+    for c, (a, b) in enumerate(ranges):
+        if c:
+            warmed[c]["frame_id"][: b - a + 1] += min(w, a)
+    R1, t1, st1, _ = D.compose_trajectory(D.renumber_warmed_chunks(gathered(warmed), world, chunks, ranges, w), world, chunks, ranges)
+    assert np.array_equal(R0, R1) and np.array_equal(t0, t1) and np.array_equal(st0, st1)
+    # chunk 2: lost at the second warm-up frame, still lost on its first two transitions (the id does not advance while lost), then tracking again
+    LOST = 2
+    lost = warmed.copy()
+    a2, b2 = ranges[2]
+    ids = lost[2]["frame_id"][: b2 - a2 + 1].copy()
+    ids[:] = [1, 1, 1] + list(range(2, b2 - a2))
+    lost[2]["frame_id"][: b2 - a2 + 1] = ids
+    lost[2]["status"][1:3] = LOST
+    R2, t2, st2, _ = D.compose_trajectory(D.renumber_warmed_chunks(gathered(lost), world, chunks, ranges, w), world, chunks, ranges)
+    assert st2[a2 + 1] == LOST and st2[a2 + 2] == LOST and np.array_equal(R2, R0) and np.array_equal(t2, t0)
+    never = warmed.copy()
+    never[3]["frame_id"][: ranges[3][1] - ranges[3][0] + 1] = np.arange(ranges[3][1] - ranges[3][0] + 1)
+    with pytest.raises(RgbidError):
+        D.renumber_warmed_chunks(gathered(never), world, chunks, ranges, w)
+
+
 def test_tcp_rendezvous_ignores_strangers_and_duplicates():
     """rank 0 keeps accepting when something that is not a rank of this job connects (a port scanner, a stale process with another nonce, a
     rank that was served already); host names resolve (getaddrinfo)"""

@@ -29,7 +29,7 @@ def make_lanes(n_lanes, n_frames, rows, cols, K, **kw):
     return seqs, depth, rgb
 
 
-def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, map_outliers=5e-3, sigma_tol=1e-3, pose_tol=1e-4):
+def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, map_outliers=5e-3, sigma_tol=1e-3, pose_tol=1e-4, chi_margin_tol=0.0):
     seqs, depth, rgb = make_lanes(n_lanes, n_frames, rows, cols, K, **seq_kw)
     eng = E.Engine(ctx, E.default_config(rows=rows, cols=cols, lanes=n_lanes, K=K, use_graph=use_graph, record_capacity=n_frames, **cfg_kw))
     for k in range(n_frames):
@@ -40,6 +40,8 @@ def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, m
     worst_r = worst_t = 0.0
     imposed = 0
     frames_checked = widened_flip = widened_stop = 0
+    chi_margin = np.full((n_lanes, n_frames), 1e30)      # termination = CHI_SQUARED: how close each oracle frame came to the other branch of RMSE > RMSE_prev
+    chi_stops = chi_on_threshold = 0
     th_o, th_i = cfg_kw.get("visratio_odo", 0.9), cfg_kw.get("visratio_integr", 0.7)
     fin = cfg_kw.get("finest_level", 0)
     n_lattice = device.error_lattice_size(rows >> fin, cols >> fin, cfg_kw.get("nsamples", 10000))[0]
@@ -59,6 +61,7 @@ def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, m
             if k == 0:
                 assert st & E.ST_FIRST
                 continue
+            chi_margin[l, k] = info.chi_stop_margin_frame; chi_stops += info.chi_stops_frame
             assert bool(st & E.ST_TRACKED) == ret, (l, k, st, ret)
             if not ret:
                 continue
@@ -70,7 +73,12 @@ def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, m
             if bool(st & E.ST_INTEGR_KF) != bool(info.integr_kf_natural):
                 assert abs(info.visratio_integr - th_i) < 5e-4, (l, k, st, info.visratio_integr)
                 imposed += 1
-            assert rec[k, l]["nu_depthinv"] == info.nu_depthinv and rec[k, l]["nu_int"] == info.nu_int, (l, k)
+            # FAST class x CHI_SQUARED (round 6): `RMSE > RMSE_prev` (visodo.cpp:1150) is a discontinuity -- where the two RMSEs agree to within the class's value
+            # tolerance the engine may take the other branch, i.e. run a different number of iterations on that level: the frame's last-iteration statistics
+            # and, below, its pose are then compared with the wider bound, under that condition only, counted and reported
+            on_chi = chi_margin_tol > 0 and chi_margin[l, max(1, k - 1):k + 1].min() < chi_margin_tol
+            if not on_chi:
+                assert rec[k, l]["nu_depthinv"] == info.nu_depthinv and rec[k, l]["nu_int"] == info.nu_int, (l, k)
             # sigma is the scale of the residuals AT the current pose estimate, which itself agrees to ~1e-5: 1e-3 relative on a full-size lattice.
             # Two discontinuities of the reference algorithm widen that: (1) a pose difference of 1e-7 can move a point-sampled or range-checked
             # pixel across a pixel boundary; a Student-t sample's weighted square is bounded by (nu + 1) sigma^2, so ONE flipped sample moves sigma by
@@ -83,7 +91,9 @@ def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, m
             ds = abs(rec[k, l]["sigma_int"] - info.sigma_int)
             frames_checked += 1
             if not ds < sigma_tol * info.sigma_int:
-                if ds < 15.0 / n_lattice * info.sigma_int:
+                if on_chi and ds < 5e-2 * info.sigma_int:
+                    pass
+                elif ds < 15.0 / n_lattice * info.sigma_int:
                     widened_flip += 1
                 else:
                     assert info.sigma_stop_margin_frame < 1e-4 and ds < 2e-2 * info.sigma_int, (l, k, rec[k, l]["sigma_int"], info.sigma_int, info.sigma_stop_margin_frame, n_lattice)
@@ -94,10 +104,15 @@ def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, m
         for k in range(1, n_frames):
             er, et = rot_angle(Rs[k], rec[k, l]["R"]), float(np.linalg.norm(ts[k] - rec[k, l]["t"]))
             worst_r, worst_t = max(worst_r, er), max(worst_t, et)
-            assert er < pose_tol and et < pose_tol, (l, k, er, et)
-            assert rot_angle(oR[k], rec[k, l]["odo_R"]) < pose_tol and np.linalg.norm(ot[k] - rec[k, l]["odo_t"]) < pose_tol
+            tol_k, cov_tol = pose_tol, 1e-2
+            if not (er < pose_tol and et < pose_tol) and chi_margin_tol > 0:
+                # the oracle's own RMSE comparison of this frame (or of the frame before: the velocity prior carries one frame) sat inside the value tolerance
+                assert chi_margin[l, max(1, k - 1):k + 1].min() < chi_margin_tol, (l, k, er, et, chi_margin[l])
+                chi_on_threshold += 1; tol_k, cov_tol = 10 * pose_tol, 1e-1
+            assert er < tol_k and et < tol_k, (l, k, er, et)
+            assert rot_angle(oR[k], rec[k, l]["odo_R"]) < tol_k and np.linalg.norm(ot[k] - rec[k, l]["odo_t"]) < tol_k
             sc = np.sqrt(np.outer(np.diag(ocov[k]), np.diag(ocov[k]))) + 1e-30
-            assert (np.abs(ocov[k] - rec[k, l]["odo_cov"]) / sc).max() < 1e-2, (l, k)
+            assert (np.abs(ocov[k] - rec[k, l]["odo_cov"]) / sc).max() < cov_tol, (l, k)
         # fused keyframe maps of the lane vs the oracle tracker's
         kd, kw, kv, kn, km = eng.keyframe_maps(l)
         od, ow = trk.kf_depthinv(), trk.kf_weight()
@@ -119,6 +134,12 @@ def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, m
     eng.close()
     if imposed:
         print(f"keyframe decisions on the threshold, imposed on the oracle: {imposed}")
+    if cfg_kw.get("termination") == O.CHI_SQUARED:
+        fin_ = chi_margin[:, 1:][chi_margin[:, 1:] < 1e29]
+        print(f"chi-squared termination: {chi_stops} early level exits in the oracle over {n_lanes * (n_frames - 1)} frames; smallest relative RMSE margin {fin_.min() if fin_.size else float('nan'):.2e}; "
+              f"{chi_on_threshold} frames beyond {pose_tol:g} with the comparison inside the value tolerance ({chi_margin_tol:g})")
+        assert chi_stops > 0                                # the early exit really fires on these sequences
+        assert chi_on_threshold <= max(1, 0.15 * n_lanes * (n_frames - 1))
     if widened_flip or widened_stop:
         print(f"sigma: {widened_flip} of {frames_checked} frames used the flipped-sample bound (15 / n_lattice), {widened_stop} the stopping-threshold bound")
     assert widened_flip + widened_stop <= max(2, 0.15 * frames_checked), (widened_flip, widened_stop, frames_checked)
@@ -398,6 +419,14 @@ def test_engine_step_accepts_torch_temporaries_async():
     # round 5: termination = CHI_SQUARED (visodo.cpp:1134-1164) inside the engine -- a per-lane flag ends the level; with WARP_FIRST the level-0 warped maps the
     # test reads are fresh at every level; exact numerics class (an RMSE comparison is a discontinuity the value tolerance of the FAST class could sit on)
     ("chi-squared termination, warp first", 120, 160, dict(termination=O.CHI_SQUARED, warping=O.WARP_FIRST, fast_numerics=0)),
+    # round 6: PYR_FIRST x CHI_SQUARED -- at levels > 0 the test reads whatever the LAST level-0 warp left in the level-0 warped maps
+    # (the previous frame's final iteration; all-zero on the first tracked frame, where the reference reads uninitialised memory: both implementations
+    # under test start from zero-filled maps, so frame 1 is compared too and the statement about the reference begins at frame 2)
+    ("chi-squared termination, pyr first (stale level-0 maps)", 120, 160, dict(termination=O.CHI_SQUARED, warping=O.PYR_FIRST, fast_numerics=0)),
+    # ... and both in the class the engine runs by default: a frame may leave the pose bar only where the oracle's RMSE comparison sat inside the class's
+    # value tolerance (oracle diagnostic chi_stop_margin_frame, used like sigma_stop_margin_frame), counted and reported
+    ("chi-squared termination, warp first, FAST class", 120, 160, dict(termination=O.CHI_SQUARED, warping=O.WARP_FIRST)),
+    ("chi-squared termination, pyr first, FAST class", 120, 160, dict(termination=O.CHI_SQUARED, warping=O.PYR_FIRST)),
 ])
 def test_engine_configurations(ctx, name, rows, cols, cfg_kw):
     """every run-time switch of the tracker through the batched engine, each held to the oracle (1e-4 rad / 1e-4 m, same keyframe decisions)"""
@@ -410,19 +439,22 @@ def test_engine_configurations(ctx, name, rows, cols, cfg_kw):
     # 8.3e-5 / 8.7e-5, sigma 2.3e-3, 2 % of the map (tools/experiments/geom_only_diag.py; exact kernels: 5e-6 / 1.2e-5).  The pose tolerance stays
     # 1e-4; the derived quantities get the room that pose difference needs.
     geom = cfg_kw.get("weighting") == O.GEOM_ONLY
-    run_case(ctx, rows, cols, K, n_lanes=2, n_frames=5, cfg_kw=cfg_kw, seq_kw=dict(trans_step=(0.003, 0.01), rot_step_deg=(0.1, 0.6)), use_graph=0,
-             map_outliers=4e-2 if geom else 5e-3, sigma_tol=5e-3 if geom else 1e-3)
+    chi_fast = cfg_kw.get("termination") == O.CHI_SQUARED and cfg_kw.get("fast_numerics", 1) != 0
+    run_case(ctx, rows, cols, K, n_lanes=3 if chi_fast else 2, n_frames=8 if chi_fast else 5, cfg_kw=cfg_kw, seq_kw=dict(trans_step=(0.003, 0.01), rot_step_deg=(0.1, 0.6)), use_graph=0,
+             map_outliers=4e-2 if geom else 5e-3, sigma_tol=5e-3 if geom else 1e-3, chi_margin_tol=1e-4 if chi_fast else 0.0)
 
 
-def test_engine_chi_squared_stops_lanes_independently(ctx):
+@pytest.mark.parametrize("warping,fast", [(O.WARP_FIRST, 0), (O.PYR_FIRST, 0), (O.WARP_FIRST, 1), (O.PYR_FIRST, 1)])
+def test_engine_chi_squared_stops_lanes_independently(ctx, warping, fast):
     """the CHI_SQUARED stop is taken PER LANE: a batch of different streams equals the same streams run one lane at a time, bit for bit, and the early exit
-    really fires (the records differ from an ALL_ITERS run)"""
+    really fires (the records differ from an ALL_ITERS run).  Round 6: also PYR_FIRST (the test reads the stale level-0 warped maps, per lane and per mask)
+    and the FAST class."""
     K = (131.25, 131.25, 79.5, 59.5)
     T, B = 5, 3
     seqs, depth, rgb = make_lanes(B, T, 120, 160, K, trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8))
 
     def run(lanes, term, graph=0):
-        eng = E.Engine(ctx, E.default_config(rows=120, cols=160, lanes=len(lanes), K=K, use_graph=graph, record_capacity=T, termination=term, warping=O.WARP_FIRST, fast_numerics=0))
+        eng = E.Engine(ctx, E.default_config(rows=120, cols=160, lanes=len(lanes), K=K, use_graph=graph, record_capacity=T, termination=term, warping=warping, fast_numerics=fast))
         for k in range(T):
             eng.step(depth[k][lanes].contiguous(), rgb[k][lanes].contiguous())
         r = eng.records().copy(); eng.close()

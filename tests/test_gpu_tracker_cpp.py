@@ -89,18 +89,20 @@ def test_cpp_tracker_sigma_const_no_motion_model(engine_backed):
 
 
 @both_modes
-def test_cpp_tracker_chi_squared_termination(engine_backed):
+@pytest.mark.parametrize("warping", [O.WARP_FIRST, O.PYR_FIRST])
+def test_cpp_tracker_chi_squared_termination(engine_backed, warping):
     """termination = CHI_SQUARED (visodo.cpp:1134-1164): a level ends, and the last increment is undone, as soon as the full-lattice
-    RMSE grows.  Run with WARP_FIRST, where the level-0 warped maps the test reads are fresh at every level.  Engine-backed (round 5): the stop is a
+    RMSE grows.  With WARP_FIRST the level-0 warped maps the test reads are fresh at every level; with PYR_FIRST (round 6) they are what the last
+    level-0 warp left (zero-filled before the first one, in the tracker and in the oracle alike).  Engine-backed (round 5): the stop is a
     per-lane flag written by a decision kernel that masks the rest of the level."""
-    kw = dict(warping=O.WARP_FIRST, termination=O.CHI_SQUARED)
+    kw = dict(warping=warping, termination=O.CHI_SQUARED)
     run(120, 160, SMALL_K, 5, kw, SLOW, engine_backed=engine_backed)
     # the early exit really fires on this sequence: the oracle's trajectory differs from the all-iterations one
     seq = synth.make_sequence(5, K=SMALL_K, rows=120, cols=160, device="cuda", **SLOW)
     d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
     out = []
     for term in (O.CHI_SQUARED, O.ALL_ITERS):
-        t = O.Tracker(O.default_config(rows=120, cols=160, fx=SMALL_K[0], fy=SMALL_K[1], cx=SMALL_K[2], cy=SMALL_K[3], warping=O.WARP_FIRST, termination=term))
+        t = O.Tracker(O.default_config(rows=120, cols=160, fx=SMALL_K[0], fy=SMALL_K[1], cx=SMALL_K[2], cy=SMALL_K[3], warping=warping, termination=term))
         for k in range(5):
             t.track(d[k], c[k])
         out.append(t.poses()[1])
@@ -687,7 +689,7 @@ def test_engine_backed_is_the_default_and_the_mode_is_settled_at_the_first_frame
         del os.environ["RGBID_VISODO_HOST_DRIVEN"]
 
 
-@pytest.mark.parametrize("case", ["chi_squared_warp_first", "custom_calibration"])
+@pytest.mark.parametrize("case", ["chi_squared_warp_first", "chi_squared_pyr_first", "custom_calibration"])
 def test_engine_backed_equals_host_driven_in_the_round5_configurations(case, tmp_path):
     """The two configurations that were host-driven only until round 4 -- CHI_SQUARED termination (visodo.cpp:1134-1164) and the custom-calibration front-end
     (prepareImagesCustomCalibration, :775-824) -- through the engine: poses, covariances, lastInfo, current and fused maps IDENTICAL to the host-driven loop."""
@@ -698,7 +700,7 @@ def test_engine_backed_equals_host_driven_in_the_round5_configurations(case, tmp
     d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
     kw = dict(rows=rows, cols=cols, fx=K[0], fy=K[1], cx=K[2], cy=K[3])
     if not full:
-        kw.update(warping=O.WARP_FIRST, termination=O.CHI_SQUARED)
+        kw.update(warping=O.WARP_FIRST if case == "chi_squared_warp_first" else O.PYR_FIRST, termination=O.CHI_SQUARED)
     out = []
     for eb in (False, True):
         trk = host.Tracker(host.default_config(**kw), engine_backed=eb)
