@@ -111,6 +111,9 @@ int rgbid_keyframe_align_mode(int device, int rows, int cols, const float* depth
                               const float* depthinv_end, const unsigned char* grey_end, float fx, float fy, float cx, float cy,
                               double R[9], double t[3], double cov[36], int host_driven);
 
+/* the interpolation mode of the calling thread's default bridge context -- what VisodoTracker::setInterpMode sets; KeyframeAlign samples with it in both of its loops */
+int rgbid_default_ctx_set_interp_mode(int mode);
+
 /* ---- dataset I/O (tools/evaluation.cpp:122-351,380-439): PNG codec, TUM/ICL association files, trajectory writer ---- */
 int rgbid_png_info(const char* path, int* rows, int* cols, int* channels, int* bit_depth);
 int rgbid_png_read(const char* path, void* dst, size_t dst_bytes);             /* interleaved, host-endian samples */

@@ -392,9 +392,18 @@ void launch_fill(hipStream_t s, int B, ImgB dst, int elem_size, uint32_t bits, L
 // cy outer / cx inner -- all as in the reference.  The Gaussian weights exp(-d2/2), d2 = dx^2+dy^2 in {0,1,2,4,5,8}, are
 // evaluated ONCE on the host with expf (the reference evaluates __expf per tap: 25 transcendentals per output pixel)
 // and reach the kernel as scalar arguments.
-struct PyrWeights { float w[9]; };
+struct PyrWeights { float w[9]; float sum_all; };
 static const PyrWeights& pyr_weights() {
-  static const PyrWeights W = [] { PyrWeights t; for (int d2 = 0; d2 < 9; ++d2) t.w[d2] = expf(-((float)d2 * 0.5f)); return t; }();
+  static const PyrWeights W = [] {
+    PyrWeights t;
+    for (int d2 = 0; d2 < 9; ++d2) t.w[d2] = expf(-((float)d2 * 0.5f));
+    // the weight sum of a window without an invalid tap, added in the kernel's tap order: fmaf(1, w, s) = fl(s + w), so this IS the value the mask-weighted
+    // chain reaches when every mask is 1 (round 6: k_pyr_down_dpp's all-valid fast path divides by it)
+    volatile float s = 0.f;
+    for (int dy = -2; dy <= 2; ++dy) for (int dx = -2; dx <= 2; ++dx) s = s + t.w[dx * dx + dy * dy];
+    t.sum_all = getenv("RGBID_PYRDOWN_NO_FASTPATH") ? 0.f : (float)s;   // 0: the fast path is off (bit-identity test, A/B timing)
+    return t;
+  }();
   return W;
 }
 static constexpr int PD_ROWS = 8;    // output rows a thread walks down (16 rows: < 4 % either way)
@@ -419,12 +428,14 @@ __device__ __forceinline__ float2 pyr_issue_pair(const FMap& S, int rows, int cy
   const unsigned rb = S.row((cy >= 0 && cy < rows) ? cy : 0);
   return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(S.rsrc, rb + colb, 0, 0));
 }
-__device__ __forceinline__ void pyr_finish_shared(float2 p, bool row_in, bool c0, bool c1, PyrRow& r) {
+// returns: both columns of EVERY lane of the wave are valid in this row (wave-uniform)
+__device__ __forceinline__ bool pyr_finish_shared(float2 p, bool row_in, bool c0, bool c1, PyrRow& r) {
   const bool ok0 = row_in && c0 && !isnan(p.x), ok1 = row_in && c1 && !isnan(p.y);
   const float v0 = ok0 ? p.x : 0.f, v1 = ok1 ? p.y : 0.f, m0 = ok0 ? 1.f : 0.f, m1 = ok1 ? 1.f : 0.f;
   r.v[2] = v0; r.v[3] = v1; r.m[2] = m0; r.m[3] = m1;
   r.v[0] = dpp_shift<0x138>(v0); r.v[1] = dpp_shift<0x138>(v1); r.m[0] = dpp_shift<0x138>(m0); r.m[1] = dpp_shift<0x138>(m1);
   r.v[4] = dpp_shift<0x130>(v0); r.m[4] = dpp_shift<0x130>(m0);
+  return __ballot(ok0 && ok1) == ~0ull;
 }
 static constexpr int PD_WAVE_OUT = 62;   // outputs per wave (lanes 1 .. 62)
 // src1 / dst1: a second map of the SAME geometry reduced by the same launch (the intensity and inverse-depth pyramids of a frame: one launch per
@@ -450,11 +461,12 @@ __global__ __launch_bounds__(256) void k_pyr_down_dpp(ImgB src0, ImgB dst0, ImgB
   const unsigned colb = (unsigned)max(2 * x, 0) << 3 >> 1;   // byte offset of column 2x (0 for the halo lane left of the image, whose values are masked off)
   const bool writer = lid >= 1 && lid <= PD_WAVE_OUT && x < dst.cols;
   PyrRow win[2 * PD_ROWS + 3];
+  bool full[2 * PD_ROWS + 3];   // round 6: rows without an invalid tap anywhere in the wave (scalars) -- five of them in a row make an all-valid window for every output
   float2 raw[2 * PD_ROWS + 3];
 #pragma unroll
   for (int r = 0; r < 3 + 2 * PD_AHEAD; ++r) raw[r] = pyr_issue_pair(S, src.rows, 2 * y_begin - 2 + r, colb);
 #pragma unroll
-  for (int r = 0; r < 3; ++r) { const int cy = 2 * y_begin - 2 + r; pyr_finish_shared(raw[r], cy >= 0 && cy < src.rows, c0, c1, win[r]); }
+  for (int r = 0; r < 3; ++r) { const int cy = 2 * y_begin - 2 + r; full[r] = pyr_finish_shared(raw[r], cy >= 0 && cy < src.rows, c0, c1, win[r]); }
 #pragma unroll
   for (int j = 0; j < PD_ROWS; ++j) {
     const int y = y_begin + j;
@@ -463,8 +475,20 @@ __global__ __launch_bounds__(256) void k_pyr_down_dpp(ImgB src0, ImgB dst0, ImgB
         raw[2 * (j + PD_AHEAD) + 3] = pyr_issue_pair(S, src.rows, 2 * (y + PD_AHEAD) + 1, colb);
         raw[2 * (j + PD_AHEAD) + 4] = pyr_issue_pair(S, src.rows, 2 * (y + PD_AHEAD) + 2, colb);
       }
-      pyr_finish_shared(raw[2 * j + 3], 2 * y + 1 < src.rows, c0, c1, win[2 * j + 3]);
-      pyr_finish_shared(raw[2 * j + 4], 2 * y + 2 < src.rows, c0, c1, win[2 * j + 4]);
+      full[2 * j + 3] = pyr_finish_shared(raw[2 * j + 3], 2 * y + 1 < src.rows, c0, c1, win[2 * j + 3]);
+      full[2 * j + 4] = pyr_finish_shared(raw[2 * j + 4], 2 * y + 2 < src.rows, c0, c1, win[2 * j + 4]);
+      if (W.sum_all > 0.f && full[2 * j] && full[2 * j + 1] && full[2 * j + 2] && full[2 * j + 3] && full[2 * j + 4]) {
+        // all 25 taps of every output of the wave are valid (an intensity map away from the image border, an inverse-depth map without holes here): the
+        // tap count is 25 and the mask-weighted sum is the constant the same chain reaches with every mask at 1 (PyrWeights::sum_all) -- the 50 instructions
+        // that form them are skipped; sum1 is the same chain, the quotient the same IEEE division: bit-identical
+        float sum1 = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 5; ++dx) sum1 = sum1 + win[2 * j + dy].v[dx] * W.w[(dx - 2) * (dx - 2) + (dy - 2) * (dy - 2)];
+        if (writer) px<float>(dst, lane, y, x) = sum1 / W.sum_all;
+        continue;
+      }
       // (a per-row tap count shared by the outputs that hold the row saves 12 adds per output but costs 6 VGPRs: 7 -> 6 waves / SIMD, 0.34 -> 0.43 us
       // per lane; forcing 8 waves / SIMD spills: 0.49)
       float sum1 = 0.f, sum2 = 0.f, count = 0.f;
@@ -495,145 +519,7 @@ void launch_pyr_down2(hipStream_t s, int B, ImgB src0, ImgB dst0, ImgB src1, Img
   hipLaunchKernelGGL(k_pyr_down_dpp, dim3(2u * (unsigned)wgs * (unsigned)B), dim3(256), 0, s, src0, dst0, src1, dst1, pyr_weights(), strips, wpr, wgs, wgs * B, m);
 }
 
-// ---- bilateralKernel (filters.cu:86-135), clipped 5x5 window -------------------------------------
-static constexpr int BR = 2, BIL_TILES = 4;
-// the 24 off-centre taps of one pixel.  FAST: the per-tap division by sigma (a constant of the launch) as the 3-instruction exact sequence of
-// common.h div_const_fast; the caller recomputes the pixel with the IEEE division if any tap left its verified range.  The centre tap is the
-// pixel itself: its weight is expf(-0) = 1 exactly, so it enters the sums as (value, 1) without arithmetic -- at its place in the tap order.
-template <bool FAST>
-__device__ __forceinline__ float bilateral_px(const float (*tile)[TX + 2 * BR + 1], int ty, int tx, float value, float sigma_floatmap, DivConst dc, float s2ih,
-                                              bool& all_ok) {
-  float sum1 = 0.f, sum2 = 0.f;
-  // clipped window == full window over the NaN-padded tile (NaN taps are skipped either way); tap order cy outer, cx inner
-#pragma unroll
-  for (int dy = -BR; dy <= BR; ++dy)
-#pragma unroll
-    for (int dx = -BR; dx <= BR; ++dx) {
-      if (dx == 0 && dy == 0) { sum1 = sum1 + value; sum2 = sum2 + 1.f; continue; }   // value * 1.f, weight 1.f
-      const float tmp = tile[ty + dy][tx + dx];
-      const float space2 = (float)(dx * dx + dy * dy);
-      float fn;
-      if (FAST) { bool ok_; fn = div_const_fast(value - tmp, dc, ok_); all_ok = all_ok && (ok_ || isnan(tmp)); }
-      else fn = (value - tmp) / sigma_floatmap;
-      // the source mixes float and double here (`0.5*fn*fn`): keep the double evaluation
-      const double arg = (double)(s2ih * space2) + (0.5 * (double)fn) * (double)fn;
-      const float weight = expf((float)(-arg));
-      const bool ok = !isnan(tmp);
-      sum1 = ok ? sum1 + tmp * weight : sum1;
-      sum2 = ok ? sum2 + weight : sum2;
-    }
-  return sum1 / sum2;
-}
-// reference-build-class numerics (engine fast_numerics / rgbid_ctx_set_numerics): the reference's own tap weight is
-// __expf(-(space2 / 50 + 0.5 fn^2)) = ex2.approx(log2e * arg) (filters.cu:124 under nvcc's fast exp); here the same exponent is formed with
-// the constants folded -- arg2 = c_space[dy][dx] + k d^2, k = 0.5 log2e / sigma^2 -- and handed to v_exp_f32: 8 instructions per tap
-// instead of ~50 (exact division, double-precision exponent, full-range expf), results within a few 1e-7 relative of the exact kernel.
-// Invalid taps (NaN in the map, window positions outside the image) are stored in the tile as BIL_SENTINEL, a large FINITE value: the range
-// term k d^2 of such a tap is >= 1e36, v_exp_f32 returns exactly 0 and 0 * sentinel adds exactly 0 to both sums -- the tap drops out without a
-// compare and two selects per tap (a third of the kernel's issue time).  So that no VALID value can collide with the sentinel or overflow the
-// range term on its own, this class treats |v| >= BIL_MAXABS (and +-inf) as invalid when the tile is loaded -- one compare per loaded value,
-// nothing per tap; inverse depths (<= 1e3 m^-1) and intensities (<= 255) are six orders below it.  Stated domain of the FAST filter: the
-// oracle's result on the map with such values replaced by NaN (tests/test_gpu_fuzz.py).
-static constexpr float BIL_SENTINEL = 1e19f, BIL_MAXABS = 1e9f;
-__device__ __forceinline__ float bilateral_px_fast(const float (*tile)[TX + 2 * BR + 1], int ty, int tx, float value, float k, float cs) {
-  float sum1 = value, sum2 = 1.f;   // centre tap: weight exp(-0) = 1
-#pragma unroll
-  for (int dy = -BR; dy <= BR; ++dy)
-#pragma unroll
-    for (int dx = -BR; dx <= BR; ++dx) {
-      if (dx == 0 && dy == 0) continue;
-      const float tmp = tile[ty + dy][tx + dx];
-      const float d = value - tmp;
-      const float w = __builtin_amdgcn_exp2f(-__builtin_fmaf(k * d, d, cs * (float)(dx * dx + dy * dy)));
-      sum1 = __builtin_fmaf(tmp, w, sum1);
-      sum2 += w;
-    }
-  return sum1 * __builtin_amdgcn_rcpf(sum2);
-}
-struct BilSet { ImgB src, dst; float sigma; DivConst dc; };
-// ny: tile rows of one map; blockIdx.y >= ny: the second map of the launch (same geometry, its own range sigma -- the keyframe's inverse depth and
-// intensity: one launch instead of two)
-template <int MODE>   // 0: IEEE division per tap, 1: the verified 3-instruction exact division, 2: reference-build-class numerics
-__global__ __launch_bounds__(256) void k_bilateral(BilSet b0, BilSet b1, int ny, LaneMask m) {
-  constexpr bool FAST = MODE == 1;
-  // XCD-contiguous tile order inside the lane (common.h xcd_lane_local_tile; the launch is predicated): neighbouring tiles share halo columns / rows (a
-  // 68-float row segment spans 6 cache lines, 4 of them its own), and with the natural order the neighbours of a tile always run on other XCDs (round 4
-  // counted 1.68 x the algorithmic traffic)
-  const TileId tid_ = xcd_lane_local_tile();
-  const int lane = tid_.lane;
-  if (!m.on(lane)) return;
-  const bool second = tid_.by >= ny;
-  const BilSet& S = second ? b1 : b0;
-  const ImgB& src = S.src; const ImgB& dst = S.dst;
-  const float sigma_floatmap = S.sigma;
-  const DivConst dc = S.dc;
-  const int tile_y = tid_.by - (second ? ny : 0);
-  // one halo tile of BIL_TILES x TY rows per workgroup (16 + 4 rows x 68 columns: 1.33 loads per output, ONE barrier and ONE exposed memory round
-  // trip per four outputs of a thread; four separate 4-row tiles cost 2.1 loads per output and four round trips)
-  __shared__ float tile[TY * BIL_TILES + 2 * BR][TX + 2 * BR + 1];
-  const int x0 = tid_.bx * TX;
-  const float sigma_space = 5.f;
-  const float s2ih = (float)(0.5 / (double)(sigma_space * sigma_space));
-  const int y0 = tile_y * (TY * BIL_TILES);
-  for (int ty = threadIdx.y; ty < TY * BIL_TILES + 2 * BR; ty += TY) {
-    const int cy = y0 + ty - BR;
-    const bool row_in = cy >= 0 && cy < src.rows;
-    const float* rp = row_ptr<float>(src, lane, row_in ? cy : 0);
-    for (int tx = threadIdx.x; tx < TX + 2 * BR; tx += TX) {
-      const int cx = x0 + tx - BR;
-      float v = (row_in && cx >= 0 && cx < src.cols) ? rp[cx] : qnan();
-      if (MODE == 2) v = fabsf(v) < BIL_MAXABS ? v : BIL_SENTINEL;   // NaN fails the compare too
-      tile[ty][tx] = v;
-    }
-  }
-  __syncthreads();
-  const int x = x0 + threadIdx.x;
-  if (x >= src.cols) return;
-#pragma unroll
-  for (int it_ = 0; it_ < BIL_TILES; ++it_) {
-    const int ly = it_ * TY + threadIdx.y, y = y0 + ly;
-    if (y >= src.rows) break;
-    const float value = tile[ly + BR][threadIdx.x + BR];
-    if (MODE == 2 ? value == BIL_SENTINEL : isnan(value)) { px<float>(dst, lane, y, x) = qnan(); continue; }
-    float res;
-    if (MODE == 2) {
-      const float log2e = 1.44269504088896341f;
-      res = bilateral_px_fast(tile, ly + BR, threadIdx.x + BR, value, 0.5f * log2e / (sigma_floatmap * sigma_floatmap), s2ih * log2e);
-    } else if (FAST) {
-      bool all_ok = true;
-      res = bilateral_px<true>(tile, ly + BR, threadIdx.x + BR, value, sigma_floatmap, dc, s2ih, all_ok);
-      if (__builtin_expect(!all_ok, 0)) res = bilateral_px<false>(tile, ly + BR, threadIdx.x + BR, value, sigma_floatmap, dc, s2ih, all_ok);
-    } else {
-      bool unused = true;
-      res = bilateral_px<false>(tile, ly + BR, threadIdx.x + BR, value, sigma_floatmap, dc, s2ih, unused);
-    }
-    px<float>(dst, lane, y, x) = res;
-  }
-}
-// constants whose 3-instruction division has been verified exhaustively (rgbid_selftest_div_const in the GPU tests): the tracker's two
-// range sigmas, 2 * 0.0025 (inverse depth) and 3 (intensity), visodo.cpp:843-844
-bool div_const_verified(float c) { return c == 2.f * 0.0025f || c == 3.f; }
-void launch_bilateral(hipStream_t s, int B, ImgB src, ImgB dst, float sigma_floatmap, LaneMask m, bool fast) {
-  const BilSet bs{src, dst, sigma_floatmap, DivConst{sigma_floatmap, 1.0f / sigma_floatmap}};
-  const int ny = div_up(src.rows, TY * BIL_TILES);
-  const dim3 g(div_up(src.cols, TX), ny, B), b(TX, TY);
-  if (fast) hipLaunchKernelGGL(k_bilateral<2>, g, b, 0, s, bs, bs, ny, m);
-  else if (div_const_verified(sigma_floatmap)) hipLaunchKernelGGL(k_bilateral<1>, g, b, 0, s, bs, bs, ny, m);
-  else hipLaunchKernelGGL(k_bilateral<0>, g, b, 0, s, bs, bs, ny, m);
-}
-void launch_bilateral2(hipStream_t s, int B, ImgB src0, ImgB dst0, float sigma0, ImgB src1, ImgB dst1, float sigma1, LaneMask m, bool fast) {
-  const bool both_verified = div_const_verified(sigma0) && div_const_verified(sigma1);
-  if (!same_geometry(src0, src1) || (!fast && !both_verified && (div_const_verified(sigma0) || div_const_verified(sigma1)))) {   // the two maps need different kernels
-    launch_bilateral(s, B, src0, dst0, sigma0, m, fast); launch_bilateral(s, B, src1, dst1, sigma1, m, fast);
-    return;
-  }
-  const BilSet b0{src0, dst0, sigma0, DivConst{sigma0, 1.0f / sigma0}}, b1{src1, dst1, sigma1, DivConst{sigma1, 1.0f / sigma1}};
-  const int ny = div_up(src0.rows, TY * BIL_TILES);
-  const dim3 g(div_up(src0.cols, TX), 2 * ny, B), b(TX, TY);
-  if (fast) hipLaunchKernelGGL(k_bilateral<2>, g, b, 0, s, b0, b1, ny, m);
-  else if (both_verified) hipLaunchKernelGGL(k_bilateral<1>, g, b, 0, s, b0, b1, ny, m);
-  else hipLaunchKernelGGL(k_bilateral<0>, g, b, 0, s, b0, b1, ny, m);
-}
+// (the bilateral filter lives in kernels_bilateral.hip)
 // exhaustive check of div_const_fast for one constant: every x whose fast result is flagged ok must equal x / c bit for bit (a zero result
 // only up to its sign); returns the number of violations over all 2^32 bit patterns of x
 __global__ __launch_bounds__(256) void k_selftest_div_const(DivConst d, unsigned long long* mismatches) {

@@ -74,6 +74,9 @@ __device__ __forceinline__ void acc_pk_unpack(const AccPk& A, float acc[SYS_TERM
 #ifndef RGBID_PK_ACC
 #define RGBID_PK_ACC 1
 #endif
+#ifndef RGBID_PK_JROWS
+#define RGBID_PK_JROWS 0   // the fused fast kernel's Jacobian rows built as packed pairs (needs RGBID_PK_ACC)
+#endif
 #if RGBID_PK_ACC
 using AccM = AccPk;
 #else
@@ -203,6 +206,15 @@ __device__ __forceinline__ void accumulate_pixel_m(AccM& accm, float px_, float 
   float gz0 = gz + w0, gz1 = gz + w1;
   float mm = fmaf(gx, gx, fmaf(gy, gy, gz0 * gz0)), pp = fmaf(px_, px_, pp_y);
   float nfac = fabsf(w0) * __builtin_amdgcn_rsqf(mm * pp);             // |n^ . p^|
+#if RGBID_PK_JROWS
+  // the row directly in the pair layout acc_pk_row consumes (round 6): the same products and FMAs, two per issue.  fmaf(a, b, -0.f) == a * b bit for bit
+  // (the sum of a product and -0 is the product, signed zeros included)
+  const f32x2 w0w0 = {w0, w0}, pxpx = {px_, px_};
+  f32x2 Vd[3];
+  Vd[0] = f32x2{gx, gy} * w0w0;
+  Vd[1] = pk_fma(f32x2{gz1, gz1}, f32x2{w0, py_}, f32x2{-0.f, -gy});
+  Vd[2] = pk_fma(f32x2{-gz1, gy}, pxpx, f32x2{gx, -(gx * py_)});
+#else
   float Jd[6];
   Jd[0] = gx * w0;
   Jd[1] = gy * w0;
@@ -210,6 +222,7 @@ __device__ __forceinline__ void accumulate_pixel_m(AccM& accm, float px_, float 
   Jd[3] = fmaf(gz1, py_, -gy);
   Jd[4] = fmaf(-gz1, px_, gx);
   Jd[5] = fmaf(gy, px_, -(gx * py_));
+#endif
   float ed = w0 - w1;
   float eu = fmaf(ed, C.inv_sd, -C.be_d);
   float wd = snu ? C.nud1_m * __builtin_amdgcn_rcpf(fmaf(eu, eu, P.nu_d)) : m_weight(eu, mest) * C.wmul_d;
@@ -217,6 +230,12 @@ __device__ __forceinline__ void accumulate_pixel_m(AccM& accm, float px_, float 
   // ---- intensity row (times sigma_i; its weight carries rho2)
   float hx = gix * P.fx, hy = giy * P.fy;
   float hz = -fmaf(hx, px_, hy * py_);
+#if RGBID_PK_JROWS
+  f32x2 Vi[3];
+  Vi[0] = f32x2{hx, hy} * w0w0;
+  Vi[1] = pk_fma(f32x2{hz, hz}, f32x2{w0, py_}, f32x2{-0.f, -hy});
+  Vi[2] = pk_fma(f32x2{-hz, hy}, pxpx, f32x2{hx, -(hx * py_)});
+#else
   float Ji[6];
   Ji[0] = hx * w0;
   Ji[1] = hy * w0;
@@ -224,6 +243,7 @@ __device__ __forceinline__ void accumulate_pixel_m(AccM& accm, float px_, float 
   Ji[3] = fmaf(hz, py_, -hy);
   Ji[4] = fmaf(-hz, px_, hx);
   Ji[5] = fmaf(hy, px_, -(hx * py_));
+#endif
   float ei = i0 - i1;
   ei = vi ? ei : 0.f;
   float eiu = fmaf(ei, C.inv_si, -C.be_i);
@@ -237,7 +257,12 @@ __device__ __forceinline__ void accumulate_pixel_m(AccM& accm, float px_, float 
     wi = vi ? wi : 0.f;
   }
   float sd = nfac * wd;
+#if RGBID_PK_JROWS
+  acc_pk_row(accm, Vi, ei, wi);
+  acc_pk_row(accm, Vd, ed, sd);
+#else
   accumulate_rows(accm, Ji, ei, wi, Jd, ed, sd);
+#endif
 }
 
 __device__ __forceinline__ SysConst make_const(const SysParams& P) {

@@ -270,6 +270,7 @@ int rgbid_keyframe_align_mode(int device, int rows, int cols, const float* depth
   std::memcpy(R, Rm.m, 72); std::memcpy(t, tv.v, 24); std::memcpy(cov, c.data(), 288);
   return RGBID_OK;
 }
+int rgbid_default_ctx_set_interp_mode(int mode) { return rgbid_ctx_set_interp_mode(pcl::gpu::default_ctx(), mode); }
 int rgbid_keyframe_align(int device, int rows, int cols, const float* depthinv_ini, const unsigned char* grey_ini, const float* depthinv_end,
                          const unsigned char* grey_end, float fx, float fy, float cx, float cy, double R[9], double t[3], double cov[36]) {
   return rgbid_keyframe_align_mode(device, rows, cols, depthinv_ini, grey_ini, depthinv_end, grey_end, fx, fy, cx, cy, R, t, cov, 0);

@@ -80,7 +80,7 @@ def test_dist_library_exports_every_declared_symbol():
         pytest.skip("librgbid_dist.so is not built on hosts without RCCL (csrc/Makefile says so); every other library is")
     L = D.dlib()
     names = [n for n in _declared("rgbid_dist.h") if n.startswith("rgbid_dist_")]
-    assert len(names) == 14 and set(names) == set(D.DIST_EXPORTS), names
+    assert len(names) == 15 and set(names) == set(D.DIST_EXPORTS), names
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
     # the 392-byte record of SURVEY 8e, as the Python harness mirrors it

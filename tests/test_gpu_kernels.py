@@ -121,6 +121,66 @@ def test_bilateral_fast_numerics(ctx, rows, cols, sigma):
     assert (np.abs(got[m] - ref[m]) <= 2e-6 * np.abs(ref[m]) + 1e-30).all(), float((np.abs(got[m] - ref[m]) / np.abs(ref[m])).max())
 
 
+_BIL_WORKER = """
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/rgbid-slam_amd")
+from rgbid import device, batched
+d = np.load(sys.argv[2])
+ctx = device.Context(0); bt = batched.Batched(ctx)
+out = {}
+for k in d.files:
+    a = torch.from_numpy(d[k]).cuda()
+    o = torch.full_like(a, 7.0)
+    bt.bilateral(a, o, 3.0 if k.startswith("I") else 2 * 0.0025, fast=True)
+    out[k] = o.cpu().numpy()
+    if a.shape[1] >= 8 and a.shape[2] >= 8:
+        h = torch.full((a.shape[0], a.shape[1] // 2, a.shape[2] // 2), 7.0, device="cuda")
+        bt.pyr_down(a, h)
+        out["pyr_" + k] = h.cpu().numpy()
+np.savez(sys.argv[3], **out)
+"""
+
+
+def test_bilateral_shared_weights_equals_the_two_sided_kernel(ctx, tmp_path):
+    """round 6: the engine's FAST bilateral filter evaluates every pair weight ONCE (k_bilateral_shared: forward taps, the backward ones from the neighbouring
+    lanes / earlier steps) -- the pair weight is symmetric bit for bit and every output adds its taps in the same order, so the result must be the two-sided
+    kernel's (k_bilateral<2>, kept behind RGBID_BILATERAL_TWO_SIDED for this test and for A/B timing) BYTE for byte: sizes that are / are not multiples of the
+    60-column strips and 30 / 60-row blocks, several lanes, NaN, the sentinel's special values.  (Both are held to the oracle by test_bilateral_fast_numerics,
+    tests/test_gpu_batched.py and the fuzz suite.)"""
+    import os
+    import subprocess
+    import sys
+    from rgbid import batched
+    r = util.rng(606)
+    specials = np.array([np.inf, -np.inf, 3e38, 1e19, -1e19, 1e10, 1e9, 9.9e8, -9.9e8, 0.0, -0.0, 1e-45, 1e-39], np.float32)
+    maps = {}
+    for i, (B, rows, cols) in enumerate([(1, 480, 640), (3, 120, 160), (2, 61, 83), (40, 65, 127), (1, 5, 5), (2, 31, 61), (1, 92, 181)]):
+        for kind in ("W", "I"):
+            a = np.stack([util.rand_invdepth(r, rows, cols, nan_frac=0.1) if kind == "W" else util.rand_intensity(r, rows, cols, nan_frac=0.02) for _ in range(B)])
+            idx = r.integers(0, a.size, size=max(1, a.size // 40))
+            a.reshape(-1)[idx] = specials[r.integers(0, specials.size, size=idx.size)]
+            maps[f"{kind}{i}"] = a.astype(np.float32)
+    maps["I_clean"] = np.stack([util.rand_intensity(r, 480, 640) for _ in range(2)])      # no invalid pixel: the fast paths run everywhere but at the border
+    maps["W_clean"] = np.stack([util.rand_invdepth(r, 240, 320, nan_frac=0.0) for _ in range(2)])
+    np.savez(tmp_path / "in.npz", **maps)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RGBID_BILATERAL_TWO_SIDED="1", RGBID_PYRDOWN_NO_FASTPATH="1")
+    subprocess.run([sys.executable, "-c", _BIL_WORKER, root, str(tmp_path / "in.npz"), str(tmp_path / "two_sided.npz")], check=True, env=env, timeout=600)
+    ref = np.load(tmp_path / "two_sided.npz")
+    bt = batched.Batched(ctx)
+    for k, a in maps.items():
+        src = dev(a); o = torch.full_like(src, 7.0)
+        bt.bilateral(src, o, 3.0 if k.startswith("I") else 2 * 0.0025, fast=True)
+        got = o.cpu().numpy()
+        assert got.tobytes() == ref[k].tobytes(), (k, a.shape, int(np.count_nonzero(got.view(np.uint32) != ref[k].view(np.uint32))))
+        # ... and the pyramid reduction's all-valid fast path (round 6: tap count and mask-weighted sum skipped where a wave's five window rows hold no
+        # invalid tap) against the kernel without it
+        if "pyr_" + k in ref.files:
+            h = torch.full((a.shape[0], a.shape[1] // 2, a.shape[2] // 2), 7.0, device="cuda")
+            bt.pyr_down(src, h)
+            assert h.cpu().numpy().tobytes() == ref["pyr_" + k].tobytes(), ("pyrDown", k, a.shape)
+
+
 def _warp_case(rows, cols, seed, trans=0.03, rot=1.5):
     r = util.rng(seed)
     K = K_for(rows, cols)

@@ -159,6 +159,27 @@ def test_keyframe_align_device_resident_equals_host_driven():
         assert np.array_equal(x, y)
 
 
+def test_keyframe_align_follows_the_interpolation_mode_in_both_loops():
+    """ADVICE r5: the device-resident aligner runs on a context of its own; it must sample like the thread's default context (VisodoTracker::setInterpMode),
+    which the host-driven loop uses -- with the exact bilinear mode selected both loops still agree bit for bit, and differ from the TEX8 result"""
+    seq = synth.make_sequence(4, device="cuda", trans_step=(0.01, 0.02), rot_step_deg=(0.5, 1.0))
+    d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+    iD, grey, _, _ = _kf_pair(seq, d, c, 0, 3)
+    L = host.lib()
+    tex8 = host.keyframe_align(iD[0], grey[0], iD[1], grey[1], synth.TUM_K, host_driven=False)
+    host.check(L.rgbid_default_ctx_set_interp_mode(O.INTERP_EXACT))
+    try:
+        a = host.keyframe_align(iD[0], grey[0], iD[1], grey[1], synth.TUM_K, host_driven=True)
+        b = host.keyframe_align(iD[0], grey[0], iD[1], grey[1], synth.TUM_K, host_driven=False)
+    finally:
+        host.check(L.rgbid_default_ctx_set_interp_mode(O.INTERP_TEX8))
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert not np.array_equal(a[1], tex8[1])
+    again = host.keyframe_align(iD[0], grey[0], iD[1], grey[1], synth.TUM_K, host_driven=False)
+    assert all(np.array_equal(x, y) for x, y in zip(again, tex8))
+
+
 @pytest.mark.parametrize("rows,cols", [(120, 160), (480, 640)])
 def test_keyframe_align_batched(rows, cols):
     """rgbid_kfalign_batched: N keyframe pairs with their own intrinsics and initial guesses in lock-step, no host round trip: every pair within the north-star
