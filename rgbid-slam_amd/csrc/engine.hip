@@ -12,6 +12,7 @@
 #include "kernels.h"
 #include "../../include/rgbid/se3.h"
 #include "engine_device.h"
+#include "sigma_device.h"   // FusedLatticeGetter: the lattice pre-pass that carries the few-lane plan's update prologue
 
 #include <algorithm>
 #include <cstdio>
@@ -159,13 +160,64 @@ __global__ __launch_bounds__(64) RGBID_SCALAR_KERNEL void k_step_begin(LaneState
 // VGPRs, so the one-wave form may share a SIMD three ways (170 VGPRs each): 12 lanes per compute unit at a time, 2 048 lanes in one round.
 template <int NT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, NT == 64 ? 3 : 1))) void k_solve_update(const double* partials, int nblk, LaneState* st, Flags f, WarpParams* wp,
-                                                      StepCfg c, int next_level, SysParams* sp, int sys_level, int sys_cov) {
+                                                      StepCfg c, int next_level, SysParams* sp, int sys_level, int sys_cov, int pin) {
   int lane = blockIdx.x;
   if (sys_level >= 0 && threadIdx.x == NT / 4) set_sys_lane(sp, st, f.track, c, sys_level, sys_cov, lane);   // NT = 256: a wave of its own, beside thread 0's solve
   if (!f.lvl[lane]) return;   // lvl == gn unless CHI_SQUARED termination has ended this lane's level early
   __shared__ double sm[8][32];
   __shared__ double sums[SYS_TERMS];
-  solve_update_block<NT>(partials, nblk, st, f, wp, c, next_level, lane, (int)threadIdx.x, sm, sums);
+  solve_update_block<NT>(partials, nblk, st, f, wp, c, next_level, lane, (int)threadIdx.x, sm, sums, pin);
+}
+
+// ---- few-lane plan (round 6): the update of iteration k as the PROLOGUE of iteration k + 1's lattice pre-pass -----------------------------------------------
+// With a handful of lanes a step is a chain of ~96 dependent launches of 4.5 - 5 us each whatever they do; the 6x6 solve + pose update is a
+// launch of its own only because the NEXT kernel needs its result.  Here every workgroup of that next kernel -- the residual-lattice pre-pass -- reduces the
+// lane's partial sums in the fixed order and runs the update itself, redundantly (the same doubles in every workgroup: bit-identical to the separate launch),
+// keeps the new warp in LDS for its own samples, and workgroup 0 of the lane stores what the later launches read (pose, increment, warp, flags, the next
+// stage's SysParams).  The kernel boundary gives the visibility that sank the update as the TAIL of the normal-equation kernel (device-scope fences:
+// profiles/r04_experiments/gn_solve_tail.md).  The pose a workgroup reads must be the one the launch began with even if workgroup 0 has finished: the updates
+// alternate between the lane's two pose buffers (pin: this launch reads alt_*, writes cur_*; else the other way round).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) void k_lattice_after_update(ImgB Wcur, ImgB W0, ImgB Icur, ImgB I0, int interp_mode, int n, int lcols, int stride, float* res,
+                                                                                  size_t res_lane_stride, const float* kf_lat, size_t kf_lat_lane_stride, int fast,
+                                                                                  const double* partials, int nblk, LaneState* st, Flags f, WarpParams* wp, StepCfg c, int level,
+                                                                                  SysParams* sp, int sys_level, int sys_cov, int pin) {
+  const int lane = blockIdx.y, tid = (int)threadIdx.x;
+  if (sys_level >= 0 && blockIdx.x == 0 && tid == 64) set_sys_lane(sp, st, f.track, c, sys_level, sys_cov, lane);
+  if (!f.lvl[lane]) return;
+  __shared__ double sm[8][32];
+  __shared__ double sums[SYS_TERMS];
+  __shared__ WarpParams next_warp;
+  __shared__ int update_ok;
+  reduce_partials<256>(partials, nblk, lane, tid, sm, sums);
+  if (tid == 0) {
+    LaneState& s = st[lane];
+    GnUpdate u;
+    gn_update(sums, pin ? s.alt_R : s.cur_R, pin ? s.alt_t : s.cur_t, u);
+    if (!u.failed) set_warp_from_pose(c, level, u.R, u.t, next_warp);
+    update_ok = u.failed ? 0 : 1;
+    if (blockIdx.x == 0) gn_commit(u, s, pin ? s.cur_R : s.alt_R, pin ? s.cur_t : s.alt_t, f, wp, &next_warp, c, level, lane);
+  }
+  __syncthreads();
+  if (!update_ok) return;   // the lane's Gauss-Newton has failed (NaN): workgroup 0 has cleared its flags, nothing reads these residuals
+  const int i = blockIdx.x * 256 + tid;
+  if (i >= n) return;
+  FusedLatticeGetter g{Wcur, Icur, W0, I0, next_warp, lane, stride, interp_mode, fast};
+  const int ly = i / lcols, lx = i - ly * lcols;
+  float rd, ri;
+  if (kf_lat) {
+    const float* k = kf_lat + (size_t)lane * kf_lat_lane_stride;
+    g.both_given(ly, lx, k[i], k[n + i], rd, ri);
+  } else {
+    g.both(ly, lx, rd, ri);
+  }
+  float* r = res + (size_t)lane * res_lane_stride;
+  r[i] = rd; r[n + i] = ri;
+}
+// lanes up to which the update rides in the next launch (0: never).  The kernel may take 170 VGPRs (the update needs 147): three workgroups per compute unit, 768
+// on the chip = the ~48 lattice workgroups of 16 lanes at 640x480 in ONE round; beyond that the redundant updates queue up and stop being free
+inline int update_prologue_max_lanes() {
+  const char* e = getenv("RGBID_ENGINE_UPDATE_PROLOGUE_LANES");   // read when a step is enqueued / captured (tests and A/B runs switch it per engine)
+  return e ? atoi(e) : 16;
 }
 // workgroup size of the per-lane reduce-and-solve kernels (engine_device.h reduce_partials): one wave per lane once there are more lanes than compute units
 inline int scalar_block_threads(int B) { return B > 256 ? 64 : 256; }
@@ -527,6 +579,8 @@ struct rgbid_engine {
   std::vector<hipEvent_t> prof_ev;
   int prof_used = 0;
   bool prof_on = false;
+  size_t lane_pad = 0, map_skew = 0;   // placement of the image maps (alloc_img)
+  int n_maps = 0;
 };
 
 namespace {
@@ -543,13 +597,20 @@ int alloc_dev(rgbid_engine* e, void** p, size_t bytes, bool zero = true) {
   return RGBID_OK;
 }
 
+// Placement: a map is [lanes][rows][pitch] with the lanes `lane_stride` apart.  With lane_stride = rows * pitch the lanes of a 1280x960 map sit
+// 75 x 64 KiB apart and every map of a level starts on the same allocation granule: the same tile of every lane, and of all eight maps the dominant kernel
+// streams, then falls on the same HBM channel group -- whether the channels are loaded evenly depends on where the allocator happened to put the maps (round 5:
+// 0.47 - 0.66 of the peak for the same binary).  lane_pad (a multiple of 256 B added to every lane) and map_skew (the k-th map of the engine starts k * map_skew
+// bytes into its allocation) take both regularities out; their values are set by rgbid_engine_create (placement_defaults) and can be overridden for
+// experiments with RGBID_ENGINE_LANE_PAD / RGBID_ENGINE_MAP_SKEW (bytes).
 int alloc_img(rgbid_engine* e, ImgB* im, int rows, int cols, int elem) {
   size_t pitch = ((size_t)cols * elem + 255) & ~(size_t)255;
-  size_t lane_stride = pitch * rows;
+  size_t lane_stride = pitch * rows + e->lane_pad;
+  const size_t skew = e->map_skew * (size_t)(e->n_maps++ % 16);
   void* p = nullptr;
-  int r = alloc_dev(e, &p, lane_stride * e->B);
+  int r = alloc_dev(e, &p, lane_stride * e->B + skew);
   if (r) return r;
-  *im = ImgB{p, pitch, lane_stride, rows, cols};
+  *im = ImgB{static_cast<char*>(p) + skew, pitch, lane_stride, rows, cols};
   return RGBID_OK;
 }
 
@@ -693,6 +754,11 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
   // ---- estimateVisualOdometry (visodo.cpp:1041-1281), PYR_FIRST
   const bool chi_stop = c.termination == RGBID_CHI_SQUARED;
   const LaneMask LV = M(f.lvl);   // the lanes iterating the current level (== f.gn unless chi_stop)
+  // few-lane plan: every update but the frame's last rides in the next iteration's lattice pre-pass (k_lattice_after_update); needs that pre-pass (fused path with
+  // estimated scales; CHI_SQUARED termination runs unfused)
+  const bool prologue_plan = c.fused_gn && c.sigma_estimator == RGBID_SIGMA_PDF && !chi_stop && e->lat_res && B <= update_prologue_max_lanes();
+  struct { bool on; int nblk, sys_level, sys_cov; } pend = {false, 0, -1, 0};
+  int pose_in_alt = 0;   // which of the lane's two pose buffers holds the working pose (0: cur_*)
   for (int level = L - 1; !first && level >= c.finest_level; --level) {
     int iters = c.iters[level];
     if (iters > 0) ++stage;     // stage_level[stage]: what follows this level
@@ -722,8 +788,20 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
       }
       if (c.fused_gn) {
         if (c.sigma_estimator == RGBID_SIGMA_PDF) {
-          launch_sigma_pair_fused(s, B, e->iD_curr[level], e->iD_kf[level], e->I_curr[level], e->I_kf[level], e->wp, c.interp_mode, c.nsamples,
-                                  e->sp, c.mestimator, LV, fast_at(level), e->lat_res, 2 * e->lat_cap, e->lat_kf[level], 2 * e->lat_cap);
+          if (pend.on) {
+            // few-lane plan: the previous iteration's update rides in this launch (k_lattice_after_update)
+            int n_, lr_, lc_, st_;
+            lattice_geometry(e->iD_kf[level].rows, e->iD_kf[level].cols, c.nsamples, &n_, &lr_, &lc_, &st_);
+            const size_t kls = 2 * e->lat_cap;
+            hipLaunchKernelGGL(k_lattice_after_update, dim3(div_up(n_, 256), B), dim3(256), 0, s, e->iD_curr[level], e->iD_kf[level], e->I_curr[level], e->I_kf[level], c.interp_mode,
+                               n_, lc_, st_, e->lat_res, 2 * e->lat_cap, kls >= 2 * (size_t)n_ ? e->lat_kf[level] : nullptr, kls, fast_at(level) ? 1 : 0,
+                               e->partials, pend.nblk, e->state, f, e->wp, sc, level, e->sp, pend.sys_level, pend.sys_cov, pose_in_alt);
+            launch_sigma_pair_arrays(s, B, e->lat_res, 2 * e->lat_cap, n_, e->sp, c.mestimator, LV);
+            pose_in_alt ^= 1; pend.on = false;
+          } else {
+            launch_sigma_pair_fused(s, B, e->iD_curr[level], e->iD_kf[level], e->I_curr[level], e->I_kf[level], e->wp, c.interp_mode, c.nsamples,
+                                    e->sp, c.mestimator, LV, fast_at(level), e->lat_res, 2 * e->lat_cap, e->lat_kf[level], 2 * e->lat_cap);
+          }
           e->launches += 2;
         }
         if (prof) { set_system_kernel_events(e->prof_ev[e->prof_used], e->prof_ev[e->prof_used + 1]); e->prof_used += 2; }
@@ -771,12 +849,18 @@ int enqueue_step(rgbid_engine* e, hipStream_t s, bool first) {
         nblk = launch_build_system(s, B, e->iD_kf[level], e->I_kf[level], e->gxD[level], e->gyD[level], e->gxI[level], e->gyI[level],
                                    e->wiD[level], e->wI[level], nullptr, e->sp, e->partials, LV, level < 2 ? level : 2);
       }
+      const int sys_level = last_of_level ? stage_level[stage] : -1, sys_cov = (last_of_level && stage == n_gn_stages) ? 1 : 0;
+      if (prologue_plan && more_gn) {
+        // the update is deferred into the next iteration's lattice launch (same lanes: LV == f.gn here; next_level is that launch's level)
+        pend.on = true; pend.nblk = nblk; pend.sys_level = sys_level; pend.sys_cov = sys_cov;
+        e->launches += 1;
+        continue;
+      }
       if (scalar_block_threads(B) == 64)
-        hipLaunchKernelGGL(k_solve_update<64>, dim3(B), dim3(64), 0, s, e->partials, nblk, e->state, f, e->wp, sc, next_level, e->sp,
-                           last_of_level ? stage_level[stage] : -1, (last_of_level && stage == n_gn_stages) ? 1 : 0);
+        hipLaunchKernelGGL(k_solve_update<64>, dim3(B), dim3(64), 0, s, e->partials, nblk, e->state, f, e->wp, sc, next_level, e->sp, sys_level, sys_cov, pose_in_alt);
       else
-        hipLaunchKernelGGL(k_solve_update<256>, dim3(B), dim3(256), 0, s, e->partials, nblk, e->state, f, e->wp, sc, next_level, e->sp,
-                           last_of_level ? stage_level[stage] : -1, (last_of_level && stage == n_gn_stages) ? 1 : 0);
+        hipLaunchKernelGGL(k_solve_update<256>, dim3(B), dim3(256), 0, s, e->partials, nblk, e->state, f, e->wp, sc, next_level, e->sp, sys_level, sys_cov, pose_in_alt);
+      pose_in_alt = 0;
       e->launches += 2;
     }
   }
@@ -967,6 +1051,8 @@ int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_c
   if (cfg->termination == RGBID_CHI_SQUARED) e->cfg.fused_gn = 0;   // the chi-square test reads the stored warped maps
   hipSetDevice(ctx->device);
   const int B = e->B, rows = cfg->rows, cols = cfg->cols;
+  if (const char* v = getenv("RGBID_ENGINE_LANE_PAD")) e->lane_pad = (size_t)strtoull(v, nullptr, 0) & ~(size_t)255;
+  if (const char* v = getenv("RGBID_ENGINE_MAP_SKEW")) e->map_skew = (size_t)strtoull(v, nullptr, 0) & ~(size_t)255;
   int r = RGBID_OK;
 #define A_IMG(im, rr, cc, el) if (!r) r = alloc_img(e, &(im), rr, cc, el)
   A_IMG(e->in_depth, rows, cols, 2); A_IMG(e->in_rgb, rows, cols, 3);

@@ -33,6 +33,9 @@ struct LaneState {
   // CHI_SQUARED termination (visodo.cpp:1134-1164): the last increment (to undo it) and the previous RMSE of estimateVisualOdometry
   double inc_inv_R[9], inc_t[3];
   float rmse_prev;
+  // round 6, few-lane plan: the Gauss-Newton update of an iteration runs as the prologue of the NEXT iteration's first launch, in every workgroup of it; the
+  // working pose then alternates between cur_* and this second buffer (a workgroup that starts late must still read the pose its launch began with)
+  double alt_R[9], alt_t[3];
 };
 
 struct Flags {  // int[B] each; consumed through LaneMask
@@ -113,14 +116,10 @@ __device__ inline void reduce_partials(const double* partials, int nblk, int lan
   __syncthreads();
 }
 
-// one GN update of one lane by the first NT threads of a workgroup (every thread of the workgroup must call it: two barriers): fixed-order reduction
-// of the lane's partial sums, LLT solve, exp-map, pose update, next warp (visodo.cpp:1242-1274).  sm: [8][32] doubles, sums: [SYS_TERMS] doubles of LDS.
-template <int NT = 256>
-__device__ inline void solve_update_block(const double* partials, int nblk, LaneState* st, const Flags& f, WarpParams* wp, const StepCfg& c, int next_level, int lane,
-                                          int tid, double (*sm)[32], double* sums) { RGBID_FP_STRICT
-  reduce_partials<NT>(partials, nblk, lane, tid, sm, sums);
-  if (tid != 0) return;
-  LaneState& s = st[lane];
+// the arithmetic of one GN update (visodo.cpp:1242-1274) from the 27 reduced sums and the pose (Rin, tin): the new pose, the increment a CHI_SQUARED stop
+// undoes, and whether the update failed (NaN, :1265-1274).  Pure: callers decide who stores what.
+struct GnUpdate { double R[9], t[3], inc_inv[9], tinc[3]; bool failed; };
+__device__ inline void gn_update(const double* sums, const double* Rin, const double* tin, GnUpdate& u) { RGBID_FP_STRICT
   double A[36], b[6], x[6];
   int shift = 0;  // estimate_VO.cu:774-786
   for (int i = 0; i < 6; ++i)
@@ -129,22 +128,44 @@ __device__ inline void solve_update_block(const double* partials, int nblk, Lane
       if (j == 6) b[i] = v; else A[j * 6 + i] = A[i * 6 + j] = v;
     }
   se3::llt_solve6(A, b, x);
-  double inc_inv[9], inc[9], tinc[3], tmp[3];
-  se3::expmap_rot(x + 3, inc_inv);
-  se3::m3_inv(inc_inv, inc);
-  se3::m3_mulv(inc, x, tinc);
-  tinc[0] = -tinc[0]; tinc[1] = -tinc[1]; tinc[2] = -tinc[2];
-  se3::m3_mulv(inc, s.cur_t, tmp);
-  for (int i = 0; i < 3; ++i) s.cur_t[i] = tmp[i] + tinc[i];
-  se3::m3_mul(inc, s.cur_R, s.cur_R);
-  se3::m3_copy(inc_inv, s.inc_inv_R);   // cam_rot_incremental_inv / cam_trans_incremental: what a CHI_SQUARED stop undoes
-  for (int i = 0; i < 3; ++i) s.inc_t[i] = tinc[i];
-  if (se3::has_nan(s.cur_R, s.cur_t)) {  // :1265-1274
+  double inc[9], tmp[3];
+  se3::expmap_rot(x + 3, u.inc_inv);
+  se3::m3_inv(u.inc_inv, inc);
+  se3::m3_mulv(inc, x, u.tinc);
+  u.tinc[0] = -u.tinc[0]; u.tinc[1] = -u.tinc[1]; u.tinc[2] = -u.tinc[2];
+  se3::m3_mulv(inc, tin, tmp);
+  for (int i = 0; i < 3; ++i) u.t[i] = tmp[i] + u.tinc[i];
+  se3::m3_mul(inc, Rin, u.R);
+  u.failed = se3::has_nan(u.R, u.t);
+}
+// what an update leaves in the lane's state: the pose into (Rout, tout), the increment, the failure flags, the next warp
+__device__ inline void gn_commit(const GnUpdate& u, LaneState& s, double* Rout, double* tout, const Flags& f, WarpParams* wp, const WarpParams* next_warp, const StepCfg& c,
+                                 int next_level, int lane) { RGBID_FP_STRICT
+  se3::m3_copy(u.R, Rout);
+  for (int i = 0; i < 3; ++i) tout[i] = u.t[i];
+  se3::m3_copy(u.inc_inv, s.inc_inv_R);   // cam_rot_incremental_inv / cam_trans_incremental: what a CHI_SQUARED stop undoes
+  for (int i = 0; i < 3; ++i) s.inc_t[i] = u.tinc[i];
+  if (u.failed) {  // :1265-1274
     s.gn_failed = 1;
     f.gn[lane] = 0; f.lvl[lane] = 0;
     return;
   }
-  set_warp_from_pose(c, next_level, s.cur_R, s.cur_t, wp[lane]);
+  if (next_warp) wp[lane] = *next_warp;
+  else set_warp_from_pose(c, next_level, Rout, tout, wp[lane]);
+}
+
+// one GN update of one lane by the first NT threads of a workgroup (every thread of the workgroup must call it: two barriers): fixed-order reduction
+// of the lane's partial sums, LLT solve, exp-map, pose update, next warp (visodo.cpp:1242-1274).  sm: [8][32] doubles, sums: [SYS_TERMS] doubles of LDS.
+// pin: the working pose is in the lane's second buffer (the few-lane plan's prologue updates left it there); the result always goes to cur_*.
+template <int NT = 256>
+__device__ inline void solve_update_block(const double* partials, int nblk, LaneState* st, const Flags& f, WarpParams* wp, const StepCfg& c, int next_level, int lane,
+                                          int tid, double (*sm)[32], double* sums, int pin = 0) { RGBID_FP_STRICT
+  reduce_partials<NT>(partials, nblk, lane, tid, sm, sums);
+  if (tid != 0) return;
+  LaneState& s = st[lane];
+  GnUpdate u;
+  gn_update(sums, pin ? s.alt_R : s.cur_R, pin ? s.alt_t : s.cur_t, u);
+  gn_commit(u, s, s.cur_R, s.cur_t, f, wp, nullptr, c, next_level, lane);
 }
 
 }  // namespace eng

@@ -468,6 +468,44 @@ def test_engine_chi_squared_stops_lanes_independently(ctx, warping, fast):
     assert run([0, 1, 2], O.CHI_SQUARED, graph=1).tobytes() == batch.tobytes()     # the per-lane stop is data in flag arrays: the step stays one replayable hipGraph
 
 
+@pytest.mark.parametrize("lanes,use_graph", [(1, 0), (1, 1), (3, 0), (16, 0)])
+def test_engine_update_prologue_is_bit_identical(ctx, lanes, use_graph):
+    """round 6, few-lane plan: up to 16 lanes the Gauss-Newton update of an iteration runs as the prologue of the next iteration's lattice launch, redundantly in
+    every workgroup (k_lattice_after_update), instead of as a launch of its own: the same doubles in the same order -- records, fused keyframe maps and launch
+    count (17 launches fewer per tracked frame of the shipped schedule) must say so"""
+    import os
+    K = (131.25, 131.25, 79.5, 59.5)
+    T = 6
+    seqs, depth, rgb = make_lanes(lanes, T, 120, 160, K, trans_step=(0.003, 0.012), rot_step_deg=(0.1, 0.8))
+    if lanes == 3:
+        depth[3, 1] = 0          # lane 1 loses frame 3: its Gauss-Newton fails inside a prologue (NaN) while the other lanes go on
+
+    def run(prologue):
+        old = os.environ.get("RGBID_ENGINE_UPDATE_PROLOGUE_LANES")
+        os.environ["RGBID_ENGINE_UPDATE_PROLOGUE_LANES"] = "16" if prologue else "0"
+        try:
+            eng = E.Engine(ctx, E.default_config(rows=120, cols=160, lanes=lanes, K=K, use_graph=use_graph, record_capacity=T))
+            for k in range(T):
+                eng.step(depth[k], rgb[k])
+            rec = eng.records().copy()
+            maps = [np.concatenate([m.reshape(-1).view(np.uint8) for m in eng.keyframe_maps(l)]) for l in range(lanes)]
+            n_launch = eng.launches_per_step()
+            eng.close()
+        finally:
+            if old is None:
+                del os.environ["RGBID_ENGINE_UPDATE_PROLOGUE_LANES"]
+            else:
+                os.environ["RGBID_ENGINE_UPDATE_PROLOGUE_LANES"] = old
+        return rec, maps, n_launch
+    a, ma, la = run(False)
+    b, mb, lb = run(True)
+    assert a.tobytes() == b.tobytes()
+    for x, y in zip(ma, mb):
+        assert np.array_equal(x, y)
+    assert la - lb == 17, (la, lb)
+    assert np.count_nonzero(a["status"] & E.ST_TRACKED) >= lanes * (T - 2)
+
+
 @pytest.mark.parametrize("use_graph", [0, 1])
 def test_engine_custom_calibration(ctx, use_graph):
     """cfg.custom_registration = 1 (round 5): prepareImagesCustomCalibration (visodo.cpp:775-824) as predicated prep-stage launches of the engine -- undistort,
