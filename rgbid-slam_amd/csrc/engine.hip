@@ -214,10 +214,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
   r[i] = rd; r[n + i] = ri;
 }
 // lanes up to which the update rides in the next launch (0: never).  The kernel may take 170 VGPRs (the update needs 147): three workgroups per compute unit, 768
-// on the chip = the ~48 lattice workgroups of 16 lanes at 640x480 in ONE round; beyond that the redundant updates queue up and stop being free
+// on the chip = the ~48 lattice workgroups of 16 lanes at 640x480 in ONE round.  Measured (profiles/r06_experiments/update_prologue.md): 1 - 2 % per frame at 1 and 8
+// lanes, eager and as a hipGraph -- a dependent launch's ~4.5 us floor is mostly the short kernel's own run time, so folding 17 launches away returns 10 - 16 us, not
+// 17 x 4.5 --, 5 % SLOWER at 16 lanes and 9 % at 32 (the redundant updates start to queue): on up to 8 lanes
 inline int update_prologue_max_lanes() {
   const char* e = getenv("RGBID_ENGINE_UPDATE_PROLOGUE_LANES");   // read when a step is enqueued / captured (tests and A/B runs switch it per engine)
-  return e ? atoi(e) : 16;
+  return e ? atoi(e) : 8;
 }
 // workgroup size of the per-lane reduce-and-solve kernels (engine_device.h reduce_partials): one wave per lane once there are more lanes than compute units
 inline int scalar_block_threads(int B) { return B > 256 ? 64 : 256; }
@@ -1051,6 +1053,7 @@ int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_c
   if (cfg->termination == RGBID_CHI_SQUARED) e->cfg.fused_gn = 0;   // the chi-square test reads the stored warped maps
   hipSetDevice(ctx->device);
   const int B = e->B, rows = cfg->rows, cols = cfg->cols;
+  e->lane_pad = 0; e->map_skew = 0x11100;   // 64 KiB + 4 KiB + 256 B per map (alloc_img; measured: profiles/r06_experiments/placement.md)
   if (const char* v = getenv("RGBID_ENGINE_LANE_PAD")) e->lane_pad = (size_t)strtoull(v, nullptr, 0) & ~(size_t)255;
   if (const char* v = getenv("RGBID_ENGINE_MAP_SKEW")) e->map_skew = (size_t)strtoull(v, nullptr, 0) & ~(size_t)255;
   int r = RGBID_OK;
