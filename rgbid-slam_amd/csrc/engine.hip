@@ -1053,7 +1053,7 @@ int rgbid_engine_create(rgbid_engine** out, rgbid_ctx* ctx, const rgbid_engine_c
   if (cfg->termination == RGBID_CHI_SQUARED) e->cfg.fused_gn = 0;   // the chi-square test reads the stored warped maps
   hipSetDevice(ctx->device);
   const int B = e->B, rows = cfg->rows, cols = cfg->cols;
-  e->lane_pad = 0; e->map_skew = 0x11100;   // 64 KiB + 4 KiB + 256 B per map (alloc_img; measured: profiles/r06_experiments/placement.md)
+  e->lane_pad = 0; e->map_skew = 0x1100;   // 4 KiB + 256 B per map (alloc_img; measured: profiles/r06_experiments/placement.md)
   if (const char* v = getenv("RGBID_ENGINE_LANE_PAD")) e->lane_pad = (size_t)strtoull(v, nullptr, 0) & ~(size_t)255;
   if (const char* v = getenv("RGBID_ENGINE_MAP_SKEW")) e->map_skew = (size_t)strtoull(v, nullptr, 0) & ~(size_t)255;
   int r = RGBID_OK;

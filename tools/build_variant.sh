@@ -6,7 +6,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 C=$ROOT/rgbid-slam_amd/csrc
 name=$1; file=$2; flags=$3
 base="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-result -Wno-unused-value"
-{ [ "$file" = kernels_system.hip ] || [ "$file" = kernels_bilateral.hip ]; } && base="$base -fno-slp-vectorize"
+{ [ "$file" = kernels_system.hip ] || [ "$file" = kernels_bilateral.hip ] || [ "$file" = kernels_warp.hip ]; } && base="$base -fno-slp-vectorize"
 make -C $C -j8 > /dev/null
 /opt/rocm/bin/hipcc $base $flags -c $C/$file -o /tmp/variant_$name.o
 objs=""

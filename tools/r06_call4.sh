@@ -31,6 +31,12 @@ for rep in 1 2 3; do
 done
 unset RGBID_PYRDOWN_NO_FASTPATH
 cat $O/ab_warp.txt $O/ab_prep.txt $O/ab_pyr.txt
+# is the fused kernel faster when a launch's maps fit the 256 MB memory-side cache? (9.8 MB of level-0 maps per lane; repeated launches on the same lanes)
+for L in 8 16 24 48 128 1024; do
+  echo "== lanes $L" >> $O/mall.txt
+  python tools/kernel_bench.py --lanes $L --only gn,unfused --reps 30 2>&1 | grep -E "us/lane" >> $O/mall.txt
+done
+cat $O/mall.txt
 for rep in 1 2; do
   for sk in 0 69888; do
     RGBID_ENGINE_MAP_SKEW=$sk python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_skew${sk}_$rep.json 2>/dev/null
