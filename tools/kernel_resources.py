@@ -17,7 +17,7 @@ FLAGS = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-un
 
 
 def resources(src):
-    extra = ["-fno-slp-vectorize"] if src == "kernels_system.hip" else []
+    extra = ["-fno-slp-vectorize"] if src in ("kernels_system.hip", "kernels_bilateral.hip", "kernels_warp.hip") else []   # csrc/Makefile
     p = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=CSRC)
     rows, cur = [], None
