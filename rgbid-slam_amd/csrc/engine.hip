@@ -603,8 +603,9 @@ int alloc_dev(rgbid_engine* e, void** p, size_t bytes, bool zero = true) {
 // 75 x 64 KiB apart and every map of a level starts on the same allocation granule: the same tile of every lane, and of all eight maps the dominant kernel
 // streams, then falls on the same HBM channel group -- whether the channels are loaded evenly depends on where the allocator happened to put the maps (round 5:
 // 0.47 - 0.66 of the peak for the same binary).  lane_pad (a multiple of 256 B added to every lane) and map_skew (the k-th map of the engine starts k * map_skew
-// bytes into its allocation) take both regularities out; their values are set by rgbid_engine_create (placement_defaults) and can be overridden for
-// experiments with RGBID_ENGINE_LANE_PAD / RGBID_ENGINE_MAP_SKEW (bytes).
+// bytes into its allocation) take both regularities out.  Defaults (rgbid_engine_create): map_skew = 4 KiB + 256 B (+0.5 - 1 % on the 640x480 level-0 kernel, the
+// best of the sweep at 1280x960), lane_pad = 0 (no gain measured); RGBID_ENGINE_LANE_PAD / RGBID_ENGINE_MAP_SKEW (bytes) override them for experiments
+// (profiles/r06_experiments/placement.md: the 0.47 case itself did not reproduce in 44 runs).
 int alloc_img(rgbid_engine* e, ImgB* im, int rows, int cols, int elem) {
   size_t pitch = ((size_t)cols * elem + 255) & ~(size_t)255;
   size_t lane_stride = pitch * rows + e->lane_pad;
