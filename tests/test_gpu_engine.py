@@ -468,6 +468,42 @@ def test_engine_chi_squared_stops_lanes_independently(ctx, warping, fast):
     assert run([0, 1, 2], O.CHI_SQUARED, graph=1).tobytes() == batch.tobytes()     # the per-lane stop is data in flag arrays: the step stays one replayable hipGraph
 
 
+def test_engine_records_do_not_depend_on_the_map_placement(ctx):
+    """round 6: the engine skews its maps against each other in memory (alloc_img: the k-th map starts k x 4 352 B into its allocation, so that the streams of the
+    dominant kernel do not walk the HBM channels in lock-step) -- placement must not change a single bit of what the engine computes: no skew, the default, a skew that
+    keeps only 256-byte alignment together with a lane pad, all give the same records, fused maps and exported keyframes"""
+    import os
+    K = (131.25, 131.25, 79.5, 59.5)
+    T, B = 6, 3
+    seqs, depth, rgb = make_lanes(B, T, 120, 160, K, trans_step=(0.01, 0.02), rot_step_deg=(0.5, 1.0))
+
+    def run(skew, pad):
+        old = {k: os.environ.get(k) for k in ("RGBID_ENGINE_MAP_SKEW", "RGBID_ENGINE_LANE_PAD")}
+        if skew is not None:
+            os.environ["RGBID_ENGINE_MAP_SKEW"] = str(skew); os.environ["RGBID_ENGINE_LANE_PAD"] = str(pad)
+        try:
+            eng = E.Engine(ctx, E.default_config(rows=120, cols=160, lanes=B, K=K, use_graph=0, record_capacity=T, keyframe_capacity=3, visratio_odo=0.985, visratio_integr=0.97))
+            for k in range(T):
+                eng.step(depth[k], rgb[k])
+            rec = eng.records().copy()
+            maps = [np.concatenate([m.reshape(-1).view(np.uint8) for m in eng.keyframe_maps(l)]) for l in range(B)]
+            nkf = [int(v) for v in eng.keyframe_counts()]
+            eng.close()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        return rec, maps, nkf
+    ref = run(0, 0)
+    for skew, pad in ((None, None), (256, 768), (69888, 0)):
+        got = run(skew, pad)
+        assert got[0].tobytes() == ref[0].tobytes(), (skew, pad)
+        assert all(np.array_equal(a, b) for a, b in zip(got[1], ref[1])) and got[2] == ref[2], (skew, pad)
+    assert sum(ref[2]) > 0    # keyframes were exported on these sequences
+
+
 @pytest.mark.parametrize("lanes,use_graph", [(1, 0), (1, 1), (3, 0), (16, 0)])
 def test_engine_update_prologue_is_bit_identical(ctx, lanes, use_graph):
     """round 6, few-lane plan: up to 16 lanes the Gauss-Newton update of an iteration runs as the prologue of the next iteration's lattice launch, redundantly in
