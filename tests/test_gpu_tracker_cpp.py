@@ -218,6 +218,38 @@ def test_keyframe_align_batched(rows, cols):
     al.close(); ctx.close()
 
 
+def test_keyframe_align_batched_partials_fit_every_pair_count_of_a_wide_geometry():
+    """the aligner sized its partial-sum buffer for the 1-pair launch plan, assuming it has the most blocks per pair; the few-pair plans come from a
+    schedule-length model, so at 2432x560 (tile rows not divisible by 3 or 4, more than 1 280 tiles) the 2-pair plan has MORE blocks per pair than the 1-pair plan and the
+    normal-equation kernel wrote past the buffer.  The buffer now covers every pair count up to the capacity (and a plan that would not fit is refused): 1, 2 and 3 pairs
+    of that geometry run, agree pairwise with the pairs aligned alone, and find the true motion."""
+    import torch
+    from rgbid import device, kfalign
+    rows, cols = 560, 2432
+    s = cols / 640.0
+    K0 = (525.0 * s, 525.0 * s, (319.5 + 0.5) * s - 0.5, 279.5)
+    n = 3
+    iDa, ga, iDb, gb, Rgs, tgs = [], [], [], [], [], []
+    for i in range(n):
+        seq = synth.make_sequence(3, seed=synth.SEED + 77 * i, K=K0, rows=rows, cols=cols, device="cuda", trans_step=(0.008, 0.02), rot_step_deg=(0.3, 1.0))
+        d = seq["depth"].cpu().numpy().astype(np.uint16); c = seq["rgb"].cpu().numpy()
+        iD, grey, Rg, tg = _kf_pair(seq, d, c, 0, 2)
+        iDa.append(iD[0]); iDb.append(iD[1]); ga.append(grey[0]); gb.append(grey[1]); Rgs.append(Rg); tgs.append(tg)
+    iDa, iDb, ga, gb = [np.stack(x) for x in (iDa, iDb, ga, gb)]
+    Ks = np.asarray([K0] * n, np.float32)
+    R0 = np.stack([np.eye(3)] * n); t0 = np.zeros((n, 3))
+    ctx = device.Context(0)
+    al = kfalign.KfAlign(ctx, rows, cols, n)
+    alone = [al.align(iDa[i:i + 1], ga[i:i + 1], iDb[i:i + 1], gb[i:i + 1], Ks[i:i + 1], R0[i:i + 1], t0[i:i + 1]) for i in range(n)]
+    for m in (2, 3):
+        R, t, cov = al.align(iDa[:m], ga[:m], iDb[:m], gb[:m], Ks[:m], R0[:m], t0[:m])
+        for i in range(m):
+            assert np.isfinite(R[i]).all() and np.isfinite(cov[i]).all()
+            assert rot_angle(R[i], alone[i][0][0]) < 2e-6 and np.linalg.norm(t[i] - alone[i][1][0]) < 2e-6, (m, i)
+            assert rot_angle(R[i], Rgs[i]) < 4e-3 and np.linalg.norm(t[i] - tgs[i]) < 1.5e-2, (m, i, rot_angle(R[i], Rgs[i]), np.linalg.norm(t[i] - tgs[i]))
+    al.close(); ctx.close()
+
+
 def test_keyframe_align_batched_many_pairs_one_wave_solve():
     """More pairs than compute units: the per-pair reduce-and-solve kernel runs as ONE wave per pair (kfalign.hip k_kfa_solve<64>: four slices of the fixed-order
     reduction per thread, the same doubles).  272 pairs carrying 4 distinct ones: duplicates agree to the last bit, and every pair agrees with its 4-pair run
